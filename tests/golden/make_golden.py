@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the REAL reference.
+
+Runs only in the build container (needs oracle/_ref/libref3dsift.so, i.e. /root/reference compiled by
+``make -C oracle ref``).  The fixtures are data: inputs (or the seed that regenerates them plus a
+sha256 of the resulting array) and the outputs the untouched reference produced for them.  No
+reference source text is stored.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+Fixture inventory (the reference has no golden vectors of its own):
+  g2_smooth.npz     GaussianSmooth_3D on a 20x14x10 ramp+noise volume, sigma in {0.538701, 2.452547}
+                    (both boundary rules on all three axes), plus a 9x12x7 volume with sigma 1.2262
+  g3_pyramid.npz    full GSS + DoG pyramids of a 24x20x28 volume (2 octaves) -- raw fp32
+  g4_hashes.npz     sha256 of every GSS/DoG level, per-level abs-max, extrema lists for 40x48x56
+                    (3 octaves, last 10x12x14: no out-of-bounds reads) and 64^3 (4 octaves; the
+                    8^3 level-5 shell is undefined in the reference and excluded from the hash)
+  g5_orient.npz     Assign_Orientation_Imp result for every extremum of the 40x48x56 volume
+                    (return code, win, eigvalue, str_tensor, Rotation)
+  g6_keypoints.npz  final keypoints + 768-d descriptors for 40x48x56 and 64^3
+  g7_mesh.npz       icosahedron mesh + Check_intersect_faces on 1000 random vectors (+ face
+                    vertices / edge midpoints, where the eps-tolerant first-hit rule matters)
+  g8_match.npz      muBruteMatcher inject/biject/enhanced on two 64^3 keypoint sets (target = blobs
+                    shifted +1 voxel in x), plus a permuted copy that puts a best match on index 0
+"""
+import hashlib
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+import oracle_lib as ol  # noqa: E402
+
+synth = importlib.import_module("3dsift_amd.synth")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def ramp_noise(shape, seed):
+    nz, ny, nx = shape
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return (0.01 * x + 0.02 * y - 0.015 * z + rng.uniform(-0.5, 0.5, shape)).astype(np.float32)
+
+
+def interior_mask_hash(level, shell):
+    """sha256 of a level; with shell=True only the [1:-1]^3 interior is hashed."""
+    return sha(level[1:-1, 1:-1, 1:-1]) if shell else sha(level)
+
+
+def main():
+    ref = ol.load("ref")
+    ref.set_threads(8)
+    out = {}
+
+    # ---- G2 ---------------------------------------------------------------------------------
+    v1 = ramp_noise((10, 14, 20), 1)
+    v2 = ramp_noise((7, 12, 9), 2)
+    g2 = dict(v1=v1, v2=v2)
+    for name, v, sig in (("v1_s0", v1, 0.538701), ("v1_s5", v1, 2.452547), ("v2_s2", v2, 1.226273)):
+        g2[name] = ref.gaussian_smooth(v, np.float32(sig))
+        g2[name + "_sigma"] = np.float32(sig)
+    np.savez_compressed(os.path.join(HERE, "g2_smooth.npz"), **g2)
+
+    # ---- G3 ---------------------------------------------------------------------------------
+    shape3 = (28, 20, 24)  # nz, ny, nx  -> nx=24, ny=20, nz=28
+    vol3 = synth.blobs(shape3, seed=11, noise=0.01, nblobs=12)
+    ex = ref.extractor(vol3).run(3)
+    g3 = dict(vol=vol3, noct=np.int32(ex.num_octaves), input=ex.input())
+    for o in range(ex.num_octaves):
+        for i in range(6):
+            g3[f"gss_{o}_{i}"] = ex.gss(o, i)
+        for i in range(5):
+            g3[f"dog_{o}_{i}"] = ex.dog(o, i)
+    e = ex.extrema()
+    g3["extrema"] = np.stack([e["octave"], e["level"], e["x"].astype(np.int32), e["y"].astype(np.int32), e["z"].astype(np.int32)], 1)
+    np.savez_compressed(os.path.join(HERE, "g3_pyramid.npz"), **g3)
+
+    # ---- G4 / G5 / G6 -----------------------------------------------------------------------
+    cases = {
+        "a": dict(shape=(56, 48, 40), seed=7, noise=0.01),   # nx=40, ny=48, nz=56
+        "b": dict(shape=(64, 64, 64), seed=1234, noise=0.0),
+    }
+    g4, g6 = {}, {}
+    for tag, c in cases.items():
+        vol = synth.blobs(c["shape"], seed=c["seed"], noise=c["noise"])
+        g4[f"{tag}_shape"] = np.array(c["shape"], np.int32)
+        g4[f"{tag}_seed"] = np.int32(c["seed"])
+        g4[f"{tag}_noise"] = np.float64(c["noise"])
+        g4[f"{tag}_vol_sha"] = sha(vol)
+        ex = ref.extractor(vol).run(5)
+        noct = ex.num_octaves
+        g4[f"{tag}_noct"] = np.int32(noct)
+        g4[f"{tag}_input_sha"] = sha(ex.input())
+        hashes, absmax, scales = [], [], []
+        for o in range(noct):
+            for i in range(6):
+                lv = ex.gss(o, i)
+                shell = min(lv.shape) <= 9 and i == 5
+                hashes.append(f"gss_{o}_{i}:{int(shell)}:" + interior_mask_hash(lv, shell))
+                scales.append(ex.level_info(0, o * 6 + i)[2])
+            for i in range(5):
+                lv = ex.dog(o, i)
+                shell = min(lv.shape) <= 9 and i == 4
+                hashes.append(f"dog_{o}_{i}:{int(shell)}:" + interior_mask_hash(lv, shell))
+                absmax.append(np.abs(lv).max())
+        g4[f"{tag}_hashes"] = np.array(hashes)
+        g4[f"{tag}_dog_absmax"] = np.array(absmax, np.float32)
+        g4[f"{tag}_gss_scales"] = np.array(scales, np.float32)
+        e = ex.extrema()
+        g4[f"{tag}_extrema"] = np.stack([e["octave"], e["level"], e["x"].astype(np.int32), e["y"].astype(np.int32), e["z"].astype(np.int32)], 1)
+        g4[f"{tag}_extrema_scale"] = e["scale"].copy()
+        kp, desc = ex.keypoints()
+        g6[f"{tag}_kp"] = kp
+        g6[f"{tag}_desc"] = desc
+
+        if tag == "a":
+            # G5: orientation of every extremum, through the reference's free function
+            codes, outs = [], np.zeros(len(e), ol.KP_DTYPE)
+            for j, k in enumerate(e):
+                lvl = ex.gss(int(k["octave"]), int(k["level"]))
+                unit = ex.level_info(0, int(k["octave"]) * 6 + int(k["level"]))[1][0]
+                code, ko = ref.orient_one(k, lvl, unit, np.float32(1.5) * k["scale"])
+                codes.append(code)
+                outs[j] = ko
+            np.savez_compressed(os.path.join(HERE, "g5_orient.npz"), codes=np.array(codes, np.int32),
+                                win=outs["win"], eigvalue=outs["eigvalue"], str_tensor=outs["str_tensor"],
+                                Rotation=outs["Rotation"], eigvector=outs["eigvector"])
+    np.savez_compressed(os.path.join(HERE, "g4_hashes.npz"), **g4)
+    np.savez_compressed(os.path.join(HERE, "g6_keypoints.npz"), **g6)
+
+    # ---- G7 ---------------------------------------------------------------------------------
+    verts, idx = ref.mesh()
+    rng = np.random.Generator(np.random.PCG64(5))
+    dirs = rng.normal(size=(1000, 3)).astype(np.float32)
+    dirs[:50] *= 1e-4   # some below the |g|^2 < eps rejection
+    special = [verts.reshape(-1, 3)]                                   # exactly on vertices
+    special.append(((verts[:, 0] + verts[:, 1]) * 0.5))                # edge midpoints
+    special.append(verts.mean(1))                                      # face centres
+    dirs = np.concatenate([dirs] + [s.astype(np.float32) for s in special], 0)
+    faces = np.zeros(len(dirs), np.int32)
+    bary = np.zeros((len(dirs), 3), np.float32)
+    for j, d in enumerate(dirs):
+        faces[j], b = ref.intersect(d)
+        bary[j] = b if faces[j] >= 0 else 0
+    np.savez_compressed(os.path.join(HERE, "g7_mesh.npz"), verts=verts, idx=idx, dirs=dirs, faces=faces, bary=bary)
+
+    # ---- G8 ---------------------------------------------------------------------------------
+    va = synth.blobs((64, 64, 64), seed=1234)
+    vb = synth.blobs((64, 64, 64), seed=1234, shift=(1.0, 0.0, 0.0))
+    ka, da = ref.extractor(va).run(5).keypoints()
+    kb, db = ref.extractor(vb).run(5).keypoints()
+    xa = np.stack([ka["rx"], ka["ry"], ka["rz"]], 1)
+    xb = np.stack([kb["rx"], kb["ry"], kb["rz"]], 1)
+    g8 = dict(da=da, db=db, xa=xa, xb=xb)
+    sets = {"p": (da, xa, db, xb)}
+    # permuted target so that some ref keypoint's best match is target index 0 (the
+    # "index 0 can never be rejected" quirk, cMatcher.cc:93,142)
+    r0 = ref.match(da, xa, db, xb, 0.85, 1)
+    hit = int(r0["gIdx"][np.nonzero(r0["gIdx"] > 0)[0][0]])
+    perm = np.arange(len(db)); perm[0], perm[hit] = perm[hit], perm[0]
+    sets["q"] = (da, xa, db[perm], xb[perm])
+    g8["perm"] = perm.astype(np.int32)
+    for tag, (a, ax, b, bx) in sets.items():
+        for mode in (1, 2, 3):
+            for thr in (0.85, 0.95):
+                r = ref.match(a, ax, b, bx, thr, mode)
+                key = f"{tag}_m{mode}_t{int(thr * 100)}"
+                for k, v in r.items():
+                    g8[f"{key}_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "g8_match.npz"), **g8)
+
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
