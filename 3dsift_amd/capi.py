@@ -1,0 +1,277 @@
+"""ctypes binding of the C-ABI in include/sift3d_hip.h (lib: 3dsift_amd/libsift3d_hip.so).
+
+This is plumbing for tests/ and bench.py: the product is the HIP library itself and the C++ shell
+in 3dsift_amd/host/ (namespace CPUSIFT).  There is NO CPU fallback anywhere in this module: if the
+library is missing or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsift3d_hip.so")
+DESC = 768
+
+KP_DTYPE = np.dtype(
+    [
+        ("x", "<f4"), ("y", "<f4"), ("z", "<f4"),
+        ("scale", "<f4"),
+        ("octave", "<i4"), ("level", "<i4"),
+        ("rx", "<f4"), ("ry", "<f4"), ("rz", "<f4"),
+        ("win", "<f4", (3,)),
+        ("eigvalue", "<f4", (3,)),
+        ("eigvector", "<f4", (9,)),
+        ("Rotation", "<f4", (9,)),
+        ("str_tensor", "<f4", (9,)),
+    ]
+)
+assert KP_DTYPE.itemsize == 168
+
+# every symbol include/sift3d_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "sift3d_default_params", "sift3d_create", "sift3d_destroy", "sift3d_run", "sift3d_run_stages",
+    "sift3d_stage_times", "sift3d_num_keypoints", "sift3d_get_keypoints", "sift3d_device_results",
+    "sift3d_num_octaves", "sift3d_level_info", "sift3d_copy_level", "sift3d_copy_input", "sift3d_num_extrema",
+    "sift3d_get_extrema", "sift3d_get_orientation_codes", "sift3d_gaussian_smooth", "sift3d_match",
+    "sift3d_device_count", "sift3d_error_string", "sift3d_last_error",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("num_kp_levels", C.c_int), ("sigma_default", C.c_float), ("sigma_n_default", C.c_float),
+                ("peak_thresh", C.c_float), ("max_eig_thres", C.c_float), ("corner_thresh", C.c_float)]
+
+
+class Sift3dError(RuntimeError):
+    pass
+
+
+_lib = None
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int)
+
+
+def lib():
+    """Load the HIP library; fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Sift3dError(f"{LIB_PATH} is missing: build it with `make -C 3dsift_amd/csrc` "
+                              f"(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.sift3d_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int]
+        L.sift3d_destroy.argtypes = [C.c_void_p]
+        L.sift3d_run.argtypes = [C.c_void_p]
+        L.sift3d_run_stages.argtypes = [C.c_void_p, C.c_int]
+        L.sift3d_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.sift3d_num_keypoints.argtypes = [C.c_void_p, _ip]
+        L.sift3d_get_keypoints.argtypes = [C.c_void_p, C.c_void_p, _fp]
+        L.sift3d_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _ip]
+        L.sift3d_num_octaves.argtypes = [C.c_void_p, _ip]
+        L.sift3d_level_info.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _fp, _fp]
+        L.sift3d_copy_level.argtypes = [C.c_void_p, C.c_int, C.c_int, _fp]
+        L.sift3d_copy_input.argtypes = [C.c_void_p, _fp]
+        L.sift3d_num_extrema.argtypes = [C.c_void_p, _ip]
+        L.sift3d_get_extrema.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_get_orientation_codes.argtypes = [C.c_void_p, _ip]
+        L.sift3d_gaussian_smooth.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, C.c_int]
+        L.sift3d_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
+                                   C.c_int, C.c_int, _ip, _ip, _fp, _fp, _fp, _ip, C.POINTER(C.c_double)]
+        L.sift3d_device_count.argtypes = [_ip]
+        L.sift3d_error_string.argtypes = [C.c_int]
+        L.sift3d_error_string.restype = C.c_char_p
+        L.sift3d_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        L = lib()
+        raise Sift3dError(f"{L.sift3d_error_string(rc).decode()}: {L.sift3d_last_error().decode()}")
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().sift3d_device_count(C.byref(n))
+    return n.value
+
+
+class CSIFT3D:
+    """Python mirror of CPUSIFT::CSIFT3D over the C-ABI (same method names as the reference class,
+    Include/cSIFT3D.h:118-181).  vol is [z, y, x] fp32 (x fastest)."""
+
+    def __init__(self, volume, num_kp_levels=3, sigma_default=1.6, sigma_n_default=1.15, peak_thresh=0.1,
+                 max_eig_thres=0.9, corner_thresh=0.4, device=0, device_ptr=None, shape=None):
+        L = lib()
+        self._h = C.c_void_p()
+        p = Params(num_kp_levels, sigma_default, sigma_n_default, peak_thresh, max_eig_thres, corner_thresh)
+        self.levels = num_kp_levels
+        if device_ptr is not None:
+            nz, ny, nx = shape
+            self.shape = tuple(shape)
+            _check(L.sift3d_create(C.byref(self._h), C.c_void_p(device_ptr), nx, ny, nz, C.byref(p), device, 1))
+        else:
+            vol = np.ascontiguousarray(volume, dtype=np.float32)
+            nz, ny, nx = vol.shape
+            self.shape = vol.shape
+            _check(L.sift3d_create(C.byref(self._h), vol.ctypes.data_as(C.c_void_p), nx, ny, nz, C.byref(p), device, 0))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sift3d_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- reference API names -------------------------------------------------------------------
+    def KpSiftAlgorithm(self):
+        _check(lib().sift3d_run(self._h))
+        return self
+
+    def run_stages(self, upto):
+        _check(lib().sift3d_run_stages(self._h, int(upto)))
+        return self
+
+    def GetKeypoints(self, with_desc=True):
+        n = C.c_int(0)
+        _check(lib().sift3d_num_keypoints(self._h, C.byref(n)))
+        kp = np.zeros(n.value, KP_DTYPE)
+        desc = np.zeros((n.value, DESC), np.float32)
+        if n.value:
+            _check(lib().sift3d_get_keypoints(self._h, kp.ctypes.data, _f(desc) if with_desc else None))
+        return kp, desc
+
+    @property
+    def m_timer(self):
+        t = (C.c_double * 8)()
+        _check(lib().sift3d_stage_times(self._h, t))
+        keys = ["d_TotalTime", "d_Allocation", "d_BuildGSS", "d_BuildDOG", "d_Detect", "d_AssignOrientation", "d_Extraction", "d_release"]
+        return dict(zip(keys, list(t)))
+
+    # --- checking accessors (GET_GSS / GET_DOG / GET_LEVEL) ---------------------------------------
+    @property
+    def num_octaves(self):
+        n = C.c_int(0)
+        _check(lib().sift3d_num_octaves(self._h, C.byref(n)))
+        return n.value
+
+    def level_info(self, is_dog, idx):
+        d = np.zeros(3, np.int32); u = np.zeros(3, np.float32); s = np.zeros(1, np.float32)
+        _check(lib().sift3d_level_info(self._h, int(is_dog), idx, d.ctypes.data_as(_ip), _f(u), _f(s)))
+        return tuple(int(v) for v in d), tuple(float(v) for v in u), float(s[0])
+
+    def level(self, is_dog, idx):
+        (nx, ny, nz), _, _ = self.level_info(is_dog, idx)
+        out = np.empty((nz, ny, nx), np.float32)
+        _check(lib().sift3d_copy_level(self._h, int(is_dog), idx, _f(out)))
+        return out
+
+    def gss(self, octave, i):
+        return self.level(0, octave * (self.levels + 3) + i)
+
+    def dog(self, octave, i):
+        return self.level(1, octave * (self.levels + 2) + i)
+
+    def input(self):
+        out = np.empty(self.shape, np.float32)
+        _check(lib().sift3d_copy_input(self._h, _f(out)))
+        return out
+
+    def extrema(self):
+        n = C.c_int(0)
+        _check(lib().sift3d_num_extrema(self._h, C.byref(n)))
+        out = np.zeros(n.value, KP_DTYPE)
+        if n.value:
+            _check(lib().sift3d_get_extrema(self._h, out.ctypes.data))
+        return out
+
+    def orientation_codes(self):
+        n = C.c_int(0)
+        _check(lib().sift3d_num_extrema(self._h, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        if n.value:
+            _check(lib().sift3d_get_orientation_codes(self._h, out.ctypes.data_as(_ip)))
+        return out
+
+    def device_results(self):
+        d = C.c_void_p(); x = C.c_void_p(); n = C.c_int(0)
+        _check(lib().sift3d_device_results(self._h, C.byref(d), C.byref(x), C.byref(n)))
+        return d.value, x.value, n.value
+
+
+def CreateCSIFT3D(volume, **kw):
+    """CSIFT3DFactory::CreateCSIFT3D (Include/cSIFT3D.h:184-194)."""
+    return CSIFT3D(volume, **kw)
+
+
+def gaussian_smooth(vol, sigma, device=0):
+    vol = np.ascontiguousarray(vol, dtype=np.float32)
+    nz, ny, nx = vol.shape
+    out = np.empty_like(vol)
+    _check(lib().sift3d_gaussian_smooth(_f(vol), nx, ny, nz, float(sigma), _f(out), device))
+    return out
+
+
+class muBruteMatcher:
+    """Python mirror of CPUSIFT::muBruteMatcher (Include/cMatcher.h:12-88)."""
+
+    MODES = {"inject": 1, "biject": 2, "enhanced": 3}
+
+    def __init__(self, device=0):
+        self.device = device
+        self.totalTime = 0.0
+        self._last = None
+
+    def _match(self, ref_desc, ref_xyz, tar_desc, tar_xyz, thresHold, mode, on_device=False, n=None, m=None):
+        L = lib()
+        if on_device:
+            pa, px, pb, py = (C.c_void_p(int(v)) for v in (ref_desc, ref_xyz, tar_desc, tar_xyz))
+        else:
+            a = np.ascontiguousarray(ref_desc, np.float32); b = np.ascontiguousarray(tar_desc, np.float32)
+            ax = np.ascontiguousarray(ref_xyz, np.float32); bx = np.ascontiguousarray(tar_xyz, np.float32)
+            n, m = a.shape[0], b.shape[0]
+            pa, px, pb, py = (v.ctypes.data_as(C.c_void_p) for v in (a, ax, b, bx))
+        nn = max(n, 1)
+        gi = np.zeros(nn, np.int32); si = np.zeros(nn, np.int32)
+        gd = np.zeros(nn, np.float32); sd = np.zeros(nn, np.float32)
+        pairs = np.zeros((nn, 6), np.float32)
+        k = C.c_int(0); sec = C.c_double(0)
+        _check(L.sift3d_match(pa, px, n, pb, py, m, float(thresHold), int(mode), int(bool(on_device)), self.device,
+                              gi.ctypes.data_as(_ip), si.ctypes.data_as(_ip), _f(gd), _f(sd), _f(pairs), C.byref(k), C.byref(sec)))
+        self.totalTime = sec.value
+        self._last = dict(gIdx=gi[:n], sIdx=si[:n], gDist=gd[:n], sDist=sd[:n], pairs=pairs[:k.value].copy())
+        return self._last
+
+    def injectMatch(self, ref_desc, ref_xyz, tar_desc, tar_xyz, thresHold=0.85, **kw):
+        return self._match(ref_desc, ref_xyz, tar_desc, tar_xyz, thresHold, 1, **kw)
+
+    def bijectMatch(self, ref_desc, ref_xyz, tar_desc, tar_xyz, thresHold=0.85, **kw):
+        return self._match(ref_desc, ref_xyz, tar_desc, tar_xyz, thresHold, 2, **kw)
+
+    def enhancedMatch(self, ref_desc, ref_xyz, tar_desc, tar_xyz, thresHold=0.85, **kw):
+        return self._match(ref_desc, ref_xyz, tar_desc, tar_xyz, thresHold, 3, **kw)
+
+    def getCalculationTime(self):
+        return self.totalTime
+
+    def getGlodenIdx(self):
+        return self._last["gIdx"]
+
+    def getSilverIdx(self):
+        return self._last["sIdx"]
+
+    def getGlodenDistSquare(self):
+        return self._last["gDist"]
+
+    def getSilverDistSquare(self):
+        return self._last["sDist"]

@@ -1,0 +1,600 @@
+// context.hip -- host orchestration + the C-ABI (include/sift3d_hip.h).
+//
+// One sift3d_ctx owns a device arena (both pyramids, scratch, keypoint lists), a HIP stream and
+// the host-built constant tables.  sift3d_run enqueues the whole KpSiftAlgorithm pipeline
+// (reference Src/cSIFT3D.cc:165-235) on that stream with no host synchronisation inside; the
+// only sync is the final one that also brings the keypoint count back.
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "sift3d_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace s3d {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &s) { g_last_error = s; }
+
+// ---------------------------------------------------------------------------------------------
+// host-side constant builders (each mirrors a reference routine; same fp32/fp64 mix)
+// ---------------------------------------------------------------------------------------------
+// GaussianSmooth_3D kernel generation, Src/cSIFT3D.cc:541-572
+static bool build_taps(float sigma, Taps &t) {
+	sigma = sigma > 0 ? sigma : 0;
+	int hw = 1;
+	if (sigma > 0) {
+		hw = (int)ceil((double)sigma * 3.0);
+		if (hw < 1) hw = 1;
+	}
+	if (hw > kMaxHW) return false;
+	t.hw = hw;
+	const int width = 2 * hw + 1;
+	float acc = 0;
+	for (int i = 0; i < width; i++) {
+		float x = (float)(i - hw);
+		x = (float)((double)x / ((double)sigma + DBL_EPSILON));
+		t.w[i] = (float)exp(-0.5 * (double)x * (double)x);
+		acc += t.w[i];
+	}
+	for (int i = 0; i < width; i++) t.w[i] /= acc;
+	for (int i = width; i < kMaxTaps; i++) t.w[i] = 0.f;
+	return true;
+}
+
+// incremental blur schedule, Src/cSIFT3D.cc:272-287, 299
+static void level_sigmas(const sift3d_params &p, std::vector<float> &sig, float &base_sigma) {
+	const int ng = p.num_kp_levels + 3;
+	sig.assign(ng, 0.f);
+	const float k = (float)pow(2.0, 1.0 / (double)p.num_kp_levels);
+	const float base = (float)((double)p.sigma_default * pow(2.0, -1.0 / 3.0));
+	sig[0] = base;
+	for (int i = 1; i < ng; i++) {
+		const float sig_prev = (float)(pow((double)k, (double)(i - 1)) * (double)base);
+		const float sig_total = sig_prev * k;
+		sig[i] = sqrtf(sig_total * sig_total - sig_prev * sig_prev);
+	}
+	base_sigma = sqrtf(sig[0] * sig[0] - p.sigma_n_default * p.sigma_n_default);
+}
+
+// icosahedron + hoisted cart2bary constants, Src/cUtil.cc:19-55, 113-175; Src/cSIFT3D.cc:1599-1619
+static void cross3(const float *a, const float *b, float *o) {
+	o[0] = a[1] * b[2] - a[2] * b[1];
+	o[1] = a[2] * b[0] - a[0] * b[2];
+	o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static float dot3(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static void build_faces(FaceConst *F) {
+	const double gr = 1.6180339887;
+	const double vert[12][3] = {{0, 1, gr}, {0, -1, gr}, {0, 1, -gr}, {0, -1, -gr}, {1, gr, 0}, {-1, gr, 0},
+	                            {1, -gr, 0}, {-1, -gr, 0}, {gr, 0, 1}, {-gr, 0, 1}, {gr, 0, -1}, {-gr, 0, -1}};
+	static const int faces[kFaces][3] = {{0, 1, 8}, {0, 8, 4}, {0, 4, 5}, {0, 5, 9}, {0, 9, 1}, {1, 6, 8}, {8, 6, 10},
+	                                     {8, 10, 4}, {4, 10, 2}, {4, 2, 5}, {5, 2, 11}, {5, 11, 9}, {9, 11, 7}, {9, 7, 1},
+	                                     {1, 7, 6}, {3, 6, 7}, {3, 7, 11}, {3, 11, 2}, {3, 2, 10}, {3, 10, 6}};
+	for (int f = 0; f < kFaces; f++) {
+		float v[3][3];
+		for (int j = 0; j < 3; j++) {
+			F[f].idx[j] = faces[f][j];
+			float raw[3] = {(float)vert[faces[f][j]][0], (float)vert[faces[f][j]][1], (float)vert[faces[f][j]][2]};
+			const double mag = (double)sqrtf(dot3(raw, raw));
+			const double sca = 1.0 / mag;
+			for (int c = 0; c < 3; c++) v[j][c] = (float)((double)raw[c] * sca);
+		}
+		float a[3], b[3], n[3];
+		for (int c = 0; c < 3; c++) { a[c] = v[2][c] - v[1][c]; b[c] = v[1][c] - v[0][c]; }
+		cross3(a, b, n);
+		if (dot3(n, v[0]) < 0)
+			for (int c = 0; c < 3; c++) std::swap(v[0][c], v[1][c]);
+		for (int c = 0; c < 3; c++) {
+			F[f].e1[c] = v[1][c] - v[0][c];
+			F[f].e2[c] = v[2][c] - v[0][c];
+			F[f].t[c] = (float)((double)v[0][c] * (-1.0));
+		}
+		cross3(F[f].t, F[f].e1, F[f].q);
+		F[f].qe2 = dot3(F[f].q, F[f].e2);
+	}
+}
+
+}  // namespace s3d
+
+using namespace s3d;
+
+// ---------------------------------------------------------------------------------------------
+// the context
+// ---------------------------------------------------------------------------------------------
+struct sift3d_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	sift3d_params p{};
+	int nx = 0, ny = 0, nz = 0;
+	int noct = 0, ng = 0, nd = 0;
+
+	// device memory
+	float *arena = nullptr;       // input + pyramids + scratch (one allocation)
+	size_t arena_floats = 0;
+	Level in;
+	std::vector<Level> gss, dog;
+	float *tmpA = nullptr, *tmpB = nullptr;  // separable-pass scratch, V0 floats each
+	unsigned *d_words = nullptr;  // [0] input max bits, [1..] per-DoG-level max bits, then counters
+	unsigned *d_inmax = nullptr, *d_dogmax = nullptr, *d_total = nullptr, *d_nkp = nullptr;
+	DetectBufs det{};
+	size_t det_blocks = 0;
+	DevKp *d_ext = nullptr;
+	unsigned ext_cap = 0, kp_cap = 0;
+	LevelRef *d_levels = nullptr;
+	WinLut *d_luts = nullptr;
+	float *d_lutpool = nullptr;
+	sift3d_keypoint *d_kpout = nullptr;
+	float *d_desc = nullptr, *d_xyz = nullptr;
+
+	// host tables
+	std::vector<Taps> taps;  // per GSS level index within an octave
+	Taps base_taps{};
+
+	// results / state
+	int stage = 0;  // highest stage run
+	unsigned n_ext = 0, n_kp = 0;
+	hipEvent_t ev[8] = {};
+	double times[8] = {};
+};
+
+static int set_device(int device) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+		set_last_error("no HIP device visible: this library has no CPU fallback");
+		return SIFT3D_ERR_NO_DEVICE;
+	}
+	if (device < 0 || device >= n) { set_last_error("device index out of range"); return SIFT3D_ERR_ARG; }
+	S3D_HIP(hipSetDevice(device));
+	return SIFT3D_OK;
+}
+
+static void free_lists(sift3d_ctx *c) {
+	hipFree(c->d_ext); c->d_ext = nullptr;
+	hipFree(c->d_kpout); c->d_kpout = nullptr;
+	hipFree(c->d_desc); c->d_desc = nullptr;
+	hipFree(c->d_xyz); c->d_xyz = nullptr;
+}
+
+static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
+	free_lists(c);
+	c->ext_cap = ext_cap;
+	c->kp_cap = ext_cap;  // every extremum could survive orientation
+	S3D_HIP(hipMalloc(&c->d_ext, sizeof(DevKp) * (size_t)c->ext_cap));
+	S3D_HIP(hipMalloc(&c->d_kpout, sizeof(sift3d_keypoint) * (size_t)c->kp_cap));
+	S3D_HIP(hipMalloc(&c->d_desc, sizeof(float) * kDesc * (size_t)c->kp_cap));
+	S3D_HIP(hipMalloc(&c->d_xyz, sizeof(float) * 3 * (size_t)c->kp_cap));
+	return SIFT3D_OK;
+}
+
+extern "C" void sift3d_default_params(sift3d_params *p) {
+	if (!p) return;
+	p->num_kp_levels = 3;
+	p->sigma_default = 1.6f;
+	p->sigma_n_default = 1.15f;
+	p->peak_thresh = 0.1f;
+	p->max_eig_thres = 0.9f;
+	p->corner_thresh = 0.4f;
+}
+
+extern "C" int sift3d_device_count(int *n) {
+	int k = 0;
+	if (hipGetDeviceCount(&k) != hipSuccess) k = 0;
+	if (n) *n = k;
+	return SIFT3D_OK;
+}
+
+extern "C" const char *sift3d_error_string(int code) {
+	switch (code) {
+	case SIFT3D_OK: return "ok";
+	case SIFT3D_ERR_ARG: return "bad argument";
+	case SIFT3D_ERR_NO_DEVICE: return "no usable HIP device (no CPU fallback)";
+	case SIFT3D_ERR_HIP: return "HIP runtime error";
+	case SIFT3D_ERR_STATE: return "call out of order";
+	case SIFT3D_ERR_CAPACITY: return "device list capacity exceeded";
+	default: return "unknown error";
+	}
+}
+
+extern "C" const char *sift3d_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int sift3d_destroy(sift3d_handle c) {
+	if (!c) return SIFT3D_OK;
+	hipSetDevice(c->device);
+	if (c->stream) hipStreamSynchronize(c->stream);
+	free_lists(c);
+	hipFree(c->arena);
+	hipFree(c->d_words);
+	hipFree(c->det.masks); hipFree(c->det.block_counts); hipFree(c->det.block_offsets);
+	hipFree(c->d_levels); hipFree(c->d_luts); hipFree(c->d_lutpool);
+	for (auto &e : c->ev) if (e) hipEventDestroy(e);
+	if (c->stream) hipStreamDestroy(c->stream);
+	delete c;
+	return SIFT3D_OK;
+}
+
+// Initialize + Initialize_Pyramid geometry, Src/cSIFT3D.cc:237-266, Src/cUtil.cc:177-235
+static void plan_pyramid(sift3d_ctx *c) {
+	int mn = std::min(c->nx, std::min(c->ny, c->nz));
+	const int last = (int)log2f((float)mn) - 3;
+	c->noct = std::max(0, last + 1);
+	c->ng = c->p.num_kp_levels + 3;
+	c->nd = c->p.num_kp_levels + 2;
+	c->gss.assign((size_t)c->noct * c->ng, Level());
+	c->dog.assign((size_t)c->noct * c->nd, Level());
+	const double sigma0 = (double)c->p.sigma_default * pow(2.0, -1.0 / 3.0);
+	for (int pyr = 0; pyr < 2; pyr++) {
+		const int interval = pyr ? c->nd : c->ng;
+		std::vector<Level> &P = pyr ? c->dog : c->gss;
+		int nx = c->nx, ny = c->ny, nz = c->nz;
+		float u = 1.0f;
+		for (int o = 0; o < c->noct; o++) {
+			for (int s = 0; s < interval; s++) {
+				Level &L = P[(size_t)o * interval + s];
+				L.nx = nx; L.ny = ny; L.nz = nz; L.unit = u;
+				const double scale_factor = pow(2.0, (double)o + (double)s / (double)c->p.num_kp_levels);
+				L.scale = (float)(scale_factor * sigma0);
+			}
+			nx /= 2; ny /= 2; nz /= 2;
+			u *= 2;
+		}
+	}
+}
+
+// Gaussian window tables (see WinLut): orientation (Src/cSIFT3D.cc:915, 968-971) and descriptor
+// (Src/cSIFT3D.cc:1155-1156, 1270, 1312) windows of every (octave, keypoint level).
+static int build_luts(sift3d_ctx *c) {
+	std::vector<WinLut> luts((size_t)std::max(1, c->noct) * 8 * 2);
+	std::vector<float> pool;
+	for (auto &l : luts) { l.off = 0; l.len = 0; l.radius = 0; l.sigma = 0; }
+	for (int o = 0; o < c->noct; o++)
+		for (int lv = 1; lv <= c->p.num_kp_levels && lv < 8; lv++) {
+			const Level &D = c->dog[(size_t)o * c->nd + lv];  // keypoint scale = DoG level scale (Src/cSIFT3D.cc:407)
+			const float u = D.unit, scale = D.scale;
+			for (int which = 0; which < 2; which++) {
+				float sigma, radius;
+				if (which == 0) { sigma = 1.5f * scale; radius = sigma * 3.0f; }
+				else { sigma = scale * 7.071067812f; radius = 2.0f * sigma; }
+				const float r2 = radius * radius, uu = u * u;
+				const int len = (int)floor((double)r2 / (double)uu) + 2;
+				WinLut &L = luts[((size_t)o * 8 + lv) * 2 + which];
+				L.off = (int)pool.size(); L.len = len; L.radius = radius; L.sigma = sigma;
+				for (int n = 0; n < len; n++) {
+					const float sq = (float)n * uu;  // exact: equals the reference's fp32 sum of squares
+					float w;
+					if (sq > r2) w = -1.0f;
+					else if (which == 0) w = expf((float)(-0.5 * (double)sq / (double)(sigma * sigma)));
+					else w = expf(-0.5f * sq / (sigma * sigma));
+					pool.push_back(w);
+				}
+			}
+		}
+	if (pool.empty()) pool.push_back(-1.0f);
+	S3D_HIP(hipMalloc(&c->d_luts, sizeof(WinLut) * luts.size()));
+	S3D_HIP(hipMalloc(&c->d_lutpool, sizeof(float) * pool.size()));
+	S3D_HIP(hipMemcpy(c->d_luts, luts.data(), sizeof(WinLut) * luts.size(), hipMemcpyHostToDevice));
+	S3D_HIP(hipMemcpy(c->d_lutpool, pool.data(), sizeof(float) * pool.size(), hipMemcpyHostToDevice));
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
+                             int device, int volume_on_device) {
+	if (!out || !volume || nx <= 0 || ny <= 0 || nz <= 0) { set_last_error("sift3d_create: bad argument"); return SIFT3D_ERR_ARG; }
+	if ((size_t)nx * ny * nz >= ((size_t)1 << 31)) { set_last_error("volume too large for int32 voxel indices"); return SIFT3D_ERR_ARG; }
+	*out = nullptr;
+	int rc = set_device(device);
+	if (rc) return rc;
+	sift3d_ctx *c = new sift3d_ctx();
+	c->device = device;
+	if (params) c->p = *params; else sift3d_default_params(&c->p);
+	if (c->p.num_kp_levels < 1 || c->p.num_kp_levels > 5) { delete c; set_last_error("num_kp_levels must be in [1,5]"); return SIFT3D_ERR_ARG; }
+	c->nx = nx; c->ny = ny; c->nz = nz;
+	plan_pyramid(c);
+
+	// host tables
+	std::vector<float> sig;
+	float base_sigma;
+	level_sigmas(c->p, sig, base_sigma);
+	c->taps.resize(c->ng);
+	bool ok = build_taps(base_sigma, c->base_taps);
+	for (int i = 1; i < c->ng; i++) ok = ok && build_taps(sig[i], c->taps[i]);
+	if (!ok) { delete c; set_last_error("Gaussian kernel wider than the supported 33 taps"); return SIFT3D_ERR_ARG; }
+
+#define CHECKED(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); sift3d_destroy(c); return SIFT3D_ERR_HIP; } } while (0)
+	CHECKED(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	for (auto &e : c->ev) CHECKED(hipEventCreate(&e));
+
+	// ---- arena: input | scratch A | scratch B | GSS levels | DoG levels (each 256-B aligned) ----
+	const size_t V0 = (size_t)nx * ny * nz;
+	auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
+	size_t total = al(V0) * 3;
+	for (auto &L : c->gss) total += al(L.n());
+	for (auto &L : c->dog) total += al(L.n());
+	c->arena_floats = total;
+	CHECKED(hipMalloc(&c->arena, sizeof(float) * total));
+	float *p = c->arena;
+	c->in.d = p; c->in.nx = nx; c->in.ny = ny; c->in.nz = nz; c->in.unit = 1.f; c->in.scale = 1.f; p += al(V0);
+	c->tmpA = p; p += al(V0);
+	c->tmpB = p; p += al(V0);
+	for (auto &L : c->gss) { L.d = p; p += al(L.n()); }
+	for (auto &L : c->dog) { L.d = p; p += al(L.n()); }
+
+	const size_t nwords = 1 + (size_t)std::max(1, c->noct * c->nd) + 4;
+	CHECKED(hipMalloc(&c->d_words, sizeof(unsigned) * nwords));
+	CHECKED(hipMemset(c->d_words, 0, sizeof(unsigned) * nwords));
+	c->d_inmax = c->d_words;
+	c->d_dogmax = c->d_words + 1;
+	c->d_total = c->d_words + 1 + std::max(1, c->noct * c->nd);  // [0] extrema total, [1] overflow flag
+	c->d_nkp = c->d_total + 2;
+
+	c->det_blocks = (V0 + 1023) / 1024;
+	CHECKED(hipMalloc(&c->det.masks, sizeof(unsigned long long) * c->det_blocks * 16));
+	CHECKED(hipMalloc(&c->det.block_counts, sizeof(unsigned) * c->det_blocks));
+	CHECKED(hipMalloc(&c->det.block_offsets, sizeof(unsigned) * c->det_blocks));
+	c->det.total = c->d_total;
+
+	std::vector<LevelRef> lr((size_t)std::max(1, c->noct) * 8, LevelRef{nullptr, 0, 0, 0, 1.f});
+	for (int o = 0; o < c->noct; o++)
+		for (int i = 0; i < c->ng && i < 8; i++) {
+			const Level &L = c->gss[(size_t)o * c->ng + i];
+			lr[(size_t)o * 8 + i] = LevelRef{L.d, L.nx, L.ny, L.nz, L.unit};
+		}
+	CHECKED(hipMalloc(&c->d_levels, sizeof(LevelRef) * lr.size()));
+	CHECKED(hipMemcpy(c->d_levels, lr.data(), sizeof(LevelRef) * lr.size(), hipMemcpyHostToDevice));
+	rc = build_luts(c);
+	if (rc) { sift3d_destroy(c); return rc; }
+	FaceConst faces[kFaces];
+	build_faces(faces);
+	upload_faces(faces);
+
+	// keypoint lists: synthetic blob volumes give ~6e-4*V0 extrema; leave 8x headroom, regrow on overflow
+	unsigned cap = (unsigned)std::min<size_t>(std::max<size_t>(4096, V0 / 256), 4u << 20);
+	rc = alloc_lists(c, cap);
+	if (rc) { sift3d_destroy(c); return rc; }
+
+	// ---- constructor work proper: copy + data_scale (Src/cSIFT3D.cc:161-162) ----
+	CHECKED(hipMemcpyAsync(c->in.d, volume, sizeof(float) * V0, volume_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+	launch_absmax(c->in.d, V0, c->d_inmax, c->stream);
+	launch_scale_by_max(c->in.d, V0, c->d_inmax, c->stream);
+	CHECKED(hipStreamSynchronize(c->stream));
+	CHECKED(hipGetLastError());
+#undef CHECKED
+	*out = c;
+	return SIFT3D_OK;
+}
+
+// GaussianSmooth_3D (Src/cSIFT3D.cc:535-622) on device buffers: X -> Y -> Z(+DoG)
+static void smooth_level(sift3d_ctx *c, const float *src, const Level &dst, const Taps &t, const float *prev, float *dog,
+                         unsigned *dogmax) {
+	launch_conv_axis(0, src, c->tmpA, dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, c->stream);
+	launch_conv_axis(1, c->tmpA, c->tmpB, dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, c->stream);
+	launch_conv_axis(2, c->tmpB, dst.d, dst.nx, dst.ny, dst.nz, t, prev, dog, dogmax, c->stream);
+}
+
+static int run_impl(sift3d_ctx *c, int upto) {
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	if (upto < 1) upto = 1;
+	if (upto > 5) upto = 5;
+	hipStream_t st = c->stream;
+	for (int attempt = 0; attempt < 4; attempt++) {
+		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(std::max(1, c->noct * c->nd) + 4), st));
+		S3D_HIP(hipEventRecord(c->ev[0], st));
+		// ---- Build_Gaussian_Scale_Space (Src/cSIFT3D.cc:268-319) with the DoG (346-360) fused into the z pass ----
+		for (int o = 0; o < c->noct; o++)
+			for (int i = 0; i < c->ng; i++) {
+				const Level &L = c->gss[(size_t)o * c->ng + i];
+				if (o == 0 && i == 0) {
+					smooth_level(c, c->in.d, L, c->base_taps, nullptr, nullptr, nullptr);
+				} else if (i == 0) {
+					const Level &P = c->gss[(size_t)(o - 1) * c->ng + c->p.num_kp_levels];
+					launch_downsample(P.d, P.nx, P.ny, L.d, L.nx, L.ny, L.nz, st);
+				} else {
+					const Level &P = c->gss[(size_t)o * c->ng + i - 1];
+					const Level &D = c->dog[(size_t)o * c->nd + i - 1];
+					smooth_level(c, P.d, L, c->taps[i], P.d, D.d, c->d_dogmax + (size_t)o * c->nd + i - 1);
+				}
+			}
+		S3D_HIP(hipEventRecord(c->ev[1], st));
+		S3D_HIP(hipEventRecord(c->ev[2], st));  // DoG is fused: zero-length stage
+		// ---- Detect_KeyPoints (Src/cSIFT3D.cc:362-425) ----
+		if (upto >= 3)
+			for (int o = 0; o < c->noct; o++)
+				for (int i = 1; i < c->nd - 1; i++) {
+					const Level &C = c->dog[(size_t)o * c->nd + i];
+					launch_detect_level(c->dog[(size_t)o * c->nd + i - 1].d, C.d, c->dog[(size_t)o * c->nd + i + 1].d, C.nx, C.ny,
+					                    C.nz, c->d_dogmax + (size_t)o * c->nd + i, c->p.peak_thresh, o, i, C.scale, c->det, c->d_ext,
+					                    c->ext_cap, st);
+				}
+		S3D_HIP(hipEventRecord(c->ev[3], st));
+		// ---- Assign_Orientation (Src/cSIFT3D.cc:427-482) ----
+		if (upto >= 4) {
+			launch_orient(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
+			              c->p.corner_thresh, st);
+			launch_slots(c->d_ext, c->d_total, c->ext_cap, c->d_nkp, st);
+		}
+		S3D_HIP(hipEventRecord(c->ev[4], st));
+		// ---- Extract_Description (Src/cSIFT3D.cc:484-502) ----
+		if (upto >= 5) launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, st);
+		if (upto >= 4) launch_finalize(c->d_ext, c->d_total, c->ext_cap, upto >= 5, c->d_kpout, c->d_xyz, c->kp_cap, st);
+		S3D_HIP(hipEventRecord(c->ev[5], st));
+		unsigned host_words[3] = {0, 0, 0};  // total, overflow, nkp
+		S3D_HIP(hipMemcpyAsync(host_words, c->d_total, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, st));
+		S3D_HIP(hipStreamSynchronize(st));
+		S3D_HIP(hipGetLastError());
+		if (host_words[1] != 0 || host_words[0] > c->ext_cap) {
+			// list overflow: regrow to fit and rerun (rare; sizes are generous)
+			const unsigned need = std::max(host_words[0], c->ext_cap) * 2u;
+			rc = alloc_lists(c, need);
+			if (rc) return rc;
+			continue;
+		}
+		c->n_ext = host_words[0];
+		c->n_kp = upto >= 4 ? host_words[2] : 0;
+		c->stage = upto;
+		float ms = 0;
+		auto dt = [&](int a, int b) { hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return (double)ms * 1e-3; };
+		c->times[0] = dt(0, 5); c->times[1] = 0; c->times[2] = dt(0, 1); c->times[3] = dt(1, 2);
+		c->times[4] = dt(2, 3); c->times[5] = dt(3, 4); c->times[6] = dt(4, 5); c->times[7] = 0;
+		return SIFT3D_OK;
+	}
+	set_last_error("extrema list kept overflowing");
+	return SIFT3D_ERR_CAPACITY;
+}
+
+extern "C" int sift3d_run(sift3d_handle c) {
+	if (!c) return SIFT3D_ERR_ARG;
+	return run_impl(c, 5);
+}
+
+extern "C" int sift3d_run_stages(sift3d_handle c, int upto) {
+	if (!c) return SIFT3D_ERR_ARG;
+	return run_impl(c, upto);
+}
+
+extern "C" int sift3d_stage_times(sift3d_handle c, double t[8]) {
+	if (!c || !t) return SIFT3D_ERR_ARG;
+	if (c->stage < 1) return SIFT3D_ERR_STATE;
+	memcpy(t, c->times, sizeof(double) * 8);
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_num_keypoints(sift3d_handle c, int *n) {
+	if (!c || !n) return SIFT3D_ERR_ARG;
+	*n = (c->stage >= 4) ? (int)c->n_kp : 0;  // GetKeypoints before KpSiftAlgorithm returns empty
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_get_keypoints(sift3d_handle c, sift3d_keypoint *out, float *desc) {
+	if (!c) return SIFT3D_ERR_ARG;
+	if (c->stage < 4 || c->n_kp == 0) return SIFT3D_OK;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	if (out) S3D_HIP(hipMemcpy(out, c->d_kpout, sizeof(sift3d_keypoint) * (size_t)c->n_kp, hipMemcpyDeviceToHost));
+	if (desc) {
+		if (c->stage < 5) return SIFT3D_ERR_STATE;
+		S3D_HIP(hipMemcpy(desc, c->d_desc, sizeof(float) * kDesc * (size_t)c->n_kp, hipMemcpyDeviceToHost));
+	}
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_device_results(sift3d_handle c, const float **d_desc, const float **d_xyz, int *n) {
+	if (!c) return SIFT3D_ERR_ARG;
+	if (c->stage < 5) return SIFT3D_ERR_STATE;
+	if (d_desc) *d_desc = c->d_desc;
+	if (d_xyz) *d_xyz = c->d_xyz;
+	if (n) *n = (int)c->n_kp;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_num_octaves(sift3d_handle c, int *n) {
+	if (!c || !n) return SIFT3D_ERR_ARG;
+	*n = c->noct;
+	return SIFT3D_OK;
+}
+
+static const Level *pick_level(sift3d_ctx *c, int is_dog, int idx) {
+	const std::vector<Level> &P = is_dog ? c->dog : c->gss;
+	if (idx < 0 || (size_t)idx >= P.size()) return nullptr;
+	return &P[idx];
+}
+
+extern "C" int sift3d_level_info(sift3d_handle c, int is_dog, int idx, int dims3[3], float units3[3], float *scale) {
+	if (!c) return SIFT3D_ERR_ARG;
+	const Level *L = pick_level(c, is_dog, idx);
+	if (!L) return SIFT3D_ERR_ARG;
+	if (dims3) { dims3[0] = L->nx; dims3[1] = L->ny; dims3[2] = L->nz; }
+	if (units3) units3[0] = units3[1] = units3[2] = L->unit;
+	if (scale) *scale = L->scale;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_copy_level(sift3d_handle c, int is_dog, int idx, float *out) {
+	if (!c || !out) return SIFT3D_ERR_ARG;
+	if (c->stage < 1) return SIFT3D_ERR_STATE;
+	const Level *L = pick_level(c, is_dog, idx);
+	if (!L) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	S3D_HIP(hipMemcpy(out, L->d, sizeof(float) * L->n(), hipMemcpyDeviceToHost));
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_copy_input(sift3d_handle c, float *out) {
+	if (!c || !out) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	S3D_HIP(hipMemcpy(out, c->in.d, sizeof(float) * c->in.n(), hipMemcpyDeviceToHost));
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_num_extrema(sift3d_handle c, int *n) {
+	if (!c || !n) return SIFT3D_ERR_ARG;
+	*n = c->stage >= 3 ? (int)c->n_ext : 0;
+	return SIFT3D_OK;
+}
+
+static int fetch_ext(sift3d_ctx *c, std::vector<DevKp> &h) {
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	h.resize(c->n_ext);
+	if (c->n_ext) S3D_HIP(hipMemcpy(h.data(), c->d_ext, sizeof(DevKp) * (size_t)c->n_ext, hipMemcpyDeviceToHost));
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_get_extrema(sift3d_handle c, sift3d_keypoint *out) {
+	if (!c || !out) return SIFT3D_ERR_ARG;
+	if (c->stage < 3) return SIFT3D_ERR_STATE;
+	std::vector<DevKp> h;
+	int rc = fetch_ext(c, h);
+	if (rc) return rc;
+	for (size_t i = 0; i < h.size(); i++) {
+		sift3d_keypoint &o = out[i];
+		memset(&o, 0, sizeof(o));
+		o.x = (float)h[i].x; o.y = (float)h[i].y; o.z = (float)h[i].z;
+		o.scale = h[i].scale; o.octave = h[i].octave; o.level = h[i].level;
+		o.rx = o.ry = o.rz = -1.0f;
+		memcpy(o.win, h[i].win, sizeof(o.win));
+		memcpy(o.eigvalue, h[i].eigvalue, sizeof(o.eigvalue));
+		memcpy(o.eigvector, h[i].eigvector, sizeof(o.eigvector));
+		memcpy(o.Rotation, h[i].rot, sizeof(o.Rotation));
+		memcpy(o.str_tensor, h[i].st, sizeof(o.str_tensor));
+	}
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_get_orientation_codes(sift3d_handle c, int *codes) {
+	if (!c || !codes) return SIFT3D_ERR_ARG;
+	if (c->stage < 4) return SIFT3D_ERR_STATE;
+	std::vector<DevKp> h;
+	int rc = fetch_ext(c, h);
+	if (rc) return rc;
+	for (size_t i = 0; i < h.size(); i++) codes[i] = h[i].code;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_gaussian_smooth(const float *src, int nx, int ny, int nz, float sigma, float *dst, int device) {
+	if (!src || !dst || nx <= 0 || ny <= 0 || nz <= 0) return SIFT3D_ERR_ARG;
+	int rc = set_device(device);
+	if (rc) return rc;
+	Taps t;
+	if (!build_taps(sigma, t)) { set_last_error("kernel too wide"); return SIFT3D_ERR_ARG; }
+	const size_t n = (size_t)nx * ny * nz;
+	float *d = nullptr;
+	S3D_HIP(hipMalloc(&d, sizeof(float) * n * 3));
+	hipError_t e = hipMemcpy(d, src, sizeof(float) * n, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		launch_conv_axis(0, d, d + n, nx, ny, nz, t, nullptr, nullptr, nullptr, nullptr);
+		launch_conv_axis(1, d + n, d + 2 * n, nx, ny, nz, t, nullptr, nullptr, nullptr, nullptr);
+		launch_conv_axis(2, d + 2 * n, d, nx, ny, nz, t, nullptr, nullptr, nullptr, nullptr);
+		e = hipDeviceSynchronize();
+	}
+	if (e == hipSuccess) e = hipMemcpy(dst, d, sizeof(float) * n, hipMemcpyDeviceToHost);
+	hipFree(d);
+	if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return SIFT3D_ERR_HIP; }
+	return SIFT3D_OK;
+}

@@ -1,0 +1,126 @@
+// sift3d_internal.h -- shared declarations of the HIP library (not part of the public C-ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/sift3d_hip.h"
+
+// All arithmetic that must reproduce the reference bit-for-bit is written as separate IEEE
+// multiplies and adds.  The library is compiled with -ffp-contract=off; the pragma makes the
+// translation units safe even if someone drops the flag.
+#pragma clang fp contract(off)
+
+namespace s3d {
+
+constexpr int kMaxHW = 16;              // largest Gaussian half width supported (33 taps)
+constexpr int kMaxTaps = 2 * kMaxHW + 1;
+constexpr int kDesc = SIFT3D_DESC_NUMEL;
+constexpr int kFaces = 20;
+
+// 1-D Gaussian kernel of one pyramid level, built on the host exactly like
+// GaussianSmooth_3D (reference Src/cSIFT3D.cc:541-572) and passed to kernels by value.
+struct Taps {
+	int hw;
+	float w[kMaxTaps];
+};
+
+struct Level {
+	float *d = nullptr;
+	int nx = 0, ny = 0, nz = 0;
+	float unit = 1.f;   // 2^octave (Src/cUtil.cc:215-225)
+	float scale = 0.f;  // scale-space location (Src/cUtil.cc:207-210)
+	size_t n() const { return (size_t)nx * ny * nz; }
+};
+
+// One DoG extremum / keypoint while it lives on the device.
+struct DevKp {
+	int x, y, z;
+	int octave, level;
+	float scale;
+	int code;   // Assign_Orientation_Imp result: 1 ok, -1 weak gradient, -2 eigen ratio, -3 corner; 0 = not run
+	int slot;   // index among accepted keypoints (exclusive scan of code==1), -1 otherwise
+	float win[3];
+	float eigvalue[3];
+	float eigvector[9];
+	float rot[9];   // as written by orientation (not transposed)
+	float st[9];
+};
+
+// Per-face constants of the icosahedron intersection test, hoisted from cart2bary
+// (reference Src/cSIFT3D.cc:1592-1637): pure functions of the mesh.
+struct FaceConst {
+	float e1[3], e2[3], t[3], q[3];
+	float qe2;  // dot(q, e2)
+	int idx[3];
+};
+
+// Gaussian window weight tables indexed by the INTEGER squared voxel offset
+// n = dx^2+dy^2+dz^2 (the fp32 squared distance n*u^2 is exact), one per (octave, level 1..3):
+// value = weight, or -1 outside the window sphere.  Built on the host with the same libm expf the
+// reference uses, so the weights are bit-identical to the CPU path (no device exp on the path).
+struct WinLut {
+	int off;      // offset into the lut pool
+	int len;      // entries; n >= len is outside
+	float radius; // win_radius (fp32) for the box bounds
+	float sigma;
+};
+
+// ---- kernels_pyramid.hip -------------------------------------------------------------------
+void launch_absmax(const float *src, size_t n, unsigned *d_max_bits, hipStream_t st);
+void launch_scale_by_max(float *data, size_t n, const unsigned *d_max_bits, hipStream_t st);
+// separable pass along AXIS (0 x, 1 y, 2 z); for AXIS==2 optionally also emits
+// dog = -(dst - prev) and accumulates max|dog| (bits) into d_dogmax.
+void launch_conv_axis(int axis, const float *src, float *dst, int nx, int ny, int nz, const Taps &t,
+                      const float *prev, float *dog, unsigned *d_dogmax, hipStream_t st);
+void launch_downsample(const float *src, int snx, int sny, float *dst, int nx, int ny, int nz, hipStream_t st);
+
+// ---- kernels_detect.hip --------------------------------------------------------------------
+struct DetectBufs {
+	unsigned long long *masks;  // one ballot word per wave
+	unsigned *block_counts;     // per block
+	unsigned *block_offsets;    // exclusive scan (+ running base)
+	unsigned *total;            // [0] running total over all levels, [1] overflow flag
+};
+void launch_detect_level(const float *prev, const float *cur, const float *next, int nx, int ny, int nz,
+                         const unsigned *d_absmax_bits, float peak_thresh, int octave, int level, float scale,
+                         const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st);
+
+// ---- kernels_orient.hip --------------------------------------------------------------------
+struct LevelRef {
+	const float *d;
+	int nx, ny, nz;
+	float unit;
+};
+void launch_orient(DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels /*[noct*8]*/,
+                   const WinLut *d_luts, const float *d_lutpool, float max_eig, float corner, hipStream_t st);
+void launch_slots(DevKp *kps, const unsigned *d_count, unsigned cap, unsigned *d_nkp, hipStream_t st);
+
+// ---- kernels_desc.hip ----------------------------------------------------------------------
+void upload_faces(const FaceConst *faces);  // into __constant__ memory
+void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels,
+                     const WinLut *d_luts, const float *d_lutpool, float *d_desc, unsigned kp_cap, hipStream_t st);
+void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, int transposed,
+                     sift3d_keypoint *d_out, float *d_xyz, unsigned kp_cap, hipStream_t st);
+
+// ---- kernels_match.hip ---------------------------------------------------------------------
+// best / second-best dot of every listed row of A against all m rows of B (calMatches);
+// d_row_ids == nullptr means rows 0..nrows-1; outputs are indexed by the ORIGINAL row id.
+int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const float *d_b, int m, int *d_cand /*nrows*4*/,
+                      float *d_gd, float *d_sd, int *d_gi, int *d_si, hipStream_t st);
+
+// error plumbing
+void set_last_error(const std::string &s);
+#define S3D_HIP(call)                                                                                   \
+	do {                                                                                                \
+		hipError_t e_ = (call);                                                                         \
+		if (e_ != hipSuccess) {                                                                         \
+			s3d::set_last_error(std::string(#call) + ": " + hipGetErrorString(e_));                     \
+			return SIFT3D_ERR_HIP;                                                                      \
+		}                                                                                               \
+	} while (0)
+
+}  // namespace s3d

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mvoxels/s of end-to-end KpSiftAlgorithm on a 512^3 fp32 volume.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one full CSIFT3D::KpSiftAlgorithm (Gaussian/DoG pyramid, extrema, orientation,
+descriptors) on one synthetic 512^3 volume that is ALREADY resident and normalised in HBM (the
+reference does copy + normalise in the constructor too, outside KpSiftAlgorithm).  With N ranks every
+GPU processes its own 512^3 volume (BASELINE.json configs[4], independent volumes => weak scaling, no
+data-path collective); value = N * 512^3 * K / max-over-ranks time.
+
+The JSON line also carries
+  roofline      pyramid build (the HBM-bound part north_star sets a target for): algorithmic bytes
+                68 B x pyramid voxels / HIP-event time of that stage on the library's own
+                stream, against the 8 TB/s HBM3E peak
+  cpu_baseline  the CPU oracle (our restatement of the reference, OpenMP) timed on this host on a
+                bounded sample of the same workload
+  parity        the GPU result on that sample checked against the oracle
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def pyramid_voxels(shape, levels=3):
+    nz, ny, nx = shape
+    noct = max(0, int(np.log2(np.float32(min(shape)))) - 3 + 1)
+    tot = 0
+    for _ in range(noct):
+        tot += nx * ny * nz
+        nx, ny, nz = nx // 2, ny // 2, nz // 2
+    return tot, noct
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=512, help="cubic volume edge (BASELINE metric: 512)")
+    ap.add_argument("--cpu-sample", type=int, default=192, help="edge of the CPU-baseline sample crop (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    capi = importlib.import_module("3dsift_amd.capi")
+    synth = importlib.import_module("3dsift_amd.synth")
+
+    n = args.size
+    shape = (n, n, n)
+    vol = synth.blobs_torch(shape, dev, seed=1234 + rank)  # one volume per GPU
+    torch.cuda.synchronize()
+    ex = capi.CSIFT3D(None, device=local, device_ptr=vol.data_ptr(), shape=shape)  # ctor: D2D copy + normalise
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ex.KpSiftAlgorithm()
+    barrier()
+    t0 = time.perf_counter()
+    stage = {}
+    for _ in range(args.steps):
+        ex.KpSiftAlgorithm()  # returns after its stream drained
+        for k, v in ex.m_timer.items():
+            stage[k] = stage.get(k, 0.0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    kp, _ = ex.GetKeypoints(with_desc=False)
+    nkp = len(kp)
+    next_ = len(ex.extrema())
+    stage = {k: v / args.steps for k, v in stage.items()}
+
+    pv, noct = pyramid_voxels(shape)
+    t_pyr = stage["d_BuildGSS"] + stage["d_BuildDOG"]
+    alg_bytes = 68.0 * pv
+    achieved = alg_bytes / t_pyr / 1e9
+    out = {
+        "metric": "Mvoxels/s end-to-end KpSiftAlgorithm on 512^3 fp32",
+        "value": world * n ** 3 * args.steps / dt / 1e6,
+        "unit": "Mvoxels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{n}^3 fp32 synthetic blob volume per GPU, default SIFT params, full KpSiftAlgorithm "
+                               f"({noct} octaves, {next_} DoG extrema -> {nkp} keypoints)",
+                   "volumes_per_gpu": 1, "parallelism": f"independent volumes x{world}"},
+        "stage_ms": {k: round(v * 1e3, 4) for k, v in stage.items()},
+        "descriptor_keypoints_per_s": (nkp / stage["d_Extraction"]) if stage["d_Extraction"] > 0 else None,
+        "roofline": {"bound": "hbm", "kernel": "pyramid build (all Gaussian/DoG level kernels of one KpSiftAlgorithm)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "algorithmic_bytes": alg_bytes, "seconds": t_pyr, "traffic": None},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
+        # ---- CPU baseline + parity on a bounded sample: the [0:s]^3 crop of the same volume ----
+        import oracle_lib as ol  # test infrastructure, used here ONLY as the timed baseline / checker
+
+        s = min(args.cpu_sample, n)
+        crop = vol[:s, :s, :s].contiguous().cpu().numpy()
+        orc = ol.load("orc")
+        cores = os.cpu_count() or 1
+        orc.set_threads(cores)
+        o = orc.extractor(crop)
+        tc = time.perf_counter()
+        o.run(5)
+        tcpu = time.perf_counter() - tc
+        okp, odesc = o.keypoints()
+        out["cpu_baseline"] = {"value": s ** 3 / tcpu / 1e6, "unit": "Mvoxels/s", "cores": cores, "kind": "port",
+                               "sample": f"[0:{s}]^3 crop of the benchmark volume, full KpSiftAlgorithm, {tcpu:.2f} s, "
+                                         f"{len(okp)} keypoints; stages {json.dumps({k: round(v, 3) for k, v in o.times.items()})}"}
+        g = capi.CSIFT3D(crop, device=local).KpSiftAlgorithm()
+        gkp, gdesc = g.GetKeypoints()
+        same = len(gkp) == len(okp) and all(np.array_equal(gkp[f], okp[f]) for f in ("x", "y", "z", "octave", "level"))
+        rms = float(np.sqrt(np.mean((gdesc.astype(np.float64) - odesc) ** 2))) if same and len(okp) else None
+        out["parity"] = {"sample_keypoints_gpu": len(gkp), "sample_keypoints_cpu": len(okp), "same_keypoint_set": bool(same),
+                         "descriptor_rms": rms}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/*
+ * sift3d_hip.h -- C-ABI of the MI355X-native 3D SIFT library (lib: 3dsift_amd/libsift3d_hip.so).
+ *
+ * This is the drop-in boundary: plain C types, opaque handle, int error codes, no exceptions, no
+ * torch types.  The C++ shell in 3dsift_amd/host/ (namespace CPUSIFT, same class / method names as
+ * the reference) and the python ctypes binding in 3dsift_amd/capi.py are both thin layers over
+ * exactly these entry points.  Each entry point cites the reference interface it replaces
+ * (paths relative to the reference repo, 3DSIFT/...).
+ *
+ * Pointers are HOST pointers unless the name says otherwise (d_ prefix / "device" flag).
+ * All volumes are fp32, x fastest: idx = x + nx*(y + ny*z)   (Include/Util/cTexImage.h:5,35).
+ * A handle serialises its calls on one HIP stream; different handles are independent.
+ */
+#ifndef SIFT3D_HIP_H
+#define SIFT3D_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIFT3D_DESC_NUMEL 768 /* Include/cSIFT3D.h:27 DESC_NUMEL = 4*4*4*12 */
+
+/* error codes (the reference has none: it prints and carries on, Include/Util/cMemManager.h:35-39) */
+enum {
+	SIFT3D_OK = 0,
+	SIFT3D_ERR_ARG = 1,      /* bad argument */
+	SIFT3D_ERR_NO_DEVICE = 2,/* no usable HIP device: the library never falls back to the CPU */
+	SIFT3D_ERR_HIP = 3,      /* a HIP runtime call failed (see sift3d_last_error) */
+	SIFT3D_ERR_STATE = 4,    /* call out of order (e.g. results requested before run) */
+	SIFT3D_ERR_CAPACITY = 5  /* an internal device list overflowed even after regrowing */
+};
+
+typedef struct sift3d_ctx *sift3d_handle;
+
+/* Constructor parameters; defaults = Include/cSIFT3D.h:13-20 (factory default args :187-202). */
+typedef struct sift3d_params {
+	int num_kp_levels;      /* NUM_KP_LEVELS 3 */
+	float sigma_default;    /* SIGMA_DEFAULT 1.6 */
+	float sigma_n_default;  /* SIGMA_N_DEFAULT 1.15 */
+	float peak_thresh;      /* PEAK_THRESH 0.1 */
+	float max_eig_thres;    /* EIG_THRES 0.9 */
+	float corner_thresh;    /* CORNER_THRESH 0.4 */
+} sift3d_params;
+
+/* POD mirror of CPUSIFT::Keypoint without the desc pointer (Include/cSIFT3D.h:54-70): 168 bytes. */
+typedef struct sift3d_keypoint {
+	float x, y, z;
+	float scale;
+	int octave, level;
+	float rx, ry, rz;
+	float win[3];
+	float eigvalue[3];
+	float eigvector[9];
+	float Rotation[9];   /* returned TRANSPOSED after the descriptor stage, like Src/cSIFT3D.cc:1214 */
+	float str_tensor[9];
+} sift3d_keypoint;
+
+void sift3d_default_params(sift3d_params *p);
+
+/* Replaces CSIFT3DFactory::CreateCSIFT3D(float*, nx, ny, nz, ...) + CSIFT3D::CSIFT3D
+ * (Src/cSIFT3D.cc:103-110, 146-163): copies the caller's volume (caller keeps ownership), uploads it
+ * to `device` and max-abs normalises it there (data_scale, Src/cUtil.cc:536-564).  Also reserves the
+ * whole device arena (both pyramids, scratch, keypoint lists) so that sift3d_run allocates nothing.
+ * volume_on_device != 0: `volume` is a device pointer on `device` (copied D2D). */
+int sift3d_create(sift3d_handle *out, const float *volume, int nx, int ny, int nz,
+                  const sift3d_params *params, int device, int volume_on_device);
+
+/* Replaces CSIFT3D::~CSIFT3D (Src/cSIFT3D.cc:140-144). */
+int sift3d_destroy(sift3d_handle h);
+
+/* Replaces CSIFT3D::KpSiftAlgorithm (Src/cSIFT3D.cc:165-235): whole pipeline, results stay on the
+ * device until sift3d_get_keypoints.  Returns after the stream has drained. */
+int sift3d_run(sift3d_handle h);
+
+/* Replaces calling the public stage methods one by one (Include/cSIFT3D.h:157-165); `upto`:
+ * 1 Initialize+Build_Gaussian_Scale_Space(+fused DoG), 2 Build_DOG_Scale_Space, 3 Detect_KeyPoints,
+ * 4 Assign_Orientation, 5 Extract_Description.  Used by the parity tests. */
+int sift3d_run_stages(sift3d_handle h, int upto);
+
+/* Replaces SIFT_TimerPara m_timer (Include/Util/common.h:22-41; filled Src/cSIFT3D.cc:228-233).
+ * Seconds, from HIP events on the handle's stream:
+ * t[0] total, t[1] allocation(=0, arena is reserved at create), t[2] GSS(+fused DoG), t[3] DoG(=0 when
+ * fused), t[4] detect, t[5] orientation, t[6] description, t[7] release(=0). */
+int sift3d_stage_times(sift3d_handle h, double t[8]);
+
+/* Replaces CSIFT3D::GetKeypoints (Src/cSIFT3D.cc:1686-1688).  Order = reference order:
+ * (octave, level, z, y, x) scan order (Src/cSIFT3D.cc:373-416, 459-466). */
+int sift3d_num_keypoints(sift3d_handle h, int *n);
+int sift3d_get_keypoints(sift3d_handle h, sift3d_keypoint *out, float *desc /* n*768, may be NULL */);
+
+/* Device-resident results for a matcher that never leaves the GPU: row-major n*768
+ * descriptors and n*3 (rx,ry,rz); valid until the next run / destroy. */
+int sift3d_device_results(sift3d_handle h, const float **d_desc, const float **d_xyz, int *n);
+
+/* Checking accessors, replace GET_GSS / GET_DOG / GET_LEVEL (Include/cSIFT3D.h:167-177). */
+int sift3d_num_octaves(sift3d_handle h, int *n);
+int sift3d_level_info(sift3d_handle h, int is_dog, int idx, int dims3[3], float units3[3], float *scale);
+int sift3d_copy_level(sift3d_handle h, int is_dog, int idx, float *out);
+int sift3d_copy_input(sift3d_handle h, float *out);
+int sift3d_num_extrema(sift3d_handle h, int *n);
+int sift3d_get_extrema(sift3d_handle h, sift3d_keypoint *out);
+/* per-extremum result code of Assign_Orientation_Imp (1 / -1 / -2 / -3), Src/cSIFT3D.cc:913-1138 */
+int sift3d_get_orientation_codes(sift3d_handle h, int *codes);
+
+/* Replaces the free function GaussianSmooth_3D (Include/cSIFT3D.h:212; Src/cSIFT3D.cc:535-622) on a
+ * host volume (unit-level parity tests). */
+int sift3d_gaussian_smooth(const float *src, int nx, int ny, int nz, float sigma, float *dst, int device);
+
+/* Replaces muBruteMatcher::injectMatch / bijectMatch / enhancedMatch (Src/cMatcher.cc:146-228).
+ * mode 1 inject, 2 biject, 3 enhanced.  desc: n*768 / m*768, xyz: n*3 / m*3 (rx,ry,rz).
+ * on_device != 0: the four input pointers are device pointers on `device`.
+ * Outputs (host, any may be NULL): gIdx/sIdx/gDist/sDist sized n = getGlodenIdx / getSilverIdx /
+ * getGlodenDistSquare / getSilverDistSquare (Include/cMatcher.h:69-73); pairs6: up to n rows of
+ * (ref rx,ry,rz, tar rx,ry,rz) in ascending ref index (toCvec, Src/cMatcher.cc:99-112). */
+int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, const float *tar_desc,
+                 const float *tar_xyz, int m, double thresHold, int mode, int on_device, int device,
+                 int *gIdx, int *sIdx, float *gDist, float *sDist, float *pairs6, int *npairs,
+                 double *seconds /* device time of the call, may be NULL */);
+
+/* Z-slab sharding hooks, used by the multi-GPU driver; see DESIGN.md. */
+int sift3d_device_count(int *n);
+
+const char *sift3d_error_string(int code);
+const char *sift3d_last_error(void); /* thread-local detail of the last failure */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

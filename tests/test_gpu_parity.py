@@ -1,0 +1,173 @@
+"""-m gpu: the HIP path, called through the C-ABI (3dsift_amd/libsift3d_hip.so), against
+ (1) the committed golden vectors produced by the real reference and
+ (2) the CPU oracle on seeded inputs.
+Bars: Gaussian / DoG pyramid, abs-max thresholds, extrema lists, keypoint coordinates and the
+matcher outputs are BIT-EXACT; orientation frames and descriptors are fp32 sums evaluated in a
+different order on the GPU -> tolerance 1e-4 RMS on descriptors (BASELINE.json), measured ~1e-7."""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from hipcheck import bits, compare_keypoints, compare_pyramids, extrema_table
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    m = importlib.import_module("3dsift_amd.capi")
+    assert m.device_count() >= 1, "GPU tests need a visible MI355X (no CPU fallback exists)"
+    return m
+
+
+def test_library_is_the_hip_build(capi):
+    import os
+
+    assert os.path.exists(capi.LIB_PATH)
+    with open("/proc/self/maps") as f:
+        assert "libsift3d_hip.so" in f.read()
+
+
+def test_g2_gaussian_smooth_golden(capi, orc):
+    g = golden("g2_smooth.npz")
+    for name, src in (("v1_s0", "v1"), ("v1_s5", "v1"), ("v2_s2", "v2")):
+        out = capi.gaussian_smooth(g[src], g[name + "_sigma"])
+        assert np.array_equal(bits(out), bits(g[name])), name
+    rng = np.random.Generator(np.random.PCG64(3))
+    for shape, sigma in (((33, 17, 70), 1.9466), ((5, 40, 9), 0.9733), ((64, 64, 64), 2.452547), ((3, 3, 3), 0.5387)):
+        v = rng.normal(size=shape).astype(np.float32)
+        assert np.array_equal(bits(capi.gaussian_smooth(v, sigma)), bits(orc.gaussian_smooth(v, sigma))), shape
+
+
+def test_g3_pyramid_golden_bitexact(capi):
+    g = golden("g3_pyramid.npz")
+    ex = capi.CreateCSIFT3D(g["vol"]).run_stages(3)
+    assert ex.num_octaves == int(g["noct"])
+    assert np.array_equal(bits(ex.input()), bits(g["input"]))
+    for o in range(ex.num_octaves):
+        for i in range(6):
+            assert np.array_equal(bits(ex.gss(o, i)), bits(g[f"gss_{o}_{i}"])), (o, i)
+        for i in range(5):
+            assert np.array_equal(bits(ex.dog(o, i)), bits(g[f"dog_{o}_{i}"])), (o, i)
+    assert np.array_equal(extrema_table(ex.extrema()), g["extrema"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g4_g6_golden_keypoints(capi, synth, tag):
+    g4, g6 = golden("g4_hashes.npz"), golden("g6_keypoints.npz")
+    shape = tuple(int(v) for v in g4[f"{tag}_shape"])
+    vol = synth.blobs(shape, seed=int(g4[f"{tag}_seed"]), noise=float(g4[f"{tag}_noise"]))
+    ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+    assert np.array_equal(extrema_table(ex.extrema()), g4[f"{tag}_extrema"])
+    kp, desc = ex.GetKeypoints()
+    rms = compare_keypoints(kp, desc, g6[f"{tag}_kp"], g6[f"{tag}_desc"])
+    assert rms < 1e-5
+
+
+@pytest.mark.parametrize("shape,seed,noise", [
+    ((64, 64, 64), 1234, 0.0),      # BASELINE configs[0]
+    ((40, 56, 72), 5, 0.01),        # ragged, 3 octaves
+    ((17, 33, 20), 23, 0.05),       # one octave, everything is boundary
+    ((128, 96, 80), 9, 0.0),        # 4 octaves, non-cubic
+])
+def test_full_pipeline_vs_oracle(capi, orc, synth, shape, seed, noise):
+    vol = synth.blobs(shape, seed=seed, noise=noise)
+    g = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+    o = orc.extractor(vol).run(5)
+    assert np.array_equal(bits(g.input()), bits(o.input()))
+    compare_pyramids(g, o)
+    assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema()))
+    kp, desc = g.GetKeypoints()
+    okp, odesc = o.keypoints()
+    compare_keypoints(kp, desc, okp, odesc)
+    t = g.m_timer
+    assert t["d_TotalTime"] > 0 and t["d_BuildGSS"] > 0
+
+
+def test_orientation_codes_vs_oracle(capi, orc, synth):
+    vol = synth.blobs((56, 48, 40), seed=7, noise=0.01)
+    g = capi.CreateCSIFT3D(vol).run_stages(4)
+    o = orc.extractor(vol).run(3)
+    e = o.extrema()
+    codes = g.orientation_codes()
+    assert len(codes) == len(e)
+    want = []
+    for k in e:
+        lvl = o.gss(int(k["octave"]), int(k["level"]))
+        unit = o.level_info(0, int(k["octave"]) * 6 + int(k["level"]))[1][0]
+        want.append(orc.orient_one(k, lvl, unit, np.float32(1.5) * k["scale"])[0])
+    assert np.array_equal(codes, np.array(want, np.int32))
+    assert set(want) >= {1, -2} or set(want) >= {1, -3}
+
+
+def test_256_cubed_config(capi, orc, synth):
+    """BASELINE configs[1] size: full KpSiftAlgorithm on 256^3 (the NIfTI container is host-side IO)."""
+    vol = synth.blobs((256, 256, 256), seed=1234)
+    g = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+    o = orc.extractor(vol).run(5)
+    compare_pyramids(g, o)
+    assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema()))
+    kp, desc = g.GetKeypoints()
+    okp, odesc = o.keypoints()
+    assert len(kp) > 500
+    compare_keypoints(kp, desc, okp, odesc)
+
+
+def test_edge_cases(capi):
+    ex = capi.CreateCSIFT3D(np.ones((6, 6, 6), np.float32)).KpSiftAlgorithm()
+    assert ex.num_octaves == 0 and len(ex.GetKeypoints()[0]) == 0
+    ex = capi.CreateCSIFT3D(np.zeros((16, 16, 16), np.float32)).KpSiftAlgorithm()
+    assert np.isnan(ex.input()).all() and len(ex.extrema()) == 0 and len(ex.GetKeypoints()[0]) == 0
+    ex = capi.CreateCSIFT3D(np.full((16, 20, 24), 3.0, np.float32)).KpSiftAlgorithm()
+    assert len(ex.extrema()) == 0
+    # GetKeypoints before KpSiftAlgorithm returns empty (reference: `filter` is empty)
+    ex = capi.CreateCSIFT3D(np.random.default_rng(0).random((16, 16, 16), dtype=np.float32))
+    assert len(ex.GetKeypoints()[0]) == 0
+    # rerunning an extractor gives the same result (arena reuse)
+    vol = np.random.default_rng(1).random((32, 32, 32), dtype=np.float32)
+    ex = capi.CreateCSIFT3D(vol)
+    k1, d1 = ex.KpSiftAlgorithm().GetKeypoints()
+    k2, d2 = ex.KpSiftAlgorithm().GetKeypoints()
+    assert k1.tobytes() == k2.tobytes()
+
+
+def test_g8_matcher_golden(capi):
+    g = golden("g8_match.npz")
+    perm = g["perm"]
+    sets = {"p": (g["da"], g["xa"], g["db"], g["xb"]), "q": (g["da"], g["xa"], g["db"][perm], g["xb"][perm])}
+    mt = capi.muBruteMatcher()
+    for tag, (a, ax, b, bx) in sets.items():
+        for mode, fn in ((1, mt.injectMatch), (2, mt.bijectMatch), (3, mt.enhancedMatch)):
+            for thr in (0.85, 0.95):
+                r = fn(a, ax, b, bx, thr)
+                key = f"{tag}_m{mode}_t{int(thr * 100)}"
+                for k, v in r.items():
+                    assert np.array_equal(v, g[f"{key}_{k}"]), (key, k)
+
+
+def test_matcher_vs_oracle_random(capi, orc):
+    rng = np.random.Generator(np.random.PCG64(17))
+
+    def descs(n):
+        d = np.clip(rng.normal(0.02, 0.03, size=(n, 768)), 0, None).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        return d.astype(np.float32)
+
+    a, b = descs(300), descs(333)
+    b[:100] = a[100:200] + rng.normal(0, 0.004, size=(100, 768)).astype(np.float32)   # true correspondences
+    b[7] = b[3]                                                                        # exact duplicate rows -> ties
+    ax = rng.uniform(0, 100, (300, 3)).astype(np.float32); bx = rng.uniform(0, 100, (333, 3)).astype(np.float32)
+    mt = capi.muBruteMatcher()
+    for mode in (1, 2, 3):
+        got = mt._match(a, ax, b, bx, 0.85, mode)
+        want = orc.match(a, ax, b, bx, 0.85, mode)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (mode, k)
+    # empty / ragged
+    e = np.zeros((0, 768), np.float32); ex = np.zeros((0, 3), np.float32)
+    assert len(mt.enhancedMatch(e, ex, b, bx)["pairs"]) == 0
+    got = mt.enhancedMatch(a, ax, e, ex); want = orc.match(a, ax, e, ex, 0.85, 3)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
