@@ -6,6 +6,7 @@
 // only sync is the final one that also brings the keypoint count back.
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -134,6 +135,8 @@ struct sift3d_ctx {
 	// host tables
 	std::vector<Taps> taps;  // per GSS level index within an octave
 	Taps base_taps{};
+
+	bool use_fused = true;  // S3D_SEPARABLE=1 forces the generic three-pass kernels (A/B + parity cross-check)
 
 	// results / state
 	int stage = 0;  // highest stage run
@@ -293,6 +296,7 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 	if (params) c->p = *params; else sift3d_default_params(&c->p);
 	if (c->p.num_kp_levels < 1 || c->p.num_kp_levels > 5) { delete c; set_last_error("num_kp_levels must be in [1,5]"); return SIFT3D_ERR_ARG; }
 	c->nx = nx; c->ny = ny; c->nz = nz;
+	{ const char *e = getenv("S3D_SEPARABLE"); c->use_fused = !(e && e[0] == '1'); }
 	plan_pyramid(c);
 
 	// host tables
@@ -370,6 +374,10 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 // GaussianSmooth_3D (Src/cSIFT3D.cc:535-622) on device buffers: X -> Y -> Z(+DoG)
 static void smooth_level(sift3d_ctx *c, const float *src, const Level &dst, const Taps &t, const float *prev, float *dog,
                          unsigned *dogmax) {
+	// hot path: one fused pass (x, y, z blur + DoG + abs-max); prev == src for every DoG-producing level
+	if (c->use_fused && (prev == nullptr || prev == src) &&
+	    launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.nz, t, c->stream))
+		return;
 	launch_conv_axis(0, src, c->tmpA, dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, c->stream);
 	launch_conv_axis(1, c->tmpA, c->tmpB, dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, c->stream);
 	launch_conv_axis(2, c->tmpB, dst.d, dst.nx, dst.ny, dst.nz, t, prev, dog, dogmax, c->stream);

@@ -76,6 +76,9 @@ void launch_scale_by_max(float *data, size_t n, const unsigned *d_max_bits, hipS
 // dog = -(dst - prev) and accumulates max|dog| (bits) into d_dogmax.
 void launch_conv_axis(int axis, const float *src, float *dst, int nx, int ny, int nz, const Taps &t,
                       const float *prev, float *dog, unsigned *d_dogmax, hipStream_t st);
+// fused single-pass level kernel (kernels_fused.hip); false => no instantiation for this half width
+bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, int nz, const Taps &t,
+                        hipStream_t st);
 void launch_downsample(const float *src, int snx, int sny, float *dst, int nx, int ny, int nz, hipStream_t st);
 
 // ---- kernels_detect.hip --------------------------------------------------------------------

@@ -49,24 +49,41 @@ def blobs(shape, seed=1234, shift=(0.0, 0.0, 0.0), noise=0.0, noise_seed=99, nbl
     return vol.astype(np.float32)
 
 
-def blobs_torch(shape, device, seed=1234, shift=(0.0, 0.0, 0.0), nblobs=None):
-    """Same blob list rendered on a torch device (fp32 accumulate); returns a torch tensor [z,y,x]."""
+def blobs_torch(shape, device, seed=1234, shift=(0.0, 0.0, 0.0), nblobs=None, brick=64):
+    """Same blob list rendered on a torch device, brick by brick: every brick accumulates the blobs
+    whose 5-sigma boxes overlap it as one small contraction sum_k gz[k,z] gy[k,y] gx[k,x] (a few
+    thousand kernels instead of ~20 per blob).  fp32; returns a torch tensor [z, y, x]."""
     import torch
 
     nz, ny, nx = shape
     cx, cy, cz, sg, am = blob_params(shape, seed, nblobs)
+    cx = cx + shift[0]; cy = cy + shift[1]; cz = cz + shift[2]
+    r = 5.0 * sg
+    lo = [np.maximum(0, np.floor(c - r)).astype(np.int64) for c in (cx, cy, cz)]
+    hi = [np.minimum(n - 1, np.ceil(c + r)).astype(np.int64) for c, n in ((cx, nx), (cy, ny), (cz, nz))]
     vol = torch.zeros(shape, dtype=torch.float32, device=device)
-    ax = torch.arange(max(shape), dtype=torch.float32, device=device)
-    for i in range(len(cx)):
-        x0, y0, z0, s, a = cx[i] + shift[0], cy[i] + shift[1], cz[i] + shift[2], float(sg[i]), float(am[i])
-        r = 5.0 * s
-        xl, xh = max(0, int(np.floor(x0 - r))), min(nx - 1, int(np.ceil(x0 + r)))
-        yl, yh = max(0, int(np.floor(y0 - r))), min(ny - 1, int(np.ceil(y0 + r)))
-        zl, zh = max(0, int(np.floor(z0 - r))), min(nz - 1, int(np.ceil(z0 + r)))
-        if xl > xh or yl > yh or zl > zh:
-            continue
-        gx = torch.exp(-0.5 * ((ax[xl:xh + 1] - float(x0)) / s) ** 2)
-        gy = torch.exp(-0.5 * ((ax[yl:yh + 1] - float(y0)) / s) ** 2)
-        gz = torch.exp(-0.5 * ((ax[zl:zh + 1] - float(z0)) / s) ** 2) * a
-        vol[zl:zh + 1, yl:yh + 1, xl:xh + 1] += gz[:, None, None] * gy[None, :, None] * gx[None, None, :]
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device)
+    for z0 in range(0, nz, brick):
+        z1 = min(nz, z0 + brick)
+        mz = (hi[2] >= z0) & (lo[2] < z1)
+        for y0 in range(0, ny, brick):
+            y1 = min(ny, y0 + brick)
+            mzy = mz & (hi[1] >= y0) & (lo[1] < y1)
+            for x0 in range(0, nx, brick):
+                x1 = min(nx, x0 + brick)
+                idx = np.nonzero(mzy & (hi[0] >= x0) & (lo[0] < x1))[0]
+                if len(idx) == 0:
+                    continue
+
+                def factor(c, s_, l, h, a0, a1, amp=None):
+                    ax = torch.arange(a0, a1, dtype=torch.float32, device=device)[None, :]
+                    g = torch.exp(-0.5 * ((ax - t(c)[:, None]) / t(s_)[:, None]) ** 2)
+                    g = g * ((ax >= t(l)[:, None]) & (ax <= t(h)[:, None]))
+                    return g if amp is None else g * t(amp)[:, None]
+
+                gx = factor(cx[idx], sg[idx], lo[0][idx], hi[0][idx], x0, x1)
+                gy = factor(cy[idx], sg[idx], lo[1][idx], hi[1][idx], y0, y1)
+                gz = factor(cz[idx], sg[idx], lo[2][idx], hi[2][idx], z0, z1, am[idx])
+                yx = (gy[:, :, None] * gx[:, None, :]).reshape(len(idx), -1)
+                vol[z0:z1, y0:y1, x0:x1] = (gz.t() @ yx).reshape(z1 - z0, y1 - y0, x1 - x0)
     return vol
