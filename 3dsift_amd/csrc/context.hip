@@ -97,7 +97,33 @@ static void build_faces(FaceConst *F) {
 		}
 		cross3(F[f].t, F[f].e1, F[f].q);
 		F[f].qe2 = dot3(F[f].q, F[f].e2);
+		for (int c = 0; c < 3; c++) F[f].centre[c] = (v[0][c] + v[1][c] + v[2][c]) / 3.0f;
 	}
+}
+
+// prediction table (see FacePredict): group the 20 face centres by |centre| and sign pattern
+static void build_predict(const FaceConst *F, FacePredict *P) {
+	int nk = 0;
+	for (int f = 0; f < kFaces; f++) {
+		float a[3], n = sqrtf(dot3(F[f].centre, F[f].centre));
+		for (int c = 0; c < 3; c++) a[c] = fabsf(F[f].centre[c]) / n;
+		bool seen = false;
+		for (int k = 0; k < nk; k++)
+			if (fabsf(P->n[k][0] - a[0]) + fabsf(P->n[k][1] - a[1]) + fabsf(P->n[k][2] - a[2]) < 1e-3f) seen = true;
+		if (!seen && nk < 4) { for (int c = 0; c < 3; c++) P->n[nk][c] = a[c]; nk++; }
+	}
+	for (int k = 0; k < 4; k++)
+		for (int bits = 0; bits < 8; bits++) {
+			const float d[3] = {(bits & 1) ? -P->n[k][0] : P->n[k][0], (bits & 2) ? -P->n[k][1] : P->n[k][1],
+			                    (bits & 4) ? -P->n[k][2] : P->n[k][2]};
+			int best = 0;
+			float bs = -1e30f;
+			for (int f = 0; f < kFaces; f++) {
+				const float sc = dot3(d, F[f].centre);
+				if (sc > bs) { bs = sc; best = f; }
+			}
+			P->face[k * 8 + bits] = best;
+		}
 }
 
 }  // namespace s3d
@@ -253,7 +279,7 @@ static void plan_pyramid(sift3d_ctx *c) {
 static int build_luts(sift3d_ctx *c) {
 	std::vector<WinLut> luts((size_t)std::max(1, c->noct) * 8 * 2);
 	std::vector<float> pool;
-	for (auto &l : luts) { l.off = 0; l.len = 0; l.radius = 0; l.sigma = 0; }
+	for (auto &l : luts) { l.off = 0; l.len = 0; l.nin = -1; l.radius = 0; l.sigma = 0; }
 	for (int o = 0; o < c->noct; o++)
 		for (int lv = 1; lv <= c->p.num_kp_levels && lv < 8; lv++) {
 			const Level &D = c->dog[(size_t)o * c->nd + lv];  // keypoint scale = DoG level scale (Src/cSIFT3D.cc:407)
@@ -265,10 +291,12 @@ static int build_luts(sift3d_ctx *c) {
 				const float r2 = radius * radius, uu = u * u;
 				const int len = (int)floor((double)r2 / (double)uu) + 2;
 				WinLut &L = luts[((size_t)o * 8 + lv) * 2 + which];
-				L.off = (int)pool.size(); L.len = len; L.radius = radius; L.sigma = sigma;
+				L.off = (int)pool.size(); L.len = len; L.nin = -1; L.radius = radius; L.sigma = sigma;
+				if (which == 1 && len > kMaxDescLut) { set_last_error("descriptor window larger than the LDS weight table"); return SIFT3D_ERR_ARG; }
 				for (int n = 0; n < len; n++) {
 					const float sq = (float)n * uu;  // exact: equals the reference's fp32 sum of squares
 					float w;
+					if (!(sq > r2)) L.nin = n;
 					if (sq > r2) w = -1.0f;
 					else if (which == 0) w = expf((float)(-0.5 * (double)sq / (double)(sigma * sigma)));
 					else w = expf(-0.5f * sq / (sigma * sigma));
@@ -353,7 +381,9 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 	if (rc) { sift3d_destroy(c); return rc; }
 	FaceConst faces[kFaces];
 	build_faces(faces);
-	upload_faces(faces);
+	FacePredict pred;
+	build_predict(faces, &pred);
+	upload_faces(faces, &pred);
 
 	// keypoint lists: synthetic blob volumes give ~6e-4*V0 extrema; leave 8x headroom, regrow on overflow
 	unsigned cap = (unsigned)std::min<size_t>(std::max<size_t>(4096, V0 / 256), 4u << 20);

@@ -10,13 +10,20 @@
 // reference's eps tolerances) -> barycentric weights; trilinear scatter of |g| into 8 cells x 3
 // face vertices of the 768-bin histogram.  Then L2-normalise, clamp at 0.2*128/768, normalise.
 //
-// MI355X mapping: 256 threads sweep the (y,x) planes of the window with coalesced loads from the
-// L2-resident level; the histogram lives in LDS and is updated with ds_add_f32 atomics; face
-// constants sit in __constant__ memory (wave-uniform scalar loads); the Gaussian weight and the
-// in-sphere test come from the host-built integer-offset table (bit-identical to the CPU expf).
+// MI355X mapping (256 threads per keypoint, window data is L2 resident):
+//   * threads own (x,y) COLUMNS of the window (lanes along x => coalesced) and march along z over the
+//     in-sphere chord only; the centre column is carried in registers (z-1, z, z+1)
+//   * the Gaussian weight / in-sphere test come from the host-built table indexed by the integer
+//     squared offset, staged in LDS (bit-identical to the CPU expf; no device exp on the path)
+//   * face lookup: the face is PREDICTED from |g| (4 dot products + sign bits -> table), verified with
+//     the reference's exact Moller-Trumbore arithmetic for that face and accepted only when all three
+//     barycentrics clear a 1e-4 margin (then no other face can pass the reference's -1.19e-6 test, so
+//     "first passing face in mesh order" is this face); otherwise the literal 20-face ordered scan runs
+//   * consecutive z voxels of a column mostly hit the same 8 cells x 3 vertices: their 24 products are
+//     accumulated in registers and flushed to the LDS histogram (ds_add_f32) only when the (cell, face)
+//     key changes -> ~10x fewer LDS atomics, no same-address serialisation inside a wave
 // Every per-voxel contribution is bit-identical to the reference; only the ORDER of the fp32
-// histogram additions differs (LDS atomics), i.e. ~1e-7 relative -- tolerance 1e-4 RMS stated by
-// BASELINE.json, measured ~1e-7.
+// histogram additions differs, i.e. ~1e-7 relative -- tolerance 1e-4 RMS (BASELINE.json).
 #include <float.h>
 
 #include "sift3d_internal.h"
@@ -24,8 +31,12 @@
 namespace s3d {
 
 __constant__ FaceConst c_faces[kFaces];
+__constant__ FacePredict c_pred;
 
-void upload_faces(const FaceConst *faces) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_faces), faces, sizeof(FaceConst) * kFaces); }
+void upload_faces(const FaceConst *faces, const FacePredict *pred) {
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_faces), faces, sizeof(FaceConst) * kFaces);
+	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_pred), pred, sizeof(FacePredict));
+}
 
 __device__ __forceinline__ void win_bounds_d(float c, float rad, float u, int n, int &lo, int &hi) {
 	int s = (int)floorf(c - __fdiv_rn(rad, u));
@@ -35,13 +46,30 @@ __device__ __forceinline__ void win_bounds_d(float c, float rad, float u, int n,
 }
 
 constexpr float kBaryEps = (float)(FLT_EPSILON * 1E1);  // Src/cSIFT3D.cc:23
+constexpr float kFastMargin = 1.0e-4f;
+constexpr int kFaceStride = 16;  // floats per face in the LDS table
 
-// Check_intersect_faces: first face in mesh order whose barycentrics are all >= -eps and k >= 0.
-__device__ __forceinline__ int intersect_faces(float gx, float gy, float gz, float &b0, float &b1, float &b2) {
+// reference Moller-Trumbore for ONE face whose constants sit at F[0..15]:
+// e1(0..2) e2(3..5) t(6..8) q(9..11) qe2(12); returns pass/fail exactly like Check_intersect_faces' body
+__device__ __forceinline__ bool face_test(const float *F, float gx, float gy, float gz, float &b0, float &b1, float &b2) {
+	const float px = gy * F[5] - gz * F[4];
+	const float py = gz * F[3] - gx * F[5];
+	const float pz = gx * F[4] - gy * F[3];
+	const float det = F[0] * px + F[1] * py + F[2] * pz;
+	if (fabsf(det) < kBaryEps) return false;
+	const float det_inv = (float)(1.0 / (double)det);
+	b1 = det_inv * (px * F[6] + py * F[7] + pz * F[8]);
+	b2 = det_inv * (gx * F[9] + gy * F[10] + gz * F[11]);
+	b0 = 1.0f - b1 - b2;
+	const float k = det_inv * F[12];
+	return !(b0 < -kBaryEps || b1 < -kBaryEps || b2 < -kBaryEps || k < 0.0f);
+}
+
+// literal Check_intersect_faces: first face in mesh order that passes (wave-uniform loop, constant memory)
+__device__ __forceinline__ int intersect_scan(float gx, float gy, float gz, float &b0, float &b1, float &b2) {
 	int found = -1;
 	for (int f = 0; f < kFaces; f++) {
 		const FaceConst &F = c_faces[f];
-		// p = g x e2
 		const float px = gy * F.e2[2] - gz * F.e2[1];
 		const float py = gz * F.e2[0] - gx * F.e2[2];
 		const float pz = gx * F.e2[1] - gy * F.e2[0];
@@ -54,7 +82,7 @@ __device__ __forceinline__ int intersect_faces(float gx, float gy, float gz, flo
 		const float k = det_inv * F.qe2;
 		ok = ok && !(x < -kBaryEps || y < -kBaryEps || z < -kBaryEps || k < 0.0f);
 		if (ok) { found = f; b0 = x; b1 = y; b2 = z; }
-		if (__all(found >= 0)) break;  // wave-uniform early exit
+		if (__all(found >= 0)) break;
 	}
 	return found;
 }
@@ -63,9 +91,28 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
                                                   const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap) {
 	__shared__ float hist[kDesc];
+	__shared__ float s_lut[kMaxDescLut];
+	__shared__ __attribute__((aligned(16))) float s_face[kFaces * kFaceStride];
+	__shared__ int s_fidx[kFaces * 4];
 	__shared__ float red[4];
 	const unsigned count = min(d_count[0], cap);
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+	// face constants -> LDS (per-lane face index => LDS gather instead of a 20-way constant waterfall)
+	for (int i = tid; i < kFaces * kFaceStride; i += 256) {
+		const int f = i / kFaceStride, j = i - f * kFaceStride;
+		const FaceConst &F = c_faces[f];
+		float v = 0.f;
+		if (j < 3) v = F.e1[j];
+		else if (j < 6) v = F.e2[j - 3];
+		else if (j < 9) v = F.t[j - 6];
+		else if (j < 12) v = F.q[j - 9];
+		else if (j == 12) v = F.qe2;
+		s_face[i] = v;
+	}
+	for (int i = tid; i < kFaces * 4; i += 256) s_fidx[i] = (i & 3) < 3 ? c_faces[i >> 2].idx[i & 3] : 0;
+	int cur_lut = -1;
+
 	for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
 		const int slot = kps[k].slot;
 		if (slot < 0 || (unsigned)slot >= kp_cap) continue;  // rejected by orientation (block-uniform)
@@ -74,7 +121,6 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		const float scale = kps[k].scale;
 		const LevelRef L = levels[li];
 		const WinLut lut = luts[li * 2 + 1];
-		const float *__restrict__ wtab = lutpool + lut.off;
 		// R <- R^T (Transpose_Matrix, Src/cSIFT3D.cc:1214)
 		const float R0 = kps[k].rot[0], R1 = kps[k].rot[3], R2 = kps[k].rot[6];
 		const float R3 = kps[k].rot[1], R4 = kps[k].rot[4], R5 = kps[k].rot[7];
@@ -91,68 +137,135 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		win_bounds_d((float)cyi, win_radius, u, L.ny, y0, y1);
 		win_bounds_d((float)czi, win_radius, u, L.nz, z0, z1);
 		const int wx = x1 - x0 + 1, wy = y1 - y0 + 1;
-		const int plane = (wx > 0 && wy > 0) ? wx * wy : 0;
+		const int ncol = (wx > 0 && wy > 0) ? wx * wy : 0;
 		const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1);
-		const size_t sy = (size_t)L.nx, sz = (size_t)L.nx * L.ny;
+		const int sy = L.nx, sz = L.nx * L.ny;  // levels are < 2^31 voxels
+		const int nin = lut.nin;                 // largest integer squared offset inside the sphere
 
+		__syncthreads();  // previous keypoint finished with hist / s_lut
 		for (int i = tid; i < kDesc; i += 256) hist[i] = 0.0f;
+		if (cur_lut != li) {
+			for (int i = tid; i < lut.len && i < kMaxDescLut; i += 256) s_lut[i] = lutpool[lut.off + i];
+			cur_lut = li;
+		}
 		__syncthreads();
 
-		for (int z = z0; z <= z1; z++) {
-			const int dz = z - czi;
-			const float vzd = (float)dz * u;
-			for (int v = tid; v < plane; v += 256) {
-				const int ly = (int)(((float)v + 0.5f) * inv_wx);
-				const int lx = v - ly * wx;
-				const int x = x0 + lx, y = y0 + ly;
-				const int dx = x - cxi, dy = y - cyi;
-				const int n = dx * dx + dy * dy + dz * dz;
-				bool act = n < lut.len;
-				const float w = act ? wtab[n] : -1.0f;
-				act = act && !(w < 0.0f);
-				const float vxd = (float)dx * u, vyd = (float)dy * u;
-				// rotate into the keypoint frame and convert to bin coordinates
-				float bx = R0 * vxd + R1 * vyd + R2 * vzd;
-				float by = R3 * vxd + R4 * vyd + R5 * vzd;
-				float bz = R6 * vxd + R7 * vyd + R8 * vzd;
+		for (int col = tid; col < ncol; col += 256) {
+			const int ly = (int)(((float)col + 0.5f) * inv_wx);
+			const int lx = col - ly * wx;
+			const int x = x0 + lx, y = y0 + ly;
+			const int dx = x - cxi, dy = y - cyi;
+			const int rr = dx * dx + dy * dy;
+			if (rr > nin) continue;
+			// in-sphere chord: dz^2 <= nin - rr
+			int h = (int)__fsqrt_rn((float)(nin - rr));
+			while ((h + 1) * (h + 1) <= nin - rr) h++;
+			while (h * h > nin - rr) h--;
+			const int za = max(z0, czi - h), zb = min(z1, czi + h);
+			if (za > zb) continue;
+			const float vxd = (float)dx * u, vyd = (float)dy * u;
+			// partial rotations: (R0*vx + R1*vy) is evaluated first in the reference's left-to-right sums
+			const float px = R0 * vxd + R1 * vyd, py = R3 * vxd + R4 * vyd, pz = R6 * vxd + R7 * vyd;
+			const float *c = L.d + (size_t)x + (size_t)sy * (size_t)y + (size_t)sz * (size_t)za;
+			float cm = *(c - sz), cc = *c;  // centre column at z-1, z
+
+			float acc[24];
+#pragma unroll
+			for (int i = 0; i < 24; i++) acc[i] = 0.0f;
+			int key = -1;  // (ix+1) | (iy+1)<<3 | (iz+1)<<6 | face<<9
+
+			for (int z = za; z <= zb; z++, c += sz) {
+				const float cp = c[sz];  // z+1
+				const int dz = z - czi;
+				const float vzd = (float)dz * u;
+				float bx = px + R2 * vzd, by = py + R5 * vzd, bz = pz + R8 * vzd;
 				bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
 				bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
-				act = act && !(bx <= -0.5f || by <= -0.5f || bz <= -0.5f || bx >= 3.5f || by >= 3.5f || bz >= 3.5f);
-				float gx = 0.f, gy = 0.f, gz = 0.f;
+				bool act = !(bx <= -0.5f || by <= -0.5f || bz <= -0.5f || bx >= 3.5f || by >= 3.5f || bz >= 3.5f);
+				float rx = 0.f, ry = 0.f, rz = 0.f, g2 = 0.f;
 				if (act) {
-					const float *c = L.d + (size_t)x + sy * (size_t)y + sz * (size_t)z;
-					gx = 0.5f * (c[1] - c[-1]);
-					gy = 0.5f * (c[sy] - *(c - sy));
-					gz = 0.5f * (c[sz] - *(c - sz));
+					const float w = s_lut[rr + dz * dz];
+					float gx = 0.5f * (c[1] - c[-1]);
+					float gy = 0.5f * (c[sy] - *(c - sy));
+					float gz = 0.5f * (cp - cm);
 					gx = gx * inv_u; gy = gy * inv_u; gz = gz * inv_u;
 					gx = gx * w; gy = gy * w; gz = gz * w;
+					rx = R0 * gx + R1 * gy + R2 * gz;
+					ry = R3 * gx + R4 * gy + R5 * gz;
+					rz = R6 * gx + R7 * gy + R8 * gz;
+					g2 = rx * rx + ry * ry + rz * rz;
+					act = !(g2 < kBaryEps);
 				}
-				const float rx = R0 * gx + R1 * gy + R2 * gz;
-				const float ry = R3 * gx + R4 * gy + R5 * gz;
-				const float rz = R6 * gx + R7 * gy + R8 * gz;
-				const float g2 = rx * rx + ry * ry + rz * rz;
-				act = act && !(g2 < kBaryEps);
+				cm = cc; cc = cp;
 				if (!__any(act)) continue;
 				float b0 = 0.f, b1 = 0.f, b2 = 0.f;
 				int f = -1;
-				if (act) f = intersect_faces(rx, ry, rz, b0, b1, b2);
-				if (f < 0) continue;
-				const float mag = __fsqrt_rn(g2);
-				const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
-				const int ix = (int)bx, iy = (int)by, iz = (int)bz;  // truncation toward zero, like the reference
-				const int i0 = c_faces[f].idx[0], i1 = c_faces[f].idx[1], i2 = c_faces[f].idx[2];
+				bool slow = false;
+				if (act) {
+					// predicted face: best of the 4 face normals of the positive octant, then the sign bits
+					const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
+					float best = ax * c_pred.n[0][0] + ay * c_pred.n[0][1] + az * c_pred.n[0][2];
+					int kb = 0;
+#pragma unroll
+					for (int t = 1; t < 4; t++) {
+						const float s = ax * c_pred.n[t][0] + ay * c_pred.n[t][1] + az * c_pred.n[t][2];
+						if (s > best) { best = s; kb = t; }
+					}
+					const int bits = (rx < 0.f ? 1 : 0) | (ry < 0.f ? 2 : 0) | (rz < 0.f ? 4 : 0);
+					f = c_pred.face[kb * 8 + bits];
+					const bool ok = face_test(&s_face[f * kFaceStride], rx, ry, rz, b0, b1, b2);
+					slow = !(ok && b0 >= kFastMargin && b1 >= kFastMargin && b2 >= kFastMargin);
+				}
+				if (__any(slow)) {
+					if (slow) f = intersect_scan(rx, ry, rz, b0, b1, b2);
+				}
+				if (f < 0) act = false;
+				if (act) {
+					const float mag = __fsqrt_rn(g2);
+					const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
+					const int ix = (int)bx, iy = (int)by, iz = (int)bz;  // truncation toward zero, like the reference
+					const int nk = (ix + 1) | ((iy + 1) << 3) | ((iz + 1) << 6) | (f << 9);
+					if (nk != key) {
+						if (key >= 0) {
+							const int kx = (key & 7) - 1, ky = ((key >> 3) & 7) - 1, kz = ((key >> 6) & 7) - 1, kf = key >> 9;
+							const int i0 = s_fidx[kf * 4], i1 = s_fidx[kf * 4 + 1], i2 = s_fidx[kf * 4 + 2];
+#pragma unroll
+							for (int d = 0; d < 8; d++) {
+								const int ccx = kx + (d >> 2), ccy = ky + ((d >> 1) & 1), ccz = kz + (d & 1);
+								if (ccx < 0 || ccy < 0 || ccz < 0 || ccx >= 4 || ccy >= 4 || ccz >= 4) continue;
+								const int hh = (ccx + ccy * 4 + ccz * 16) * 12;
+								atomicAdd(&hist[hh + i0], acc[3 * d]);
+								atomicAdd(&hist[hh + i1], acc[3 * d + 1]);
+								atomicAdd(&hist[hh + i2], acc[3 * d + 2]);
+							}
+						}
+#pragma unroll
+						for (int i = 0; i < 24; i++) acc[i] = 0.0f;
+						key = nk;
+					}
+					const double dfx = (double)fx, dfy = (double)fy, dfz = (double)fz;
+#pragma unroll
+					for (int d = 0; d < 8; d++) {
+						const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;  // dx outer, dz inner (Src/cSIFT3D.cc:1492-1496)
+						const float wgt = (float)((ddx ? dfx : (1.0 - dfx)) * (ddy ? dfy : (1.0 - dfy)) * (ddz ? dfz : (1.0 - dfz)));
+						const float mw = mag * wgt;
+						acc[3 * d] = acc[3 * d] + mw * b0;
+						acc[3 * d + 1] = acc[3 * d + 1] + mw * b1;
+						acc[3 * d + 2] = acc[3 * d + 2] + mw * b2;
+					}
+				}
+			}
+			if (key >= 0) {
+				const int kx = (key & 7) - 1, ky = ((key >> 3) & 7) - 1, kz = ((key >> 6) & 7) - 1, kf = key >> 9;
+				const int i0 = s_fidx[kf * 4], i1 = s_fidx[kf * 4 + 1], i2 = s_fidx[kf * 4 + 2];
 #pragma unroll
 				for (int d = 0; d < 8; d++) {
-					const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;  // dx outer, dz inner (Src/cSIFT3D.cc:1492-1496)
-					const int cx = ix + ddx, cy = iy + ddy, cz = iz + ddz;
-					if (cx < 0 || cy < 0 || cz < 0 || cx >= 4 || cy >= 4 || cz >= 4) continue;
-					const float wgt = (float)((ddx ? (double)fx : (1.0 - (double)fx)) * (ddy ? (double)fy : (1.0 - (double)fy)) *
-					                          (ddz ? (double)fz : (1.0 - (double)fz)));
-					const int h = (cx + cy * 4 + cz * 16) * 12;
-					const float mw = mag * wgt;
-					atomicAdd(&hist[h + i0], mw * b0);
-					atomicAdd(&hist[h + i1], mw * b1);
-					atomicAdd(&hist[h + i2], mw * b2);
+					const int ccx = kx + (d >> 2), ccy = ky + ((d >> 1) & 1), ccz = kz + (d & 1);
+					if (ccx < 0 || ccy < 0 || ccz < 0 || ccx >= 4 || ccy >= 4 || ccz >= 4) continue;
+					const int hh = (ccx + ccy * 4 + ccz * 16) * 12;
+					atomicAdd(&hist[hh + i0], acc[3 * d]);
+					atomicAdd(&hist[hh + i1], acc[3 * d + 1]);
+					atomicAdd(&hist[hh + i2], acc[3 * d + 2]);
 				}
 			}
 		}
@@ -180,7 +293,6 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		}
 		float *out = d_desc + (size_t)slot * kDesc;
 		out[tid] = v0; out[tid + 256] = v1; out[tid + 512] = v2;
-		__syncthreads();
 	}
 }
 

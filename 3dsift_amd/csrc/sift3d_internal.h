@@ -56,6 +56,7 @@ struct FaceConst {
 	float e1[3], e2[3], t[3], q[3];
 	float qe2;  // dot(q, e2)
 	int idx[3];
+	float centre[3];  // face centroid (prediction table only)
 };
 
 // Gaussian window weight tables indexed by the INTEGER squared voxel offset
@@ -65,8 +66,18 @@ struct FaceConst {
 struct WinLut {
 	int off;      // offset into the lut pool
 	int len;      // entries; n >= len is outside
+	int nin;      // largest n that is still inside the sphere (tables are monotone)
 	float radius; // win_radius (fp32) for the box bounds
 	float sigma;
+};
+constexpr int kMaxDescLut = 1536;  // descriptor window table entries staged in LDS (default params: 1293)
+
+// Face PREDICTION table for the descriptor kernel (speed only, never correctness: the predicted face
+// is verified with the exact reference test and a margin, otherwise the ordered 20-face scan runs).
+// n[k] = the 4 distinct |face centre| directions of the icosahedron; face[k*8 + signbits] = mesh index.
+struct FacePredict {
+	float n[4][3];
+	int face[32];
 };
 
 // ---- kernels_pyramid.hip -------------------------------------------------------------------
@@ -103,7 +114,7 @@ void launch_orient(DevKp *kps, const unsigned *d_count, unsigned cap, const Leve
 void launch_slots(DevKp *kps, const unsigned *d_count, unsigned cap, unsigned *d_nkp, hipStream_t st);
 
 // ---- kernels_desc.hip ----------------------------------------------------------------------
-void upload_faces(const FaceConst *faces);  // into __constant__ memory
+void upload_faces(const FaceConst *faces, const FacePredict *pred);  // into __constant__ memory
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels,
                      const WinLut *d_luts, const float *d_lutpool, float *d_desc, unsigned kp_cap, hipStream_t st);
 void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, int transposed,
