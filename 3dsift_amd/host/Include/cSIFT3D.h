@@ -1,0 +1,119 @@
+// cSIFT3D.h -- public C++ API of the MI355X-native 3D SIFT extractor.
+//
+// Drop-in for the reference header 3DSIFT/Include/cSIFT3D.h: same namespace, class, method, field
+// and macro names (factory :184-204, CSIFT3D public part :142-177, Keypoint :54-70, Cvec :38-52), so
+// user code such as the reference's Example.cpp compiles unchanged.  Everything behind it is
+// different: a CSIFT3D object is a thin shell around an opaque sift3d_handle (include/sift3d_hip.h);
+// volumes, both pyramids, keypoints and descriptors live on the GPU.
+#ifndef S3D_HOST_CSIFT3D_H
+#define S3D_HOST_CSIFT3D_H
+
+#include <string>
+#include <vector>
+
+#include "Util/cTexImage.h"
+#include "Util/common.h"
+
+namespace CPUSIFT {
+
+// defaults of the factory arguments (reference values)
+#define SIGMA_DEFAULT 1.6
+#define SIGMA_N_DEFAULT 1.15
+#define NUM_KP_LEVELS 3
+#define PEAK_THRESH 0.1
+#define EIG_THRES 0.9
+#define CORNER_THRESH 0.4
+// fixed algorithm constants
+#define IMG_BORDER 1
+#define NHIST_PER_DIM 4
+#define ICOS_NFACES 20
+#define ICOS_NVERT 12
+#define DESC_NUMEL (NHIST_PER_DIM * NHIST_PER_DIM * NHIST_PER_DIM * ICOS_NVERT)
+
+// kept for source compatibility: thread count of the reference's OpenMP stages; unused on the GPU
+extern int sift_thread_num;
+
+typedef struct _cCvec {
+	float x, y, z;
+	_cCvec(float x_ = 0, float y_ = 0, float z_ = 0) : x(x_), y(y_), z(z_) {}
+} SIFT_LIBRARY_API Cvec;
+
+// Field order and types match the reference record, so binaries that copy Keypoints around keep working.
+typedef struct _cKeypoint {
+	float x, y, z;       // voxel coordinates inside the keypoint's octave
+	float scale;         // scale-space location of its DoG level
+	int octave, level;
+	float rx, ry, rz;    // coordinates in the original volume (x * 2^octave)
+	Cvec win;            // weighted mean gradient of the orientation window
+	float eigvalue[3];   // ascending
+	float eigvector[9];
+	float Rotation[9];   // returned transposed (inverse), as the reference leaves it after describing
+	float str_tensor[9];
+	float *desc = nullptr;  // DESC_NUMEL floats owned by the extractor: valid while the CSIFT3D lives
+} SIFT_LIBRARY_API Keypoint;
+
+bool cmp_kp(const Keypoint &a, const Keypoint &b);
+bool cmp_kp_orig(const Keypoint &a, const Keypoint &b);
+
+class CSIFT3D {
+protected:
+	struct Impl;
+	Impl *impl = nullptr;
+	std::vector<Keypoint> filter;
+	std::vector<TexImage> Gss_Pyramid, DoG_Pyramid;  // host copies, filled by GET_GSS()/GET_DOG()
+	std::vector<std::vector<Keypoint>> level_extrema;
+	float *global_descriptor = nullptr;
+	void fetch_results();
+
+public:
+	SIFT_TimerPara m_timer;
+
+	SIFT_LIBRARY_API CSIFT3D();
+	SIFT_LIBRARY_API CSIFT3D(float *volume, int x_dim, int y_dim, int z_dim, int num_kp_levels_, float sigma_default_,
+	                         float sigma_n_default_, float peak_thresh_, float max_eig_thres_, float corner_thresh_);
+	SIFT_LIBRARY_API ~CSIFT3D();
+	CSIFT3D(const CSIFT3D &) = delete;
+	CSIFT3D &operator=(const CSIFT3D &) = delete;
+
+	SIFT_LIBRARY_API void KpSiftAlgorithm();
+	SIFT_LIBRARY_API void SetNumThreads(int t_num);
+	SIFT_LIBRARY_API std::vector<Keypoint> GetKeypoints();
+
+	// the reference exposes its stages publicly; here each call runs the device pipeline up to that stage
+	void Initialize();
+	void Build_Gaussian_Scale_Space();
+	void Build_DOG_Scale_Space();
+	void Detect_KeyPoints();
+	void Assign_Orientation();
+	void Extract_Description();
+	void Release_SIFT();
+	void SetHostImNull() {}
+
+	// checking accessors: copy the pyramids / per-level extrema back from the device
+	SIFT_LIBRARY_API std::vector<TexImage> *GET_GSS();
+	SIFT_LIBRARY_API std::vector<TexImage> *GET_DOG();
+	SIFT_LIBRARY_API std::vector<std::vector<Keypoint>> *GET_LEVEL();
+
+	// extension: device-resident descriptors / coordinates for a matcher that never leaves the GPU
+	SIFT_LIBRARY_API bool GetDeviceResults(const float **d_desc, const float **d_xyz, int *n, int *device);
+};
+
+class SIFT_LIBRARY_API CSIFT3DFactory {
+public:
+	static CSIFT3D *CreateCSIFT3D(float *volume, int x_dim, int y_dim, int z_dim, int num_kp_levels = NUM_KP_LEVELS,
+	                              float sigma_default = SIGMA_DEFAULT, float sigma_n_default = SIGMA_N_DEFAULT,
+	                              float peak_thresh = PEAK_THRESH, float max_eigo_thres = EIG_THRES,
+	                              float corner_thresh = CORNER_THRESH);
+
+	// raw-matrix file overload (12-byte int32 header m,n,p + fp32 payload)
+	static CSIFT3D *CreateCSIFT3D(std::string path_, int num_kp_levels = NUM_KP_LEVELS, float sigma_default = SIGMA_DEFAULT,
+	                              float sigma_n_default = SIGMA_N_DEFAULT, float peak_thresh = PEAK_THRESH,
+	                              float max_eigo_thres = EIG_THRES, float corner_thresh = CORNER_THRESH);
+};
+
+// device selection for subsequently created extractors / matchers (default 0, or env SIFT3D_DEVICE)
+SIFT_LIBRARY_API void SetDevice(int device);
+SIFT_LIBRARY_API int GetDevice();
+
+}  // namespace CPUSIFT
+#endif

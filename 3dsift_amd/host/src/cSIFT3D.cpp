@@ -1,0 +1,215 @@
+// cSIFT3D.cpp -- the CPUSIFT::CSIFT3D shell over the C-ABI (include/sift3d_hip.h).
+// Mirrors the reference's construction / run / read-back contract (3DSIFT/Src/cSIFT3D.cc:103-235,
+// 1659-1688): ctor copies + normalises the caller's volume, KpSiftAlgorithm() runs the pipeline,
+// GetKeypoints() returns records whose desc pointers alias extractor-owned memory.  Like the
+// reference it reports problems on stderr and carries on with an empty result (no exceptions).
+#include "../Include/cSIFT3D.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../../include/sift3d_hip.h"
+#include "../Include/Util/matrixIO3D.h"
+
+namespace CPUSIFT {
+
+int sift_thread_num = 1;
+
+static int g_device = -1;
+void SetDevice(int device) { g_device = device; }
+int GetDevice() {
+	if (g_device < 0) {
+		const char *e = getenv("SIFT3D_DEVICE");
+		g_device = e ? atoi(e) : 0;
+	}
+	return g_device;
+}
+
+struct CSIFT3D::Impl {
+	sift3d_handle h = nullptr;
+	int device = 0;
+	int levels = 3;
+	int stage = 0;
+	bool fetched = false;
+};
+
+static void complain(const char *where, int rc) {
+	if (rc != SIFT3D_OK) fprintf(stderr, "[3dsift_amd] %s: %s (%s)\n", where, sift3d_error_string(rc), sift3d_last_error());
+}
+
+bool cmp_kp(const Keypoint &a, const Keypoint &b) {
+	if (a.rz != b.rz) return a.rz < b.rz;
+	if (a.ry != b.ry) return a.ry < b.ry;
+	return a.rx < b.rx;
+}
+
+bool cmp_kp_orig(const Keypoint &a, const Keypoint &b) {
+	if (a.z != b.z) return a.z < b.z;
+	if (a.y != b.y) return a.y < b.y;
+	return a.x < b.x;
+}
+
+CSIFT3D::CSIFT3D() : impl(new Impl()) {}
+
+CSIFT3D::CSIFT3D(float *volume, int x_dim, int y_dim, int z_dim, int num_kp_levels_, float sigma_default_,
+                 float sigma_n_default_, float peak_thresh_, float max_eig_thres_, float corner_thresh_)
+    : impl(new Impl()) {
+	sift3d_params p;
+	p.num_kp_levels = num_kp_levels_;
+	p.sigma_default = sigma_default_;
+	p.sigma_n_default = sigma_n_default_;
+	p.peak_thresh = peak_thresh_;
+	p.max_eig_thres = max_eig_thres_;
+	p.corner_thresh = corner_thresh_;
+	impl->levels = num_kp_levels_;
+	impl->device = GetDevice();
+	complain("CSIFT3D (upload + normalise)", sift3d_create(&impl->h, volume, x_dim, y_dim, z_dim, &p, impl->device, 0));
+}
+
+CSIFT3D::~CSIFT3D() {
+	if (impl) {
+		if (impl->h) sift3d_destroy(impl->h);
+		delete impl;
+	}
+	if (global_descriptor) free(global_descriptor);
+}
+
+void CSIFT3D::fetch_results() {
+	filter.clear();
+	if (global_descriptor) { free(global_descriptor); global_descriptor = nullptr; }
+	impl->fetched = true;
+	if (!impl->h || impl->stage < 4) return;
+	int n = 0;
+	sift3d_num_keypoints(impl->h, &n);
+	if (n <= 0) return;
+	std::vector<sift3d_keypoint> pod((size_t)n);
+	const bool with_desc = impl->stage >= 5;
+	global_descriptor = (float *)calloc((size_t)n * DESC_NUMEL, sizeof(float));
+	int rc = sift3d_get_keypoints(impl->h, pod.data(), with_desc ? global_descriptor : nullptr);
+	complain("GetKeypoints", rc);
+	if (rc != SIFT3D_OK) return;
+	filter.resize((size_t)n);
+	for (int i = 0; i < n; i++) {
+		Keypoint &k = filter[i];
+		const sift3d_keypoint &s = pod[i];
+		k.x = s.x; k.y = s.y; k.z = s.z; k.scale = s.scale; k.octave = s.octave; k.level = s.level;
+		k.rx = s.rx; k.ry = s.ry; k.rz = s.rz;
+		k.win = Cvec(s.win[0], s.win[1], s.win[2]);
+		memcpy(k.eigvalue, s.eigvalue, sizeof(k.eigvalue));
+		memcpy(k.eigvector, s.eigvector, sizeof(k.eigvector));
+		memcpy(k.Rotation, s.Rotation, sizeof(k.Rotation));
+		memcpy(k.str_tensor, s.str_tensor, sizeof(k.str_tensor));
+		k.desc = global_descriptor + (size_t)i * DESC_NUMEL;
+	}
+}
+
+static void run_to(CSIFT3D *self, sift3d_handle h, int upto, int &stage, bool &fetched, SIFT_TimerPara &tm) {
+	if (!h) return;
+	int rc = sift3d_run_stages(h, upto);
+	complain("KpSiftAlgorithm", rc);
+	if (rc != SIFT3D_OK) return;
+	stage = upto;
+	fetched = false;
+	double t[8];
+	if (sift3d_stage_times(h, t) == SIFT3D_OK) {
+		tm.d_TotalTime = t[0]; tm.d_Allocation = t[1]; tm.d_BuildGSS = t[2]; tm.d_BuildDOG = t[3];
+		tm.d_Detect = t[4]; tm.d_AssignOrientation = t[5]; tm.d_Extraction = t[6]; tm.d_release = t[7];
+	}
+	(void)self;
+}
+
+void CSIFT3D::KpSiftAlgorithm() { run_to(this, impl->h, 5, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Initialize() {}
+void CSIFT3D::Build_Gaussian_Scale_Space() { run_to(this, impl->h, 1, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Build_DOG_Scale_Space() { run_to(this, impl->h, 2, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Detect_KeyPoints() { run_to(this, impl->h, 3, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Assign_Orientation() { run_to(this, impl->h, 4, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Extract_Description() { run_to(this, impl->h, 5, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Release_SIFT() { Gss_Pyramid.clear(); DoG_Pyramid.clear(); level_extrema.clear(); }
+
+void CSIFT3D::SetNumThreads(int t_num) {
+	if (t_num > 0) sift_thread_num = t_num;
+}
+
+std::vector<Keypoint> CSIFT3D::GetKeypoints() {
+	if (!impl->fetched) fetch_results();
+	return filter;
+}
+
+static void copy_pyramid(sift3d_handle h, int is_dog, int count, std::vector<TexImage> &out) {
+	out.clear();
+	out.resize((size_t)count);
+	for (int i = 0; i < count; i++) {
+		int d[3];
+		float u[3], s;
+		if (sift3d_level_info(h, is_dog, i, d, u, &s) != SIFT3D_OK) continue;
+		TexImage &t = out[i];
+		t.SetImageSize(d[0], d[1], d[2]);
+		t.SetImageUnit(u[0], u[1], u[2]);
+		t.SetImageScale(s);
+		t.MallocArrayMemory();
+		complain("GET_GSS/GET_DOG", sift3d_copy_level(h, is_dog, i, t._Data));
+	}
+}
+
+std::vector<TexImage> *CSIFT3D::GET_GSS() {
+	int noct = 0;
+	if (impl->h && impl->stage >= 1 && sift3d_num_octaves(impl->h, &noct) == SIFT3D_OK)
+		copy_pyramid(impl->h, 0, noct * (impl->levels + 3), Gss_Pyramid);
+	return &Gss_Pyramid;
+}
+
+std::vector<TexImage> *CSIFT3D::GET_DOG() {
+	int noct = 0;
+	if (impl->h && impl->stage >= 1 && sift3d_num_octaves(impl->h, &noct) == SIFT3D_OK)
+		copy_pyramid(impl->h, 1, noct * (impl->levels + 2), DoG_Pyramid);
+	return &DoG_Pyramid;
+}
+
+std::vector<std::vector<Keypoint>> *CSIFT3D::GET_LEVEL() {
+	level_extrema.clear();
+	int n = 0, noct = 0;
+	if (!impl->h || impl->stage < 3 || sift3d_num_extrema(impl->h, &n) != SIFT3D_OK) return &level_extrema;
+	sift3d_num_octaves(impl->h, &noct);
+	level_extrema.resize((size_t)noct * impl->levels);
+	std::vector<sift3d_keypoint> pod((size_t)(n > 0 ? n : 1));
+	if (n > 0 && sift3d_get_extrema(impl->h, pod.data()) != SIFT3D_OK) return &level_extrema;
+	for (int i = 0; i < n; i++) {
+		Keypoint k;
+		k.x = pod[i].x; k.y = pod[i].y; k.z = pod[i].z; k.scale = pod[i].scale; k.octave = pod[i].octave; k.level = pod[i].level;
+		k.rx = k.ry = k.rz = -1.0f;
+		memset(k.eigvalue, 0, sizeof(k.eigvalue)); memset(k.eigvector, 0, sizeof(k.eigvector));
+		memset(k.Rotation, 0, sizeof(k.Rotation)); memset(k.str_tensor, 0, sizeof(k.str_tensor));
+		const size_t slot = (size_t)k.octave * impl->levels + (k.level - 1);
+		if (slot < level_extrema.size()) level_extrema[slot].push_back(k);
+	}
+	return &level_extrema;
+}
+
+bool CSIFT3D::GetDeviceResults(const float **d_desc, const float **d_xyz, int *n, int *device) {
+	if (!impl->h) return false;
+	if (device) *device = impl->device;
+	return sift3d_device_results(impl->h, d_desc, d_xyz, n) == SIFT3D_OK;
+}
+
+CSIFT3D *CSIFT3DFactory::CreateCSIFT3D(float *volume, int x_dim, int y_dim, int z_dim, int num_kp_levels, float sigma_default,
+                                       float sigma_n_default, float peak_thresh, float max_eig_thres, float corner_thresh) {
+	return new CSIFT3D(volume, x_dim, y_dim, z_dim, num_kp_levels, sigma_default, sigma_n_default, peak_thresh, max_eig_thres,
+	                   corner_thresh);
+}
+
+CSIFT3D *CSIFT3DFactory::CreateCSIFT3D(std::string path_, int num_kp_levels, float sigma_default, float sigma_n_default,
+                                       float peak_thresh, float max_eig_thres, float corner_thresh) {
+	int m = 0, n = 0, p = 0;
+	float *volume = nullptr;
+	if (ReadMatrixFromDisk(path_.c_str(), &m, &n, &p, &volume) != 0 || !volume) {
+		fprintf(stderr, "[3dsift_amd] CreateCSIFT3D: cannot read %s\n", path_.c_str());
+		return new CSIFT3D();
+	}
+	CSIFT3D *s = new CSIFT3D(volume, m, n, p, num_kp_levels, sigma_default, sigma_n_default, peak_thresh, max_eig_thres, corner_thresh);
+	free(volume);
+	return s;
+}
+
+}  // namespace CPUSIFT

@@ -1,0 +1,122 @@
+// io.cpp -- host-side volume loaders + timer printing of the drop-in shell:
+//   readNiiFile          reference Src/Util/readNii.cpp:5-39 (NIfTI-1 single file, optional gzip)
+//   Read/WriteMatrix...  reference Include/Util/matrixIO3D.h:21-64, Src/Util/matrixIO3D.cpp:7-29
+//   operator<<           reference Src/Util/common.cpp:5-36
+// Own minimal implementations (the reference vendors the 11 kLoC layNii/nifti2 reader instead).
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../Include/Util/common.h"
+#include "../Include/Util/matrixIO3D.h"
+#include "../Include/Util/readNii.h"
+
+namespace {
+
+template <typename T>
+T bswap(T v) {
+	unsigned char *b = reinterpret_cast<unsigned char *>(&v);
+	for (size_t i = 0; i < sizeof(T) / 2; i++) std::swap(b[i], b[sizeof(T) - 1 - i]);
+	return v;
+}
+
+template <typename T>
+void convert(const unsigned char *raw, size_t n, bool swap, float *out) {
+	for (size_t i = 0; i < n; i++) {
+		T v;
+		memcpy(&v, raw + i * sizeof(T), sizeof(T));
+		if (swap) v = bswap(v);
+		out[i] = (float)v;
+	}
+}
+
+}  // namespace
+
+float *readNiiFile(const char *filename, int &nx, int &ny, int &nz) {
+	nx = ny = nz = 0;
+	gzFile f = gzopen(filename, "rb");  // transparently reads plain and gzip-compressed files
+	if (!f) { fprintf(stderr, "readNiiFile: cannot open %s\n", filename); return nullptr; }
+	unsigned char hdr[352];
+	if (gzread(f, hdr, 348) != 348) { gzclose(f); fprintf(stderr, "readNiiFile: short header\n"); return nullptr; }
+	int32_t sizeof_hdr;
+	memcpy(&sizeof_hdr, hdr, 4);
+	bool swap = false;
+	if (sizeof_hdr != 348) {
+		if (bswap(sizeof_hdr) == 348) swap = true;
+		else { gzclose(f); fprintf(stderr, "readNiiFile: not a NIfTI-1 file (sizeof_hdr=%d)\n", sizeof_hdr); return nullptr; }
+	}
+	int16_t dim[8], datatype, bitpix;
+	memcpy(dim, hdr + 40, 16);
+	memcpy(&datatype, hdr + 70, 2);
+	memcpy(&bitpix, hdr + 72, 2);
+	float vox_offset;
+	memcpy(&vox_offset, hdr + 108, 4);
+	if (swap) {
+		for (auto &d : dim) d = bswap(d);
+		datatype = bswap(datatype); bitpix = bswap(bitpix); vox_offset = bswap(vox_offset);
+	}
+	if (memcmp(hdr + 344, "n+1", 3) != 0) { gzclose(f); fprintf(stderr, "readNiiFile: only single-file NIfTI-1 (n+1) is supported\n"); return nullptr; }
+	nx = dim[1]; ny = dim[0] >= 2 ? dim[2] : 1; nz = dim[0] >= 3 ? dim[3] : 1;
+	const size_t n = (size_t)nx * ny * nz, bytes = n * (size_t)(bitpix / 8);
+	long skip = (long)vox_offset - 348;
+	std::vector<unsigned char> junk((size_t)(skip > 0 ? skip : 0));
+	if (skip > 0 && gzread(f, junk.data(), (unsigned)skip) != skip) { gzclose(f); return nullptr; }
+	std::vector<unsigned char> raw(bytes);
+	size_t got = 0;
+	while (got < bytes) {
+		int r = gzread(f, raw.data() + got, (unsigned)std::min<size_t>(bytes - got, 1u << 30));
+		if (r <= 0) break;
+		got += (size_t)r;
+	}
+	gzclose(f);
+	if (got != bytes) { fprintf(stderr, "readNiiFile: truncated payload\n"); return nullptr; }
+	float *out = new float[n];
+	switch (datatype) {  // NIfTI datatype codes; slope/intercept deliberately ignored (see readNii.h)
+	case 2: convert<uint8_t>(raw.data(), n, false, out); break;
+	case 4: convert<int16_t>(raw.data(), n, swap, out); break;
+	case 8: convert<int32_t>(raw.data(), n, swap, out); break;
+	case 16: convert<float>(raw.data(), n, swap, out); break;
+	case 64: convert<double>(raw.data(), n, swap, out); break;
+	case 256: convert<int8_t>(raw.data(), n, false, out); break;
+	case 512: convert<uint16_t>(raw.data(), n, swap, out); break;
+	case 768: convert<uint32_t>(raw.data(), n, swap, out); break;
+	default:
+		fprintf(stderr, "readNiiFile: unsupported datatype %d\n", (int)datatype);
+		delete[] out;
+		return nullptr;
+	}
+	return out;
+}
+
+int ReadMatrixFromDisk(const char *filename, int *m, int *n, int *p, float **volume) {
+	FILE *f = fopen(filename, "rb");
+	if (!f) return -1;
+	int32_t h[3];
+	if (fread(h, sizeof(int32_t), 3, f) != 3 || h[0] <= 0 || h[1] <= 0 || h[2] <= 0) { fclose(f); return -2; }
+	const size_t cnt = (size_t)h[0] * h[1] * h[2];
+	float *v = (float *)malloc(cnt * sizeof(float));
+	if (!v || fread(v, sizeof(float), cnt, f) != cnt) { free(v); fclose(f); return -3; }
+	fclose(f);
+	*m = h[0]; *n = h[1]; *p = h[2]; *volume = v;
+	return 0;
+}
+
+int WriteMatrixToDisk(const char *filename, int m, int n, int p, const float *volume) {
+	FILE *f = fopen(filename, "wb");
+	if (!f) return -1;
+	const int32_t h[3] = {m, n, p};
+	const size_t cnt = (size_t)m * n * p;
+	const bool ok = fwrite(h, sizeof(int32_t), 3, f) == 3 && fwrite(volume, sizeof(float), cnt, f) == cnt;
+	fclose(f);
+	return ok ? 0 : -2;
+}
+
+std::ostream &operator<<(std::ostream &os, const SIFT_TimerPara &st) {
+	os << "3D SIFT timing (s): total " << st.d_TotalTime << " | GSS+DoG " << (st.d_BuildGSS + st.d_BuildDOG) << " | detect "
+	   << st.d_Detect << " | orientation " << st.d_AssignOrientation << " | description " << st.d_Extraction << "\n";
+	return os;
+}
