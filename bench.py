@@ -49,24 +49,22 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size", type=int, default=512, help="cubic volume edge (BASELINE metric: 512)")
-    ap.add_argument("--cpu-sample", type=int, default=192, help="edge of the CPU-baseline sample crop (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU-baseline sample crop (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--allpairs", action="store_true", help="N>1: all-gather descriptors + all-pairs enhancedMatch (configs[4])")
     args = ap.parse_args()
 
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-
     capi = importlib.import_module("3dsift_amd.capi")
     synth = importlib.import_module("3dsift_amd.synth")
+    s3d_dist = importlib.import_module("3dsift_amd.dist")
+    rank, world = s3d_dist.init_from_env(backend="nccl", device=dev)  # "nccl" is RCCL on ROCm
 
     n = args.size
     shape = (n, n, n)
@@ -91,10 +89,7 @@ def main():
             stage[k] = stage.get(k, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = s3d_dist.max_over_ranks(dt, device=dev)
     kp, _ = ex.GetKeypoints(with_desc=False)
     nkp = len(kp)
     next_ = len(ex.extrema())
@@ -152,9 +147,33 @@ def main():
         rms = float(np.sqrt(np.mean((gdesc.astype(np.float64) - odesc) ** 2))) if same and len(okp) else None
         out["parity"] = {"sample_keypoints_gpu": len(gkp), "sample_keypoints_cpu": len(okp), "same_keypoint_set": bool(same),
                          "descriptor_rms": rms}
+    if args.allpairs and world > 1:
+        # BASELINE configs[4] matching leg (not part of `value`): all-gather the device-resident descriptors
+        # over RCCL, then every rank runs enhancedMatch on its share of the ordered volume pairs
+        d_desc, d_xyz, nk = ex.device_results()
+        kp_all, desc_all = ex.GetKeypoints()
+        desc_t = torch.from_numpy(desc_all).to(dev)
+        xyz_t = torch.from_numpy(np.stack([kp_all["rx"], kp_all["ry"], kp_all["rz"]], 1).astype(np.float32)).to(dev)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        descs = s3d_dist.allgather_ragged(desc_t)
+        xyzs = s3d_dist.allgather_ragged(xyz_t)
+        torch.cuda.synchronize()
+        t_gather = time.perf_counter() - ta
+        mt = capi.muBruteMatcher(device=local)
+        npairs, tm = 0, 0.0
+        for (i, j) in s3d_dist.my_pairs(rank, world):
+            r = mt.enhancedMatch(descs[i].data_ptr(), xyzs[i].data_ptr(), descs[j].data_ptr(), xyzs[j].data_ptr(), 0.85,
+                                 on_device=True, n=descs[i].shape[0], m=descs[j].shape[0])
+            npairs += len(r["pairs"]); tm += mt.totalTime
+        tm = s3d_dist.max_over_ranks(tm, device=dev)
+        if rank == 0:
+            out["allpairs"] = {"allgather_s": t_gather, "match_s_max_rank": tm, "ordered_pairs": len(s3d_dist.ordered_pairs(world)),
+                               "rank0_matched": npairs}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
