@@ -9,18 +9,33 @@
 //
 // Structure (2.5-D streaming, 256 threads = 4 waves per workgroup):
 //   * a workgroup owns a TX x TY = 64 x 16 column of the volume and marches along z over a chunk
-//   * per plane q:  global -> LDS tile with xy halo (coalesced 16-B loads)
-//                   x-blur  LDS tile -> LDS (each thread slides a register window over 8 outputs)
-//                   y-blur  LDS -> registers (each thread: 4 consecutive y of one x, lanes along x)
-//                   the xy-blurred value enters a per-thread REGISTER RING of 2*HW+2 planes
-//                   z-blur of plane p = q-HW straight from the ring, DoG against G[i-1](p), stores
+//   * per plane q (software pipelined, two barriers per plane):
+//       regs -> LDS tile of plane q (loaded one step earlier), then the global loads of plane q+1 and of
+//       the DoG centre values of plane p = q-HW are ISSUED and stay in flight during the step
+//       x-blur  LDS tile -> LDS   (each thread slides a register window over 8 outputs of one row)
+//       y-blur  LDS -> registers  (each thread: 4 consecutive y of one x, lanes along x)
+//       the xy-blurred value enters a per-thread REGISTER RING of 2*HW+2 planes; the ring never moves:
+//       a wave-uniform switch on q mod RING selects code with static register indices
+//       z-blur of plane p straight from the ring, DoG against G[i-1](p), coalesced stores, running max
 //   * block -> tile mapping is XCD aware (neighbouring tiles share their halo in one XCD's L2)
+//   * the grid is sized to whole residency rounds (CUs x workgroups/CU) to avoid a tail
 //
 // Parity: every output is the literal sum acc = acc + tap[d+hw]*term for d = -hw..+hw with separate
 // IEEE multiply and add (no FMA: file built with -ffp-contract=off), interior term = src[p-d],
 // boundary term = (1-frac)*src[lo] + frac*src[hi] with the reference's fp32 coordinate rule
-// (Src/cSIFT3D.cc:736-764), i.e. bit-identical to the CPU path.  Boundary outputs take a slow path
-// (x, y: per-output LDS gathers; z: wave-uniform ring selects) -- they are O(hw/n) of the volume.
+// (Src/cSIFT3D.cc:736-764), i.e. bit-identical to the CPU path.
+//
+// Boundaries without a slow path: for n >= 2*hw+2 the reference rule is EXACTLY the plain tap chain over an
+// extended line E:  E[-k] = src[k] (c<0 -> -c, frac = 0 so the term is tap*src[k]),  and
+// E[dim_end+k] = (1-f_k)*src[m-1] + f_k*src[m], m = dim_end-k, k = 0..hw, where f_k is the fp32 fraction the
+// reference obtains from `2*dim_end - c - 0.1f` (host table EdgeFrac; the term tap*((1-f)*lo + f*hi) evaluates
+// the bracket first, so precomputing E[] with the same two multiplies and one add is bit-identical; interior
+// outputs never reach index dim_end, boundary outputs always see it through the lerp).  Edge tiles patch their
+// LDS halo columns (x) / rows (y) with E[] and run the same fast path as interior tiles.  In z the few
+// boundary planes per volume use wave-uniform ring selects.  Levels with a dimension < 2*hw+2 use the generic
+// separable kernels of kernels_pyramid.hip.
+#include <string.h>
+
 #include "sift3d_internal.h"
 
 namespace s3d {
@@ -38,11 +53,13 @@ struct FusedCfg {
 	static constexpr int W = HXL + TX + HXH;            // tile row width (floats, multiple of 4)
 	static constexpr int W4 = W / 4;
 	static constexpr int PITCH = W + 4;                 // +16 B: rows shift by 4 banks
-	static constexpr int ROWS = TY + 2 * HW + 1;        // low halo HW+1, high halo HW
+	static constexpr int ROWS = TY + 2 * HW + 1;        // row 0 = low halo HW+1 (only bottom tiles need it), then HW + TY + HW
 	static constexpr int RING = 2 * HW + 2;             // planes p-hw-1 .. p+hw
 	static constexpr int WSTART = (HXL - HW) & ~3;      // 16-B aligned start of a thread's x window
 	static constexpr int WOFF = HXL - HW - WSTART;      // window index of input x-hw for output j=0
 	static constexpr int WN4 = (WOFF + 8 + 2 * HW + 3) / 4;
+	static constexpr int NLD = (ROWS * W4 + NT - 1) / NT;  // float4 tile loads per thread and plane
+	static constexpr int OCC = HW <= 4 ? 4 : (HW <= 5 ? 3 : 2);  // workgroups per CU the register budget is set for
 };
 
 // reference boundary coordinate rule for output position p, tap offset d, axis length n
@@ -58,14 +75,41 @@ __device__ __forceinline__ void boundary_src(int p, int d, int n, int &lo, int &
 	hi = min(max(hi, 0), dim_end);
 }
 
-template <int HW, bool DOG>
-__global__ void __launch_bounds__(256, (HW <= 4 ? 4 : (HW <= 6 ? 3 : 2))) k_fused_level(const float *__restrict__ src, float *__restrict__ dst,
-                                                     float *__restrict__ dog, unsigned *__restrict__ dogmax, int nx, int ny,
-                                                     int nz, Taps t, int ntx, int nty, int nchunks, int cz) {
+// ring slot of plane s (any sign)
+template <int RING>
+__device__ __forceinline__ int ring_slot(int s) {
+	int r = s % RING;
+	return r < 0 ? r + RING : r;
+}
+
+// ring insert + interior z-blur with the ring in place: plane s lives in slot s mod RING; K = q mod RING
+// is a compile-time constant inside each case of the caller's switch, so every ring index is static
+template <int HW, int K>
+__device__ __forceinline__ void zblur_static(float (&ring)[4][2 * HW + 2], const float (&v)[4], const Taps &t, bool interior,
+                                             float (&out)[4]) {
+	constexpr int RING = 2 * HW + 2;
+#pragma unroll
+	for (int j = 0; j < 4; j++) ring[j][K] = v[j];
+	if (interior) {
+#pragma unroll
+		for (int j = 0; j < 4; j++) {
+			float acc = 0.0f;
+#pragma unroll
+			for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * ring[j][(K - HW - d + 2 * RING) % RING];  // plane p-d, p = q-HW
+			out[j] = acc;
+		}
+	}
+}
+
+// VEC: nx % 4 == 0, so every 16-B tile piece is either fully inside the volume or fully outside and all
+// tile loads are branch-free (clamped address + select) -- essential: a branch around a load makes hipcc wait
+// for it at the join, which serialises the prefetch.  !VEC (odd widths, small volumes) keeps guarded scalar loads.
+template <int HW, bool DOG, bool VEC>
+__device__ __forceinline__ void fused_level_body(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
+                                                 unsigned *__restrict__ dogmax, int nx, int ny, int nz, const Taps &t,
+                                                 const EdgeFrac &ef, int ntx, int nty, int cz, float *in_t, float *xb,
+                                                 float *s_red) {
 	using C = FusedCfg<HW>;
-	__shared__ __attribute__((aligned(16))) float in_t[C::ROWS * C::PITCH];
-	__shared__ __attribute__((aligned(16))) float xb[C::ROWS * C::TX];
-	__shared__ float s_red[4];
 
 	// ---- XCD-aware, bijective block -> (chunk, tile) mapping: blocks b, b+8, ... share an XCD ----
 	const int nblocks = gridDim.x;
@@ -82,10 +126,56 @@ __global__ void __launch_bounds__(256, (HW <= 4 ? 4 : (HW <= 6 ? 3 : 2))) k_fuse
 	const int zc0 = chunk * cz, zc1 = min(nz, zc0 + cz);
 
 	const int tid = threadIdx.x, lane = tid & 63, yq = tid >> 6;
-	const bool vec_ok = (nx & 3) == 0;
 	const bool edge_x = (x0 < HW) || (x0 + C::TX - 1 > nx - 2 - HW);
 	const bool edge_y = (y0 < HW) || (y0 + C::TY - 1 > ny - 2 - HW);
-	const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+	const bool need_row0 = (y0 + C::TY - 1 > ny - 2 - HW);  // tile holds right-boundary y outputs (they reach y-hw-1)
+	const int sy = nx, sz = nx * ny;                         // levels are < 2^31 voxels (checked at create)
+	const bool full_tile = (x0 + C::TX <= nx) && (y0 + C::TY <= ny);  // every output of the tile is inside the volume
+
+	// per-thread load items (independent of the plane): plane-relative global offset or -1, LDS offset
+	int ld_goff[C::NLD], ld_lds[C::NLD];
+#pragma unroll
+	for (int i = 0; i < C::NLD; i++) {
+		const int item = tid + i * C::NT;
+		const int r = item / C::W4, c4 = item - r * C::W4;
+		const int gy = y0 - HW - 1 + r, gx = x0 - C::HXL + 4 * c4;
+		bool ok = item < C::ROWS * C::W4 && gy >= 0 && gy < ny && (r > 0 || need_row0);
+		if (VEC) ok = ok && gx >= 0 && gx + 3 < nx;
+		ld_goff[i] = ok ? gy * sy + gx : -1;
+		ld_lds[i] = item < C::ROWS * C::W4 ? r * C::PITCH + 4 * c4 : -1;
+	}
+	float4 pf[C::NLD];  // prefetched tile pieces of the NEXT plane
+#pragma unroll
+	for (int i = 0; i < C::NLD; i++) pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+	auto issue_plane_loads = [&](int q) {
+		// no branch around the loads (a join would make the compiler drain them): planes outside [0, nz) are
+		// clamped to a valid plane and simply never used
+		if (!VEC && (q < 0 || q >= nz)) return;
+		const float *plane = src + (size_t)sz * (size_t)min(max(q, 0), nz - 1);
+#pragma unroll
+		for (int i = 0; i < C::NLD; i++) {
+			float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (VEC) {
+				const int g = ld_goff[i];
+				// unconditional and always in bounds; pieces outside the volume are zeroed when the registers are
+				// written to LDS one step later (a select here would make the compiler wait for the load right away)
+				val = *reinterpret_cast<const float4 *>(plane + (g < 0 ? 0 : g));
+			} else if (ld_goff[i] >= 0) {
+				{
+					const int item = tid + i * C::NT;
+					const int r = item / C::W4, c4 = item - r * C::W4;
+					const int gx = x0 - C::HXL + 4 * c4;
+					const float *row = plane + (ld_goff[i] - gx);
+					if (gx >= 0 && gx < nx) val.x = row[gx];
+					if (gx + 1 >= 0 && gx + 1 < nx) val.y = row[gx + 1];
+					if (gx + 2 >= 0 && gx + 2 < nx) val.z = row[gx + 2];
+					if (gx + 3 >= 0 && gx + 3 < nx) val.w = row[gx + 3];
+				}
+			}
+			pf[i] = val;
+		}
+	};
 
 	float ring[4][C::RING];
 #pragma unroll
@@ -94,80 +184,126 @@ __global__ void __launch_bounds__(256, (HW <= 4 ? 4 : (HW <= 6 ? 3 : 2))) k_fuse
 		for (int k = 0; k < C::RING; k++) ring[j][k] = 0.0f;
 	float mx = 0.0f;
 
+	const int gx_out = x0 + lane;
+	const int out_off = gx_out + (y0 + yq * 4) * sy;  // plane-relative offset of this thread's first output
+	const bool col_ok = gx_out < nx;
+
 	const int q_begin = zc0 - HW - 1, q_end = zc1 - 1 + HW;  // inclusive
+	issue_plane_loads(q_begin);
 	for (int q = q_begin; q <= q_end; q++) {
+		const bool have_plane = (q >= 0 && q < nz);
+		const int p = q - HW;
+		const bool emit = (p >= zc0 && p < zc1);
+		// ---------------- regs -> LDS tile of plane q; then prefetch plane q+1 and the DoG centres of plane p ----------------
+		if (have_plane) {
+#pragma unroll
+			for (int i = 0; i < C::NLD; i++)
+				if (ld_lds[i] >= 0) {
+					float4 w4 = pf[i];
+					if (VEC && ld_goff[i] < 0) w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+					*reinterpret_cast<float4 *>(&in_t[ld_lds[i]]) = w4;
+				}
+		}
+		issue_plane_loads(q + 1);
+		float cen[4] = {0.f, 0.f, 0.f, 0.f};
+		if (DOG && full_tile) {
+			// unconditional (plane clamped) so that the loads stay in flight across the x/y phases
+			const float *cp = src + (size_t)sz * (size_t)min(max(p, 0), nz - 1) + out_off;
+#pragma unroll
+			for (int j = 0; j < 4; j++) cen[j] = cp[j * sy];
+		} else if (DOG && emit) {
+			if (col_ok) {
+				const float *cp = src + (size_t)sz * (size_t)p + out_off;
+#pragma unroll
+				for (int j = 0; j < 4; j++)
+					if (y0 + yq * 4 + j < ny) cen[j] = cp[j * sy];
+			}
+		}
 		float v[4] = {0.f, 0.f, 0.f, 0.f};
-		if (q >= 0 && q < nz) {
-			// ---------------- global -> LDS tile (plane q, xy halo) ----------------
-			const float *plane = src + sz * (size_t)q;
-			for (int item = tid; item < C::ROWS * C::W4; item += C::NT) {
-				const int r = item / C::W4, c4 = item - r * C::W4;
-				const int gy = y0 - HW - 1 + r, gx = x0 - C::HXL + 4 * c4;
-				float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-				if (gy >= 0 && gy < ny) {
-					const float *row = plane + sy * (size_t)gy;
-					if (vec_ok && gx >= 0 && gx + 3 < nx) {
-						val = *reinterpret_cast<const float4 *>(row + gx);
+		if (have_plane) {
+			__syncthreads();  // barrier A: tile visible (and every thread is done with the previous xb)
+			if (edge_x) {
+				// x extension columns of the LDS tile (see header), every row of the tile
+				const int xend = nx - 1;
+				const int nleft = (x0 < HW) ? HW : 0;                       // x0 < HW  =>  x0 == 0
+				const int nright = (x0 + C::TX - 1 > nx - 2 - HW) ? (HW + 1) : 0;
+				const int ne = nleft + nright;
+				for (int item = tid; item < C::ROWS * ne; item += C::NT) {
+					const int r = item / ne, e = item - r * ne;
+					float *trow = &in_t[r * C::PITCH] + (C::HXL - x0);  // trow[gx] addresses volume column gx
+					if (e < nleft) {
+						const int k = e + 1;
+						trow[-k] = trow[k];
 					} else {
-						if (gx >= 0 && gx < nx) val.x = row[gx];
-						if (gx + 1 >= 0 && gx + 1 < nx) val.y = row[gx + 1];
-						if (gx + 2 >= 0 && gx + 2 < nx) val.z = row[gx + 2];
-						if (gx + 3 >= 0 && gx + 3 < nx) val.w = row[gx + 3];
+						const int k = e - nleft, m = xend - k;
+						if (xend + k - x0 < C::TX + C::HXH) {
+							const float f = ef.f[0][k];
+							const float a = trow[m - 1], b = trow[m];
+							trow[xend + k] = (1.0f - f) * a + f * b;
+						}
 					}
 				}
-				*reinterpret_cast<float4 *>(&in_t[r * C::PITCH + 4 * c4]) = val;
-			}
-			__syncthreads();
-			// ---------------- x-blur: in_t -> xb ----------------
-			for (int item = tid; item < C::ROWS * 8; item += C::NT) {
-				const int r = item >> 3, seg = item & 7;
-				const int gy = y0 - HW - 1 + r;
-				if (gy < 0 || gy >= ny) continue;
-				const float *trow = &in_t[r * C::PITCH];
-				float win[C::WN4 * 4];
-#pragma unroll
-				for (int k = 0; k < C::WN4; k++) {
-					const float4 f = *reinterpret_cast<const float4 *>(trow + C::WSTART + seg * 8 + 4 * k);
-					win[4 * k] = f.x; win[4 * k + 1] = f.y; win[4 * k + 2] = f.z; win[4 * k + 3] = f.w;
-				}
-				float o[8];
-#pragma unroll
-				for (int j = 0; j < 8; j++) {
-					float acc = 0.0f;
-#pragma unroll
-					for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * win[C::WOFF + j + HW - d];
-					o[j] = acc;
-				}
-				float4 *xo = reinterpret_cast<float4 *>(&xb[r * C::TX + seg * 8]);
-				xo[0] = make_float4(o[0], o[1], o[2], o[3]);
-				xo[1] = make_float4(o[4], o[5], o[6], o[7]);
-			}
-			if (edge_x) {
-				// slow path: boundary columns of this tile are recomputed with the reference's mirror / lerp rule
 				__syncthreads();
-				const int nleft = (x0 < HW) ? min(HW, nx) : 0;  // x0 < HW  =>  x0 == 0
-				const int rstart = max(max(x0, nx - 1 - HW), nleft);
-				const int rend = min(x0 + C::TX - 1, nx - 1);
-				const int nb = nleft + max(0, rend - rstart + 1);
-				for (int item = tid; item < C::ROWS * nb; item += C::NT) {
-					const int r = item / nb, ci = item - r * nb;
-					const int gy = y0 - HW - 1 + r;
-					if (gy < 0 || gy >= ny) continue;
-					const int gx = ci < nleft ? ci : rstart + (ci - nleft);
+			}
+			// ---------------- x-blur: in_t rows 1..ROWS-1 -> xb (exactly one item per thread) ----------------
+			{
+				const int r = 1 + (tid >> 3), seg = tid & 7;
+				const int gy = y0 - HW - 1 + r;
+				if (r < C::ROWS && gy >= 0 && gy < ny) {
 					const float *trow = &in_t[r * C::PITCH];
+					float win[C::WN4 * 4];
+#pragma unroll
+					for (int k = 0; k < C::WN4; k++) {
+						const float4 f = *reinterpret_cast<const float4 *>(trow + C::WSTART + seg * 8 + 4 * k);
+						win[4 * k] = f.x; win[4 * k + 1] = f.y; win[4 * k + 2] = f.z; win[4 * k + 3] = f.w;
+					}
+					float o[8];
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						float acc = 0.0f;
+#pragma unroll
+						for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * win[C::WOFF + j + HW - d];
+						o[j] = acc;
+					}
+					float4 *xo = reinterpret_cast<float4 *>(&xb[r * C::TX + seg * 8]);
+					xo[0] = make_float4(o[0], o[1], o[2], o[3]);
+					xo[1] = make_float4(o[4], o[5], o[6], o[7]);
+				}
+			}
+			if (need_row0) {
+				// bottom tiles only: the extra low halo row (one wave's worth of work, plain loop)
+				const int gy = y0 - HW - 1;
+				if (gy >= 0 && tid < C::TX) {
+					const float *trow = &in_t[0];
 					float acc = 0.0f;
 #pragma unroll 1
-					for (int d = -HW; d <= HW; d++) {
-						int lo, hi;
-						float frac;
-						boundary_src(gx, d, nx, lo, hi, frac);
-						const float a = trow[lo - (x0 - C::HXL)], b = trow[hi - (x0 - C::HXL)];
-						acc = acc + t.w[d + HW] * ((1.0f - frac) * a + frac * b);
-					}
-					xb[r * C::TX + (gx - x0)] = acc;
+					for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * trow[C::HXL + tid - d];
+					xb[tid] = acc;
 				}
 			}
-			__syncthreads();
+			if (edge_y) {
+				// y extension rows of xb (see header): mirror above row 0, lerp rows from dim_end on
+				__syncthreads();
+				const int yend = ny - 1;
+				const int ntop = (y0 < HW) ? HW : 0;                       // y0 < HW  =>  y0 == 0
+				const int nbot = need_row0 ? (HW + 1) : 0;
+				for (int item = tid; item < (ntop + nbot) * C::TX; item += C::NT) {
+					const int e = item >> 6, xx = item & 63;
+					if (e < ntop) {
+						const int k = e + 1;                                // E[-k] = row k
+						xb[(HW + 1 - k - y0) * C::TX + xx] = xb[(HW + 1 + k - y0) * C::TX + xx];
+					} else {
+						const int k = e - ntop, m = yend - k;               // E[yend+k] = (1-f)*row[m-1] + f*row[m]
+						const int rd = yend + k - (y0 - HW - 1);
+						if (rd < C::ROWS) {
+							const float f = ef.f[1][k];
+							const float a = xb[(m - 1 - (y0 - HW - 1)) * C::TX + xx], b = xb[(m - (y0 - HW - 1)) * C::TX + xx];
+							xb[rd * C::TX + xx] = (1.0f - f) * a + f * b;
+						}
+					}
+				}
+			}
+			__syncthreads();  // barrier B: xb visible, in_t free for the next plane
 			// ---------------- y-blur: xb -> registers (4 consecutive y of column x0+lane) ----------------
 			{
 				float yw[4 + 2 * HW];
@@ -180,55 +316,29 @@ __global__ void __launch_bounds__(256, (HW <= 4 ? 4 : (HW <= 6 ? 3 : 2))) k_fuse
 					for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * yw[j + HW - d];
 					v[j] = acc;
 				}
-				if (edge_y) {
-#pragma unroll
-					for (int j = 0; j < 4; j++) {
-						const int gy = y0 + yq * 4 + j;
-						if ((gy < HW || gy > ny - 2 - HW) && gy < ny) {
-							float acc = 0.0f;
-#pragma unroll 1
-							for (int d = -HW; d <= HW; d++) {
-								int lo, hi;
-								float frac;
-								boundary_src(gy, d, ny, lo, hi, frac);
-								const float a = xb[(lo - (y0 - HW - 1)) * C::TX + lane], b = xb[(hi - (y0 - HW - 1)) * C::TX + lane];
-								acc = acc + t.w[d + HW] * ((1.0f - frac) * a + frac * b);
-							}
-							v[j] = acc;
-						}
-					}
-				}
 			}
 		}
-		// ---------------- ring: slot k holds plane q - (RING-1) + k ----------------
-#pragma unroll
-		for (int j = 0; j < 4; j++) {
-#pragma unroll
-			for (int k = 0; k < C::RING - 1; k++) ring[j][k] = ring[j][k + 1];
-			ring[j][C::RING - 1] = v[j];
+		// ---------------- ring insert (slot q mod RING) + z-blur of plane p = q - HW ----------------
+		const bool z_interior = emit && (p >= HW) && (p <= nz - 2 - HW);
+		float out[4] = {0.f, 0.f, 0.f, 0.f};
+		const int rot = ring_slot<C::RING>(q);
+#define S3D_CASE(K) case K: if (K < C::RING) zblur_static<HW, (K < C::RING ? K : 0)>(ring, v, t, z_interior, out); break;
+		switch (rot) {
+			S3D_CASE(0) S3D_CASE(1) S3D_CASE(2) S3D_CASE(3) S3D_CASE(4) S3D_CASE(5) S3D_CASE(6) S3D_CASE(7) S3D_CASE(8)
+			S3D_CASE(9) S3D_CASE(10) S3D_CASE(11) S3D_CASE(12) S3D_CASE(13) S3D_CASE(14) S3D_CASE(15) S3D_CASE(16) S3D_CASE(17)
+		default: break;
 		}
-		// ---------------- z-blur of plane p = q - HW ----------------
-		const int p = q - HW;
-		if (p >= zc0 && p < zc1) {
-			const bool z_interior = (p >= HW) && (p <= nz - 2 - HW);
-			float out[4];
-			if (z_interior) {
-#pragma unroll
-				for (int j = 0; j < 4; j++) {
-					float acc = 0.0f;
-#pragma unroll
-					for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * ring[j][HW + 1 - d];
-					out[j] = acc;
-				}
-			} else {
-				// wave-uniform tap sources; plane s sits in slot s - (p - HW - 1)
+#undef S3D_CASE
+		if (emit) {
+			if (!z_interior) {
+				// wave-uniform tap sources; plane s sits in slot s mod RING
 				float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
 				for (int d = -HW; d <= HW; d++) {
 					int lo, hi;
 					float frac;
 					boundary_src(p, d, nz, lo, hi, frac);
-					const int slo = lo - (p - HW - 1), shi = hi - (p - HW - 1);
+					const int slo = ring_slot<C::RING>(lo), shi = ring_slot<C::RING>(hi);
 					const float tap = t.w[d + HW];
 #pragma unroll
 					for (int j = 0; j < 4; j++) {
@@ -244,28 +354,37 @@ __global__ void __launch_bounds__(256, (HW <= 4 ? 4 : (HW <= 6 ? 3 : 2))) k_fuse
 #pragma unroll
 				for (int j = 0; j < 4; j++) out[j] = acc[j];
 			}
-			const int gx = x0 + lane;
-			if (gx < nx) {
+			if (full_tile) {
+				const size_t base = (size_t)sz * (size_t)p + (size_t)out_off;
 #pragma unroll
 				for (int j = 0; j < 4; j++) {
-					const int gy = y0 + yq * 4 + j;
-					if (gy < ny) {
-						const size_t idx = (size_t)gx + sy * (size_t)gy + sz * (size_t)p;
-						dst[idx] = out[j];
+					dst[base + (size_t)(j * sy)] = out[j];
+					if (DOG) {
+						const float dg = (out[j] - cen[j]) * (-1.0f);
+						dog[base + (size_t)(j * sy)] = dg;
+						mx = absmax_step_f(mx, dg);
+					}
+				}
+			} else if (col_ok) {
+				const size_t base = (size_t)sz * (size_t)p + (size_t)out_off;
+#pragma unroll
+				for (int j = 0; j < 4; j++) {
+					if (y0 + yq * 4 + j < ny) {
+						dst[base + (size_t)(j * sy)] = out[j];
 						if (DOG) {
-							const float dg = (out[j] - src[idx]) * (-1.0f);
-							dog[idx] = dg;
+							const float dg = (out[j] - cen[j]) * (-1.0f);
+							dog[base + (size_t)(j * sy)] = dg;
 							mx = absmax_step_f(mx, dg);
 						}
 					}
 				}
 			}
 		}
-		__syncthreads();  // xb / in_t are rewritten by the next plane
 	}
 	if (DOG) {
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+		__syncthreads();
 		if (lane == 0) s_red[yq] = mx;
 		__syncthreads();
 		if (tid == 0) {
@@ -275,28 +394,69 @@ __global__ void __launch_bounds__(256, (HW <= 4 ? 4 : (HW <= 6 ? 3 : 2))) k_fuse
 	}
 }
 
+template <int HW, bool DOG>
+__global__ void __launch_bounds__(256, FusedCfg<HW>::OCC) k_fused_level(const float *__restrict__ src, float *__restrict__ dst,
+                                                                       float *__restrict__ dog, unsigned *__restrict__ dogmax,
+                                                                       int nx, int ny, int nz, Taps t, EdgeFrac ef, int ntx, int nty,
+                                                                       int cz) {
+	using C = FusedCfg<HW>;
+	__shared__ __attribute__((aligned(16))) float in_t[C::ROWS * C::PITCH];
+	__shared__ __attribute__((aligned(16))) float xb[C::ROWS * C::TX];
+	__shared__ float s_red[4];
+	if ((nx & 3) == 0) fused_level_body<HW, DOG, true>(src, dst, dog, dogmax, nx, ny, nz, t, ef, ntx, nty, cz, in_t, xb, s_red);
+	else fused_level_body<HW, DOG, false>(src, dst, dog, dogmax, nx, ny, nz, t, ef, ntx, nty, cz, in_t, xb, s_red);
+}
+
+// fp32 fractions of the reference's right-boundary rule for an axis of length n (see file header):
+// position dim_end+k maps to c' = 2*dim_end - c - 0.1f, lo = (int)c', frac = c' - lo   (Src/cSIFT3D.cc:751-760)
+static void edge_fractions(int n, int hw, float *f) {
+	const int dim_end = n - 1;
+	for (int k = 0; k <= hw; k++) {
+		const float c = (float)(dim_end + k);
+		const float cc = (float)(2 * dim_end) - c - 0.1f;
+		const int lo = (int)cc;
+		f[k] = cc - (float)lo;
+	}
+}
+
 template <int HW>
 static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, int nz, const Taps &t,
                       hipStream_t st) {
 	using C = FusedCfg<HW>;
 	const int ntx = (nx + C::TX - 1) / C::TX, nty = (ny + C::TY - 1) / C::TY;
 	const int ntiles = ntx * nty;
-	// enough workgroups to fill 256 CUs a few times over, but z chunks long enough to amortise the 2*HW+1 ramp
-	int nchunks = (1024 + ntiles - 1) / ntiles;
-	const int min_cz = 4 * (2 * HW + 1);
-	int cz = (nz + nchunks - 1) / nchunks;
-	if (cz < min_cz) cz = min_cz;
-	if (cz > nz) cz = nz;
-	nchunks = (nz + cz - 1) / cz;
+	// z chunking: pick the chunk count that minimises (residency rounds) x (planes marched per workgroup);
+	// every chunk pays a ramp of 2*HW+1 planes, every partially filled round leaves CUs idle
+	const int slots = 256 * C::OCC;
+	const int ramp = 2 * HW + 1;
+	int best_cz = nz;
+	double best_cost = 1e300;
+	for (int n = 1; n <= nz && n <= 64; n++) {
+		const int czn = (nz + n - 1) / n;
+		const int nch = (nz + czn - 1) / czn;
+		const long wgs = (long)ntiles * nch;
+		const long rounds = (wgs + slots - 1) / slots;
+		const double cost = (double)rounds * (czn + ramp);
+		if (cost < best_cost - 1e-9) { best_cost = cost; best_cz = czn; }
+	}
+	const int cz = best_cz;
+	const int nchunks = (nz + cz - 1) / cz;
+	EdgeFrac ef;
+	memset(&ef, 0, sizeof(ef));
+	edge_fractions(nx, HW, ef.f[0]);
+	edge_fractions(ny, HW, ef.f[1]);
+	edge_fractions(nz, HW, ef.f[2]);
 	dim3 grid((unsigned)(ntiles * nchunks)), block(256);
-	if (dog) hipLaunchKernelGGL((k_fused_level<HW, true>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, nz, t, ntx, nty, nchunks, cz);
-	else hipLaunchKernelGGL((k_fused_level<HW, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, nz, t, ntx, nty, nchunks, cz);
+	if (dog) hipLaunchKernelGGL((k_fused_level<HW, true>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, nz, t, ef, ntx, nty, cz);
+	else hipLaunchKernelGGL((k_fused_level<HW, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, nz, t, ef, ntx, nty, cz);
 }
 
 // returns false when no fused instantiation exists for this half width (caller uses the generic
 // separable kernels of kernels_pyramid.hip instead -- still the HIP path)
 bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, int nz, const Taps &t,
                         hipStream_t st) {
+	// the halo-extension form of the boundary rule needs n >= 2*hw+2 along x and y (see header)
+	if (nx < 2 * t.hw + 2 || ny < 2 * t.hw + 2) return false;
 	switch (t.hw) {
 	case 2: launch_hw<2>(src, dst, dog, dogmax, nx, ny, nz, t, st); return true;
 	case 3: launch_hw<3>(src, dst, dog, dogmax, nx, ny, nz, t, st); return true;

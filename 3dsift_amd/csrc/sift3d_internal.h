@@ -28,6 +28,11 @@ struct Taps {
 	float w[kMaxTaps];
 };
 
+// fp32 lerp fractions of the right-boundary rule per axis (x, y, z), see kernels_fused.hip
+struct EdgeFrac {
+	float f[3][kMaxHW + 1];
+};
+
 struct Level {
 	float *d = nullptr;
 	int nx = 0, ny = 0, nz = 0;
