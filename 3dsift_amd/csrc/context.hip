@@ -145,7 +145,12 @@ struct sift3d_ctx {
 	size_t arena_floats = 0;
 	Level in;
 	std::vector<Level> gss, dog;
-	float *tmpA = nullptr, *tmpB = nullptr;  // separable-pass scratch, V0 floats each
+	std::vector<float *> tmpA, tmpB;        // per-octave scratch of the generic separable passes (octaves may overlap)
+	// octave o >= 1 only depends on G[o-1][num_kp_levels]: each octave chain runs on its own stream so the small
+	// octaves fill the machine next to the tail of the big ones (ostream[0] == stream)
+	std::vector<hipStream_t> ostream;
+	std::vector<hipEvent_t> ev_seed, ev_done;
+	hipEvent_t ev_fork = nullptr;
 	unsigned *d_words = nullptr;  // [0] input max bits, [1..] per-DoG-level max bits, then counters
 	unsigned *d_inmax = nullptr, *d_dogmax = nullptr, *d_total = nullptr, *d_nkp = nullptr;
 	DetectBufs det{};
@@ -241,6 +246,10 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	hipFree(c->det.masks); hipFree(c->det.block_counts); hipFree(c->det.block_offsets);
 	hipFree(c->d_levels); hipFree(c->d_luts); hipFree(c->d_lutpool);
 	for (auto &e : c->ev) if (e) hipEventDestroy(e);
+	for (auto &e : c->ev_seed) if (e) hipEventDestroy(e);
+	for (auto &e : c->ev_done) if (e) hipEventDestroy(e);
+	if (c->ev_fork) hipEventDestroy(c->ev_fork);
+	for (size_t o = 1; o < c->ostream.size(); o++) if (c->ostream[o]) hipStreamDestroy(c->ostream[o]);
 	if (c->stream) hipStreamDestroy(c->stream);
 	delete c;
 	return SIFT3D_OK;
@@ -339,19 +348,35 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 #define CHECKED(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); sift3d_destroy(c); return SIFT3D_ERR_HIP; } } while (0)
 	CHECKED(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
 	for (auto &e : c->ev) CHECKED(hipEventCreate(&e));
+	CHECKED(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+	c->ostream.assign((size_t)std::max(1, c->noct), nullptr);
+	c->ev_seed.assign(c->ostream.size(), nullptr);
+	c->ev_done.assign(c->ostream.size(), nullptr);
+	c->ostream[0] = c->stream;
+	for (size_t o = 0; o < c->ostream.size(); o++) {
+		if (o > 0) CHECKED(hipStreamCreateWithFlags(&c->ostream[o], hipStreamNonBlocking));
+		CHECKED(hipEventCreateWithFlags(&c->ev_seed[o], hipEventDisableTiming));
+		CHECKED(hipEventCreateWithFlags(&c->ev_done[o], hipEventDisableTiming));
+	}
 
-	// ---- arena: input | scratch A | scratch B | GSS levels | DoG levels (each 256-B aligned) ----
+	// ---- arena: input | per-octave scratch A,B | GSS levels | DoG levels (each 256-B aligned) ----
 	const size_t V0 = (size_t)nx * ny * nz;
 	auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
-	size_t total = al(V0) * 3;
+	size_t total = al(V0);
+	for (int o = 0; o < c->noct; o++) total += 2 * al(c->gss[(size_t)o * c->ng].n());
 	for (auto &L : c->gss) total += al(L.n());
 	for (auto &L : c->dog) total += al(L.n());
 	c->arena_floats = total;
 	CHECKED(hipMalloc(&c->arena, sizeof(float) * total));
 	float *p = c->arena;
 	c->in.d = p; c->in.nx = nx; c->in.ny = ny; c->in.nz = nz; c->in.unit = 1.f; c->in.scale = 1.f; p += al(V0);
-	c->tmpA = p; p += al(V0);
-	c->tmpB = p; p += al(V0);
+	c->tmpA.assign((size_t)std::max(1, c->noct), nullptr);
+	c->tmpB.assign((size_t)std::max(1, c->noct), nullptr);
+	for (int o = 0; o < c->noct; o++) {
+		const size_t vo = al(c->gss[(size_t)o * c->ng].n());
+		c->tmpA[o] = p; p += vo;
+		c->tmpB[o] = p; p += vo;
+	}
 	for (auto &L : c->gss) { L.d = p; p += al(L.n()); }
 	for (auto &L : c->dog) { L.d = p; p += al(L.n()); }
 
@@ -402,15 +427,15 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 }
 
 // GaussianSmooth_3D (Src/cSIFT3D.cc:535-622) on device buffers: X -> Y -> Z(+DoG)
-static void smooth_level(sift3d_ctx *c, const float *src, const Level &dst, const Taps &t, const float *prev, float *dog,
+static void smooth_level(sift3d_ctx *c, int o, const float *src, const Level &dst, const Taps &t, const float *prev, float *dog,
                          unsigned *dogmax) {
+	hipStream_t st = c->ostream[o];
 	// hot path: one fused pass (x, y, z blur + DoG + abs-max); prev == src for every DoG-producing level
-	if (c->use_fused && (prev == nullptr || prev == src) &&
-	    launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.nz, t, c->stream))
+	if (c->use_fused && (prev == nullptr || prev == src) && launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.nz, t, st))
 		return;
-	launch_conv_axis(0, src, c->tmpA, dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, c->stream);
-	launch_conv_axis(1, c->tmpA, c->tmpB, dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, c->stream);
-	launch_conv_axis(2, c->tmpB, dst.d, dst.nx, dst.ny, dst.nz, t, prev, dog, dogmax, c->stream);
+	launch_conv_axis(0, src, c->tmpA[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
+	launch_conv_axis(1, c->tmpA[o], c->tmpB[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
+	launch_conv_axis(2, c->tmpB[o], dst.d, dst.nx, dst.ny, dst.nz, t, prev, dog, dogmax, st);
 }
 
 static int run_impl(sift3d_ctx *c, int upto) {
@@ -423,20 +448,32 @@ static int run_impl(sift3d_ctx *c, int upto) {
 		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(std::max(1, c->noct * c->nd) + 4), st));
 		S3D_HIP(hipEventRecord(c->ev[0], st));
 		// ---- Build_Gaussian_Scale_Space (Src/cSIFT3D.cc:268-319) with the DoG (346-360) fused into the z pass ----
-		for (int o = 0; o < c->noct; o++)
+		// fork: every octave stream starts after the main stream reached this point; octave o is seeded by
+		// G[o-1][num_kp_levels] (DownSample_3D), everything else of octave o-1 overlaps with octave o
+		S3D_HIP(hipEventRecord(c->ev_fork, st));
+		for (int o = 0; o < c->noct; o++) {
+			hipStream_t so = c->ostream[o];
+			if (o > 0) {
+				S3D_HIP(hipStreamWaitEvent(so, c->ev_fork, 0));
+				S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[o - 1], 0));
+			}
 			for (int i = 0; i < c->ng; i++) {
 				const Level &L = c->gss[(size_t)o * c->ng + i];
 				if (o == 0 && i == 0) {
-					smooth_level(c, c->in.d, L, c->base_taps, nullptr, nullptr, nullptr);
+					smooth_level(c, o, c->in.d, L, c->base_taps, nullptr, nullptr, nullptr);
 				} else if (i == 0) {
 					const Level &P = c->gss[(size_t)(o - 1) * c->ng + c->p.num_kp_levels];
-					launch_downsample(P.d, P.nx, P.ny, L.d, L.nx, L.ny, L.nz, st);
+					launch_downsample(P.d, P.nx, P.ny, L.d, L.nx, L.ny, L.nz, so);
 				} else {
 					const Level &P = c->gss[(size_t)o * c->ng + i - 1];
 					const Level &D = c->dog[(size_t)o * c->nd + i - 1];
-					smooth_level(c, P.d, L, c->taps[i], P.d, D.d, c->d_dogmax + (size_t)o * c->nd + i - 1);
+					smooth_level(c, o, P.d, L, c->taps[i], P.d, D.d, c->d_dogmax + (size_t)o * c->nd + i - 1);
 				}
+				if (i == c->p.num_kp_levels) S3D_HIP(hipEventRecord(c->ev_seed[o], so));
 			}
+			if (o > 0) S3D_HIP(hipEventRecord(c->ev_done[o], so));
+		}
+		for (int o = 1; o < c->noct; o++) S3D_HIP(hipStreamWaitEvent(st, c->ev_done[o], 0));  // join
 		S3D_HIP(hipEventRecord(c->ev[1], st));
 		S3D_HIP(hipEventRecord(c->ev[2], st));  // DoG is fused: zero-length stage
 		// ---- Detect_KeyPoints (Src/cSIFT3D.cc:362-425) ----

@@ -19,9 +19,15 @@
 //     the reference's exact Moller-Trumbore arithmetic for that face and accepted only when all three
 //     barycentrics clear a 1e-4 margin (then no other face can pass the reference's -1.19e-6 test, so
 //     "first passing face in mesh order" is this face); otherwise the literal 20-face ordered scan runs
-//   * consecutive z voxels of a column mostly hit the same 8 cells x 3 vertices: their 24 products are
-//     accumulated in registers and flushed to the LDS histogram (ds_add_f32) only when the (cell, face)
-//     key changes -> ~10x fewer LDS atomics, no same-address serialisation inside a wave
+//   * the 24 products of a voxel go straight to an LDS histogram kept in 64-BIT FIXED POINT (2^-40 units) and
+//     are added with ds_add_u64: on gfx950 an LDS float atomic (ds_add_f32) costs ~190 cycles per wave
+//     instruction, the integer forms 4-6 (scripts/microbench/lds_atomics.hip), and integer sums are order
+//     independent, so descriptors are bitwise reproducible run to run.  The fp32 product mag*w*bary is formed
+//     exactly like the reference, then converted with the 1.5*2^52 magic-add (one cvt, one f64 fma, one 64-bit
+//     subtract).  R replicas (replica = lane & (R-1), bin-major) keep neighbouring lanes that hit the same
+//     bin on different addresses; they are summed once per keypoint
+//   * the four in-plane neighbour loads of the next z step are issued unconditionally one step ahead
+//     (software pipelining; a load behind the activity branch would be waited for at the join)
 // Every per-voxel contribution is bit-identical to the reference; only the ORDER of the fp32
 // histogram additions differs, i.e. ~1e-7 relative -- tolerance 1e-4 RMS (BASELINE.json).
 #include <float.h>
@@ -46,8 +52,22 @@ __device__ __forceinline__ void win_bounds_d(float c, float rad, float u, int n,
 }
 
 constexpr float kBaryEps = (float)(FLT_EPSILON * 1E1);  // Src/cSIFT3D.cc:23
+
+// fp32 -> 64-bit fixed point (2^-40 units, round to nearest) via the 1.5*2^52 magic constant: for |v*2^40| < 2^51
+// the integer sits in the low mantissa bits and the bit patterns are linear in it (two's complement wrap included)
+constexpr double kFixedScale = 1099511627776.0;           // 2^40
+constexpr double kFixedInv = 1.0 / 1099511627776.0;
+constexpr double kFixedMagic = 6755399441055744.0;        // 1.5 * 2^52
+__device__ __forceinline__ unsigned long long to_fixed(float v) {
+	const double d = fma((double)v, kFixedScale, kFixedMagic);
+	return (unsigned long long)__double_as_longlong(d) - 0x4338000000000000ull;
+}
 constexpr float kFastMargin = 1.0e-4f;
 constexpr int kFaceStride = 16;  // floats per face in the LDS table
+#ifndef S3D_DESC_REP
+#define S3D_DESC_REP 4
+#endif
+constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = bin*kRep + (lane & (kRep-1)))
 
 // reference Moller-Trumbore for ONE face whose constants sit at F[0..15]:
 // e1(0..2) e2(3..5) t(6..8) q(9..11) qe2(12); returns pass/fail exactly like Check_intersect_faces' body
@@ -57,7 +77,9 @@ __device__ __forceinline__ bool face_test(const float *F, float gx, float gy, fl
 	const float pz = gx * F[4] - gy * F[3];
 	const float det = F[0] * px + F[1] * py + F[2] * pz;
 	if (fabsf(det) < kBaryEps) return false;
-	const float det_inv = (float)(1.0 / (double)det);
+	// reference: (float)(1.0 / (double)det).  A correctly rounded fp32 division gives the same value: double
+	// rounding is innocuous for division when the wide format has >= 2p+2 = 50 bits (binary64 has 53)
+	const float det_inv = __fdiv_rn(1.0f, det);
 	b1 = det_inv * (px * F[6] + py * F[7] + pz * F[8]);
 	b2 = det_inv * (gx * F[9] + gy * F[10] + gz * F[11]);
 	b0 = 1.0f - b1 - b2;
@@ -75,7 +97,7 @@ __device__ __forceinline__ int intersect_scan(float gx, float gy, float gz, floa
 		const float pz = gx * F.e2[1] - gy * F.e2[0];
 		const float det = F.e1[0] * px + F.e1[1] * py + F.e1[2] * pz;
 		bool ok = found < 0 && !(fabsf(det) < kBaryEps);
-		const float det_inv = (float)(1.0 / (double)det);
+		const float det_inv = __fdiv_rn(1.0f, det);  // == (float)(1.0 / (double)det), see face_test
 		const float y = det_inv * (px * F.t[0] + py * F.t[1] + pz * F.t[2]);
 		const float z = det_inv * (gx * F.q[0] + gy * F.q[1] + gz * F.q[2]);
 		const float x = 1.0f - y - z;
@@ -90,8 +112,10 @@ __device__ __forceinline__ int intersect_scan(float gx, float gy, float gz, floa
 __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
                                                   const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap) {
-	__shared__ float hist[kDesc];
+	__shared__ unsigned long long hist[kDesc * kRep];  // [bin][replica], two's-complement fixed point, 2^-40 units
 	__shared__ float s_lut[kMaxDescLut];
+	__shared__ float s_predn[12];
+	__shared__ int s_predf[32];
 	__shared__ __attribute__((aligned(16))) float s_face[kFaces * kFaceStride];
 	__shared__ int s_fidx[kFaces * 4];
 	__shared__ float red[4];
@@ -111,6 +135,8 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		s_face[i] = v;
 	}
 	for (int i = tid; i < kFaces * 4; i += 256) s_fidx[i] = (i & 3) < 3 ? c_faces[i >> 2].idx[i & 3] : 0;
+	if (tid < 12) s_predn[tid] = c_pred.n[tid / 3][tid % 3];
+	if (tid < 32) s_predf[tid] = c_pred.face[tid];
 	int cur_lut = -1;
 
 	for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
@@ -143,7 +169,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		const int nin = lut.nin;                 // largest integer squared offset inside the sphere
 
 		__syncthreads();  // previous keypoint finished with hist / s_lut
-		for (int i = tid; i < kDesc; i += 256) hist[i] = 0.0f;
+		for (int i = tid; i < kDesc * kRep; i += 256) hist[i] = 0ull;
 		if (cur_lut != li) {
 			for (int i = tid; i < lut.len && i < kMaxDescLut; i += 256) s_lut[i] = lutpool[lut.off + i];
 			cur_lut = li;
@@ -167,36 +193,33 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 			// partial rotations: (R0*vx + R1*vy) is evaluated first in the reference's left-to-right sums
 			const float px = R0 * vxd + R1 * vyd, py = R3 * vxd + R4 * vyd, pz = R6 * vxd + R7 * vyd;
 			const float *c = L.d + (size_t)x + (size_t)sy * (size_t)y + (size_t)sz * (size_t)za;
+			const int rep = lane & (kRep - 1);
 			float cm = *(c - sz), cc = *c;  // centre column at z-1, z
-
-			float acc[24];
-#pragma unroll
-			for (int i = 0; i < 24; i++) acc[i] = 0.0f;
-			int key = -1;  // (ix+1) | (iy+1)<<3 | (iz+1)<<6 | face<<9
+			float nxm = c[-1], nxp = c[1], nym = *(c - sy), nyp = c[sy];  // in-plane neighbours of plane z (pipelined)
 
 			for (int z = za; z <= zb; z++, c += sz) {
-				const float cp = c[sz];  // z+1
+				// issue next step's loads first: they stay in flight while this voxel is processed
+				const float cp = c[sz];  // z+1 (z <= nz-2 by the window bounds)
+				const float *cn = (z < zb) ? c + sz : c;
+				const float nxm1 = cn[-1], nxp1 = cn[1], nym1 = *(cn - sy), nyp1 = cn[sy];
 				const int dz = z - czi;
 				const float vzd = (float)dz * u;
 				float bx = px + R2 * vzd, by = py + R5 * vzd, bz = pz + R8 * vzd;
 				bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
 				bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
 				bool act = !(bx <= -0.5f || by <= -0.5f || bz <= -0.5f || bx >= 3.5f || by >= 3.5f || bz >= 3.5f);
-				float rx = 0.f, ry = 0.f, rz = 0.f, g2 = 0.f;
-				if (act) {
-					const float w = s_lut[rr + dz * dz];
-					float gx = 0.5f * (c[1] - c[-1]);
-					float gy = 0.5f * (c[sy] - *(c - sy));
-					float gz = 0.5f * (cp - cm);
-					gx = gx * inv_u; gy = gy * inv_u; gz = gz * inv_u;
-					gx = gx * w; gy = gy * w; gz = gz * w;
-					rx = R0 * gx + R1 * gy + R2 * gz;
-					ry = R3 * gx + R4 * gy + R5 * gz;
-					rz = R6 * gx + R7 * gy + R8 * gz;
-					g2 = rx * rx + ry * ry + rz * rz;
-					act = !(g2 < kBaryEps);
-				}
-				cm = cc; cc = cp;
+				const float w = s_lut[rr + dz * dz];
+				float gx = 0.5f * (nxp - nxm);
+				float gy = 0.5f * (nyp - nym);
+				float gz = 0.5f * (cp - cm);
+				gx = gx * inv_u; gy = gy * inv_u; gz = gz * inv_u;
+				gx = gx * w; gy = gy * w; gz = gz * w;
+				const float rx = R0 * gx + R1 * gy + R2 * gz;
+				const float ry = R3 * gx + R4 * gy + R5 * gz;
+				const float rz = R6 * gx + R7 * gy + R8 * gz;
+				const float g2 = rx * rx + ry * ry + rz * rz;
+				act = act && !(g2 < kBaryEps);
+				cm = cc; cc = cp; nxm = nxm1; nxp = nxp1; nym = nym1; nyp = nyp1;
 				if (!__any(act)) continue;
 				float b0 = 0.f, b1 = 0.f, b2 = 0.f;
 				int f = -1;
@@ -204,15 +227,15 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 				if (act) {
 					// predicted face: best of the 4 face normals of the positive octant, then the sign bits
 					const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
-					float best = ax * c_pred.n[0][0] + ay * c_pred.n[0][1] + az * c_pred.n[0][2];
+					float best = ax * s_predn[0] + ay * s_predn[1] + az * s_predn[2];
 					int kb = 0;
 #pragma unroll
 					for (int t = 1; t < 4; t++) {
-						const float s = ax * c_pred.n[t][0] + ay * c_pred.n[t][1] + az * c_pred.n[t][2];
-						if (s > best) { best = s; kb = t; }
+						const float sc = ax * s_predn[3 * t] + ay * s_predn[3 * t + 1] + az * s_predn[3 * t + 2];
+						if (sc > best) { best = sc; kb = t; }
 					}
 					const int bits = (rx < 0.f ? 1 : 0) | (ry < 0.f ? 2 : 0) | (rz < 0.f ? 4 : 0);
-					f = c_pred.face[kb * 8 + bits];
+					f = s_predf[kb * 8 + bits];
 					const bool ok = face_test(&s_face[f * kFaceStride], rx, ry, rz, b0, b1, b2);
 					slow = !(ok && b0 >= kFastMargin && b1 >= kFastMargin && b2 >= kFastMargin);
 				}
@@ -224,48 +247,25 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 					const float mag = __fsqrt_rn(g2);
 					const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
 					const int ix = (int)bx, iy = (int)by, iz = (int)bz;  // truncation toward zero, like the reference
-					const int nk = (ix + 1) | ((iy + 1) << 3) | ((iz + 1) << 6) | (f << 9);
-					if (nk != key) {
-						if (key >= 0) {
-							const int kx = (key & 7) - 1, ky = ((key >> 3) & 7) - 1, kz = ((key >> 6) & 7) - 1, kf = key >> 9;
-							const int i0 = s_fidx[kf * 4], i1 = s_fidx[kf * 4 + 1], i2 = s_fidx[kf * 4 + 2];
-#pragma unroll
-							for (int d = 0; d < 8; d++) {
-								const int ccx = kx + (d >> 2), ccy = ky + ((d >> 1) & 1), ccz = kz + (d & 1);
-								if (ccx < 0 || ccy < 0 || ccz < 0 || ccx >= 4 || ccy >= 4 || ccz >= 4) continue;
-								const int hh = (ccx + ccy * 4 + ccz * 16) * 12;
-								atomicAdd(&hist[hh + i0], acc[3 * d]);
-								atomicAdd(&hist[hh + i1], acc[3 * d + 1]);
-								atomicAdd(&hist[hh + i2], acc[3 * d + 2]);
-							}
-						}
-#pragma unroll
-						for (int i = 0; i < 24; i++) acc[i] = 0.0f;
-						key = nk;
-					}
+					const int i0 = s_fidx[f * 4], i1 = s_fidx[f * 4 + 1], i2 = s_fidx[f * 4 + 2];
+					// trilinear weights: products of three doubles rounded to fp32 (Src/cSIFT3D.cc:1510-1512),
+					// evaluated as (wx*wy)*wz with the four x-y products shared
 					const double dfx = (double)fx, dfy = (double)fy, dfz = (double)fz;
+					const double wx0 = 1.0 - dfx, wy0 = 1.0 - dfy, wz0 = 1.0 - dfz;
+					const double pxy[4] = {wx0 * wy0, wx0 * dfy, dfx * wy0, dfx * dfy};  // index ddx*2 + ddy
+					unsigned long long *hb = &hist[rep];
 #pragma unroll
 					for (int d = 0; d < 8; d++) {
 						const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;  // dx outer, dz inner (Src/cSIFT3D.cc:1492-1496)
-						const float wgt = (float)((ddx ? dfx : (1.0 - dfx)) * (ddy ? dfy : (1.0 - dfy)) * (ddz ? dfz : (1.0 - dfz)));
+						const int ccx = ix + ddx, ccy = iy + ddy, ccz = iz + ddz;
+						if (ccx < 0 || ccy < 0 || ccz < 0 || ccx >= 4 || ccy >= 4 || ccz >= 4) continue;
+						const float wgt = (float)(pxy[ddx * 2 + ddy] * (ddz ? dfz : wz0));
 						const float mw = mag * wgt;
-						acc[3 * d] = acc[3 * d] + mw * b0;
-						acc[3 * d + 1] = acc[3 * d + 1] + mw * b1;
-						acc[3 * d + 2] = acc[3 * d + 2] + mw * b2;
+						const int hh = (ccx + ccy * 4 + ccz * 16) * 12;
+						atomicAdd(hb + (hh + i0) * kRep, to_fixed(mw * b0));
+						atomicAdd(hb + (hh + i1) * kRep, to_fixed(mw * b1));
+						atomicAdd(hb + (hh + i2) * kRep, to_fixed(mw * b2));
 					}
-				}
-			}
-			if (key >= 0) {
-				const int kx = (key & 7) - 1, ky = ((key >> 3) & 7) - 1, kz = ((key >> 6) & 7) - 1, kf = key >> 9;
-				const int i0 = s_fidx[kf * 4], i1 = s_fidx[kf * 4 + 1], i2 = s_fidx[kf * 4 + 2];
-#pragma unroll
-				for (int d = 0; d < 8; d++) {
-					const int ccx = kx + (d >> 2), ccy = ky + ((d >> 1) & 1), ccz = kz + (d & 1);
-					if (ccx < 0 || ccy < 0 || ccz < 0 || ccx >= 4 || ccy >= 4 || ccz >= 4) continue;
-					const int hh = (ccx + ccy * 4 + ccz * 16) * 12;
-					atomicAdd(&hist[hh + i0], acc[3 * d]);
-					atomicAdd(&hist[hh + i1], acc[3 * d + 1]);
-					atomicAdd(&hist[hh + i2], acc[3 * d + 2]);
 				}
 			}
 		}
@@ -273,7 +273,15 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 
 		// normalise -> clamp -> normalise (Src/cSIFT3D.cc:1350-1358, 1639-1656)
 		const float trunc_thresh = (float)(0.2 * 128 / kDesc);
-		float v0 = hist[tid], v1 = hist[tid + 256], v2 = hist[tid + 512];
+		long long a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+		for (int r = 0; r < kRep; r++) {
+			const int rr2 = (r + tid) & (kRep - 1);  // stagger the replica order across lanes
+			a0 += (long long)hist[tid * kRep + rr2];
+			a1 += (long long)hist[(tid + 256) * kRep + rr2];
+			a2 += (long long)hist[(tid + 512) * kRep + rr2];
+		}
+		float v0 = (float)((double)a0 * kFixedInv), v1 = (float)((double)a1 * kFixedInv), v2 = (float)((double)a2 * kFixedInv);
 		for (int pass = 0; pass < 2; pass++) {
 			float s = v0 * v0 + v1 * v1 + v2 * v2;
 #pragma unroll
