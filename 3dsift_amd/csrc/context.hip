@@ -156,6 +156,7 @@ struct sift3d_ctx {
 	DetectBufs det{};
 	size_t det_blocks = 0;
 	DevKp *d_ext = nullptr;
+	int *d_codes = nullptr;
 	unsigned ext_cap = 0, kp_cap = 0;
 	LevelRef *d_levels = nullptr;
 	WinLut *d_luts = nullptr;
@@ -189,6 +190,7 @@ static int set_device(int device) {
 
 static void free_lists(sift3d_ctx *c) {
 	hipFree(c->d_ext); c->d_ext = nullptr;
+	hipFree(c->d_codes); c->d_codes = nullptr;
 	hipFree(c->d_kpout); c->d_kpout = nullptr;
 	hipFree(c->d_desc); c->d_desc = nullptr;
 	hipFree(c->d_xyz); c->d_xyz = nullptr;
@@ -199,6 +201,7 @@ static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
 	c->ext_cap = ext_cap;
 	c->kp_cap = ext_cap;  // every extremum could survive orientation
 	S3D_HIP(hipMalloc(&c->d_ext, sizeof(DevKp) * (size_t)c->ext_cap));
+	S3D_HIP(hipMalloc(&c->d_codes, sizeof(int) * (size_t)c->ext_cap));
 	S3D_HIP(hipMalloc(&c->d_kpout, sizeof(sift3d_keypoint) * (size_t)c->kp_cap));
 	S3D_HIP(hipMalloc(&c->d_desc, sizeof(float) * kDesc * (size_t)c->kp_cap));
 	S3D_HIP(hipMalloc(&c->d_xyz, sizeof(float) * 3 * (size_t)c->kp_cap));
@@ -388,10 +391,15 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 	c->d_total = c->d_words + 1 + std::max(1, c->noct * c->nd);  // [0] extrema total, [1] overflow flag
 	c->d_nkp = c->d_total + 2;
 
-	c->det_blocks = (V0 + 1023) / 1024;
-	CHECKED(hipMalloc(&c->det.masks, sizeof(unsigned long long) * c->det_blocks * 16));
-	CHECKED(hipMalloc(&c->det.block_counts, sizeof(unsigned) * c->det_blocks));
-	CHECKED(hipMalloc(&c->det.block_offsets, sizeof(unsigned) * c->det_blocks));
+	// detection scratch sized for octave 0 (the largest): one ballot word per 64 voxels of a row, one count per 16 rows
+	{
+		const size_t kl = (size_t)c->p.num_kp_levels;
+		const size_t words = kl * (size_t)nz * ny * ((nx + 63) / 64);
+		c->det_blocks = kl * (size_t)nz * ((ny + 15) / 16);
+		CHECKED(hipMalloc(&c->det.masks, sizeof(unsigned long long) * std::max<size_t>(words, 1)));
+		CHECKED(hipMalloc(&c->det.block_counts, sizeof(unsigned) * std::max<size_t>(c->det_blocks, 1)));
+		CHECKED(hipMalloc(&c->det.block_offsets, sizeof(unsigned) * std::max<size_t>(c->det_blocks, 1)));
+	}
 	c->det.total = c->d_total;
 
 	std::vector<LevelRef> lr((size_t)std::max(1, c->noct) * 8, LevelRef{nullptr, 0, 0, 0, 1.f});
@@ -478,19 +486,27 @@ static int run_impl(sift3d_ctx *c, int upto) {
 		S3D_HIP(hipEventRecord(c->ev[2], st));  // DoG is fused: zero-length stage
 		// ---- Detect_KeyPoints (Src/cSIFT3D.cc:362-425) ----
 		if (upto >= 3)
-			for (int o = 0; o < c->noct; o++)
-				for (int i = 1; i < c->nd - 1; i++) {
-					const Level &C = c->dog[(size_t)o * c->nd + i];
-					launch_detect_level(c->dog[(size_t)o * c->nd + i - 1].d, C.d, c->dog[(size_t)o * c->nd + i + 1].d, C.nx, C.ny,
-					                    C.nz, c->d_dogmax + (size_t)o * c->nd + i, c->p.peak_thresh, o, i, C.scale, c->det, c->d_ext,
-					                    c->ext_cap, st);
+			for (int o = 0; o < c->noct; o++) {
+				DetectLevels DL;
+				memset(&DL, 0, sizeof(DL));
+				const int nl = c->nd - 2;  // DoG levels 1 .. nd-2 (Src/cSIFT3D.cc:376)
+				for (int i = 1; i <= nl; i++) {
+					DL.cur[i - 1] = c->dog[(size_t)o * c->nd + i].d;
+					DL.prev[i - 1] = c->dog[(size_t)o * c->nd + i - 1].d;
+					DL.next[i - 1] = c->dog[(size_t)o * c->nd + i + 1].d;
+					DL.absmax_bits[i - 1] = c->d_dogmax + (size_t)o * c->nd + i;
+					DL.level_id[i - 1] = i;
+					DL.scale[i - 1] = c->dog[(size_t)o * c->nd + i].scale;
 				}
+				const Level &C = c->dog[(size_t)o * c->nd + 1];
+				launch_detect_octave(DL, nl, C.nx, C.ny, C.nz, c->p.peak_thresh, o, c->det, c->d_ext, c->ext_cap, st);
+			}
 		S3D_HIP(hipEventRecord(c->ev[3], st));
 		// ---- Assign_Orientation (Src/cSIFT3D.cc:427-482) ----
 		if (upto >= 4) {
-			launch_orient(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
+			launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
 			              c->p.corner_thresh, st);
-			launch_slots(c->d_ext, c->d_total, c->ext_cap, c->d_nkp, st);
+			launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, st);
 		}
 		S3D_HIP(hipEventRecord(c->ev[4], st));
 		// ---- Extract_Description (Src/cSIFT3D.cc:484-502) ----

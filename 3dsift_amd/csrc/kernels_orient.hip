@@ -139,7 +139,7 @@ __device__ int finish_orientation(DevKp &kp, const float T6[6], const float w3[3
 	return 1;
 }
 
-__global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
+__global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__restrict__ codes, const unsigned *__restrict__ d_count, unsigned cap,
                                                 const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                 const float *__restrict__ lutpool, float max_eig, float corner) {
 	const unsigned count = min(d_count[0], cap);
@@ -193,25 +193,26 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, const u
 			DevKp kp = kps[k];
 			kp.code = finish_orientation(kp, T6, w3, max_eig, corner);
 			kps[k] = kp;
+			codes[k] = kp.code;  // dense copy for the compaction scan
 		}
 	}
 }
 
-void launch_orient(DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels, const WinLut *d_luts,
+void launch_orient(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap, const LevelRef *d_levels, const WinLut *d_luts,
                    const float *d_lutpool, float max_eig, float corner, hipStream_t st) {
-	hipLaunchKernelGGL(k_orient, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, max_eig, corner);
+	hipLaunchKernelGGL(k_orient, dim3(256 * 8), dim3(256), 0, st, kps, codes, d_count, cap, d_levels, d_luts, d_lutpool, max_eig, corner);
 }
 
 // order-preserving compaction index: slot = exclusive scan of (code == 1); one workgroup.
-__global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
-                                                unsigned *__restrict__ d_nkp) {
+__global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const int *__restrict__ codes,
+                                                const unsigned *__restrict__ d_count, unsigned cap, unsigned *__restrict__ d_nkp) {
 	__shared__ unsigned s_wave[16];
 	const unsigned count = min(d_count[0], cap);
 	const unsigned t = threadIdx.x;
 	const unsigned chunk = (count + 1023u) / 1024u;
 	const unsigned lo = min(t * chunk, count), hi = min(lo + chunk, count);
 	unsigned sum = 0;
-	for (unsigned i = lo; i < hi; i++) sum += (kps[i].code == 1);
+	for (unsigned i = lo; i < hi; i++) sum += (codes[i] == 1);
 	unsigned v = sum;
 	const int lane = t & 63, wid = t >> 6;
 #pragma unroll
@@ -229,14 +230,14 @@ __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const u
 	const unsigned incl = v + s_wave[wid];
 	unsigned run = incl - sum;
 	for (unsigned i = lo; i < hi; i++) {
-		if (kps[i].code == 1) kps[i].slot = (int)run++;
+		if (codes[i] == 1) kps[i].slot = (int)run++;
 		else kps[i].slot = -1;
 	}
 	if (t == 1023) d_nkp[0] = incl;
 }
 
-void launch_slots(DevKp *kps, const unsigned *d_count, unsigned cap, unsigned *d_nkp, hipStream_t st) {
-	hipLaunchKernelGGL(k_slots, dim3(1), dim3(1024), 0, st, kps, d_count, cap, d_nkp);
+void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigned cap, unsigned *d_nkp, hipStream_t st) {
+	hipLaunchKernelGGL(k_slots, dim3(1), dim3(1024), 0, st, kps, codes, d_count, cap, d_nkp);
 }
 
 }  // namespace s3d

@@ -104,9 +104,16 @@ struct DetectBufs {
 	unsigned *block_offsets;    // exclusive scan (+ running base)
 	unsigned *total;            // [0] running total over all levels, [1] overflow flag
 };
-void launch_detect_level(const float *prev, const float *cur, const float *next, int nx, int ny, int nz,
-                         const unsigned *d_absmax_bits, float peak_thresh, int octave, int level, float scale,
-                         const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st);
+// the keypoint levels of one octave (DoG levels 1..num_kp_levels), handled by one launch of each detect kernel
+constexpr int kMaxKpLevels = 5;
+struct DetectLevels {
+	const float *cur[kMaxKpLevels], *prev[kMaxKpLevels], *next[kMaxKpLevels];
+	const unsigned *absmax_bits[kMaxKpLevels];
+	int level_id[kMaxKpLevels];
+	float scale[kMaxKpLevels];
+};
+void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, int nz, float peak_thresh, int octave,
+                          const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st);
 
 // ---- kernels_orient.hip --------------------------------------------------------------------
 struct LevelRef {
@@ -114,9 +121,9 @@ struct LevelRef {
 	int nx, ny, nz;
 	float unit;
 };
-void launch_orient(DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels /*[noct*8]*/,
+void launch_orient(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap, const LevelRef *d_levels /*[noct*8]*/,
                    const WinLut *d_luts, const float *d_lutpool, float max_eig, float corner, hipStream_t st);
-void launch_slots(DevKp *kps, const unsigned *d_count, unsigned cap, unsigned *d_nkp, hipStream_t st);
+void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigned cap, unsigned *d_nkp, hipStream_t st);
 
 // ---- kernels_desc.hip ----------------------------------------------------------------------
 void upload_faces(const FaceConst *faces, const FacePredict *pred);  // into __constant__ memory
