@@ -187,11 +187,33 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 			int h = (int)__fsqrt_rn((float)(nin - rr));
 			while ((h + 1) * (h + 1) <= nin - rr) h++;
 			while (h * h > nin - rr) h--;
-			const int za = max(z0, czi - h), zb = min(z1, czi + h);
+			int za = max(z0, czi - h), zb = min(z1, czi + h);
 			if (za > zb) continue;
 			const float vxd = (float)dx * u, vyd = (float)dy * u;
 			// partial rotations: (R0*vx + R1*vy) is evaluated first in the reference's left-to-right sums
 			const float px = R0 * vxd + R1 * vyd, py = R3 * vxd + R4 * vyd, pz = R6 * vxd + R7 * vyd;
+			// clip the z range to the rotated 4x4x4 cube: in exact arithmetic a voxel is inside iff
+			// -hw < p_r + R_r2*dz*u < hw for the three rows r.  The clip is only an iteration-count optimisation:
+			// it is widened by 2 voxels and the reference's exact fp32 test still runs on every visited voxel.
+			{
+				float lo = (float)(za - czi), hi = (float)(zb - czi);
+				const float pr[3] = {px, py, pz}, rr3[3] = {R2 * u, R5 * u, R8 * u};
+#pragma unroll
+				for (int r = 0; r < 3; r++) {
+					if (fabsf(rr3[r]) > 1e-6f * desc_hw) {
+						const float inv = __frcp_rn(rr3[r]);
+						const float t0 = (-desc_hw - pr[r]) * inv, t1 = (desc_hw - pr[r]) * inv;
+						lo = fmaxf(lo, fminf(t0, t1) - 2.0f);
+						hi = fminf(hi, fmaxf(t0, t1) + 2.0f);
+					} else if (fabsf(pr[r]) > desc_hw * 1.001f + 1.0f) {
+						hi = lo - 1.0f;  // this row never enters the cube
+					}
+				}
+				if (!(lo <= hi)) continue;
+				za = max(za, czi + (int)floorf(lo));
+				zb = min(zb, czi + (int)ceilf(hi));
+				if (za > zb) continue;
+			}
 			const float *c = L.d + (size_t)x + (size_t)sy * (size_t)y + (size_t)sz * (size_t)za;
 			const int rep = lane & (kRep - 1);
 			float cm = *(c - sz), cc = *c;  // centre column at z-1, z
