@@ -28,6 +28,9 @@
 //     bin on different addresses; they are summed once per keypoint
 //   * the four in-plane neighbour loads of the next z step are issued unconditionally one step ahead
 //     (software pipelining; a load behind the activity branch would be waited for at the join)
+//   * lane compaction: chords are ragged and many voxels are inactive, so each wave pushes its ACTIVE voxels
+//     (bin coordinates + rotated gradient) into a small LDS queue by ballot rank and runs the heavy part (face
+//     test, trilinear weights, 24 atomics) only on full 64-lane batches; all loops are wave-uniform
 // Every per-voxel contribution is bit-identical to the reference; only the ORDER of the fp32
 // histogram additions differs, i.e. ~1e-7 relative -- tolerance 1e-4 RMS (BASELINE.json).
 #include <float.h>
@@ -109,11 +112,70 @@ __device__ __forceinline__ int intersect_scan(float gx, float gy, float gz, floa
 	return found;
 }
 
+// heavy part of one ACTIVE voxel (inside sphere and cube, |g|^2 >= eps): face lookup, trilinear weights,
+// 24 fixed-point adds.  Runs on compacted full waves (see the queue in k_describe).
+__device__ __forceinline__ void accumulate_voxel(bool valid, float bx, float by, float bz, float rx, float ry, float rz,
+                                                 const float *s_face, const int *s_fidx, const float *s_predn, const int *s_predf,
+                                                 unsigned long long *hist_rep) {
+	float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+	int f = -1;
+	bool slow = false;
+	if (valid) {
+		// predicted face: best of the 4 face normals of the positive octant, then the sign bits
+		const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
+		float best = ax * s_predn[0] + ay * s_predn[1] + az * s_predn[2];
+		int kb = 0;
+#pragma unroll
+		for (int t = 1; t < 4; t++) {
+			const float sc = ax * s_predn[3 * t] + ay * s_predn[3 * t + 1] + az * s_predn[3 * t + 2];
+			if (sc > best) { best = sc; kb = t; }
+		}
+		const int bits = (rx < 0.f ? 1 : 0) | (ry < 0.f ? 2 : 0) | (rz < 0.f ? 4 : 0);
+		f = s_predf[kb * 8 + bits];
+		const bool ok = face_test(&s_face[f * kFaceStride], rx, ry, rz, b0, b1, b2);
+		slow = !(ok && b0 >= kFastMargin && b1 >= kFastMargin && b2 >= kFastMargin);
+	}
+	if (__any(slow)) {
+		if (slow) f = intersect_scan(rx, ry, rz, b0, b1, b2);
+	}
+	if (!valid || f < 0) return;
+	const float g2 = rx * rx + ry * ry + rz * rz;
+	const float mag = __fsqrt_rn(g2);
+	const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
+	const int ix = (int)bx, iy = (int)by, iz = (int)bz;  // truncation toward zero, like the reference: 0..3
+	// trilinear weights: products of three doubles rounded to fp32 (Src/cSIFT3D.cc:1510-1512), evaluated as
+	// (wx*wy)*wz with the four x-y products shared
+	const double dfx = (double)fx, dfy = (double)fy, dfz = (double)fz;
+	const double wx0 = 1.0 - dfx, wy0 = 1.0 - dfy, wz0 = 1.0 - dfz;
+	const double pxy[4] = {wx0 * wy0, wx0 * dfy, dfx * wy0, dfx * dfy};  // index ddx*2 + ddy
+	// cells ix+ddx etc. are >= 0 by construction; only the upper bound can fail (skip cells outside [0,3])
+	const bool okx = ix < 3, oky = iy < 3, okz = iz < 3;
+	const int base = (ix + iy * 4 + iz * 16) * 12;
+	unsigned long long *h0 = hist_rep + (base + s_fidx[f * 4]) * kRep;
+	unsigned long long *h1 = hist_rep + (base + s_fidx[f * 4 + 1]) * kRep;
+	unsigned long long *h2 = hist_rep + (base + s_fidx[f * 4 + 2]) * kRep;
+#pragma unroll
+	for (int d = 0; d < 8; d++) {
+		const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;  // dx outer, dz inner (Src/cSIFT3D.cc:1492-1496)
+		if ((ddx && !okx) || (ddy && !oky) || (ddz && !okz)) continue;
+		const float wgt = (float)(pxy[ddx * 2 + ddy] * (ddz ? dfz : wz0));
+		const float mw = mag * wgt;
+		constexpr int kCell = 12 * kRep;
+		const int off = (ddx + ddy * 4 + ddz * 16) * kCell;  // compile-time: becomes the ds_add immediate offset
+		atomicAdd(h0 + off, to_fixed(mw * b0));
+		atomicAdd(h1 + off, to_fixed(mw * b1));
+		atomicAdd(h2 + off, to_fixed(mw * b2));
+	}
+}
+
+constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <= 64, a pop removes exactly 64
+
 __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
                                                   const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap) {
 	__shared__ unsigned long long hist[kDesc * kRep];  // [bin][replica], two's-complement fixed point, 2^-40 units
 	__shared__ float s_lut[kMaxDescLut];
+	__shared__ float s_q[4][6][kQCap];                 // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
 	__shared__ float s_predn[12];
 	__shared__ int s_predf[32];
 	__shared__ __attribute__((aligned(16))) float s_face[kFaces * kFaceStride];
@@ -138,6 +200,8 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 	if (tid < 12) s_predn[tid] = c_pred.n[tid / 3][tid % 3];
 	if (tid < 32) s_predf[tid] = c_pred.face[tid];
 	int cur_lut = -1;
+	float(*q)[kQCap] = s_q[wid];
+	unsigned long long *hist_rep = &hist[lane & (kRep - 1)];
 
 	for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
 		const int slot = kps[k].slot;
@@ -167,6 +231,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1);
 		const int sy = L.nx, sz = L.nx * L.ny;  // levels are < 2^31 voxels
 		const int nin = lut.nin;                 // largest integer squared offset inside the sphere
+		const float *centre = L.d + (size_t)cxi + (size_t)sy * (size_t)cyi + (size_t)sz * (size_t)czi;  // always valid
 
 		__syncthreads();  // previous keypoint finished with hist / s_lut
 		for (int i = tid; i < kDesc * kRep; i += 256) hist[i] = 0ull;
@@ -176,26 +241,30 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		}
 		__syncthreads();
 
-		for (int col = tid; col < ncol; col += 256) {
+		int qhead = 0, qcount = 0;  // wave-uniform (every lane executes every push / pop below)
+		// All control flow from here to the drain is wave-uniform: lanes without work are predicated, never branched
+		// away, because the queue bookkeeping must see every ballot.
+		for (int col0 = 0; col0 < ncol; col0 += 256) {
+			const int col = col0 + tid;
 			const int ly = (int)(((float)col + 0.5f) * inv_wx);
 			const int lx = col - ly * wx;
 			const int x = x0 + lx, y = y0 + ly;
 			const int dx = x - cxi, dy = y - cyi;
 			const int rr = dx * dx + dy * dy;
-			if (rr > nin) continue;
-			// in-sphere chord: dz^2 <= nin - rr
-			int h = (int)__fsqrt_rn((float)(nin - rr));
-			while ((h + 1) * (h + 1) <= nin - rr) h++;
-			while (h * h > nin - rr) h--;
-			int za = max(z0, czi - h), zb = min(z1, czi + h);
-			if (za > zb) continue;
+			bool colok = col < ncol && rr <= nin;
+			int za = 0, zb = -1;
 			const float vxd = (float)dx * u, vyd = (float)dy * u;
 			// partial rotations: (R0*vx + R1*vy) is evaluated first in the reference's left-to-right sums
 			const float px = R0 * vxd + R1 * vyd, py = R3 * vxd + R4 * vyd, pz = R6 * vxd + R7 * vyd;
-			// clip the z range to the rotated 4x4x4 cube: in exact arithmetic a voxel is inside iff
-			// -hw < p_r + R_r2*dz*u < hw for the three rows r.  The clip is only an iteration-count optimisation:
-			// it is widened by 2 voxels and the reference's exact fp32 test still runs on every visited voxel.
-			{
+			if (colok) {
+				// in-sphere chord: dz^2 <= nin - rr
+				int h = (int)__fsqrt_rn((float)(nin - rr));
+				while ((h + 1) * (h + 1) <= nin - rr) h++;
+				while (h * h > nin - rr) h--;
+				za = max(z0, czi - h); zb = min(z1, czi + h);
+				// clip the z range to the rotated 4x4x4 cube: in exact arithmetic a voxel is inside iff
+				// -hw < p_r + R_r2*dz*u < hw for the three rows r.  Only an iteration-count optimisation: it is
+				// widened by 2 voxels and the reference's exact fp32 test still runs on every visited voxel.
 				float lo = (float)(za - czi), hi = (float)(zb - czi);
 				const float pr[3] = {px, py, pz}, rr3[3] = {R2 * u, R5 * u, R8 * u};
 #pragma unroll
@@ -209,28 +278,32 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 						hi = lo - 1.0f;  // this row never enters the cube
 					}
 				}
-				if (!(lo <= hi)) continue;
-				za = max(za, czi + (int)floorf(lo));
-				zb = min(zb, czi + (int)ceilf(hi));
-				if (za > zb) continue;
+				if (lo <= hi) { za = max(za, czi + (int)floorf(lo)); zb = min(zb, czi + (int)ceilf(hi)); }
+				else zb = za - 1;
 			}
-			const float *c = L.d + (size_t)x + (size_t)sy * (size_t)y + (size_t)sz * (size_t)za;
-			const int rep = lane & (kRep - 1);
+			const int zlen = (colok && zb >= za) ? zb - za + 1 : 0;
+			int maxlen = zlen;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+			maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+			if (maxlen == 0) continue;  // wave-uniform
+			// lanes without a column march on the keypoint's own column (always in bounds) and are masked
+			const float *c = zlen > 0 ? L.d + (size_t)x + (size_t)sy * (size_t)y + (size_t)sz * (size_t)za : centre;
 			float cm = *(c - sz), cc = *c;  // centre column at z-1, z
 			float nxm = c[-1], nxp = c[1], nym = *(c - sy), nyp = c[sy];  // in-plane neighbours of plane z (pipelined)
-
-			for (int z = za; z <= zb; z++, c += sz) {
-				// issue next step's loads first: they stay in flight while this voxel is processed
+			int dz = za - czi;
+			for (int step = 0; step < maxlen; step++) {
+				const bool in = step < zlen;
+				// next step's loads first: they stay in flight while this voxel is processed
+				const float *cn = (step + 1 < zlen) ? c + sz : c;
 				const float cp = c[sz];  // z+1 (z <= nz-2 by the window bounds)
-				const float *cn = (z < zb) ? c + sz : c;
 				const float nxm1 = cn[-1], nxp1 = cn[1], nym1 = *(cn - sy), nyp1 = cn[sy];
-				const int dz = z - czi;
 				const float vzd = (float)dz * u;
 				float bx = px + R2 * vzd, by = py + R5 * vzd, bz = pz + R8 * vzd;
 				bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
 				bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
-				bool act = !(bx <= -0.5f || by <= -0.5f || bz <= -0.5f || bx >= 3.5f || by >= 3.5f || bz >= 3.5f);
-				const float w = s_lut[rr + dz * dz];
+				bool act = in && !(bx <= -0.5f || by <= -0.5f || bz <= -0.5f || bx >= 3.5f || by >= 3.5f || bz >= 3.5f);
+				const float w = s_lut[in ? rr + dz * dz : 0];
 				float gx = 0.5f * (nxp - nxm);
 				float gy = 0.5f * (nyp - nym);
 				float gz = 0.5f * (cp - cm);
@@ -242,54 +315,31 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 				const float g2 = rx * rx + ry * ry + rz * rz;
 				act = act && !(g2 < kBaryEps);
 				cm = cc; cc = cp; nxm = nxm1; nxp = nxp1; nym = nym1; nyp = nyp1;
-				if (!__any(act)) continue;
-				float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-				int f = -1;
-				bool slow = false;
-				if (act) {
-					// predicted face: best of the 4 face normals of the positive octant, then the sign bits
-					const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
-					float best = ax * s_predn[0] + ay * s_predn[1] + az * s_predn[2];
-					int kb = 0;
-#pragma unroll
-					for (int t = 1; t < 4; t++) {
-						const float sc = ax * s_predn[3 * t] + ay * s_predn[3 * t + 1] + az * s_predn[3 * t + 2];
-						if (sc > best) { best = sc; kb = t; }
+				c = cn; dz += (step + 1 < zlen) ? 1 : 0;
+				// ---- push the active lanes into the wave's queue (compaction by ballot rank) ----
+				const unsigned long long m = __ballot(act);
+				if (m) {
+					if (act) {
+						const int pos = (qhead + qcount + (int)__popcll(m & ((1ull << lane) - 1ull))) & (kQCap - 1);
+						q[0][pos] = bx; q[1][pos] = by; q[2][pos] = bz; q[3][pos] = rx; q[4][pos] = ry; q[5][pos] = rz;
 					}
-					const int bits = (rx < 0.f ? 1 : 0) | (ry < 0.f ? 2 : 0) | (rz < 0.f ? 4 : 0);
-					f = s_predf[kb * 8 + bits];
-					const bool ok = face_test(&s_face[f * kFaceStride], rx, ry, rz, b0, b1, b2);
-					slow = !(ok && b0 >= kFastMargin && b1 >= kFastMargin && b2 >= kFastMargin);
+					qcount += (int)__popcll(m);
 				}
-				if (__any(slow)) {
-					if (slow) f = intersect_scan(rx, ry, rz, b0, b1, b2);
-				}
-				if (f < 0) act = false;
-				if (act) {
-					const float mag = __fsqrt_rn(g2);
-					const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
-					const int ix = (int)bx, iy = (int)by, iz = (int)bz;  // truncation toward zero, like the reference
-					const int i0 = s_fidx[f * 4], i1 = s_fidx[f * 4 + 1], i2 = s_fidx[f * 4 + 2];
-					// trilinear weights: products of three doubles rounded to fp32 (Src/cSIFT3D.cc:1510-1512),
-					// evaluated as (wx*wy)*wz with the four x-y products shared
-					const double dfx = (double)fx, dfy = (double)fy, dfz = (double)fz;
-					const double wx0 = 1.0 - dfx, wy0 = 1.0 - dfy, wz0 = 1.0 - dfz;
-					const double pxy[4] = {wx0 * wy0, wx0 * dfy, dfx * wy0, dfx * dfy};  // index ddx*2 + ddy
-					unsigned long long *hb = &hist[rep];
-#pragma unroll
-					for (int d = 0; d < 8; d++) {
-						const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;  // dx outer, dz inner (Src/cSIFT3D.cc:1492-1496)
-						const int ccx = ix + ddx, ccy = iy + ddy, ccz = iz + ddz;
-						if (ccx < 0 || ccy < 0 || ccz < 0 || ccx >= 4 || ccy >= 4 || ccz >= 4) continue;
-						const float wgt = (float)(pxy[ddx * 2 + ddy] * (ddz ? dfz : wz0));
-						const float mw = mag * wgt;
-						const int hh = (ccx + ccy * 4 + ccz * 16) * 12;
-						atomicAdd(hb + (hh + i0) * kRep, to_fixed(mw * b0));
-						atomicAdd(hb + (hh + i1) * kRep, to_fixed(mw * b1));
-						atomicAdd(hb + (hh + i2) * kRep, to_fixed(mw * b2));
-					}
+				// ---- a full wave of active voxels is ready: run the heavy part on all 64 lanes ----
+				if (qcount >= 64) {
+					const int pos = (qhead + lane) & (kQCap - 1);
+					accumulate_voxel(true, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], s_face, s_fidx, s_predn,
+					                 s_predf, hist_rep);
+					qhead = (qhead + 64) & (kQCap - 1);
+					qcount -= 64;
 				}
 			}
+		}
+		if (qcount > 0) {  // drain (wave-uniform)
+			const int pos = (qhead + lane) & (kQCap - 1);
+			const bool valid = lane < qcount;
+			accumulate_voxel(valid, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], s_face, s_fidx, s_predn, s_predf,
+			                 hist_rep);
 		}
 		__syncthreads();
 
