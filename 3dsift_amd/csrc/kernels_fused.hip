@@ -8,7 +8,7 @@
 // G[i] and DoG[i-1] once = 12 B/voxel.
 //
 // Structure (2.5-D streaming, 256 threads = 4 waves per workgroup):
-//   * a workgroup owns a TX x TY = 64 x 16 column of the volume and marches along z over a chunk
+//   * a workgroup owns a TX x TY = 32 x 32 column of the volume and marches along z over a chunk
 //   * per plane q (software pipelined, two barriers per plane):
 //       regs -> LDS tile of plane q (loaded one step earlier), then the global loads of plane q+1 and of
 //       the DoG centre values of plane p = q-HW are ISSUED and stay in flight during the step
@@ -47,7 +47,11 @@ __device__ __forceinline__ float absmax_step_f(float m, float v) {
 
 template <int HW>
 struct FusedCfg {
-	static constexpr int TX = 64, TY = 16, NT = 256;
+#ifndef S3D_TX
+#define S3D_TX 32
+#endif
+	static constexpr int TX = S3D_TX, TY = 1024 / S3D_TX, NT = 256;  // 4 outputs (consecutive y) per thread
+	static constexpr int SEGS = TX / 8;                            // x-blur items per row (8 outputs each)
 	static constexpr int HXL = ((HW + 1 + 3) / 4) * 4;  // low-side x halo: the right-boundary rule reaches p-hw-1
 	static constexpr int HXH = ((HW + 3) / 4) * 4;
 	static constexpr int W = HXL + TX + HXH;            // tile row width (floats, multiple of 4)
@@ -125,7 +129,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	const int x0 = tile_x * C::TX, y0 = tile_y * C::TY;
 	const int zc0 = chunk * cz, zc1 = min(nz, zc0 + cz);
 
-	const int tid = threadIdx.x, lane = tid & 63, yq = tid >> 6;
+	const int tid = threadIdx.x, lane = tid % C::TX, yq = tid / C::TX, wlane = tid & 63, wid = tid >> 6;
 	const bool edge_x = (x0 < HW) || (x0 + C::TX - 1 > nx - 2 - HW);
 	const bool edge_y = (y0 < HW) || (y0 + C::TY - 1 > ny - 2 - HW);
 	const bool need_row0 = (y0 + C::TY - 1 > ny - 2 - HW);  // tile holds right-boundary y outputs (they reach y-hw-1)
@@ -247,7 +251,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 			}
 			// ---------------- x-blur: in_t rows 1..ROWS-1 -> xb (exactly one item per thread) ----------------
 			{
-				const int r = 1 + (tid >> 3), seg = tid & 7;
+				const int r = 1 + tid / C::SEGS, seg = tid % C::SEGS;
 				const int gy = y0 - HW - 1 + r;
 				if (r < C::ROWS && gy >= 0 && gy < ny) {
 					const float *trow = &in_t[r * C::PITCH];
@@ -288,7 +292,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				const int ntop = (y0 < HW) ? HW : 0;                       // y0 < HW  =>  y0 == 0
 				const int nbot = need_row0 ? (HW + 1) : 0;
 				for (int item = tid; item < (ntop + nbot) * C::TX; item += C::NT) {
-					const int e = item >> 6, xx = item & 63;
+					const int e = item / C::TX, xx = item % C::TX;
 					if (e < ntop) {
 						const int k = e + 1;                                // E[-k] = row k
 						xb[(HW + 1 - k - y0) * C::TX + xx] = xb[(HW + 1 + k - y0) * C::TX + xx];
@@ -385,7 +389,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
 		__syncthreads();
-		if (lane == 0) s_red[yq] = mx;
+		if (wlane == 0) s_red[wid] = mx;
 		__syncthreads();
 		if (tid == 0) {
 			const float r = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
