@@ -120,3 +120,21 @@ std::ostream &operator<<(std::ostream &os, const SIFT_TimerPara &st) {
 	   << st.d_Detect << " | orientation " << st.d_AssignOrientation << " | description " << st.d_Extraction << "\n";
 	return os;
 }
+
+// ---- keypoint coordinate lists (reference Src/cUtil.cc:938-954 write_sift_kp, 1002-1016 read_sift_kp) ----
+#include "../Include/cUtil.h"
+namespace CPUSIFT {
+void write_sift_kp(std::vector<Cvec> &kp, const char *file_name) {
+	FILE *f = fopen(file_name, "w");
+	if (!f) { fprintf(stderr, "write_sift_kp: cannot open %s\n", file_name); return; }
+	for (const Cvec &c : kp) fprintf(f, "%.5lf,%.5lf,%.5lf\n", (double)c.x, (double)c.y, (double)c.z);
+	fclose(f);
+}
+void read_sift_kp(const char *file_name, std::vector<Cvec> &kp) {
+	FILE *f = fopen(file_name, "r");
+	if (!f) { fprintf(stderr, "read_sift_kp: cannot open %s\n", file_name); return; }
+	double x, y, z;
+	while (fscanf(f, " %lf , %lf , %lf", &x, &y, &z) == 3) kp.push_back(Cvec((float)x, (float)y, (float)z));
+	fclose(f);
+}
+}  // namespace CPUSIFT

@@ -102,3 +102,25 @@ def test_example_program_end_to_end(shell, orc, synth):
     lines = out.strip().splitlines()[-len(want):] if len(want) else []
     got = np.array([[float(v) for v in ln.replace(";", ",").split(",")] for ln in lines], np.float32).reshape(-1, 6)
     assert np.array_equal(got, want)
+
+
+def test_sift_kp_csv_roundtrip(shell):
+    """write_sift_kp / read_sift_kp (reference cUtil.cc:938-954, 1002-1016): "%.5lf,%.5lf,%.5lf" lines."""
+    src = r"""
+    #include "Include/cUtil.h"
+    #include <cstdio>
+    int main(int, char** a) {
+        std::vector<CPUSIFT::Cvec> v = {{1.5f, 2.25f, 3.0f}, {10.123456f, 0.f, -4.5f}}, w;
+        CPUSIFT::write_sift_kp(v, a[1]);
+        CPUSIFT::read_sift_kp(a[1], w);
+        if (w.size() != 2) return 1;
+        printf("%.5f %.5f %.5f\n", w[1].x, w[1].y, w[1].z);
+        return 0;
+    }"""
+    with tempfile.TemporaryDirectory() as t:
+        open(os.path.join(t, "m.cpp"), "w").write(src)
+        subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(PKG, "host"), "-o", os.path.join(t, "m"), os.path.join(t, "m.cpp"),
+                               "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-Wl,-rpath," + PKG])
+        out = subprocess.check_output([os.path.join(t, "m"), os.path.join(t, "kp.csv")]).decode()
+        assert open(os.path.join(t, "kp.csv")).read().splitlines() == ["1.50000,2.25000,3.00000", "10.12346,0.00000,-4.50000"]
+        assert out.split() == ["10.12346", "0.00000", "-4.50000"]
