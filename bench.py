@@ -96,6 +96,15 @@ def main():
     stage = {k: v / args.steps for k, v in stage.items()}
 
     pv, noct = pyramid_voxels(shape)
+    # HBM traffic of the pyramid stage from the PMC counters (scripts/measure_traffic.py, separate --pmc passes,
+    # gfx950 FETCH_SIZE correction); measured offline on the same workload and committed under profiles/
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", f"pyramid_traffic_{n}.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = float(json.load(open(tfile))["total_bytes"])
+        except Exception:
+            traffic = None
     t_pyr = stage["d_BuildGSS"] + stage["d_BuildDOG"]
     alg_bytes = 68.0 * pv
     achieved = alg_bytes / t_pyr / 1e9
@@ -119,7 +128,7 @@ def main():
         "descriptor_keypoints_per_s": (nkp / stage["d_Extraction"]) if stage["d_Extraction"] > 0 else None,
         "roofline": {"bound": "hbm", "kernel": "pyramid build (all Gaussian/DoG level kernels of one KpSiftAlgorithm)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "algorithmic_bytes": alg_bytes, "seconds": t_pyr, "traffic": None},
+                     "algorithmic_bytes": alg_bytes, "seconds": t_pyr, "traffic": traffic},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
