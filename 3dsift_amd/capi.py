@@ -35,12 +35,23 @@ SYMBOLS = [
     "sift3d_num_octaves", "sift3d_level_info", "sift3d_copy_level", "sift3d_copy_input", "sift3d_num_extrema",
     "sift3d_get_extrema", "sift3d_get_orientation_codes", "sift3d_gaussian_smooth", "sift3d_match",
     "sift3d_device_count", "sift3d_error_string", "sift3d_last_error",
+    # multi-GPU sharding (z-slabs of octave 0 + seeded replicated tail)
+    "sift3d_slab_min_halo", "sift3d_slab_arena_floats", "sift3d_slab_create", "sift3d_slab_buffer", "sift3d_slab_upload",
+    "sift3d_slab_input_absmax", "sift3d_slab_input_scale", "sift3d_slab_level", "sift3d_slab_level_hw", "sift3d_slab_halo_planes",
+    "sift3d_slab_sync", "sift3d_slab_get_dogmax", "sift3d_slab_set_dogmax", "sift3d_slab_detect", "sift3d_slab_describe",
+    "sift3d_slab_decimate", "sift3d_create_seeded", "sift3d_seed_upload", "sift3d_set_describe_partition",
+    "sift3d_export_device", "sift3d_import_descriptors_device",
 ]
 
 
 class Params(C.Structure):
     _fields_ = [("num_kp_levels", C.c_int), ("sigma_default", C.c_float), ("sigma_n_default", C.c_float),
                 ("peak_thresh", C.c_float), ("max_eig_thres", C.c_float), ("corner_thresh", C.c_float)]
+
+
+class SlabDesc(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("z0", C.c_int), ("z1", C.c_int), ("halo", C.c_int),
+                ("noct_total", C.c_int)]
 
 
 class Sift3dError(RuntimeError):
@@ -59,6 +70,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise Sift3dError(f"{LIB_PATH} is missing: build it with `make -C 3dsift_amd/csrc` "
                               f"(or __graft_entry__.build()); there is no CPU fallback")
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; a process must not end up with two HIP runtimes (the
+        # second one finds no GPU).  Loading torch's first makes this library bind to the same runtime by soname, so
+        # torch-allocated device memory (halo arenas, synthetic volumes) and this library share one HIP context.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.sift3d_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int]
         L.sift3d_destroy.argtypes = [C.c_void_p]
@@ -79,6 +97,28 @@ def lib():
         L.sift3d_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                    C.c_int, C.c_int, _ip, _ip, _fp, _fp, _fp, _ip, C.POINTER(C.c_double)]
         L.sift3d_device_count.argtypes = [_ip]
+        _sz = C.POINTER(C.c_size_t)
+        L.sift3d_slab_min_halo.argtypes = [C.POINTER(Params), _ip]
+        L.sift3d_slab_arena_floats.argtypes = [C.POINTER(SlabDesc), C.POINTER(Params), _sz]
+        L.sift3d_slab_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(SlabDesc), C.POINTER(Params), C.c_int, C.c_void_p, C.c_size_t]
+        L.sift3d_slab_buffer.argtypes = [C.c_void_p, C.c_int, C.c_int, _sz, _ip, _ip]
+        L.sift3d_slab_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.sift3d_slab_input_absmax.argtypes = [C.c_void_p, _fp]
+        L.sift3d_slab_input_scale.argtypes = [C.c_void_p, C.c_float]
+        L.sift3d_slab_level.argtypes = [C.c_void_p, C.c_int]
+        L.sift3d_slab_halo_planes.argtypes = [C.c_void_p, C.c_int, _ip]
+        L.sift3d_slab_level_hw.argtypes = [C.c_void_p, C.c_int, _ip]
+        L.sift3d_slab_sync.argtypes = [C.c_void_p]
+        L.sift3d_slab_get_dogmax.argtypes = [C.c_void_p, _fp]
+        L.sift3d_slab_set_dogmax.argtypes = [C.c_void_p, _fp]
+        L.sift3d_slab_detect.argtypes = [C.c_void_p]
+        L.sift3d_slab_describe.argtypes = [C.c_void_p]
+        L.sift3d_slab_decimate.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_create_seeded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Params), C.c_int]
+        L.sift3d_seed_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.sift3d_set_describe_partition.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.sift3d_export_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sift3d_import_descriptors_device.argtypes = [C.c_void_p, C.c_void_p]
         L.sift3d_error_string.argtypes = [C.c_int]
         L.sift3d_error_string.restype = C.c_char_p
         L.sift3d_last_error.restype = C.c_char_p
@@ -207,6 +247,129 @@ class CSIFT3D:
         d = C.c_void_p(); x = C.c_void_p(); n = C.c_int(0)
         _check(lib().sift3d_device_results(self._h, C.byref(d), C.byref(x), C.byref(n)))
         return d.value, x.value, n.value
+
+
+def _params(kw):
+    return Params(kw.get("num_kp_levels", 3), kw.get("sigma_default", 1.6), kw.get("sigma_n_default", 1.15),
+                  kw.get("peak_thresh", 0.1), kw.get("max_eig_thres", 0.9), kw.get("corner_thresh", 0.4))
+
+
+def slab_min_halo(**kw):
+    p = _params(kw); h = C.c_int(0)
+    _check(lib().sift3d_slab_min_halo(C.byref(p), C.byref(h)))
+    return h.value
+
+
+class SeededCSIFT3D(CSIFT3D):
+    """Octaves octave_base.. of a volume whose G[octave_base][0] the caller provides (multi-GPU tail, see slab.py).
+    shape = (nz, ny, nx) of that level."""
+
+    def __init__(self, shape, octave_base, noct_total, device=0, **kw):
+        self._h = C.c_void_p()
+        p = _params(kw)
+        self.levels = p.num_kp_levels
+        self.shape = tuple(shape)
+        nz, ny, nx = shape
+        _check(lib().sift3d_create_seeded(C.byref(self._h), nx, ny, nz, octave_base, noct_total, C.byref(p), device))
+
+    def seed(self, ptr, on_device=True):
+        _check(lib().sift3d_seed_upload(self._h, C.c_void_p(int(ptr)), int(bool(on_device))))
+
+    def seed_host(self, vol):
+        vol = np.ascontiguousarray(vol, np.float32)
+        _check(lib().sift3d_seed_upload(self._h, vol.ctypes.data_as(C.c_void_p), 0))
+
+    def set_partition(self, rank, world):
+        _check(lib().sift3d_set_describe_partition(self._h, rank, world))
+
+    def export_device(self, desc_ptr, xyz_ptr=None):
+        _check(lib().sift3d_export_device(self._h, C.c_void_p(int(desc_ptr)), C.c_void_p(int(xyz_ptr)) if xyz_ptr else None))
+
+    def import_descriptors(self, desc_ptr):
+        _check(lib().sift3d_import_descriptors_device(self._h, C.c_void_p(int(desc_ptr))))
+
+
+class SlabCSIFT3D(CSIFT3D):
+    """One z-slab of octave 0 (include/sift3d_hip.h, multi-GPU section).  The level buffers live in `arena_ptr`
+    (caller-owned device memory of arena_floats(...) floats) so the caller's communication layer can address halo planes."""
+
+    @staticmethod
+    def arena_floats(nx, ny, nz, z0, z1, halo, noct_total, **kw):
+        d = SlabDesc(nx, ny, nz, z0, z1, halo, noct_total); p = _params(kw); n = C.c_size_t(0)
+        _check(lib().sift3d_slab_arena_floats(C.byref(d), C.byref(p), C.byref(n)))
+        return n.value
+
+    def __init__(self, nx, ny, nz, z0, z1, halo, noct_total, arena_ptr, arena_floats, device=0, **kw):
+        self._h = C.c_void_p()
+        p = _params(kw)
+        self.levels = p.num_kp_levels
+        self.dims = (nx, ny, nz)
+        self.z0, self.z1, self.halo = z0, z1, halo
+        self.shape = (z1 - z0 + 2 * halo, ny, nx)
+        d = SlabDesc(nx, ny, nz, z0, z1, halo, noct_total)
+        _check(lib().sift3d_slab_create(C.byref(self._h), C.byref(d), C.byref(p), device, C.c_void_p(int(arena_ptr)), arena_floats))
+
+    def buffer(self, kind, idx=0):
+        """(offset in floats inside the arena, planes held, global z of plane 0); kind 0 input, 1 GSS, 2 DoG"""
+        off = C.c_size_t(0); pl = C.c_int(0); zo = C.c_int(0)
+        _check(lib().sift3d_slab_buffer(self._h, kind, idx, C.byref(off), C.byref(pl), C.byref(zo)))
+        return off.value, pl.value, zo.value
+
+    def held_level(self, is_dog, idx):
+        """all planes the buffer holds, [planes, ny, nx]; plane k is global plane (z0 - halo) + k"""
+        out = np.empty(self.shape, np.float32)
+        _check(lib().sift3d_copy_level(self._h, int(is_dog), idx, _f(out)))
+        return out
+
+    def upload(self, planes, zg0, zg1, device_ptr=None):
+        if device_ptr is not None:
+            _check(lib().sift3d_slab_upload(self._h, C.c_void_p(int(device_ptr)), zg0, zg1, 1))
+        else:
+            a = np.ascontiguousarray(planes, np.float32)
+            assert a.shape == (zg1 - zg0, self.dims[1], self.dims[0])
+            _check(lib().sift3d_slab_upload(self._h, a.ctypes.data_as(C.c_void_p), zg0, zg1, 0))
+
+    def input_absmax(self):
+        m = C.c_float(0)
+        _check(lib().sift3d_slab_input_absmax(self._h, C.byref(m)))
+        return m.value
+
+    def input_scale(self, gmax):
+        _check(lib().sift3d_slab_input_scale(self._h, C.c_float(gmax)))
+
+    def level_async(self, i):
+        _check(lib().sift3d_slab_level(self._h, i))
+
+    def level_hw(self, i):
+        n = C.c_int(0)
+        _check(lib().sift3d_slab_level_hw(self._h, i, C.byref(n)))
+        return n.value
+
+    def halo_planes(self, i):
+        n = C.c_int(0)
+        _check(lib().sift3d_slab_halo_planes(self._h, i, C.byref(n)))
+        return n.value
+
+    def sync(self):
+        _check(lib().sift3d_slab_sync(self._h))
+
+    def get_dogmax(self):
+        a = np.zeros(8, np.float32)
+        _check(lib().sift3d_slab_get_dogmax(self._h, _f(a)))
+        return a[: self.levels + 2].copy()
+
+    def set_dogmax(self, a):
+        b = np.zeros(8, np.float32); b[: self.levels + 2] = a
+        _check(lib().sift3d_slab_set_dogmax(self._h, _f(b)))
+
+    def detect(self):
+        _check(lib().sift3d_slab_detect(self._h))
+
+    def describe(self):
+        _check(lib().sift3d_slab_describe(self._h))
+
+    def decimate(self, dst_ptr):
+        _check(lib().sift3d_slab_decimate(self._h, C.c_void_p(int(dst_ptr))))
 
 
 def CreateCSIFT3D(volume, **kw):

@@ -137,8 +137,16 @@ struct sift3d_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	sift3d_params p{};
-	int nx = 0, ny = 0, nz = 0;
+	int nx = 0, ny = 0, nz = 0;     // dims of the first octave this context holds (global)
 	int noct = 0, ng = 0, nd = 0;
+	int octave_base = 0;            // absolute index of that octave (seeded contexts of the multi-GPU path start at 1)
+	bool seeded = false;            // level (0,0) is written by the caller (sift3d_seed_upload); no input volume, no base blur
+	// z-slab mode (multi-GPU sharding of octave 0): this context owns global planes [own0, own1) and every level buffer
+	// holds planes [own0-halo, own1+halo); halo planes are filled by the caller (neighbour exchange)
+	bool slab = false;
+	int own0 = 0, own1 = 0, halo = 0;
+	bool ext_arena = false;         // level buffers live in memory owned by the caller
+	int part_rank = 0, part_world = 1;  // descriptor work split of replicated octaves
 
 	// device memory
 	float *arena = nullptr;       // input + pyramids + scratch (one allocation)
@@ -244,7 +252,7 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	free_lists(c);
-	hipFree(c->arena);
+	if (!c->ext_arena) hipFree(c->arena);
 	hipFree(c->d_words);
 	hipFree(c->det.masks); hipFree(c->det.block_counts); hipFree(c->det.block_offsets);
 	hipFree(c->d_levels); hipFree(c->d_luts); hipFree(c->d_lutpool);
@@ -259,10 +267,14 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 }
 
 // Initialize + Initialize_Pyramid geometry, Src/cSIFT3D.cc:237-266, Src/cUtil.cc:177-235
-static void plan_pyramid(sift3d_ctx *c) {
-	int mn = std::min(c->nx, std::min(c->ny, c->nz));
-	const int last = (int)log2f((float)mn) - 3;
-	c->noct = std::max(0, last + 1);
+static int octaves_of(int nx, int ny, int nz) {  // Src/cSIFT3D.cc:254-255
+	const int mn = std::min(nx, std::min(ny, nz));
+	return std::max(0, (int)log2f((float)mn) - 3 + 1);
+}
+
+static void plan_pyramid(sift3d_ctx *c, int noct_total) {
+	c->noct = noct_total >= 0 ? std::max(0, noct_total - c->octave_base) : octaves_of(c->nx, c->ny, c->nz);
+	if (c->slab) c->noct = std::min(c->noct, 1);
 	c->ng = c->p.num_kp_levels + 3;
 	c->nd = c->p.num_kp_levels + 2;
 	c->gss.assign((size_t)c->noct * c->ng, Level());
@@ -272,13 +284,14 @@ static void plan_pyramid(sift3d_ctx *c) {
 		const int interval = pyr ? c->nd : c->ng;
 		std::vector<Level> &P = pyr ? c->dog : c->gss;
 		int nx = c->nx, ny = c->ny, nz = c->nz;
-		float u = 1.0f;
+		float u = (float)(1 << c->octave_base);  // units double per octave starting at 1 (Src/cUtil.cc:215-225)
 		for (int o = 0; o < c->noct; o++) {
 			for (int s = 0; s < interval; s++) {
 				Level &L = P[(size_t)o * interval + s];
 				L.nx = nx; L.ny = ny; L.nz = nz; L.unit = u;
-				const double scale_factor = pow(2.0, (double)o + (double)s / (double)c->p.num_kp_levels);
+				const double scale_factor = pow(2.0, (double)(o + c->octave_base) + (double)s / (double)c->p.num_kp_levels);
 				L.scale = (float)(scale_factor * sigma0);
+				if (c->slab) { L.bz = c->own1 - c->own0 + 2 * c->halo; L.zoff = c->own0 - c->halo; }
 			}
 			nx /= 2; ny /= 2; nz /= 2;
 			u *= 2;
@@ -289,7 +302,7 @@ static void plan_pyramid(sift3d_ctx *c) {
 // Gaussian window tables (see WinLut): orientation (Src/cSIFT3D.cc:915, 968-971) and descriptor
 // (Src/cSIFT3D.cc:1155-1156, 1270, 1312) windows of every (octave, keypoint level).
 static int build_luts(sift3d_ctx *c) {
-	std::vector<WinLut> luts((size_t)std::max(1, c->noct) * 8 * 2);
+	std::vector<WinLut> luts((size_t)std::max(1, c->noct + c->octave_base) * 8 * 2);
 	std::vector<float> pool;
 	for (auto &l : luts) { l.off = 0; l.len = 0; l.nin = -1; l.radius = 0; l.sigma = 0; }
 	for (int o = 0; o < c->noct; o++)
@@ -302,7 +315,7 @@ static int build_luts(sift3d_ctx *c) {
 				else { sigma = scale * 7.071067812f; radius = 2.0f * sigma; }
 				const float r2 = radius * radius, uu = u * u;
 				const int len = (int)floor((double)r2 / (double)uu) + 2;
-				WinLut &L = luts[((size_t)o * 8 + lv) * 2 + which];
+				WinLut &L = luts[((size_t)(o + c->octave_base) * 8 + lv) * 2 + which];
 				L.off = (int)pool.size(); L.len = len; L.nin = -1; L.radius = radius; L.sigma = sigma;
 				if (which == 1 && len > kMaxDescLut) { set_last_error("descriptor window larger than the LDS weight table"); return SIFT3D_ERR_ARG; }
 				for (int n = 0; n < len; n++) {
@@ -324,20 +337,48 @@ static int build_luts(sift3d_ctx *c) {
 	return SIFT3D_OK;
 }
 
-extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
-                             int device, int volume_on_device) {
-	if (!out || !volume || nx <= 0 || ny <= 0 || nz <= 0) { set_last_error("sift3d_create: bad argument"); return SIFT3D_ERR_ARG; }
-	if ((size_t)nx * ny * nz >= ((size_t)1 << 31)) { set_last_error("volume too large for int32 voxel indices"); return SIFT3D_ERR_ARG; }
+// how a context is built: the classic whole-volume extractor, a SEEDED tail (octaves >= octave_base starting from a
+// caller-provided G[octave_base][0]) or a z-SLAB of octave 0 (multi-GPU sharding)
+struct CreateCfg {
+	int nx = 0, ny = 0, nz = 0;   // global dims of the first octave held
+	int octave_base = 0;
+	int noct_total = -1;          // octaves counted on the ORIGINAL volume (Src/cSIFT3D.cc:254-255); -1: from nx,ny,nz
+	bool seeded = false;
+	bool slab = false;
+	int z0 = 0, z1 = 0, halo = 0;
+	float *ext_arena = nullptr;   // slab: caller-owned device memory for the level buffers (so that the caller's
+	size_t ext_arena_floats = 0;  // communication layer can address halo planes directly), see sift3d_slab_arena_floats
+};
+
+static size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+// floats needed for: input | per-octave scratch A,B | GSS levels | DoG levels
+static size_t arena_floats_of(const sift3d_ctx *c) {
+	size_t total = al64(c->in.n());
+	if (!c->slab) for (int o = 0; o < c->noct; o++) total += 2 * al64(c->gss[(size_t)o * c->ng].n());  // slabs only run the fused kernel
+	for (auto &L : c->gss) total += al64(L.n());
+	for (auto &L : c->dog) total += al64(L.n());
+	return total;
+}
+
+static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_params *params, int device) {
 	*out = nullptr;
+	if (cfg.nx <= 0 || cfg.ny <= 0 || cfg.nz <= 0) { set_last_error("bad dimensions"); return SIFT3D_ERR_ARG; }
 	int rc = set_device(device);
 	if (rc) return rc;
 	sift3d_ctx *c = new sift3d_ctx();
 	c->device = device;
 	if (params) c->p = *params; else sift3d_default_params(&c->p);
 	if (c->p.num_kp_levels < 1 || c->p.num_kp_levels > 5) { delete c; set_last_error("num_kp_levels must be in [1,5]"); return SIFT3D_ERR_ARG; }
-	c->nx = nx; c->ny = ny; c->nz = nz;
+	c->nx = cfg.nx; c->ny = cfg.ny; c->nz = cfg.nz;
+	c->octave_base = cfg.octave_base; c->seeded = cfg.seeded;
+	c->slab = cfg.slab; c->own0 = cfg.z0; c->own1 = cfg.z1; c->halo = cfg.halo;
 	{ const char *e = getenv("S3D_SEPARABLE"); c->use_fused = !(e && e[0] == '1'); }
-	plan_pyramid(c);
+	plan_pyramid(c, cfg.noct_total);
+	c->in.nx = cfg.nx; c->in.ny = cfg.ny; c->in.nz = cfg.nz; c->in.unit = (float)(1 << c->octave_base); c->in.scale = 1.f;
+	if (c->slab) { c->in.bz = c->own1 - c->own0 + 2 * c->halo; c->in.zoff = c->own0 - c->halo; }
+	if (c->seeded) c->in.bz = 1;  // no input volume: keep a token plane
+	for (auto &L : c->gss) if ((size_t)L.nx * L.ny * L.planes() >= ((size_t)1 << 31)) { delete c; set_last_error("level too large for int32 voxel indices"); return SIFT3D_ERR_ARG; }
 
 	// host tables
 	std::vector<float> sig;
@@ -363,25 +404,26 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 	}
 
 	// ---- arena: input | per-octave scratch A,B | GSS levels | DoG levels (each 256-B aligned) ----
-	const size_t V0 = (size_t)nx * ny * nz;
-	auto al = [](size_t n) { return (n + 63) & ~(size_t)63; };
-	size_t total = al(V0);
-	for (int o = 0; o < c->noct; o++) total += 2 * al(c->gss[(size_t)o * c->ng].n());
-	for (auto &L : c->gss) total += al(L.n());
-	for (auto &L : c->dog) total += al(L.n());
+	const size_t total = arena_floats_of(c);
 	c->arena_floats = total;
-	CHECKED(hipMalloc(&c->arena, sizeof(float) * total));
+	if (cfg.ext_arena) {
+		if (cfg.ext_arena_floats < total) { set_last_error("caller arena too small"); sift3d_destroy(c); return SIFT3D_ERR_ARG; }
+		c->arena = cfg.ext_arena;
+		c->ext_arena = true;
+	} else {
+		CHECKED(hipMalloc(&c->arena, sizeof(float) * total));
+	}
 	float *p = c->arena;
-	c->in.d = p; c->in.nx = nx; c->in.ny = ny; c->in.nz = nz; c->in.unit = 1.f; c->in.scale = 1.f; p += al(V0);
+	c->in.d = p; p += al64(c->in.n());
 	c->tmpA.assign((size_t)std::max(1, c->noct), nullptr);
 	c->tmpB.assign((size_t)std::max(1, c->noct), nullptr);
-	for (int o = 0; o < c->noct; o++) {
-		const size_t vo = al(c->gss[(size_t)o * c->ng].n());
+	for (int o = 0; o < c->noct && !c->slab; o++) {
+		const size_t vo = al64(c->gss[(size_t)o * c->ng].n());
 		c->tmpA[o] = p; p += vo;
 		c->tmpB[o] = p; p += vo;
 	}
-	for (auto &L : c->gss) { L.d = p; p += al(L.n()); }
-	for (auto &L : c->dog) { L.d = p; p += al(L.n()); }
+	for (auto &L : c->gss) { L.d = p; p += al64(L.n()); }
+	for (auto &L : c->dog) { L.d = p; p += al64(L.n()); }
 
 	const size_t nwords = 1 + (size_t)std::max(1, c->noct * c->nd) + 4;
 	CHECKED(hipMalloc(&c->d_words, sizeof(unsigned) * nwords));
@@ -391,22 +433,24 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 	c->d_total = c->d_words + 1 + std::max(1, c->noct * c->nd);  // [0] extrema total, [1] overflow flag
 	c->d_nkp = c->d_total + 2;
 
-	// detection scratch sized for octave 0 (the largest): one ballot word per 64 voxels of a row, one count per 16 rows
+	// detection scratch sized for the first octave (the largest): one ballot word per 64 voxels of a row, one count per 16 rows
+	const int scan_planes = c->slab ? (c->own1 - c->own0) : cfg.nz;
 	{
 		const size_t kl = (size_t)c->p.num_kp_levels;
-		const size_t words = kl * (size_t)nz * ny * ((nx + 63) / 64);
-		c->det_blocks = kl * (size_t)nz * ((ny + 15) / 16);
+		const size_t words = kl * (size_t)scan_planes * cfg.ny * ((cfg.nx + 63) / 64);
+		c->det_blocks = kl * (size_t)scan_planes * ((cfg.ny + 15) / 16);
 		CHECKED(hipMalloc(&c->det.masks, sizeof(unsigned long long) * std::max<size_t>(words, 1)));
 		CHECKED(hipMalloc(&c->det.block_counts, sizeof(unsigned) * std::max<size_t>(c->det_blocks, 1)));
 		CHECKED(hipMalloc(&c->det.block_offsets, sizeof(unsigned) * std::max<size_t>(c->det_blocks, 1)));
 	}
 	c->det.total = c->d_total;
 
-	std::vector<LevelRef> lr((size_t)std::max(1, c->noct) * 8, LevelRef{nullptr, 0, 0, 0, 1.f});
+	// level table for the keypoint kernels, indexed by ABSOLUTE octave
+	std::vector<LevelRef> lr((size_t)std::max(1, c->noct + c->octave_base) * 8, LevelRef{nullptr, 0, 0, 0, 1.f, 0});
 	for (int o = 0; o < c->noct; o++)
 		for (int i = 0; i < c->ng && i < 8; i++) {
 			const Level &L = c->gss[(size_t)o * c->ng + i];
-			lr[(size_t)o * 8 + i] = LevelRef{L.d, L.nx, L.ny, L.nz, L.unit};
+			lr[(size_t)(o + c->octave_base) * 8 + i] = LevelRef{L.d, L.nx, L.ny, L.nz, L.unit, L.zoff};
 		}
 	CHECKED(hipMalloc(&c->d_levels, sizeof(LevelRef) * lr.size()));
 	CHECKED(hipMemcpy(c->d_levels, lr.data(), sizeof(LevelRef) * lr.size(), hipMemcpyHostToDevice));
@@ -418,19 +462,36 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 	build_predict(faces, &pred);
 	upload_faces(faces, &pred);
 
-	// keypoint lists: synthetic blob volumes give ~6e-4*V0 extrema; leave 8x headroom, regrow on overflow
+	// keypoint lists: synthetic blob volumes give ~6e-4*V extrema; leave 8x headroom, regrow on overflow
+	const size_t V0 = (size_t)cfg.nx * cfg.ny * scan_planes;
 	unsigned cap = (unsigned)std::min<size_t>(std::max<size_t>(4096, V0 / 256), 4u << 20);
 	rc = alloc_lists(c, cap);
 	if (rc) { sift3d_destroy(c); return rc; }
-
-	// ---- constructor work proper: copy + data_scale (Src/cSIFT3D.cc:161-162) ----
-	CHECKED(hipMemcpyAsync(c->in.d, volume, sizeof(float) * V0, volume_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-	launch_absmax(c->in.d, V0, c->d_inmax, c->stream);
-	launch_scale_by_max(c->in.d, V0, c->d_inmax, c->stream);
 	CHECKED(hipStreamSynchronize(c->stream));
-	CHECKED(hipGetLastError());
 #undef CHECKED
 	*out = c;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
+                             int device, int volume_on_device) {
+	if (!out || !volume || nx <= 0 || ny <= 0 || nz <= 0) { set_last_error("sift3d_create: bad argument"); return SIFT3D_ERR_ARG; }
+	if ((size_t)nx * ny * nz >= ((size_t)1 << 31)) { set_last_error("volume too large for int32 voxel indices"); return SIFT3D_ERR_ARG; }
+	CreateCfg cfg;
+	cfg.nx = nx; cfg.ny = ny; cfg.nz = nz;
+	int rc = create_common(out, cfg, params, device);
+	if (rc) return rc;
+	sift3d_ctx *c = *out;
+	// ---- constructor work proper: copy + data_scale (Src/cSIFT3D.cc:161-162) ----
+	const size_t V0 = (size_t)nx * ny * nz;
+	hipError_t e = hipMemcpyAsync(c->in.d, volume, sizeof(float) * V0, volume_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) {
+		launch_absmax(c->in.d, V0, c->d_inmax, c->stream);
+		launch_scale_by_max(c->in.d, V0, c->d_inmax, c->stream);
+		e = hipStreamSynchronize(c->stream);
+	}
+	if (e == hipSuccess) e = hipGetLastError();
+	if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); sift3d_destroy(c); *out = nullptr; return SIFT3D_ERR_HIP; }
 	return SIFT3D_OK;
 }
 
@@ -439,7 +500,7 @@ static void smooth_level(sift3d_ctx *c, int o, const float *src, const Level &ds
                          unsigned *dogmax) {
 	hipStream_t st = c->ostream[o];
 	// hot path: one fused pass (x, y, z blur + DoG + abs-max); prev == src for every DoG-producing level
-	if (c->use_fused && (prev == nullptr || prev == src) && launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.nz, t, st))
+	if (c->use_fused && (prev == nullptr || prev == src) && launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.zr_all(), t, st))
 		return;
 	launch_conv_axis(0, src, c->tmpA[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
 	launch_conv_axis(1, c->tmpA[o], c->tmpB[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
@@ -447,6 +508,7 @@ static void smooth_level(sift3d_ctx *c, int o, const float *src, const Level &ds
 }
 
 static int run_impl(sift3d_ctx *c, int upto) {
+	if (c->slab) { set_last_error("a z-slab context is driven stage by stage (sift3d_slab_*)"); return SIFT3D_ERR_STATE; }
 	int rc = set_device(c->device);
 	if (rc) return rc;
 	if (upto < 1) upto = 1;
@@ -468,7 +530,8 @@ static int run_impl(sift3d_ctx *c, int upto) {
 			for (int i = 0; i < c->ng; i++) {
 				const Level &L = c->gss[(size_t)o * c->ng + i];
 				if (o == 0 && i == 0) {
-					smooth_level(c, o, c->in.d, L, c->base_taps, nullptr, nullptr, nullptr);
+					if (!c->seeded) smooth_level(c, o, c->in.d, L, c->base_taps, nullptr, nullptr, nullptr);
+					// seeded: G[octave_base][0] was written by sift3d_seed_upload
 				} else if (i == 0) {
 					const Level &P = c->gss[(size_t)(o - 1) * c->ng + c->p.num_kp_levels];
 					launch_downsample(P.d, P.nx, P.ny, L.d, L.nx, L.ny, L.nz, so);
@@ -499,7 +562,7 @@ static int run_impl(sift3d_ctx *c, int upto) {
 					DL.scale[i - 1] = c->dog[(size_t)o * c->nd + i].scale;
 				}
 				const Level &C = c->dog[(size_t)o * c->nd + 1];
-				launch_detect_octave(DL, nl, C.nx, C.ny, C.nz, c->p.peak_thresh, o, c->det, c->d_ext, c->ext_cap, st);
+				launch_detect_octave(DL, nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, c->det, c->d_ext, c->ext_cap, st);
 			}
 		S3D_HIP(hipEventRecord(c->ev[3], st));
 		// ---- Assign_Orientation (Src/cSIFT3D.cc:427-482) ----
@@ -510,7 +573,11 @@ static int run_impl(sift3d_ctx *c, int upto) {
 		}
 		S3D_HIP(hipEventRecord(c->ev[4], st));
 		// ---- Extract_Description (Src/cSIFT3D.cc:484-502) ----
-		if (upto >= 5) launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, st);
+		if (upto >= 5) {
+			if (c->part_world > 1) S3D_HIP(hipMemsetAsync(c->d_desc, 0, sizeof(float) * kDesc * (size_t)c->kp_cap, st));  // rows of other ranks stay 0
+			launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, c->part_rank,
+			                c->part_world, st);
+		}
 		if (upto >= 4) launch_finalize(c->d_ext, c->d_total, c->ext_cap, upto >= 5, c->d_kpout, c->d_xyz, c->kp_cap, st);
 		S3D_HIP(hipEventRecord(c->ev[5], st));
 		unsigned host_words[3] = {0, 0, 0};  // total, overflow, nkp
@@ -687,5 +754,326 @@ extern "C" int sift3d_gaussian_smooth(const float *src, int nx, int ny, int nz, 
 	if (e == hipSuccess) e = hipMemcpy(dst, d, sizeof(float) * n, hipMemcpyDeviceToHost);
 	hipFree(d);
 	if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return SIFT3D_ERR_HIP; }
+	return SIFT3D_OK;
+}
+
+
+// =============================================================================================================
+// Multi-GPU sharding entry points (include/sift3d_hip.h): seeded tail contexts and z-slab contexts of octave 0
+// =============================================================================================================
+extern "C" int sift3d_create_seeded(sift3d_handle *out, int nx, int ny, int nz, int octave_base, int noct_total,
+                                    const sift3d_params *params, int device) {
+	if (!out || octave_base < 0 || octave_base > 20) { set_last_error("sift3d_create_seeded: bad argument"); return SIFT3D_ERR_ARG; }
+	CreateCfg cfg;
+	cfg.nx = nx; cfg.ny = ny; cfg.nz = nz; cfg.octave_base = octave_base; cfg.noct_total = noct_total; cfg.seeded = true;
+	return create_common(out, cfg, params, device);
+}
+
+extern "C" int sift3d_seed_upload(sift3d_handle c, const float *level0, int on_device) {
+	if (!c || !level0 || !c->seeded) return SIFT3D_ERR_ARG;
+	if (c->noct <= 0) return SIFT3D_OK;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	const Level &L = c->gss[0];
+	S3D_HIP(hipMemcpyAsync(L.d, level0, sizeof(float) * L.n(), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_set_describe_partition(sift3d_handle c, int rank, int world) {
+	if (!c || world < 1 || rank < 0 || rank >= world) return SIFT3D_ERR_ARG;
+	c->part_rank = rank; c->part_world = world;
+	return SIFT3D_OK;
+}
+
+// planes a keypoint's descriptor window can reach along z in octave 0 (Src/cSIFT3D.cc:1155-1156, 1276-1290: window
+// [floor(c-r), ceil(c+r)] plus the central-difference neighbours), and never less than the widest Gaussian + 1
+extern "C" int sift3d_slab_min_halo(const sift3d_params *params, int *halo) {
+	if (!halo) return SIFT3D_ERR_ARG;
+	sift3d_params p;
+	if (params) p = *params; else sift3d_default_params(&p);
+	if (p.num_kp_levels < 1 || p.num_kp_levels > 5) return SIFT3D_ERR_ARG;
+	const double sigma0 = (double)p.sigma_default * pow(2.0, -1.0 / 3.0);
+	const float scale = (float)(pow(2.0, (double)p.num_kp_levels / (double)p.num_kp_levels) * sigma0);  // DoG level num_kp_levels, octave 0
+	const float radius = 2.0f * (scale * 7.071067812f);
+	int h = (int)ceilf(radius) + 2;
+	std::vector<float> sig;
+	float base_sigma;
+	level_sigmas(p, sig, base_sigma);
+	for (size_t i = 1; i < sig.size(); i++) {
+		Taps t;
+		if (!build_taps(sig[i], t)) return SIFT3D_ERR_ARG;
+		h = std::max(h, t.hw + 1);
+	}
+	*halo = h;
+	return SIFT3D_OK;
+}
+
+// D2D copy of the results into caller-owned device buffers (n*768 and n*3 floats), so that a communication layer that
+// only knows its own allocations can reduce / gather them
+extern "C" int sift3d_export_device(sift3d_handle c, float *d_desc_dst, float *d_xyz_dst) {
+	if (!c) return SIFT3D_ERR_ARG;
+	if (c->stage < 5) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	if (d_desc_dst && c->n_kp) S3D_HIP(hipMemcpyAsync(d_desc_dst, c->d_desc, sizeof(float) * kDesc * (size_t)c->n_kp, hipMemcpyDeviceToDevice, c->stream));
+	if (d_xyz_dst && c->n_kp) S3D_HIP(hipMemcpyAsync(d_xyz_dst, c->d_xyz, sizeof(float) * 3 * (size_t)c->n_kp, hipMemcpyDeviceToDevice, c->stream));
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	return SIFT3D_OK;
+}
+
+// the inverse: overwrite the descriptors of this handle with rows reduced elsewhere (after the all-reduce of a
+// partitioned describe), so that sift3d_get_keypoints / sift3d_device_results / sift3d_match see complete rows
+extern "C" int sift3d_import_descriptors_device(sift3d_handle c, const float *d_desc_src) {
+	if (!c || !d_desc_src) return SIFT3D_ERR_ARG;
+	if (c->stage < 5) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	if (c->n_kp) S3D_HIP(hipMemcpyAsync(c->d_desc, d_desc_src, sizeof(float) * kDesc * (size_t)c->n_kp, hipMemcpyDeviceToDevice, c->stream));
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	return SIFT3D_OK;
+}
+
+static int slab_cfg(const sift3d_slab_desc *d, CreateCfg &cfg) {
+	// even start so that DownSample_3D's plane 2k stays inside one slab; an odd end is only possible at the top of the volume
+	if (!d || d->nx <= 0 || d->ny <= 0 || d->nz <= 0 || d->z0 < 0 || d->z1 > d->nz || d->z1 <= d->z0 || (d->z0 & 1) ||
+	    ((d->z1 & 1) && d->z1 != d->nz) || d->halo < 1) {
+		set_last_error("bad slab description (owned range must be non-empty, start and end on even planes, inside the volume)");
+		return SIFT3D_ERR_ARG;
+	}
+	cfg.nx = d->nx; cfg.ny = d->ny; cfg.nz = d->nz; cfg.noct_total = d->noct_total; cfg.slab = true;
+	cfg.z0 = d->z0; cfg.z1 = d->z1; cfg.halo = d->halo;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_arena_floats(const sift3d_slab_desc *d, const sift3d_params *params, size_t *n) {
+	if (!n) return SIFT3D_ERR_ARG;
+	CreateCfg cfg;
+	int rc = slab_cfg(d, cfg);
+	if (rc) return rc;
+	sift3d_ctx tmp;  // geometry only, no device work
+	if (params) tmp.p = *params; else sift3d_default_params(&tmp.p);
+	tmp.nx = cfg.nx; tmp.ny = cfg.ny; tmp.nz = cfg.nz; tmp.slab = true; tmp.own0 = cfg.z0; tmp.own1 = cfg.z1; tmp.halo = cfg.halo;
+	plan_pyramid(&tmp, cfg.noct_total);
+	tmp.in.nx = cfg.nx; tmp.in.ny = cfg.ny; tmp.in.nz = cfg.nz; tmp.in.bz = cfg.z1 - cfg.z0 + 2 * cfg.halo;
+	*n = arena_floats_of(&tmp);
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_create(sift3d_handle *out, const sift3d_slab_desc *d, const sift3d_params *params, int device,
+                                  float *d_arena, size_t arena_floats) {
+	if (!out || !d_arena) return SIFT3D_ERR_ARG;
+	CreateCfg cfg;
+	int rc = slab_cfg(d, cfg);
+	if (rc) return rc;
+	cfg.ext_arena = d_arena; cfg.ext_arena_floats = arena_floats;
+	rc = create_common(out, cfg, params, device);
+	if (rc) return rc;
+	sift3d_ctx *c = *out;
+	if (c->noct < 1) { sift3d_destroy(c); *out = nullptr; set_last_error("volume too small for one octave"); return SIFT3D_ERR_ARG; }
+	// the fused level kernel is the only slab-aware Gaussian: default half widths and n >= 2*hw+2 along x and y
+	for (int i = 0; i < c->ng; i++) {
+		const int hw = i == 0 ? c->base_taps.hw : c->taps[i].hw;
+		const bool inst = hw == 2 || hw == 3 || hw == 4 || hw == 5 || hw == 6 || hw == 8;
+		if (!inst || c->nx < 2 * hw + 2 || c->ny < 2 * hw + 2 || hw + 1 > c->halo) {
+			sift3d_destroy(c); *out = nullptr;
+			set_last_error("slab mode needs the fused level kernel (default sigma schedule, nx,ny >= 18) and halo > hw");
+			return SIFT3D_ERR_ARG;
+		}
+	}
+	// planes outside the volume (rank 0 below z = 0, last rank above nz-1) are never read; zero everything once so that
+	// halo planes that are never exchanged hold defined values
+	hipError_t e = hipMemsetAsync(c->arena, 0, sizeof(float) * c->arena_floats, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); sift3d_destroy(c); *out = nullptr; return SIFT3D_ERR_HIP; }
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_buffer(sift3d_handle c, int kind, int idx, size_t *offset_floats, int *planes, int *zoff) {
+	if (!c || !c->slab) return SIFT3D_ERR_ARG;
+	const Level *L = nullptr;
+	if (kind == 0) L = &c->in;
+	else if (kind == 1 && idx >= 0 && idx < c->ng) L = &c->gss[idx];
+	else if (kind == 2 && idx >= 0 && idx < c->nd) L = &c->dog[idx];
+	if (!L) return SIFT3D_ERR_ARG;
+	if (offset_floats) *offset_floats = (size_t)(L->d - c->arena);
+	if (planes) *planes = L->planes();
+	if (zoff) *zoff = L->zoff;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_upload(sift3d_handle c, const float *planes, int zg0, int zg1, int on_device) {
+	if (!c || !c->slab || !planes || zg0 < c->in.zoff || zg1 > c->in.zoff + c->in.planes() || zg0 < 0 || zg1 > c->nz || zg1 <= zg0)
+		return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	const size_t pl = (size_t)c->nx * c->ny;
+	S3D_HIP(hipMemcpyAsync(c->in.d + pl * (size_t)(zg0 - c->in.zoff), planes, sizeof(float) * pl * (size_t)(zg1 - zg0),
+	                       on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_input_absmax(sift3d_handle c, float *local_max) {
+	if (!c || !c->slab || !local_max) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	const size_t pl = (size_t)c->nx * c->ny;
+	launch_absmax(c->in.d + pl * (size_t)(c->own0 - c->in.zoff), pl * (size_t)(c->own1 - c->own0), c->d_inmax, c->stream);
+	unsigned bits = 0;
+	S3D_HIP(hipMemcpyAsync(&bits, c->d_inmax, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	memcpy(local_max, &bits, sizeof(float));
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_input_scale(sift3d_handle c, float global_max) {
+	if (!c || !c->slab) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	unsigned bits;
+	memcpy(&bits, &global_max, sizeof(float));
+	S3D_HIP(hipMemcpyAsync(c->d_inmax, &bits, sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+	launch_scale_by_max(c->in.d, c->in.n(), c->d_inmax, c->stream);  // halo planes included (0/max = 0 where never uploaded)
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_halo_planes(sift3d_handle c, int i, int *planes) {
+	if (!c || !c->slab || !planes || i < 0 || i >= c->ng) return SIFT3D_ERR_ARG;
+	int need = 0;
+	if (i + 1 < c->ng) need = c->taps[i + 1].hw;               // input reach of the next Gaussian level
+	if (i >= 1 && i <= c->p.num_kp_levels) need = c->halo;       // orientation / descriptor windows on G[1..levels]
+	*planes = std::min(need, c->halo);
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_level_hw(sift3d_handle c, int i, int *hw) {
+	if (!c || !c->slab || !hw || i < 0 || i >= c->ng) return SIFT3D_ERR_ARG;
+	*hw = i == 0 ? c->base_taps.hw : c->taps[i].hw;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_level(sift3d_handle c, int i) {
+	if (!c || !c->slab || i < 0 || i >= c->ng) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	const Level &L = c->gss[i];
+	const ZRange zr = L.zr(c->own0 - L.zoff, c->own1 - L.zoff);
+	bool ok;
+	if (i == 0) {
+		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(c->nd + 4), c->stream));
+		ok = launch_fused_level(c->in.d, L.d, nullptr, nullptr, L.nx, L.ny, zr, c->base_taps, c->stream);
+	} else {
+		ok = launch_fused_level(c->gss[i - 1].d, L.d, c->dog[i - 1].d, c->d_dogmax + (i - 1), L.nx, L.ny, zr, c->taps[i], c->stream);
+	}
+	if (!ok) { set_last_error("no fused kernel for this level"); return SIFT3D_ERR_STATE; }
+	c->stage = std::max(c->stage, 1);
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_sync(sift3d_handle c) {
+	if (!c) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	S3D_HIP(hipGetLastError());
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_get_dogmax(sift3d_handle c, float *max5) {
+	if (!c || !c->slab || !max5) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	unsigned bits[8] = {0};
+	S3D_HIP(hipMemcpyAsync(bits, c->d_dogmax, sizeof(unsigned) * (size_t)c->nd, hipMemcpyDeviceToHost, c->stream));
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	memcpy(max5, bits, sizeof(float) * (size_t)c->nd);
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_set_dogmax(sift3d_handle c, const float *max5) {
+	if (!c || !c->slab || !max5) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	unsigned bits[8] = {0};
+	memcpy(bits, max5, sizeof(float) * (size_t)c->nd);
+	S3D_HIP(hipMemcpyAsync(c->d_dogmax, bits, sizeof(unsigned) * (size_t)c->nd, hipMemcpyHostToDevice, c->stream));
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	return SIFT3D_OK;
+}
+
+static int slab_count_and_regrow(sift3d_ctx *c, bool &again) {
+	unsigned host_words[3] = {0, 0, 0};
+	S3D_HIP(hipMemcpyAsync(host_words, c->d_total, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, c->stream));
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	S3D_HIP(hipGetLastError());
+	again = false;
+	if (host_words[1] != 0 || host_words[0] > c->ext_cap) {
+		int rc = alloc_lists(c, std::max(host_words[0], c->ext_cap) * 2u);
+		if (rc) return rc;
+		again = true;
+		return SIFT3D_OK;
+	}
+	c->n_ext = host_words[0];
+	c->n_kp = host_words[2];
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_detect(sift3d_handle c) {
+	if (!c || !c->slab) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	for (int attempt = 0; attempt < 4; attempt++) {
+		S3D_HIP(hipMemsetAsync(c->d_total, 0, sizeof(unsigned) * 3, c->stream));
+		DetectLevels DL;
+		memset(&DL, 0, sizeof(DL));
+		const int nl = c->nd - 2;
+		for (int i = 1; i <= nl; i++) {
+			DL.cur[i - 1] = c->dog[i].d; DL.prev[i - 1] = c->dog[i - 1].d; DL.next[i - 1] = c->dog[i + 1].d;
+			DL.absmax_bits[i - 1] = c->d_dogmax + i;
+			DL.level_id[i - 1] = i;
+			DL.scale[i - 1] = c->dog[i].scale;
+		}
+		const Level &C = c->dog[1];
+		launch_detect_octave(DL, nl, C.nx, C.ny, C.zr(c->own0 - C.zoff, c->own1 - C.zoff), c->p.peak_thresh, c->octave_base, c->det,
+		                     c->d_ext, c->ext_cap, c->stream);
+		bool again;
+		rc = slab_count_and_regrow(c, again);
+		if (rc) return rc;
+		if (!again) { c->stage = 3; c->n_kp = 0; return SIFT3D_OK; }
+	}
+	set_last_error("extrema list kept overflowing");
+	return SIFT3D_ERR_CAPACITY;
+}
+
+extern "C" int sift3d_slab_describe(sift3d_handle c) {
+	if (!c || !c->slab || c->stage < 3) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	hipStream_t st = c->stream;
+	launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
+	              c->p.corner_thresh, st);
+	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, st);
+	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, 0, 1, st);
+	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
+	bool again;
+	rc = slab_count_and_regrow(c, again);
+	if (rc) return rc;
+	c->stage = 5;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_decimate(sift3d_handle c, float *d_dst) {
+	if (!c || !c->slab || !d_dst) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	const Level &P = c->gss[c->p.num_kp_levels];
+	const size_t pl = (size_t)P.nx * P.ny;
+	// owned planes start at an even global z, so dst plane k = src global plane own0 + 2k (Src/cSIFT3D.cc:321-344)
+	const int nz2 = std::min(c->own1 / 2, c->nz / 2) - c->own0 / 2;
+	if (nz2 > 0)
+		launch_downsample(P.d + pl * (size_t)(c->own0 - P.zoff), P.nx, P.ny, d_dst, P.nx / 2, P.ny / 2, nz2, c->stream);
+	S3D_HIP(hipStreamSynchronize(c->stream));
 	return SIFT3D_OK;
 }

@@ -172,7 +172,8 @@ constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <=
 
 __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
                                                   const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
-                                                  const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap) {
+                                                  const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap,
+                                                  int part_rank, int part_world) {
 	__shared__ unsigned long long hist[kDesc * kRep];  // [bin][replica], two's-complement fixed point, 2^-40 units
 	__shared__ float s_lut[kMaxDescLut];
 	__shared__ float s_q[4][6][kQCap];                 // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
@@ -206,6 +207,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 	for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
 		const int slot = kps[k].slot;
 		if (slot < 0 || (unsigned)slot >= kp_cap) continue;  // rejected by orientation (block-uniform)
+		if (part_world > 1 && (slot % part_world) != part_rank) continue;  // another rank describes this keypoint
 		const int cxi = kps[k].x, cyi = kps[k].y, czi = kps[k].z;
 		const int li = kps[k].octave * 8 + kps[k].level;
 		const float scale = kps[k].scale;
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1);
 		const int sy = L.nx, sz = L.nx * L.ny;  // levels are < 2^31 voxels
 		const int nin = lut.nin;                 // largest integer squared offset inside the sphere
-		const float *centre = L.d + (size_t)cxi + (size_t)sy * (size_t)cyi + (size_t)sz * (size_t)czi;  // always valid
+		const float *centre = L.d + (size_t)cxi + (size_t)sy * (size_t)cyi + (size_t)sz * (size_t)(czi - L.zoff);  // always valid
 
 		__syncthreads();  // previous keypoint finished with hist / s_lut
 		for (int i = tid; i < kDesc * kRep; i += 256) hist[i] = 0ull;
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 			maxlen = __builtin_amdgcn_readfirstlane(maxlen);
 			if (maxlen == 0) continue;  // wave-uniform
 			// lanes without a column march on the keypoint's own column (always in bounds) and are masked
-			const float *c = zlen > 0 ? L.d + (size_t)x + (size_t)sy * (size_t)y + (size_t)sz * (size_t)za : centre;
+			const float *c = zlen > 0 ? L.d + (size_t)x + (size_t)sy * (size_t)y + (size_t)sz * (size_t)(za - L.zoff) : centre;
 			float cm = *(c - sz), cc = *c;  // centre column at z-1, z
 			float nxm = c[-1], nxp = c[1], nym = *(c - sy), nyp = c[sy];  // in-plane neighbours of plane z (pipelined)
 			int dz = za - czi;
@@ -377,8 +379,9 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 }
 
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels, const WinLut *d_luts,
-                     const float *d_lutpool, float *d_desc, unsigned kp_cap, hipStream_t st) {
-	hipLaunchKernelGGL(k_describe, dim3(256 * 16), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap);
+                     const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world, hipStream_t st) {
+	hipLaunchKernelGGL(k_describe, dim3(256 * 16), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
+	                   part_rank, part_world);
 }
 
 // final keypoint records (Keypoint fields incl. rx,ry,rz = x*2^octave, Src/cSIFT3D.cc:1377-1379)

@@ -21,11 +21,14 @@ constexpr int kRows = 16;   // rows per block
 constexpr int kThreads = 256;
 
 // masks layout: word index = ((lvl * nz + z) * ny + y) * wpr + xw, wpr = ceil(nx / 64): scan order
-__global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int ny, int nz, int nyb, float peak_thresh,
+__global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int ny, ZRange zr, int nyb, float peak_thresh,
                                                    unsigned long long *__restrict__ masks, unsigned *__restrict__ block_counts) {
 	__shared__ unsigned s_cnt[kThreads / 64];
 	const int b = blockIdx.x;
-	const int yb = b % nyb, z = (b / nyb) % nz, lvl = b / (nyb * nz);
+	const int nz = zr.zo1 - zr.zo0;                              // planes scanned by this launch (local range [zo0, zo1))
+	const int yb = b % nyb, zi = (b / nyb) % nz, lvl = b / (nyb * nz);
+	const int z = zr.zo0 + zi;                                   // local plane in the buffers
+	const int zg = z + zr.zoff;                                  // global plane (border rule, Src/cSIFT3D.cc:388)
 	const float *__restrict__ cur = L.cur[lvl];
 	const float *__restrict__ prev = L.prev[lvl];
 	const float *__restrict__ next = L.next[lvl];
@@ -34,7 +37,7 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
 	unsigned cnt = 0;
-	const bool z_in = (z >= 1 && z <= nz - 2);
+	const bool z_in = (zg >= 1 && zg <= zr.nzg - 2);
 	// the block's 16 rows x wpr words are dealt to its 4 waves word by word
 	const int y0 = yb * kRows;
 	const int nwords = min(kRows, ny - y0) * wpr;
@@ -54,7 +57,7 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 			}
 		}
 		const unsigned long long m = __ballot(hit);
-		if (lane == 0) masks[((size_t)(lvl * nz + z) * ny + y) * wpr + xw] = m;
+		if (lane == 0) masks[((size_t)(lvl * nz + zi) * ny + y) * wpr + xw] = m;
 		cnt += (unsigned)__popcll(m);
 	}
 	if (lane == 0) s_cnt[wid] = cnt;
@@ -96,12 +99,14 @@ __global__ void __launch_bounds__(1024) k_scan(const unsigned *__restrict__ bloc
 
 // one thread per ballot word of a block (16 rows x wpr words, same block decomposition as k_mark)
 __global__ void __launch_bounds__(kThreads) k_emit(const unsigned long long *__restrict__ masks,
-                                                   const unsigned *__restrict__ block_offsets, int nx, int ny, int nz, int nyb,
+                                                   const unsigned *__restrict__ block_offsets, int nx, int ny, ZRange zr, int nyb,
                                                    int octave, DetectLevels L, DevKp *__restrict__ out, unsigned cap,
                                                    unsigned *__restrict__ total) {
 	__shared__ unsigned s_wave[kThreads / 64];
 	const int b = blockIdx.x;
-	const int yb = b % nyb, z = (b / nyb) % nz, lvl = b / (nyb * nz);
+	const int nz = zr.zo1 - zr.zo0;
+	const int yb = b % nyb, zi = (b / nyb) % nz, lvl = b / (nyb * nz);
+	const int z = zr.zo0 + zi + zr.zoff;  // GLOBAL plane: keypoint coordinates are global
 	const int wpr = (nx + 63) >> 6;
 	const int y0 = yb * kRows;
 	const int nwords = min(kRows, ny - y0) * wpr;
@@ -117,7 +122,7 @@ __global__ void __launch_bounds__(kThreads) k_emit(const unsigned long long *__r
 			xw = wi - ry * wpr;
 			y = y0 + ry;
 			// k_mark dealt the words to waves round-robin; the layout in memory is scan order
-			m = masks[((size_t)(lvl * nz + z) * ny + y) * wpr + xw];
+			m = masks[((size_t)(lvl * nz + zi) * ny + y) * wpr + xw];
 		}
 		const unsigned c = (unsigned)__popcll(m);
 		unsigned v = c;
@@ -154,14 +159,16 @@ __global__ void __launch_bounds__(kThreads) k_emit(const unsigned long long *__r
 	}
 }
 
-void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, int nz, float peak_thresh, int octave,
+void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, float peak_thresh, int octave,
                           const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st) {
 	const int nyb = (ny + kRows - 1) / kRows;
-	const unsigned nblocks = (unsigned)(nlevels * nz * nyb);
+	const int nzl = zr.zo1 - zr.zo0;
+	if (nzl <= 0) return;
+	const unsigned nblocks = (unsigned)(nlevels * nzl * nyb);
 	if (nblocks == 0) return;
-	hipLaunchKernelGGL(k_mark, dim3(nblocks), dim3(kThreads), 0, st, L, nx, ny, nz, nyb, peak_thresh, b.masks, b.block_counts);
+	hipLaunchKernelGGL(k_mark, dim3(nblocks), dim3(kThreads), 0, st, L, nx, ny, zr, nyb, peak_thresh, b.masks, b.block_counts);
 	hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b.block_counts, b.block_offsets, nblocks, b.total);
-	hipLaunchKernelGGL(k_emit, dim3(nblocks), dim3(kThreads), 0, st, b.masks, b.block_offsets, nx, ny, nz, nyb, octave, L, out, cap,
+	hipLaunchKernelGGL(k_emit, dim3(nblocks), dim3(kThreads), 0, st, b.masks, b.block_offsets, nx, ny, zr, nyb, octave, L, out, cap,
 	                   b.total);
 }
 

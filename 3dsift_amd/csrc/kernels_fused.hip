@@ -110,7 +110,7 @@ __device__ __forceinline__ void zblur_static(float (&ring)[4][2 * HW + 2], const
 // for it at the join, which serialises the prefetch.  !VEC (odd widths, small volumes) keeps guarded scalar loads.
 template <int HW, bool DOG, bool VEC>
 __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
-                                                 unsigned *__restrict__ dogmax, int nx, int ny, int nz, const Taps &t,
+                                                 unsigned *__restrict__ dogmax, int nx, int ny, const ZRange zr, const Taps &t,
                                                  const EdgeFrac &ef, int ntx, int nty, int cz, float *in_t, float *xb,
                                                  float *s_red) {
 	using C = FusedCfg<HW>;
@@ -127,7 +127,8 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	const int tile_y = (lb / ntx) % nty;
 	const int chunk = lb / (ntx * nty);
 	const int x0 = tile_x * C::TX, y0 = tile_y * C::TY;
-	const int zc0 = chunk * cz, zc1 = min(nz, zc0 + cz);
+	const int nz = zr.nz, zoff = zr.zoff, nzg = zr.nzg;  // local planes, global z of local plane 0, global planes
+	const int zc0 = zr.zo0 + chunk * cz, zc1 = min(zr.zo1, zc0 + cz);
 
 	const int tid = threadIdx.x, lane = tid % C::TX, yq = tid / C::TX, wlane = tid & 63, wid = tid >> 6;
 	const bool edge_x = (x0 < HW) || (x0 + C::TX - 1 > nx - 2 - HW);
@@ -195,7 +196,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	const int q_begin = zc0 - HW - 1, q_end = zc1 - 1 + HW;  // inclusive
 	issue_plane_loads(q_begin);
 	for (int q = q_begin; q <= q_end; q++) {
-		const bool have_plane = (q >= 0 && q < nz);
+		const bool have_plane = (q >= 0 && q < nz) && (q + zoff >= 0) && (q + zoff < nzg);
 		const int p = q - HW;
 		const bool emit = (p >= zc0 && p < zc1);
 		// ---------------- regs -> LDS tile of plane q; then prefetch plane q+1 and the DoG centres of plane p ----------------
@@ -323,7 +324,8 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 			}
 		}
 		// ---------------- ring insert (slot q mod RING) + z-blur of plane p = q - HW ----------------
-		const bool z_interior = emit && (p >= HW) && (p <= nz - 2 - HW);
+		const int pg = p + zoff;  // global plane
+		const bool z_interior = emit && (pg >= HW) && (pg <= nzg - 2 - HW);
 		float out[4] = {0.f, 0.f, 0.f, 0.f};
 		const int rot = ring_slot<C::RING>(q);
 #define S3D_CASE(K) case K: if (K < C::RING) zblur_static<HW, (K < C::RING ? K : 0)>(ring, v, t, z_interior, out); break;
@@ -341,8 +343,8 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				for (int d = -HW; d <= HW; d++) {
 					int lo, hi;
 					float frac;
-					boundary_src(p, d, nz, lo, hi, frac);
-					const int slo = ring_slot<C::RING>(lo), shi = ring_slot<C::RING>(hi);
+					boundary_src(pg, d, nzg, lo, hi, frac);  // global rule; the ring is keyed by LOCAL plane index
+					const int slo = ring_slot<C::RING>(lo - zoff), shi = ring_slot<C::RING>(hi - zoff);
 					const float tap = t.w[d + HW];
 #pragma unroll
 					for (int j = 0; j < 4; j++) {
@@ -401,14 +403,14 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 template <int HW, bool DOG>
 __global__ void __launch_bounds__(256, FusedCfg<HW>::OCC) k_fused_level(const float *__restrict__ src, float *__restrict__ dst,
                                                                        float *__restrict__ dog, unsigned *__restrict__ dogmax,
-                                                                       int nx, int ny, int nz, Taps t, EdgeFrac ef, int ntx, int nty,
+                                                                       int nx, int ny, ZRange zr, Taps t, EdgeFrac ef, int ntx, int nty,
                                                                        int cz) {
 	using C = FusedCfg<HW>;
 	__shared__ __attribute__((aligned(16))) float in_t[C::ROWS * C::PITCH];
 	__shared__ __attribute__((aligned(16))) float xb[C::ROWS * C::TX];
 	__shared__ float s_red[4];
-	if ((nx & 3) == 0) fused_level_body<HW, DOG, true>(src, dst, dog, dogmax, nx, ny, nz, t, ef, ntx, nty, cz, in_t, xb, s_red);
-	else fused_level_body<HW, DOG, false>(src, dst, dog, dogmax, nx, ny, nz, t, ef, ntx, nty, cz, in_t, xb, s_red);
+	if ((nx & 3) == 0) fused_level_body<HW, DOG, true>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red);
+	else fused_level_body<HW, DOG, false>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red);
 }
 
 // fp32 fractions of the reference's right-boundary rule for an axis of length n (see file header):
@@ -424,8 +426,10 @@ static void edge_fractions(int n, int hw, float *f) {
 }
 
 template <int HW>
-static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, int nz, const Taps &t,
+static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
                       hipStream_t st) {
+	const int nz = zr.zo1 - zr.zo0;  // planes to produce
+	if (nz <= 0) return;
 	using C = FusedCfg<HW>;
 	const int ntx = (nx + C::TX - 1) / C::TX, nty = (ny + C::TY - 1) / C::TY;
 	const int ntiles = ntx * nty;
@@ -449,25 +453,25 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 	memset(&ef, 0, sizeof(ef));
 	edge_fractions(nx, HW, ef.f[0]);
 	edge_fractions(ny, HW, ef.f[1]);
-	edge_fractions(nz, HW, ef.f[2]);
+	edge_fractions(zr.nzg, HW, ef.f[2]);
 	dim3 grid((unsigned)(ntiles * nchunks)), block(256);
-	if (dog) hipLaunchKernelGGL((k_fused_level<HW, true>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, nz, t, ef, ntx, nty, cz);
-	else hipLaunchKernelGGL((k_fused_level<HW, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, nz, t, ef, ntx, nty, cz);
+	if (dog) hipLaunchKernelGGL((k_fused_level<HW, true>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
+	else hipLaunchKernelGGL((k_fused_level<HW, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
 }
 
 // returns false when no fused instantiation exists for this half width (caller uses the generic
 // separable kernels of kernels_pyramid.hip instead -- still the HIP path)
-bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, int nz, const Taps &t,
-                        hipStream_t st) {
+bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr,
+                        const Taps &t, hipStream_t st) {
 	// the halo-extension form of the boundary rule needs n >= 2*hw+2 along x and y (see header)
 	if (nx < 2 * t.hw + 2 || ny < 2 * t.hw + 2) return false;
 	switch (t.hw) {
-	case 2: launch_hw<2>(src, dst, dog, dogmax, nx, ny, nz, t, st); return true;
-	case 3: launch_hw<3>(src, dst, dog, dogmax, nx, ny, nz, t, st); return true;
-	case 4: launch_hw<4>(src, dst, dog, dogmax, nx, ny, nz, t, st); return true;
-	case 5: launch_hw<5>(src, dst, dog, dogmax, nx, ny, nz, t, st); return true;
-	case 6: launch_hw<6>(src, dst, dog, dogmax, nx, ny, nz, t, st); return true;
-	case 8: launch_hw<8>(src, dst, dog, dogmax, nx, ny, nz, t, st); return true;
+	case 2: launch_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
+	case 3: launch_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
+	case 4: launch_hw<4>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
+	case 5: launch_hw<5>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
+	case 6: launch_hw<6>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
+	case 8: launch_hw<8>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
 	default: return false;
 	}
 }

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 				if (n >= lut.len) continue;
 				const float w = wtab[n];
 				if (w < 0.0f) continue;  // outside the sphere
-				const float *c = L.d + (size_t)x + sy * (size_t)y + sz * (size_t)z;
+				const float *c = L.d + (size_t)x + sy * (size_t)y + sz * (size_t)(z - L.zoff);
 				float vx = 0.5f * (c[1] - c[-1]);
 				float vy = 0.5f * (c[sy] - *(c - sy));
 				float vz = 0.5f * (c[sz] - *(c - sz));

@@ -33,12 +33,28 @@ struct EdgeFrac {
 	float f[3][kMaxHW + 1];
 };
 
+// z geometry of a level buffer.  Whole volumes: {nz, 0, nz, 0, nz}.  A z-slab (multi-GPU sharding) holds only
+// planes [zoff, zoff+nz) of a level that is nzg planes tall, and a kernel produces local planes [zo0, zo1);
+// boundary rules and keypoint coordinates always use GLOBAL z = local z + zoff.
+struct ZRange {
+	int nz;    // planes held in the buffer
+	int zoff;  // global z of local plane 0 (may be negative: planes below 0 are never touched)
+	int nzg;   // global number of planes of the level
+	int zo0, zo1;  // local range of planes to produce
+};
+inline ZRange whole(int nz) { return ZRange{nz, 0, nz, 0, nz}; }
+
 struct Level {
 	float *d = nullptr;
-	int nx = 0, ny = 0, nz = 0;
+	int nx = 0, ny = 0, nz = 0;  // nz = GLOBAL number of planes of the level
 	float unit = 1.f;   // 2^octave (Src/cUtil.cc:215-225)
 	float scale = 0.f;  // scale-space location (Src/cUtil.cc:207-210)
-	size_t n() const { return (size_t)nx * ny * nz; }
+	int bz = 0;         // planes held in the buffer (0 = all nz); z-slab contexts hold [zoff, zoff+bz)
+	int zoff = 0;       // global z of buffer plane 0
+	int planes() const { return bz ? bz : nz; }
+	size_t n() const { return (size_t)nx * ny * planes(); }
+	ZRange zr(int zo0, int zo1) const { return ZRange{planes(), zoff, nz, zo0, zo1}; }
+	ZRange zr_all() const { return ZRange{planes(), zoff, nz, 0, planes()}; }
 };
 
 // One DoG extremum / keypoint while it lives on the device.
@@ -93,8 +109,8 @@ void launch_scale_by_max(float *data, size_t n, const unsigned *d_max_bits, hipS
 void launch_conv_axis(int axis, const float *src, float *dst, int nx, int ny, int nz, const Taps &t,
                       const float *prev, float *dog, unsigned *d_dogmax, hipStream_t st);
 // fused single-pass level kernel (kernels_fused.hip); false => no instantiation for this half width
-bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, int nz, const Taps &t,
-                        hipStream_t st);
+bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr,
+                        const Taps &t, hipStream_t st);
 void launch_downsample(const float *src, int snx, int sny, float *dst, int nx, int ny, int nz, hipStream_t st);
 
 // ---- kernels_detect.hip --------------------------------------------------------------------
@@ -112,14 +128,15 @@ struct DetectLevels {
 	int level_id[kMaxKpLevels];
 	float scale[kMaxKpLevels];
 };
-void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, int nz, float peak_thresh, int octave,
+void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, float peak_thresh, int octave,
                           const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st);
 
 // ---- kernels_orient.hip --------------------------------------------------------------------
 struct LevelRef {
-	const float *d;
-	int nx, ny, nz;
+	const float *d;   // local plane 0 of the buffer
+	int nx, ny, nz;   // nz = GLOBAL number of planes (window clipping, Src/cSIFT3D.cc:951-955)
 	float unit;
+	int zoff;         // global z of local plane 0 (0 for whole volumes)
 };
 void launch_orient(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap, const LevelRef *d_levels /*[noct*8]*/,
                    const WinLut *d_luts, const float *d_lutpool, float max_eig, float corner, hipStream_t st);
@@ -127,8 +144,11 @@ void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigne
 
 // ---- kernels_desc.hip ----------------------------------------------------------------------
 void upload_faces(const FaceConst *faces, const FacePredict *pred);  // into __constant__ memory
+// part_rank / part_world: only keypoints with slot % part_world == part_rank are described (multi-GPU split of
+// replicated octaves); 0 / 1 = all
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels,
-                     const WinLut *d_luts, const float *d_lutpool, float *d_desc, unsigned kp_cap, hipStream_t st);
+                     const WinLut *d_luts, const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world,
+                     hipStream_t st);
 void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, int transposed,
                      sift3d_keypoint *d_out, float *d_xyz, unsigned kp_cap, hipStream_t st);
 

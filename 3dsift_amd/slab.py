@@ -1,0 +1,390 @@
+"""Z-slab sharding of ONE large volume across the GPUs of a node (BASELINE.json configs[3]).
+
+No reference counterpart: the reference is a single process (Src/cSIFT3D.cc:165-235).  What is sharded is exactly that
+pipeline, with results equal to the single-GPU run (pyramid / extrema bit for bit, descriptors to the stated tolerance):
+
+  octave 0   rank r owns the global planes [z0_r, z1_r) of every level; level buffers carry `halo` extra planes per
+             side.  Per Gaussian level the ranks exchange the planes the NEXT consumer reaches:
+               G[i] -> level i+1 : hw_{i+1} planes per side           (urgent, awaited before level i+1 starts)
+               G[1..3]           : up to `halo` planes (orientation + descriptor windows reach +-37 planes; deferred)
+               DoG[1..3]         : 1 plane (extrema test reads z+-1; deferred)
+             as point-to-point sends between z-neighbours (RCCL over xGMI), posted while the next level computes.
+             The normalisation max and the 5 DoG maxima are all-reduced (MAX); x/y passes need no communication.
+  octaves>=1 G[1][0] = DownSample_3D(G[0][3]) is decimated slab-wise and all-gathered (1/8 of one level); the remaining
+             octaves (1/7 of the pyramid work) run replicated in a SEEDED context, only the descriptor work is dealt by
+             keypoint slot and the rows are all-reduced (SUM of disjoint rows = exact).
+
+The same lock-step driver runs over a communicator:
+  DistComm  one worker per process, torch.distributed (backend "nccl" == RCCL); works with gloo on CPU tensors for tests
+  SimComm   all workers in ONE process on one GPU (device copies instead of sends) -- the bit-exact equality test against
+            the single-volume result runs this way on a 1-GPU box (tests/test_gpu_slab.py)
+"""
+import math
+from collections import namedtuple
+
+import numpy as np
+
+Transfer = namedtuple("Transfer", "src dst kind idx zg0 zg1")  # global planes [zg0, zg1) of buffer (kind, idx): src -> dst
+
+KIND_INPUT, KIND_GSS, KIND_DOG = 0, 1, 2
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# planning (pure python, covered by the CPU tests)
+# --------------------------------------------------------------------------------------------------------------------
+def octaves_total(nx, ny, nz):
+    """Src/cSIFT3D.cc:254-255: (int)log2f(min dim) - 3 + 1"""
+    return max(0, int(np.log2(np.float32(min(nx, ny, nz)))) - 2)
+
+
+def slab_bounds(nz, world):
+    """Owned plane ranges [z0, z1) per rank: contiguous, even starts (DownSample_3D keeps plane 2k, so an even start keeps
+    the decimated planes of a slab inside it), as equal as possible; an odd last plane goes to the last rank."""
+    pairs = nz // 2
+    if pairs < world:
+        raise ValueError(f"{nz} planes cannot be split into {world} even-aligned slabs")
+    base, rem = divmod(pairs, world)
+    out, z = [], 0
+    for r in range(world):
+        n = 2 * (base + (1 if r < rem else 0))
+        out.append((z, z + n))
+        z += n
+    out[-1] = (out[-1][0], nz)
+    return out
+
+
+def halo_transfers(bounds, nz, kind, idx, lo, hi):
+    """Transfers that fill, for every rank, the global planes at distance (lo, hi] outside its owned range:
+    [z0-hi, z0-lo) and [z1+lo, z1+hi), clipped to the volume, from whichever ranks own them.  Deterministic order
+    (destination-major), identical on every rank, so matching sends and receives are posted in the same order."""
+    out = []
+    if hi <= lo:
+        return out
+    for r, (z0, z1) in enumerate(bounds):
+        for a, b in ((max(0, z0 - hi), max(0, z0 - lo)), (min(nz, z1 + lo), min(nz, z1 + hi))):
+            if b <= a:
+                continue
+            for q, (q0, q1) in enumerate(bounds):
+                if q == r:
+                    continue
+                s, e = max(a, q0), min(b, q1)
+                if e > s:
+                    out.append(Transfer(q, r, kind, idx, s, e))
+    return out
+
+
+def merge_keypoints(parts_oct0, tail):
+    """Reference order (octave, level, z, y, x) (Src/cSIFT3D.cc:373-416) from per-slab octave-0 lists plus the tail.
+    parts_oct0: list of (kp, desc) per rank; tail: (kp, desc) of octaves >= 1.  Returns (kp, desc)."""
+    kps = [p[0] for p in parts_oct0]
+    dss = [p[1] for p in parts_oct0]
+    kp = np.concatenate(kps) if kps else tail[0][:0]
+    ds = np.concatenate(dss) if dss else tail[1][:0]
+    if len(kp):
+        order = np.lexsort((kp["x"], kp["y"], kp["z"], kp["level"]))
+        kp, ds = kp[order], ds[order]
+    return np.concatenate([kp, tail[0]]), np.concatenate([ds, tail[1]])
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# communicators
+# --------------------------------------------------------------------------------------------------------------------
+class SimComm:
+    """All ranks live in this process (one GPU): sends become device copies, reductions are computed directly."""
+
+    def __init__(self, world):
+        self.world = world
+
+    def local_ranks(self):
+        return list(range(self.world))
+
+    def exchange(self, workers, transfers):
+        import torch
+        for t in transfers:
+            workers[t.dst].view(t.kind, t.idx, t.zg0, t.zg1).copy_(workers[t.src].view(t.kind, t.idx, t.zg0, t.zg1))
+        return None
+
+    def wait(self, handle):
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def allreduce_max(self, per_worker):
+        m = np.maximum.reduce([np.asarray(a, np.float32) for a in per_worker])
+        return [m.copy() for _ in per_worker]
+
+    def allgather_planes(self, per_worker_tensor, outs, counts):
+        """outs[w][off_r : off_r + counts[r]] = tensor of rank r, for every worker w"""
+        off = 0
+        for r, t in enumerate(per_worker_tensor):
+            for o in outs:
+                o[off:off + counts[r]].copy_(t[:counts[r]])
+            off += counts[r]
+        self.wait(None)
+
+    def allreduce_sum_(self, per_worker_tensor):
+        if not per_worker_tensor:
+            return
+        total = per_worker_tensor[0].clone()
+        for t in per_worker_tensor[1:]:
+            total += t
+        for t in per_worker_tensor:
+            t.copy_(total)
+        self.wait(None)
+
+    def gather_objects(self, per_worker):
+        return list(per_worker)
+
+
+class DistComm:
+    """One worker per process over torch.distributed (nccl == RCCL on ROCm; gloo with CPU tensors in the tests)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+
+    def local_ranks(self):
+        return [self.rank]
+
+    def _sync(self, tensor=None):
+        import torch
+        if torch.cuda.is_available() and (tensor is None or tensor.is_cuda):
+            torch.cuda.current_stream().synchronize()
+
+    def exchange(self, workers, transfers):
+        """workers: [the local worker].  Posts every send / receive this rank takes part in as ONE batched group."""
+        dist = self.dist
+        w = workers[0]
+        ops = []
+        for t in transfers:
+            if t.src == self.rank:
+                ops.append(dist.P2POp(dist.isend, w.view(t.kind, t.idx, t.zg0, t.zg1), t.dst))
+            elif t.dst == self.rank:
+                ops.append(dist.P2POp(dist.irecv, w.view(t.kind, t.idx, t.zg0, t.zg1), t.src))
+        if not ops:
+            return []
+        return dist.batch_isend_irecv(ops)
+
+    def wait(self, handle):
+        for r in handle or []:
+            r.wait()
+        self._sync()
+
+    def allreduce_max(self, per_worker):
+        import torch
+        a = np.asarray(per_worker[0], np.float32)
+        t = torch.from_numpy(a.copy())
+        dev = "cuda" if (self.dist.get_backend() == "nccl") else "cpu"
+        t = t.to(dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [t.cpu().numpy()]
+
+    def allgather_planes(self, per_worker_tensor, outs, counts):
+        import torch
+        t, out = per_worker_tensor[0], outs[0]
+        if len(set(counts)) == 1 and t.shape[0] == counts[0]:
+            self.dist.all_gather_into_tensor(out, t.contiguous())
+        else:  # uneven slabs: pad to the thickest
+            mx = max(counts)
+            pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            pad[: counts[self.rank]] = t[: counts[self.rank]]
+            bufs = [torch.empty_like(pad) for _ in range(self.world)]
+            self.dist.all_gather(bufs, pad)
+            off = 0
+            for r in range(self.world):
+                out[off:off + counts[r]].copy_(bufs[r][: counts[r]])
+                off += counts[r]
+        self._sync(out)
+
+    def allreduce_sum_(self, per_worker_tensor):
+        t = per_worker_tensor[0]
+        if t.numel():
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self._sync(t)
+
+    def gather_objects(self, per_worker):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, per_worker[0])
+        return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# one rank's device state
+# --------------------------------------------------------------------------------------------------------------------
+class SlabWorker:
+    """Slab context + seeded tail context + the torch-owned arena of one rank."""
+
+    def __init__(self, rank, world, dims, device=0, halo=None, **params):
+        import torch
+        from . import capi
+        nx, ny, nz = dims
+        self.rank, self.world, self.dims, self.device = rank, world, dims, device
+        self.params = params
+        self.levels = params.get("num_kp_levels", 3)
+        self.bounds = slab_bounds(nz, world)
+        self.z0, self.z1 = self.bounds[rank]
+        self.halo = int(halo) if halo is not None else capi.slab_min_halo(**params)
+        self.noct = octaves_total(nx, ny, nz)
+        dev = torch.device("cuda", device)
+        n = capi.SlabCSIFT3D.arena_floats(nx, ny, nz, self.z0, self.z1, self.halo, self.noct, **params)
+        self.arena = torch.zeros(n, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize(dev)
+        self.ctx = capi.SlabCSIFT3D(nx, ny, nz, self.z0, self.z1, self.halo, self.noct, self.arena.data_ptr(), n, device=device, **params)
+        self.plane = nx * ny
+        self._buf = {}
+        # replicated tail (octaves >= 1)
+        self.tail = None
+        self.seed = self.seed_mine = None
+        if self.noct >= 2:
+            n2 = (nz // 2, ny // 2, nx // 2)
+            self.tail = capi.SeededCSIFT3D(n2, 1, self.noct, device=device, **params)
+            self.tail.set_partition(rank, world)
+            self.seed = torch.empty(n2, dtype=torch.float32, device=dev)
+            self.counts2 = [min(b[1] // 2, nz // 2) - b[0] // 2 for b in self.bounds]
+            self.seed_mine = torch.empty((max(self.counts2), ny // 2, nx // 2), dtype=torch.float32, device=dev)
+
+    def view(self, kind, idx, zg0, zg1):
+        """arena view of the global planes [zg0, zg1) of a level buffer (contiguous: buffers are plane-major)"""
+        key = (kind, idx)
+        if key not in self._buf:
+            self._buf[key] = self.ctx.buffer(kind, idx)
+        off, planes, zoff = self._buf[key]
+        assert zoff <= zg0 < zg1 <= zoff + planes, (kind, idx, zg0, zg1, zoff, planes)
+        return self.arena[off + (zg0 - zoff) * self.plane: off + (zg1 - zoff) * self.plane]
+
+    def close(self):
+        if self.tail is not None:
+            self.tail.close()
+        self.ctx.close()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the lock-step driver
+# --------------------------------------------------------------------------------------------------------------------
+class SlabExtractor:
+    """CSIFT3D for a volume sharded over `world` ranks.  `comm.local_ranks()` are the ranks living in this process."""
+
+    def __init__(self, dims, comm, device=0, halo=None, **params):
+        self.dims, self.comm = dims, comm
+        self.world = comm.world
+        devs = device if isinstance(device, (list, tuple)) else [device] * len(comm.local_ranks())
+        self.workers = {r: SlabWorker(r, self.world, dims, device=d, halo=halo, **params) for r, d in zip(comm.local_ranks(), devs)}
+        w0 = next(iter(self.workers.values()))
+        self.bounds, self.halo, self.levels, self.noct = w0.bounds, w0.halo, w0.levels, w0.noct
+        self.ng = self.levels + 3
+        self.need = [w0.ctx.halo_planes(i) for i in range(self.ng)]   # planes of G[i] its consumers reach
+        self.hws = [w0.ctx.level_hw(i) for i in range(self.ng)]       # half width of the Gaussian producing G[i]
+        self.times = {}
+
+    # workers as the list the communicator expects ([mine] for DistComm, all ranks for SimComm)
+    def _wl(self):
+        if isinstance(self.comm, SimComm):
+            return [self.workers[r] for r in range(self.world)]
+        return list(self.workers.values())
+
+    def load(self, volume=None, device_slabs=None):
+        """CSIFT3D constructor work (Src/cSIFT3D.cc:146-163): copy the owned planes, max-abs normalise over the WHOLE
+        volume (all-reduce of the maxima), exchange the input halo of the base blur.
+        volume: host array [nz, ny, nx] (every rank reads its own planes) or device_slabs: {rank: torch [z1-z0, ny, nx]}."""
+        ws = self._wl()
+        for w in ws:
+            if device_slabs is not None:
+                t = device_slabs[w.rank]
+                assert tuple(t.shape) == (w.z1 - w.z0, self.dims[1], self.dims[0]) and t.is_contiguous()
+                w.ctx.upload(None, w.z0, w.z1, device_ptr=t.data_ptr())
+            else:
+                w.ctx.upload(volume[w.z0:w.z1], w.z0, w.z1)
+        mx = self.comm.allreduce_max([[w.ctx.input_absmax()] for w in ws])
+        for w, m in zip(ws, mx):
+            w.ctx.input_scale(float(m[0]))
+        nz = self.dims[2]
+        hw0 = self.hws[0]
+        self.comm.wait(self.comm.exchange(ws, halo_transfers(self.bounds, nz, KIND_INPUT, 0, 0, hw0)))
+
+    def KpSiftAlgorithm(self):
+        """CSIFT3D::KpSiftAlgorithm (Src/cSIFT3D.cc:165-235) over the slabs."""
+        import time
+        import torch
+        comm, ws, nz = self.comm, self._wl(), self.dims[2]
+        deferred = []
+        seed_pending = False
+        t0 = time.perf_counter()
+        for i in range(self.ng):
+            for w in ws:
+                w.ctx.level_async(i)
+            for w in ws:
+                w.ctx.sync()
+            urgent_h = self.hws[i + 1] if i + 1 < self.ng else 0
+            # the planes level i+1 needs first, the wider keypoint-window halo and the DoG plane behind it
+            h_urgent = comm.exchange(ws, halo_transfers(self.bounds, nz, KIND_GSS, i, 0, urgent_h))
+            late = halo_transfers(self.bounds, nz, KIND_GSS, i, urgent_h, self.need[i])
+            if 1 <= i - 1 <= self.levels:
+                late += halo_transfers(self.bounds, nz, KIND_DOG, i - 1, 0, 1)
+            deferred.append(comm.exchange(ws, late))
+            if i == self.levels and self.noct >= 2:
+                # G[1][0] = DownSample_3D(G[0][levels]) (Src/cSIFT3D.cc:293-296, 321-344): owned planes only
+                for w in ws:
+                    w.ctx.decimate(w.seed_mine.data_ptr())
+                seed_pending = True
+            comm.wait(h_urgent)
+        # DoG[levels + 1] needs no halo; DoG maxima -> global (threshold of Detect_KeyPoints, Src/cSIFT3D.cc:379-384)
+        mx = comm.allreduce_max([w.ctx.get_dogmax() for w in ws])
+        for w, m in zip(ws, mx):
+            w.ctx.set_dogmax(m)
+        for h in deferred:
+            comm.wait(h)
+        self.times["pyramid"] = time.perf_counter() - t0
+        if seed_pending:
+            comm.allgather_planes([w.seed_mine for w in ws], [w.seed for w in ws], ws[0].counts2)
+            for w in ws:
+                w.tail.seed(w.seed.data_ptr())
+        t1 = time.perf_counter()
+        for w in ws:
+            w.ctx.detect()
+        for w in ws:
+            w.ctx.describe()
+        self.times["keypoints0"] = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        if self.noct >= 2:
+            for w in ws:
+                w.tail.KpSiftAlgorithm()
+            # descriptor rows were dealt by slot % world: all-reduce(SUM) of disjoint rows restores all of them
+            bufs = []
+            for w in ws:
+                _, _, n = w.tail.device_results()
+                b = torch.empty(n * 768, dtype=torch.float32, device=w.arena.device)
+                if n:
+                    w.tail.export_device(b.data_ptr())
+                bufs.append(b)
+            comm.allreduce_sum_(bufs)
+            for w, b in zip(ws, bufs):
+                if b.numel():
+                    w.tail.import_descriptors(b.data_ptr())
+        self.times["tail"] = time.perf_counter() - t2
+        self.times["total"] = time.perf_counter() - t0
+        return self
+
+    def num_local_keypoints(self):
+        """keypoints this process produced: octave-0 of its slabs (+ the replicated tail once)"""
+        ws = self._wl()
+        n = sum(int(w.ctx.device_results()[2]) for w in ws)
+        if self.noct >= 2:
+            n += int(ws[0].tail.device_results()[2])
+        return n
+
+    def GetKeypoints(self):
+        """Global result in reference order on every rank (gathers through the host; not part of the timed path)."""
+        ws = self._wl()
+        parts = self.comm.gather_objects([w.ctx.GetKeypoints() for w in ws])
+        if self.noct >= 2:
+            tail = ws[0].tail.GetKeypoints()
+        else:
+            kp, ds = parts[0]
+            tail = (kp[:0], ds[:0])
+        return merge_keypoints(parts, tail)
+
+    def close(self):
+        for w in self.workers.values():
+            w.close()

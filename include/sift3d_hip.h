@@ -119,8 +119,61 @@ int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, const float
                  int *gIdx, int *sIdx, float *gDist, float *sDist, float *pairs6, int *npairs,
                  double *seconds /* device time of the call, may be NULL */);
 
-/* Z-slab sharding hooks, used by the multi-GPU driver; see DESIGN.md. */
 int sift3d_device_count(int *n);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-GPU sharding of ONE large volume (no reference counterpart: the reference is single process).
+ * Octave 0 is split into z-slabs, one per rank; every level buffer of a slab context holds the owned global planes
+ * [z0, z1) plus `halo` planes on each side, which the CALLER fills by exchanging planes with the z-neighbours
+ * (3dsift_amd/slab.py does it with torch.distributed P2P over RCCL).  Boundary rules and keypoint coordinates use
+ * global z.  Octaves >= 1 run replicated from the all-gathered G[1][0] in a SEEDED context, with the descriptor
+ * work split by keypoint slot.  Results equal the single-GPU results bit for bit (pyramid, extrema) / to the
+ * descriptor tolerance.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct sift3d_slab_desc {
+	int nx, ny, nz;      /* GLOBAL dims of the volume */
+	int z0, z1;          /* owned global planes [z0, z1) of octave 0; z0 even, z1 even or == nz */
+	int halo;            /* margin planes per side; >= 38 for default parameters (descriptor window reach) */
+	int noct_total;      /* octaves of the whole volume: (int)log2f(min(nx,ny,nz)) - 2 */
+} sift3d_slab_desc;
+
+/* smallest admissible halo for `params`: the z reach of a descriptor window in octave 0 (38 for the defaults) */
+int sift3d_slab_min_halo(const sift3d_params *params, int *halo);
+/* floats the caller must provide for the level buffers (input, GSS and DoG levels of octave 0) */
+int sift3d_slab_arena_floats(const sift3d_slab_desc *d, const sift3d_params *params, size_t *n);
+int sift3d_slab_create(sift3d_handle *out, const sift3d_slab_desc *d, const sift3d_params *params, int device,
+                       float *d_arena, size_t arena_floats);
+/* kind 0 input, 1 GSS level idx, 2 DoG level idx: offset of the buffer inside the arena (floats), planes held and
+ * the global z of its plane 0 (= z0 - halo); plane k of the buffer is global plane zoff + k, planes are nx*ny floats */
+int sift3d_slab_buffer(sift3d_handle h, int kind, int idx, size_t *offset_floats, int *planes, int *zoff);
+/* copy global planes [zg0, zg1) of the RAW volume into the input buffer (host or device source) */
+int sift3d_slab_upload(sift3d_handle h, const float *planes, int zg0, int zg1, int on_device);
+int sift3d_slab_input_absmax(sift3d_handle h, float *local_max);   /* over the OWNED planes (data_scale pass 1) */
+int sift3d_slab_input_scale(sift3d_handle h, float global_max);    /* v /= max on every held plane (pass 2) */
+/* GSS level i (and DoG i-1, local max|DoG i-1|) on the owned planes; needs level i-1 (input for i = 0) valid on
+ * [z0-hw_i-1, z1+hw_i] -- i.e. after the caller exchanged that many halo planes.  Asynchronous on the handle's stream;
+ * sift3d_slab_sync waits. */
+int sift3d_slab_level(sift3d_handle h, int i);
+int sift3d_slab_level_hw(sift3d_handle h, int i, int *hw);   /* half width of the Gaussian that produces GSS level i */
+int sift3d_slab_halo_planes(sift3d_handle h, int gss_level, int *planes); /* planes of GSS level i its consumers need per side */
+int sift3d_slab_sync(sift3d_handle h);
+int sift3d_slab_get_dogmax(sift3d_handle h, float *max5);          /* local maxima of the DoG levels (host) */
+int sift3d_slab_set_dogmax(sift3d_handle h, const float *max5);    /* global maxima after the all-reduce */
+int sift3d_slab_detect(sift3d_handle h);                            /* extrema of the owned planes (DoG halos of 1 plane exchanged) */
+int sift3d_slab_describe(sift3d_handle h);                          /* orientation + descriptors; results via sift3d_get_keypoints */
+/* DownSample_3D of the owned planes of G[0][num_kp_levels] -> d_dst = (nx/2) x (ny/2) x ((z1-z0)/2) floats (device) */
+int sift3d_slab_decimate(sift3d_handle h, float *d_dst);
+
+/* Seeded context: octaves octave_base.. of a volume whose G[octave_base][0] (dims nx,ny,nz) the caller provides */
+int sift3d_create_seeded(sift3d_handle *out, int nx, int ny, int nz, int octave_base, int noct_total,
+                         const sift3d_params *params, int device);
+int sift3d_seed_upload(sift3d_handle h, const float *level0, int on_device);
+/* only keypoints with slot % world == rank are described by this handle (rows of the others stay zero) */
+int sift3d_set_describe_partition(sift3d_handle h, int rank, int world);
+/* D2D copies between the handle's results and caller-owned device buffers (n*768, n*3 floats): lets a communication
+ * layer that only addresses its own allocations all-reduce the partitioned descriptor rows and hand them back */
+int sift3d_export_device(sift3d_handle h, float *d_desc_dst, float *d_xyz_dst);
+int sift3d_import_descriptors_device(sift3d_handle h, const float *d_desc_src);
 
 const char *sift3d_error_string(int code);
 const char *sift3d_last_error(void); /* thread-local detail of the last failure */

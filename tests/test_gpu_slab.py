@@ -1,0 +1,100 @@
+"""Z-slab sharding: the sharded pipeline, run with all ranks simulated on ONE GPU (3dsift_amd/slab.py SimComm:
+neighbour sends become device copies, everything else is the code the RCCL path runs), must reproduce the single-volume
+result BIT FOR BIT -- same arithmetic, only data placement changes."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+capi = importlib.import_module("3dsift_amd.capi")
+slab = importlib.import_module("3dsift_amd.slab")
+synth = importlib.import_module("3dsift_amd.synth")
+
+
+def _volume(shape, seed):
+    return synth.blobs(shape, seed=seed, noise=0.01)
+
+
+def _single(vol):
+    s = capi.CreateCSIFT3D(vol)
+    s.KpSiftAlgorithm()
+    return s
+
+
+@pytest.mark.parametrize("shape,world", [((128, 128, 128), 2), ((128, 128, 128), 4), ((160, 80, 96), 3)])
+def test_slab_equals_single_volume(shape, world):
+    vol = _volume(shape, seed=11 + world)
+    nz, ny, nx = shape
+    ref = _single(vol)
+    kp_ref, ds_ref = ref.GetKeypoints()
+    assert len(kp_ref) > 50
+
+    ex = slab.SlabExtractor((nx, ny, nz), slab.SimComm(world))
+    ex.load(volume=vol)
+    ex.KpSiftAlgorithm()
+
+    # pyramid of octave 0: owned planes of every level, bit for bit
+    ng, nd = ref.levels + 3, ref.levels + 2
+    for i in range(ng):
+        want = ref.gss(0, i)
+        for w in ex._wl():
+            got = w.ctx.held_level(0, i)[w.halo:w.halo + (w.z1 - w.z0)]
+            assert np.array_equal(got, want[w.z0:w.z1]), f"GSS level {i} rank {w.rank}"
+    for i in range(nd):
+        want = ref.dog(0, i)
+        for w in ex._wl():
+            got = w.ctx.held_level(1, i)[w.halo:w.halo + (w.z1 - w.z0)]
+            assert np.array_equal(got, want[w.z0:w.z1]), f"DoG level {i} rank {w.rank}"
+
+    # extrema of octave 0: union over the slabs == single-volume list
+    ext_ref = ref.extrema()
+    e0 = ext_ref[ext_ref["octave"] == 0]
+    got = np.concatenate([w.ctx.extrema() for w in ex._wl()])
+    key = lambda a: sorted(zip(a["level"].tolist(), a["z"].tolist(), a["y"].tolist(), a["x"].tolist()))
+    assert key(got) == key(e0)
+
+    # keypoints + descriptors, in reference order
+    kp, ds = ex.GetKeypoints()
+    assert len(kp) == len(kp_ref)
+    for f in kp_ref.dtype.names:
+        assert np.array_equal(kp[f], kp_ref[f]), f
+    assert np.array_equal(ds, ds_ref)
+    ex.close()
+    ref.close()
+
+
+def test_slab_halo_too_small_is_refused():
+    import torch
+    nx = ny = nz = 64
+    n = capi.SlabCSIFT3D.arena_floats(nx, ny, nz, 0, 32, 4, 4)
+    arena = torch.zeros(n, dtype=torch.float32, device="cuda")
+    with pytest.raises(capi.Sift3dError):
+        capi.SlabCSIFT3D(nx, ny, nz, 0, 32, 4, 4, arena.data_ptr(), n)   # halo 4 < widest Gaussian (hw 8)
+    with pytest.raises(capi.Sift3dError):
+        capi.SlabCSIFT3D(nx, ny, nz, 1, 33, 40, 4, arena.data_ptr(), n)  # odd start
+
+
+def test_seeded_tail_equals_octaves_of_single_volume():
+    """a seeded context fed G[1][0] of a single-volume run reproduces octaves >= 1 exactly"""
+    vol = _volume((96, 96, 96), seed=5)
+    ref = _single(vol)
+    kp_ref, ds_ref = ref.GetKeypoints()
+    g10 = ref.gss(1, 0)
+    t = capi.SeededCSIFT3D(g10.shape, 1, ref.num_octaves)
+    t.seed_host(g10)
+    t.KpSiftAlgorithm()
+    kp, ds = t.GetKeypoints()
+    m = kp_ref["octave"] >= 1
+    assert m.sum() > 0 and len(kp) == m.sum()
+    for f in kp_ref.dtype.names:
+        assert np.array_equal(kp[f], kp_ref[f][m]), f
+    assert np.array_equal(ds, ds_ref[m])
+    # descriptor partition: rows not owned stay zero, owned rows are identical
+    t.set_partition(1, 3)
+    t.KpSiftAlgorithm()
+    kp2, ds2 = t.GetKeypoints()
+    own = (np.arange(len(kp2)) % 3) == 1
+    assert np.array_equal(ds2[own], ds[own]) and not ds2[~own].any()
+    t.close(); ref.close()
