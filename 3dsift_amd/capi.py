@@ -40,8 +40,10 @@ SYMBOLS = [
     "sift3d_slab_input_absmax", "sift3d_slab_input_scale", "sift3d_slab_level", "sift3d_slab_level_hw", "sift3d_slab_halo_planes",
     "sift3d_slab_sync", "sift3d_slab_get_dogmax", "sift3d_slab_set_dogmax", "sift3d_slab_detect", "sift3d_slab_describe",
     "sift3d_slab_decimate", "sift3d_create_seeded", "sift3d_seed_upload", "sift3d_set_describe_partition",
-    "sift3d_export_device", "sift3d_import_descriptors_device",
+    "sift3d_export_device", "sift3d_import_descriptors_device", "sift3d_run_partial_orientation",
+    "sift3d_export_orientation_device", "sift3d_import_orientation_device", "sift3d_run_describe",
 ]
+ORIENT_WORDS = 34
 
 
 class Params(C.Structure):
@@ -118,6 +120,10 @@ def lib():
         L.sift3d_seed_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.sift3d_set_describe_partition.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.sift3d_export_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sift3d_run_partial_orientation.argtypes = [C.c_void_p]
+        L.sift3d_export_orientation_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_import_orientation_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_run_describe.argtypes = [C.c_void_p]
         L.sift3d_import_descriptors_device.argtypes = [C.c_void_p, C.c_void_p]
         L.sift3d_error_string.argtypes = [C.c_int]
         L.sift3d_error_string.restype = C.c_char_p
@@ -281,6 +287,23 @@ class SeededCSIFT3D(CSIFT3D):
 
     def set_partition(self, rank, world):
         _check(lib().sift3d_set_describe_partition(self._h, rank, world))
+
+    def run_partial_orientation(self):
+        _check(lib().sift3d_run_partial_orientation(self._h))
+
+    def export_orientation(self, ptr):
+        _check(lib().sift3d_export_orientation_device(self._h, C.c_void_p(int(ptr))))
+
+    def import_orientation(self, ptr):
+        _check(lib().sift3d_import_orientation_device(self._h, C.c_void_p(int(ptr))))
+
+    def run_describe(self):
+        _check(lib().sift3d_run_describe(self._h))
+
+    def num_extrema(self):
+        n = C.c_int(0)
+        _check(lib().sift3d_num_extrema(self._h, C.byref(n)))
+        return n.value
 
     def export_device(self, desc_ptr, xyz_ptr=None):
         _check(lib().sift3d_export_device(self._h, C.c_void_p(int(desc_ptr)), C.c_void_p(int(xyz_ptr)) if xyz_ptr else None))

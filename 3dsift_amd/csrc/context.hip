@@ -164,7 +164,7 @@ struct sift3d_ctx {
 	DetectBufs det{};
 	size_t det_blocks = 0;
 	DevKp *d_ext = nullptr;
-	int *d_codes = nullptr;
+	int *d_codes = nullptr, *d_order = nullptr;  // d_order: slot -> extremum index
 	unsigned ext_cap = 0, kp_cap = 0;
 	LevelRef *d_levels = nullptr;
 	WinLut *d_luts = nullptr;
@@ -199,6 +199,7 @@ static int set_device(int device) {
 static void free_lists(sift3d_ctx *c) {
 	hipFree(c->d_ext); c->d_ext = nullptr;
 	hipFree(c->d_codes); c->d_codes = nullptr;
+	hipFree(c->d_order); c->d_order = nullptr;
 	hipFree(c->d_kpout); c->d_kpout = nullptr;
 	hipFree(c->d_desc); c->d_desc = nullptr;
 	hipFree(c->d_xyz); c->d_xyz = nullptr;
@@ -210,6 +211,7 @@ static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
 	c->kp_cap = ext_cap;  // every extremum could survive orientation
 	S3D_HIP(hipMalloc(&c->d_ext, sizeof(DevKp) * (size_t)c->ext_cap));
 	S3D_HIP(hipMalloc(&c->d_codes, sizeof(int) * (size_t)c->ext_cap));
+	S3D_HIP(hipMalloc(&c->d_order, sizeof(int) * (size_t)c->kp_cap));
 	S3D_HIP(hipMalloc(&c->d_kpout, sizeof(sift3d_keypoint) * (size_t)c->kp_cap));
 	S3D_HIP(hipMalloc(&c->d_desc, sizeof(float) * kDesc * (size_t)c->kp_cap));
 	S3D_HIP(hipMalloc(&c->d_xyz, sizeof(float) * 3 * (size_t)c->kp_cap));
@@ -507,7 +509,7 @@ static void smooth_level(sift3d_ctx *c, int o, const float *src, const Level &ds
 	launch_conv_axis(2, c->tmpB[o], dst.d, dst.nx, dst.ny, dst.nz, t, prev, dog, dogmax, st);
 }
 
-static int run_impl(sift3d_ctx *c, int upto) {
+static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 	if (c->slab) { set_last_error("a z-slab context is driven stage by stage (sift3d_slab_*)"); return SIFT3D_ERR_STATE; }
 	int rc = set_device(c->device);
 	if (rc) return rc;
@@ -568,15 +570,14 @@ static int run_impl(sift3d_ctx *c, int upto) {
 		// ---- Assign_Orientation (Src/cSIFT3D.cc:427-482) ----
 		if (upto >= 4) {
 			launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
-			              c->p.corner_thresh, st);
-			launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, st);
+			              c->p.corner_thresh, part_orient ? c->part_rank : 0, part_orient ? c->part_world : 1, st);
+			launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, st);
 		}
 		S3D_HIP(hipEventRecord(c->ev[4], st));
 		// ---- Extract_Description (Src/cSIFT3D.cc:484-502) ----
 		if (upto >= 5) {
-			if (c->part_world > 1) S3D_HIP(hipMemsetAsync(c->d_desc, 0, sizeof(float) * kDesc * (size_t)c->kp_cap, st));  // rows of other ranks stay 0
 			launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, c->part_rank,
-			                c->part_world, st);
+			                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st);
 		}
 		if (upto >= 4) launch_finalize(c->d_ext, c->d_total, c->ext_cap, upto >= 5, c->d_kpout, c->d_xyz, c->kp_cap, st);
 		S3D_HIP(hipEventRecord(c->ev[5], st));
@@ -834,6 +835,60 @@ extern "C" int sift3d_import_descriptors_device(sift3d_handle c, const float *d_
 	return SIFT3D_OK;
 }
 
+// ---- partitioned orientation of a replicated context: each rank orients the extrema k with k % world == rank, the
+// caller all-reduces (integer SUM) the packed rows and hands them back, then every rank describes its share of slots
+extern "C" int sift3d_run_partial_orientation(sift3d_handle c) {
+	if (!c) return SIFT3D_ERR_ARG;
+	return run_impl(c, 4, true);
+}
+
+extern "C" int sift3d_export_orientation_device(sift3d_handle c, int *d_dst) {
+	if (!c || !d_dst) return SIFT3D_ERR_ARG;
+	if (c->stage < 4) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	launch_orient_pack(c->d_ext, c->d_total, c->ext_cap, d_dst, c->part_rank, c->part_world, c->stream);
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_import_orientation_device(sift3d_handle c, const int *d_src) {
+	if (!c || !d_src) return SIFT3D_ERR_ARG;
+	if (c->stage < 4) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	launch_orient_unpack(c->d_ext, c->d_codes, c->d_total, c->ext_cap, d_src, c->stream);
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	return SIFT3D_OK;
+}
+
+// Extract_Description (Src/cSIFT3D.cc:484-502) on the current orientation results (after an import): slots, this
+// handle's share of the descriptors, final records
+extern "C" int sift3d_run_describe(sift3d_handle c) {
+	if (!c) return SIFT3D_ERR_ARG;
+	if (c->stage < 4 || c->slab) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	hipStream_t st = c->stream;
+	S3D_HIP(hipEventRecord(c->ev[6], st));
+	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, st);
+	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, c->part_rank,
+	                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st);
+	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
+	S3D_HIP(hipEventRecord(c->ev[7], st));
+	unsigned host_words[3] = {0, 0, 0};
+	S3D_HIP(hipMemcpyAsync(host_words, c->d_total, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, st));
+	S3D_HIP(hipStreamSynchronize(st));
+	S3D_HIP(hipGetLastError());
+	c->n_kp = host_words[2];
+	c->stage = 5;
+	float ms = 0;
+	hipEventElapsedTime(&ms, c->ev[6], c->ev[7]);
+	c->times[6] = (double)ms * 1e-3;
+	c->times[0] = c->times[2] + c->times[3] + c->times[4] + c->times[5] + c->times[6];
+	return SIFT3D_OK;
+}
+
 static int slab_cfg(const sift3d_slab_desc *d, CreateCfg &cfg) {
 	// even start so that DownSample_3D's plane 2k stays inside one slab; an odd end is only possible at the top of the volume
 	if (!d || d->nx <= 0 || d->ny <= 0 || d->nz <= 0 || d->z0 < 0 || d->z1 > d->nz || d->z1 <= d->z0 || (d->z0 & 1) ||
@@ -1053,9 +1108,10 @@ extern "C" int sift3d_slab_describe(sift3d_handle c) {
 	if (rc) return rc;
 	hipStream_t st = c->stream;
 	launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
-	              c->p.corner_thresh, st);
-	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, st);
-	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, 0, 1, st);
+	              c->p.corner_thresh, 0, 1, st);
+	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, st);
+	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, 0, 1, c->d_order, c->d_nkp,
+	                c->d_nkp + 1, st);
 	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
 	bool again;
 	rc = slab_count_and_regrow(c, again);

@@ -173,7 +173,9 @@ constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <=
 __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
                                                   const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap,
-                                                  int part_rank, int part_world) {
+                                                  int part_rank, int part_world, const int *__restrict__ order,
+                                                  const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work) {
+	__shared__ unsigned s_item;
 	__shared__ unsigned long long hist[kDesc * kRep];  // [bin][replica], two's-complement fixed point, 2^-40 units
 	__shared__ float s_lut[kMaxDescLut];
 	__shared__ float s_q[4][6][kQCap];                 // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
@@ -204,10 +206,25 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 	float(*q)[kQCap] = s_q[wid];
 	unsigned long long *hist_rep = &hist[lane & (kRep - 1)];
 
-	for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
-		const int slot = kps[k].slot;
-		if (slot < 0 || (unsigned)slot >= kp_cap) continue;  // rejected by orientation (block-uniform)
-		if (part_world > 1 && (slot % part_world) != part_rank) continue;  // another rank describes this keypoint
+	// The accepted keypoints (slot -> extremum list from k_slots) are handed out one at a time through a global counter:
+	// window sizes differ 4x between keypoint levels, so a static deal leaves a long tail.  A partitioned run (multi-GPU
+	// split of replicated octaves) takes the slots rank, rank + world, ... and zeroes the rows of the other ranks.
+	(void)count;
+	const unsigned nkp = min(d_nkp[0], kp_cap);
+	const unsigned pw = part_world > 1 ? (unsigned)part_world : 1u, pr = part_world > 1 ? (unsigned)part_rank : 0u;
+	if (pw > 1)
+		for (unsigned row = blockIdx.x; row < nkp; row += gridDim.x)
+			if (row % pw != pr)
+				for (int i = tid; i < kDesc; i += 256) d_desc[(size_t)row * kDesc + i] = 0.0f;
+	const unsigned nown = nkp > pr ? (nkp - pr + pw - 1) / pw : 0u;
+	for (;;) {
+		__syncthreads();
+		if (tid == 0) s_item = atomicAdd(d_work, 1u);
+		__syncthreads();
+		const unsigned item = s_item;
+		if (item >= nown) break;  // block-uniform
+		const int slot = (int)(item * pw + pr);
+		const unsigned k = (unsigned)order[slot];
 		const int cxi = kps[k].x, cyi = kps[k].y, czi = kps[k].z;
 		const int li = kps[k].octave * 8 + kps[k].level;
 		const float scale = kps[k].scale;
@@ -379,9 +396,11 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 }
 
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels, const WinLut *d_luts,
-                     const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world, hipStream_t st) {
-	hipLaunchKernelGGL(k_describe, dim3(256 * 16), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-	                   part_rank, part_world);
+                     const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world, const int *order,
+                     const unsigned *d_nkp, unsigned *d_work, hipStream_t st) {
+	(void)hipMemsetAsync(d_work, 0, sizeof(unsigned), st);
+	hipLaunchKernelGGL(k_describe, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
+	                   part_rank, part_world, order, d_nkp, d_work);
 }
 
 // final keypoint records (Keypoint fields incl. rx,ry,rz = x*2^octave, Src/cSIFT3D.cc:1377-1379)

@@ -141,12 +141,20 @@ __device__ int finish_orientation(DevKp &kp, const float T6[6], const float w3[3
 
 __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__restrict__ codes, const unsigned *__restrict__ d_count, unsigned cap,
                                                 const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
-                                                const float *__restrict__ lutpool, float max_eig, float corner) {
+                                                const float *__restrict__ lutpool, float max_eig, float corner, int part_rank,
+                                                int part_world) {
 	const unsigned count = min(d_count[0], cap);
 	const int lane = threadIdx.x & 63;
 	const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
-	for (unsigned k = wave; k < count; k += nwaves) {
+	// partitioned run: this rank orients the extrema k = j * world + rank (dealt densely to the waves); the others get code 0
+	const unsigned pw = part_world > 1 ? (unsigned)part_world : 1u, pr = part_world > 1 ? (unsigned)part_rank : 0u;
+	if (pw > 1)
+		for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
+			if (k % pw != pr) { kps[k].code = 0; codes[k] = 0; }
+	const unsigned owned = count > pr ? (count - pr + pw - 1) / pw : 0u;
+	for (unsigned j = wave; j < owned; j += nwaves) {
+		const unsigned k = j * pw + pr;
 		const int cxi = kps[k].x, cyi = kps[k].y, czi = kps[k].z;
 		const int li = kps[k].octave * 8 + kps[k].level;
 		const LevelRef L = levels[li];
@@ -199,13 +207,53 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 }
 
 void launch_orient(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap, const LevelRef *d_levels, const WinLut *d_luts,
-                   const float *d_lutpool, float max_eig, float corner, hipStream_t st) {
-	hipLaunchKernelGGL(k_orient, dim3(256 * 8), dim3(256), 0, st, kps, codes, d_count, cap, d_levels, d_luts, d_lutpool, max_eig, corner);
+                   const float *d_lutpool, float max_eig, float corner, int part_rank, int part_world, hipStream_t st) {
+	hipLaunchKernelGGL(k_orient, dim3(256 * 8), dim3(256), 0, st, kps, codes, d_count, cap, d_levels, d_luts, d_lutpool, max_eig, corner,
+	                   part_rank, part_world);
+}
+
+// Orientation results as kOrientWords int32 words per extremum (code, then the bit patterns of win, eigvalue, eigvector,
+// rot, st): rows of extrema this rank did not orient are zero, so an integer all-reduce(SUM) over the ranks of a
+// partitioned run restores every row exactly; k_orient_unpack writes the reduced rows back.
+static_assert(offsetof(DevKp, st) + sizeof(float) * 9 - offsetof(DevKp, win) == sizeof(float) * (kOrientWords - 1), "DevKp layout");
+
+__global__ void __launch_bounds__(256) k_orient_pack(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
+                                                     int *__restrict__ dst, int part_rank, int part_world) {
+	const unsigned count = min(d_count[0], cap);
+	const unsigned total = count * (unsigned)kOrientWords;
+	for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+		const unsigned k = i / kOrientWords, w = i - k * kOrientWords;
+		int v = 0;
+		if (part_world <= 1 || (int)(k % (unsigned)part_world) == part_rank)
+			v = w == 0 ? kps[k].code : __float_as_int(kps[k].win[w - 1]);  // win..st are contiguous floats
+		dst[i] = v;
+	}
+}
+
+__global__ void __launch_bounds__(256) k_orient_unpack(DevKp *__restrict__ kps, int *__restrict__ codes, const unsigned *__restrict__ d_count,
+                                                       unsigned cap, const int *__restrict__ src) {
+	const unsigned count = min(d_count[0], cap);
+	const unsigned total = count * (unsigned)kOrientWords;
+	for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+		const unsigned k = i / kOrientWords, w = i - k * kOrientWords;
+		const int v = src[i];
+		if (w == 0) { kps[k].code = v; codes[k] = v; }
+		else kps[k].win[w - 1] = __int_as_float(v);
+	}
+}
+
+void launch_orient_pack(const DevKp *kps, const unsigned *d_count, unsigned cap, int *dst, int part_rank, int part_world, hipStream_t st) {
+	hipLaunchKernelGGL(k_orient_pack, dim3(1024), dim3(256), 0, st, kps, d_count, cap, dst, part_rank, part_world);
+}
+
+void launch_orient_unpack(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap, const int *src, hipStream_t st) {
+	hipLaunchKernelGGL(k_orient_unpack, dim3(1024), dim3(256), 0, st, kps, codes, d_count, cap, src);
 }
 
 // order-preserving compaction index: slot = exclusive scan of (code == 1); one workgroup.
 __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const int *__restrict__ codes,
-                                                const unsigned *__restrict__ d_count, unsigned cap, unsigned *__restrict__ d_nkp) {
+                                                const unsigned *__restrict__ d_count, unsigned cap, unsigned *__restrict__ d_nkp,
+                                                int *__restrict__ order, unsigned kp_cap) {
 	__shared__ unsigned s_wave[16];
 	const unsigned count = min(d_count[0], cap);
 	const unsigned t = threadIdx.x;
@@ -230,14 +278,17 @@ __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const i
 	const unsigned incl = v + s_wave[wid];
 	unsigned run = incl - sum;
 	for (unsigned i = lo; i < hi; i++) {
-		if (codes[i] == 1) kps[i].slot = (int)run++;
-		else kps[i].slot = -1;
+		if (codes[i] == 1) {
+			if (run < kp_cap) order[run] = (int)i;  // slot -> extremum: the descriptor kernel walks the accepted keypoints only
+			kps[i].slot = (int)run++;
+		} else kps[i].slot = -1;
 	}
 	if (t == 1023) d_nkp[0] = incl;
 }
 
-void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigned cap, unsigned *d_nkp, hipStream_t st) {
-	hipLaunchKernelGGL(k_slots, dim3(1), dim3(1024), 0, st, kps, codes, d_count, cap, d_nkp);
+void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigned cap, unsigned *d_nkp, int *order, unsigned kp_cap,
+                  hipStream_t st) {
+	hipLaunchKernelGGL(k_slots, dim3(1), dim3(1024), 0, st, kps, codes, d_count, cap, d_nkp, order, kp_cap);
 }
 
 }  // namespace s3d

@@ -138,9 +138,16 @@ struct LevelRef {
 	float unit;
 	int zoff;         // global z of local plane 0 (0 for whole volumes)
 };
+// part_rank / part_world: only extrema with index % part_world == part_rank are oriented (the others get code 0)
 void launch_orient(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap, const LevelRef *d_levels /*[noct*8]*/,
-                   const WinLut *d_luts, const float *d_lutpool, float max_eig, float corner, hipStream_t st);
-void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigned cap, unsigned *d_nkp, hipStream_t st);
+                   const WinLut *d_luts, const float *d_lutpool, float max_eig, float corner, int part_rank, int part_world,
+                   hipStream_t st);
+constexpr int kOrientWords = 34;  // code + win[3] + eigvalue[3] + eigvector[9] + rot[9] + st[9]  (== SIFT3D_ORIENT_WORDS)
+void launch_orient_pack(const DevKp *kps, const unsigned *d_count, unsigned cap, int *dst, int part_rank, int part_world, hipStream_t st);
+void launch_orient_unpack(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap, const int *src, hipStream_t st);
+// slot = order-preserving index among the accepted keypoints; order[slot] = extremum index
+void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigned cap, unsigned *d_nkp, int *order, unsigned kp_cap,
+                  hipStream_t st);
 
 // ---- kernels_desc.hip ----------------------------------------------------------------------
 void upload_faces(const FaceConst *faces, const FacePredict *pred);  // into __constant__ memory
@@ -148,6 +155,7 @@ void upload_faces(const FaceConst *faces, const FacePredict *pred);  // into __c
 // replicated octaves); 0 / 1 = all
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels,
                      const WinLut *d_luts, const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world,
+                     const int *order, const unsigned *d_nkp, unsigned *d_work /* device counter, zeroed by the launch */,
                      hipStream_t st);
 void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, int transposed,
                      sift3d_keypoint *d_out, float *d_xyz, unsigned kp_cap, hipStream_t st);

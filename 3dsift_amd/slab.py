@@ -73,6 +73,11 @@ def halo_transfers(bounds, nz, kind, idx, lo, hi):
     return out
 
 
+def capi_words():
+    from . import capi
+    return capi.ORIENT_WORDS
+
+
 def merge_keypoints(parts_oct0, tail):
     """Reference order (octave, level, z, y, x) (Src/cSIFT3D.cc:373-416) from per-slab octave-0 lists plus the tail.
     parts_oct0: list of (kp, desc) per rank; tail: (kp, desc) of octaves >= 1.  Returns (kp, desc)."""
@@ -348,26 +353,28 @@ class SlabExtractor:
         self.times["keypoints0"] = time.perf_counter() - t1
         t2 = time.perf_counter()
         if self.noct >= 2:
+            # replicated pyramid + extrema of octaves >= 1; orientation dealt by extremum index, results restored on every
+            # rank by an integer all-reduce(SUM) of zero-padded rows (exact); descriptors dealt by keypoint slot and LEFT
+            # distributed, like the octave-0 keypoints (GetKeypoints / the matcher's all-gather collect them)
             for w in ws:
-                w.tail.KpSiftAlgorithm()
-            # descriptor rows were dealt by slot % world: all-reduce(SUM) of disjoint rows restores all of them
+                w.tail.run_partial_orientation()
             bufs = []
             for w in ws:
-                _, _, n = w.tail.device_results()
-                b = torch.empty(n * 768, dtype=torch.float32, device=w.arena.device)
-                if n:
-                    w.tail.export_device(b.data_ptr())
+                b = torch.empty(w.tail.num_extrema() * capi_words(), dtype=torch.int32, device=w.arena.device)
+                if b.numel():
+                    w.tail.export_orientation(b.data_ptr())
                 bufs.append(b)
             comm.allreduce_sum_(bufs)
             for w, b in zip(ws, bufs):
                 if b.numel():
-                    w.tail.import_descriptors(b.data_ptr())
+                    w.tail.import_orientation(b.data_ptr())
+                w.tail.run_describe()
         self.times["tail"] = time.perf_counter() - t2
         self.times["total"] = time.perf_counter() - t0
         return self
 
     def num_local_keypoints(self):
-        """keypoints this process produced: octave-0 of its slabs (+ the replicated tail once)"""
+        """keypoints this process holds records for: octave-0 of its slabs (+ the replicated tail records once)"""
         ws = self._wl()
         n = sum(int(w.ctx.device_results()[2]) for w in ws)
         if self.noct >= 2:
@@ -379,7 +386,12 @@ class SlabExtractor:
         ws = self._wl()
         parts = self.comm.gather_objects([w.ctx.GetKeypoints() for w in ws])
         if self.noct >= 2:
-            tail = ws[0].tail.GetKeypoints()
+            # tail keypoint records are complete everywhere; descriptor row i lives on rank i % world
+            rows = self.comm.gather_objects([w.tail.GetKeypoints()[1][w.rank::self.world] for w in ws])
+            tkp, tds = ws[0].tail.GetKeypoints()
+            for r, part in enumerate(rows):
+                tds[r::self.world] = part
+            tail = (tkp, tds)
         else:
             kp, ds = parts[0]
             tail = (kp[:0], ds[:0])

@@ -49,10 +49,11 @@ def blobs(shape, seed=1234, shift=(0.0, 0.0, 0.0), noise=0.0, noise_seed=99, nbl
     return vol.astype(np.float32)
 
 
-def blobs_torch(shape, device, seed=1234, shift=(0.0, 0.0, 0.0), nblobs=None, brick=64):
+def blobs_torch(shape, device, seed=1234, shift=(0.0, 0.0, 0.0), nblobs=None, brick=64, zrange=None):
     """Same blob list rendered on a torch device, brick by brick: every brick accumulates the blobs
     whose 5-sigma boxes overlap it as one small contraction sum_k gz[k,z] gy[k,y] gx[k,x] (a few
-    thousand kernels instead of ~20 per blob).  fp32; returns a torch tensor [z, y, x]."""
+    thousand kernels instead of ~20 per blob).  fp32; returns a torch tensor [z, y, x].
+    zrange = (za, zb): render only those planes of the volume (z-slab of a sharded volume), tensor [zb-za, y, x]."""
     import torch
 
     nz, ny, nx = shape
@@ -61,10 +62,11 @@ def blobs_torch(shape, device, seed=1234, shift=(0.0, 0.0, 0.0), nblobs=None, br
     r = 5.0 * sg
     lo = [np.maximum(0, np.floor(c - r)).astype(np.int64) for c in (cx, cy, cz)]
     hi = [np.minimum(n - 1, np.ceil(c + r)).astype(np.int64) for c, n in ((cx, nx), (cy, ny), (cz, nz))]
-    vol = torch.zeros(shape, dtype=torch.float32, device=device)
+    za, zb = (0, nz) if zrange is None else zrange
+    vol = torch.zeros((zb - za, ny, nx), dtype=torch.float32, device=device)
     t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device)
-    for z0 in range(0, nz, brick):
-        z1 = min(nz, z0 + brick)
+    for z0 in range(za, zb, brick):
+        z1 = min(zb, z0 + brick)
         mz = (hi[2] >= z0) & (lo[2] < z1)
         for y0 in range(0, ny, brick):
             y1 = min(ny, y0 + brick)
@@ -85,5 +87,5 @@ def blobs_torch(shape, device, seed=1234, shift=(0.0, 0.0, 0.0), nblobs=None, br
                 gy = factor(cy[idx], sg[idx], lo[1][idx], hi[1][idx], y0, y1)
                 gz = factor(cz[idx], sg[idx], lo[2][idx], hi[2][idx], z0, z1, am[idx])
                 yx = (gy[:, :, None] * gx[:, None, :]).reshape(len(idx), -1)
-                vol[z0:z1, y0:y1, x0:x1] = (gz.t() @ yx).reshape(z1 - z0, y1 - y0, x1 - x0)
+                vol[z0 - za:z1 - za, y0:y1, x0:x1] = (gz.t() @ yx).reshape(z1 - z0, y1 - y0, x1 - x0)
     return vol

@@ -9,6 +9,13 @@ reference does copy + normalise in the constructor too, outside KpSiftAlgorithm)
 GPU processes its own 512^3 volume (BASELINE.json configs[4], independent volumes => weak scaling, no
 data-path collective); value = N * 512^3 * K / max-over-ranks time.
 
+    python bench.py --workload slab [--slab-dims 1024x1024x512] [--sim-ranks R]
+
+times BASELINE.json configs[3] instead: ONE volume sharded as z-slabs over the N ranks (3dsift_amd/slab.py: halo
+exchange + all-reduce over RCCL; strong scaling, N=1 is the plain single-GPU extractor on the whole volume).
+--sim-ranks R runs R simulated ranks on one GPU (functional check / redundancy accounting, not a speed claim).
+A default N>1 run appends the slab measurement as "slab": {...} to its JSON line, behind a watchdog.
+
 The JSON line also carries
   roofline      pyramid build (the HBM-bound part north_star sets a target for): algorithmic bytes
                 68 B x pyramid voxels / HIP-event time of that stage on the library's own
@@ -43,6 +50,96 @@ def pyramid_voxels(shape, levels=3):
     return tot, noct
 
 
+def parse_dims(txt):
+    nx, ny, nz = (int(v) for v in txt.lower().split("x"))
+    return nx, ny, nz
+
+
+def run_slab(dims, world, rank, local, dev, steps, warmup, sim_ranks=0, seed=4321):
+    """Strong-scaling workload: one nx x ny x nz volume, z-slabs over the ranks.  Returns a dict (same on all ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    capi = importlib.import_module("3dsift_amd.capi")
+    synth = importlib.import_module("3dsift_amd.synth")
+    slab = importlib.import_module("3dsift_amd.slab")
+    s3d_dist = importlib.import_module("3dsift_amd.dist")
+    nx, ny, nz = dims
+    shape = (nz, ny, nx)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    nranks = sim_ranks if sim_ranks else world
+    if nranks == 1:
+        vol = synth.blobs_torch(shape, dev, seed=seed)
+        torch.cuda.synchronize()
+        ex = capi.CSIFT3D(None, device=local, device_ptr=vol.data_ptr(), shape=shape)
+        del vol
+        step = ex.KpSiftAlgorithm
+        count = lambda: len(ex.GetKeypoints(with_desc=False)[0])
+        detail = lambda: {k: round(v * 1e3, 3) for k, v in ex.m_timer.items()}
+    else:
+        comm = slab.SimComm(sim_ranks) if sim_ranks else slab.DistComm()
+        ex = slab.SlabExtractor(dims, comm, device=local)
+        slabs = {r: synth.blobs_torch(shape, dev, seed=seed, zrange=ex.bounds[r]) for r in comm.local_ranks()}
+        torch.cuda.synchronize()
+        ex.load(device_slabs=slabs)
+        del slabs
+        step = ex.KpSiftAlgorithm
+
+        def count():
+            n0 = sum(int(w.ctx.device_results()[2]) for w in ex._wl())
+            t = torch.tensor([n0], dtype=torch.int64, device=dev)
+            if world > 1 and not sim_ranks:
+                dist.all_reduce(t)
+            nt = int(ex._wl()[0].tail.device_results()[2]) if ex.noct >= 2 else 0
+            return int(t.item()) + nt
+
+        detail = lambda: {k: round(v * 1e3, 3) for k, v in ex.times.items()}
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = s3d_dist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    res = {"workload": f"{nx}x{ny}x{nz} fp32 synthetic blob volume, z-slabs over {nranks} rank(s)"
+                       + (" SIMULATED on one GPU" if sim_ranks else ""),
+           "value": nx * ny * nz * steps / dt / 1e6, "unit": "Mvoxels/s", "ms_per_step": dt / steps * 1e3,
+           "keypoints": count(), "last_step_ms": detail()}
+    if nranks > 1:
+        res["halo_planes"] = ex.halo
+        res["slab_planes"] = [b[1] - b[0] for b in ex.bounds]
+    ex.close()
+    return res
+
+
+def guarded(fn, seconds):
+    """run fn() in a thread; (result, None) or (None, reason) when it raised or did not finish in time"""
+    import threading
+    box = {}
+
+    def body():
+        try:
+            box["ok"] = fn()
+        except BaseException as e:  # noqa: BLE001 -- reported in the JSON line
+            box["err"] = f"{type(e).__name__}: {e}"
+
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return None, f"timeout after {seconds} s"
+    if "err" in box:
+        return None, box["err"]
+    return box["ok"], None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,6 +149,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU-baseline sample crop (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--allpairs", action="store_true", help="N>1: all-gather descriptors + all-pairs enhancedMatch (configs[4])")
+    ap.add_argument("--workload", choices=["volumes", "slab"], default="volumes")
+    ap.add_argument("--slab-dims", default="1024x1024x512", help="nx x ny x nz of the sharded volume (configs[3])")
+    ap.add_argument("--sim-ranks", type=int, default=0, help="slab workload: simulate R ranks on one GPU")
+    ap.add_argument("--no-slab-leg", action="store_true", help="N>1: do not append the configs[3] measurement")
     args = ap.parse_args()
 
     import torch
@@ -65,6 +166,20 @@ def main():
     synth = importlib.import_module("3dsift_amd.synth")
     s3d_dist = importlib.import_module("3dsift_amd.dist")
     rank, world = s3d_dist.init_from_env(backend="nccl", device=dev)  # "nccl" is RCCL on ROCm
+
+    if args.workload == "slab":
+        dims = parse_dims(args.slab_dims)
+        r = run_slab(dims, world, rank, local, dev, args.steps, args.warmup, sim_ranks=args.sim_ranks)
+        out = {"metric": "Mvoxels/s end-to-end KpSiftAlgorithm, one volume sharded as z-slabs", "value": r["value"],
+               "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": r["workload"], "parallelism": f"z-slabs x{args.sim_ranks or world}"}, "slab": r}
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     n = args.size
     shape = (n, n, n)
@@ -179,8 +294,20 @@ def main():
         if rank == 0:
             out["allpairs"] = {"allgather_s": t_gather, "match_s_max_rank": tm, "ordered_pairs": len(s3d_dist.ordered_pairs(world)),
                                "rank0_matched": npairs}
+    slab_attempted = False
+    if world > 1 and not args.no_slab_leg:
+        # BASELINE configs[3] next to the headline number: one 1024x1024x512 volume over the same ranks.  The RCCL halo
+        # path cannot be exercised on the 1-GPU development boxes, so it runs behind a watchdog: whatever happens, the
+        # headline line is printed.
+        slab_attempted = True
+        ex.close(); del vol
+        res, err = guarded(lambda: run_slab(parse_dims(args.slab_dims), world, rank, local, dev, 3, 1), 240)
+        out["slab"] = res if err is None else {"error": err}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if slab_attempted:
+        sys.stdout.flush()
+        os._exit(0)  # a wedged collective must not keep the job alive; nothing is left to clean up
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -170,6 +170,16 @@ int sift3d_create_seeded(sift3d_handle *out, int nx, int ny, int nz, int octave_
 int sift3d_seed_upload(sift3d_handle h, const float *level0, int on_device);
 /* only keypoints with slot % world == rank are described by this handle (rows of the others stay zero) */
 int sift3d_set_describe_partition(sift3d_handle h, int rank, int world);
+/* Partitioned orientation of a replicated context: sift3d_run_partial_orientation runs the pyramid, the extrema scan and
+ * Assign_Orientation for the extrema k with k % world == rank only; sift3d_export_orientation_device packs the results as
+ * SIFT3D_ORIENT_WORDS int32 words per extremum (zero rows for the extrema of other ranks), so that an integer
+ * all-reduce(SUM) over the ranks yields every row exactly; after sift3d_import_orientation_device, sift3d_run_describe
+ * runs Extract_Description for this handle's share of the keypoint slots. */
+#define SIFT3D_ORIENT_WORDS 34
+int sift3d_run_partial_orientation(sift3d_handle h);
+int sift3d_export_orientation_device(sift3d_handle h, int *d_dst /* num_extrema * SIFT3D_ORIENT_WORDS */);
+int sift3d_import_orientation_device(sift3d_handle h, const int *d_src);
+int sift3d_run_describe(sift3d_handle h);
 /* D2D copies between the handle's results and caller-owned device buffers (n*768, n*3 floats): lets a communication
  * layer that only addresses its own allocations all-reduce the partitioned descriptor rows and hand them back */
 int sift3d_export_device(sift3d_handle h, float *d_desc_dst, float *d_xyz_dst);

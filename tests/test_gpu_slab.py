@@ -97,4 +97,34 @@ def test_seeded_tail_equals_octaves_of_single_volume():
     kp2, ds2 = t.GetKeypoints()
     own = (np.arange(len(kp2)) % 3) == 1
     assert np.array_equal(ds2[own], ds[own]) and not ds2[~own].any()
+    # partitioned orientation: three handles orient a third of the extrema each; the integer sum of the packed rows
+    # restores the full orientation result on every one of them
+    import torch
+    hs = []
+    for r in range(3):
+        h = capi.SeededCSIFT3D(g10.shape, 1, ref.num_octaves)
+        h.seed_host(g10); h.set_partition(r, 3); h.run_partial_orientation()
+        hs.append(h)
+    n_ext = hs[0].num_extrema()
+    assert n_ext == len(t.extrema())
+    bufs = [torch.empty(n_ext * capi.ORIENT_WORDS, dtype=torch.int32, device="cuda") for _ in hs]
+    for h, b in zip(hs, bufs):
+        h.export_orientation(b.data_ptr())
+    torch.cuda.synchronize()
+    rows = [b.view(n_ext, -1).cpu().numpy() for b in bufs]
+    for r in range(3):
+        assert not rows[r][np.arange(n_ext) % 3 != r].any()
+    total = bufs[0] + bufs[1] + bufs[2]
+    torch.cuda.synchronize()
+    full = np.zeros((len(kp), 768), np.float32)
+    for r, h in enumerate(hs):
+        h.import_orientation(total.data_ptr()); h.run_describe()
+        kp3, ds3 = h.GetKeypoints()
+        for f in kp.dtype.names:
+            assert np.array_equal(kp3[f], kp[f]), f
+        assert np.array_equal(h.orientation_codes(), t.orientation_codes())
+        full[r::3] = ds3[r::3]
+        assert not ds3[(r + 1) % 3::3].any()
+        h.close()
+    assert np.array_equal(full, ds)
     t.close(); ref.close()
