@@ -19,7 +19,7 @@
 //     the reference's exact Moller-Trumbore arithmetic for that face and accepted only when all three
 //     barycentrics clear a 1e-4 margin (then no other face can pass the reference's -1.19e-6 test, so
 //     "first passing face in mesh order" is this face); otherwise the literal 20-face ordered scan runs
-//   * the 24 products of a voxel go straight to an LDS histogram kept in 64-BIT FIXED POINT (2^-40 units) and
+//   * the 24 products of a voxel go straight to an LDS histogram kept in 64-BIT FIXED POINT (2^-29 units) and
 //     are added with ds_add_u64: on gfx950 an LDS float atomic (ds_add_f32) costs ~190 cycles per wave
 //     instruction, the integer forms 4-6 (scripts/microbench/lds_atomics.hip), and integer sums are order
 //     independent, so descriptors are bitwise reproducible run to run.  The fp32 product mag*w*bary is formed
@@ -56,15 +56,10 @@ __device__ __forceinline__ void win_bounds_d(float c, float rad, float u, int n,
 
 constexpr float kBaryEps = (float)(FLT_EPSILON * 1E1);  // Src/cSIFT3D.cc:23
 
-// fp32 -> 64-bit fixed point (2^-40 units, round to nearest) via the 1.5*2^52 magic constant: for |v*2^40| < 2^51
-// the integer sits in the low mantissa bits and the bit patterns are linear in it (two's complement wrap included)
-constexpr double kFixedScale = 1099511627776.0;           // 2^40
-constexpr double kFixedInv = 1.0 / 1099511627776.0;
-constexpr double kFixedMagic = 6755399441055744.0;        // 1.5 * 2^52
-__device__ __forceinline__ unsigned long long to_fixed(float v) {
-	const double d = fma((double)v, kFixedScale, kFixedMagic);
-	return (unsigned long long)__double_as_longlong(d) - 0x4338000000000000ull;
-}
+// Histogram bins are 64-bit two's-complement fixed point in 2^-29 units: integer LDS atomics are ~40x faster than
+// ds_add_f32 on gfx950 (scripts/microbench/lds_atomics.hip) and make the sums order-independent (deterministic).
+constexpr float kFixedScaleF = 536870912.0f;              // 2^29
+constexpr double kFixedInv = 1.0 / 536870912.0;
 constexpr float kFastMargin = 1.0e-4f;
 constexpr int kFaceStride = 16;  // floats per face in the LDS table
 #ifndef S3D_DESC_REP
@@ -143,28 +138,46 @@ __device__ __forceinline__ void accumulate_voxel(bool valid, float bx, float by,
 	const float mag = __fsqrt_rn(g2);
 	const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
 	const int ix = (int)bx, iy = (int)by, iz = (int)bz;  // truncation toward zero, like the reference: 0..3
-	// trilinear weights: products of three doubles rounded to fp32 (Src/cSIFT3D.cc:1510-1512), evaluated as
-	// (wx*wy)*wz with the four x-y products shared
-	const double dfx = (double)fx, dfy = (double)fy, dfz = (double)fz;
-	const double wx0 = 1.0 - dfx, wy0 = 1.0 - dfy, wz0 = 1.0 - dfz;
-	const double pxy[4] = {wx0 * wy0, wx0 * dfy, dfx * wy0, dfx * dfy};  // index ddx*2 + ddy
+	// Trilinear weights (Src/cSIFT3D.cc:1510-1512 forms them as double products rounded to fp32; fp32 products differ
+	// from that by <= 1.5 ulp, far inside the descriptor tolerance) and 2^-29 fixed-point contributions: |value| <= sqrt(3)
+	// < 4 because the normalised, Gaussian-smoothed data is bounded by 1, so value * 2^29 fits an int32.
+	const float wx0 = 1.0f - fx, wy0 = 1.0f - fy, wz0 = 1.0f - fz;
+	const float pxy[4] = {wx0 * wy0, wx0 * fy, fx * wy0, fx * fy};  // index ddx*2 + ddy
+	const float ms = mag * kFixedScaleF;                            // exact (power of two)
+	const float m0 = ms * b0, m1 = ms * b1, m2 = ms * b2;
 	// cells ix+ddx etc. are >= 0 by construction; only the upper bound can fail (skip cells outside [0,3])
 	const bool okx = ix < 3, oky = iy < 3, okz = iz < 3;
 	const int base = (ix + iy * 4 + iz * 16) * 12;
 	unsigned long long *h0 = hist_rep + (base + s_fidx[f * 4]) * kRep;
 	unsigned long long *h1 = hist_rep + (base + s_fidx[f * 4 + 1]) * kRep;
 	unsigned long long *h2 = hist_rep + (base + s_fidx[f * 4 + 2]) * kRep;
+	// a barycentric coordinate can be negative by at most bary_eps (only after the exact face scan): then the
+	// contribution needs its sign extended to 64 bits; otherwise the high word is a constant zero (wave-uniform choice)
+	const bool neg = b0 < 0.0f || b1 < 0.0f || b2 < 0.0f;
+	if (__any(neg)) {
+#pragma unroll
+		for (int d = 0; d < 8; d++) {
+			const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;  // dx outer, dz inner (Src/cSIFT3D.cc:1492-1496)
+			if ((ddx && !okx) || (ddy && !oky) || (ddz && !okz)) continue;
+			const float wgt = pxy[ddx * 2 + ddy] * (ddz ? fz : wz0);
+			constexpr int kCell = 12 * kRep;
+			const int off = (ddx + ddy * 4 + ddz * 16) * kCell;
+			atomicAdd(h0 + off, (unsigned long long)(long long)__float2int_rn(wgt * m0));
+			atomicAdd(h1 + off, (unsigned long long)(long long)__float2int_rn(wgt * m1));
+			atomicAdd(h2 + off, (unsigned long long)(long long)__float2int_rn(wgt * m2));
+		}
+		return;
+	}
 #pragma unroll
 	for (int d = 0; d < 8; d++) {
-		const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;  // dx outer, dz inner (Src/cSIFT3D.cc:1492-1496)
+		const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;
 		if ((ddx && !okx) || (ddy && !oky) || (ddz && !okz)) continue;
-		const float wgt = (float)(pxy[ddx * 2 + ddy] * (ddz ? dfz : wz0));
-		const float mw = mag * wgt;
+		const float wgt = pxy[ddx * 2 + ddy] * (ddz ? fz : wz0);
 		constexpr int kCell = 12 * kRep;
 		const int off = (ddx + ddy * 4 + ddz * 16) * kCell;  // compile-time: becomes the ds_add immediate offset
-		atomicAdd(h0 + off, to_fixed(mw * b0));
-		atomicAdd(h1 + off, to_fixed(mw * b1));
-		atomicAdd(h2 + off, to_fixed(mw * b2));
+		atomicAdd(h0 + off, (unsigned long long)(unsigned)__float2int_rn(wgt * m0));
+		atomicAdd(h1 + off, (unsigned long long)(unsigned)__float2int_rn(wgt * m1));
+		atomicAdd(h2 + off, (unsigned long long)(unsigned)__float2int_rn(wgt * m2));
 	}
 }
 
@@ -176,7 +189,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
                                                   int part_rank, int part_world, const int *__restrict__ order,
                                                   const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work) {
 	__shared__ unsigned s_item;
-	__shared__ unsigned long long hist[kDesc * kRep];  // [bin][replica], two's-complement fixed point, 2^-40 units
+	__shared__ unsigned long long hist[kDesc * kRep];  // [bin][replica], two's-complement fixed point, 2^-29 units
 	__shared__ float s_lut[kMaxDescLut];
 	__shared__ float s_q[4][6][kQCap];                 // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
 	__shared__ float s_predn[12];
@@ -247,10 +260,10 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		win_bounds_d((float)czi, win_radius, u, L.nz, z0, z1);
 		const int wx = x1 - x0 + 1, wy = y1 - y0 + 1;
 		const int ncol = (wx > 0 && wy > 0) ? wx * wy : 0;
-		const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1);
 		const int sy = L.nx, sz = L.nx * L.ny;  // levels are < 2^31 voxels
 		const int nin = lut.nin;                 // largest integer squared offset inside the sphere
-		const float *centre = L.d + (size_t)cxi + (size_t)sy * (size_t)cyi + (size_t)sz * (size_t)(czi - L.zoff);  // always valid
+		const gfloat_p Ld = as_global(L.d);  // global_load instead of flat_load: in-order vmcnt, loads stay in flight
+		const gfloat_p centre = Ld + (size_t)cxi + (size_t)sy * (size_t)cyi + (size_t)sz * (size_t)(czi - L.zoff);  // always valid
 
 		__syncthreads();  // previous keypoint finished with hist / s_lut
 		for (int i = tid; i < kDesc * kRep; i += 256) hist[i] = 0ull;
@@ -260,17 +273,25 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		}
 		__syncthreads();
 
+#if defined(S3D_EXP) && S3D_EXP == 5
+		int exp_steps = 0, exp_lanes = 0, exp_pops = 0;
+#endif
 		int qhead = 0, qcount = 0;  // wave-uniform (every lane executes every push / pop below)
 		// All control flow from here to the drain is wave-uniform: lanes without work are predicated, never branched
 		// away, because the queue bookkeeping must see every ballot.
-		for (int col0 = 0; col0 < ncol; col0 += 256) {
-			const int col = col0 + tid;
-			const int ly = (int)(((float)col + 0.5f) * inv_wx);
-			const int lx = col - ly * wx;
+		// Columns are dealt to the waves as 8x8 tiles of the window's (x, y) footprint: chord lengths (and the cube clip)
+		// vary slowly across a tile, so the lanes of a wave finish their z-march together (a 64x1 row segment spans
+		// the circle from rim to centre and leaves ~40 % of the lane-steps idle)
+		const int tiles_x = (wx + 7) >> 3, tiles_y = (wy + 7) >> 3;
+		const int ntiles = ncol > 0 ? tiles_x * tiles_y : 0;
+		for (int t0 = 0; t0 < ntiles; t0 += 4) {
+			const int tile = t0 + wid;                 // wave-uniform
+			const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+			const int lx = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
 			const int x = x0 + lx, y = y0 + ly;
 			const int dx = x - cxi, dy = y - cyi;
 			const int rr = dx * dx + dy * dy;
-			bool colok = col < ncol && rr <= nin;
+			bool colok = tile < ntiles && lx < wx && ly < wy && rr <= nin;
 			int za = 0, zb = -1;
 			const float vxd = (float)dx * u, vyd = (float)dy * u;
 			// partial rotations: (R0*vx + R1*vy) is evaluated first in the reference's left-to-right sums
@@ -306,22 +327,29 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 			for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
 			maxlen = __builtin_amdgcn_readfirstlane(maxlen);
 			if (maxlen == 0) continue;  // wave-uniform
+#if defined(S3D_EXP) && S3D_EXP == 5
+			exp_steps += maxlen; exp_lanes += zlen;
+#endif
 			// lanes without a column march on the keypoint's own column (always in bounds) and are masked
-			const float *c = zlen > 0 ? L.d + (size_t)x + (size_t)sy * (size_t)y + (size_t)sz * (size_t)(za - L.zoff) : centre;
-			float cm = *(c - sz), cc = *c;  // centre column at z-1, z
-			float nxm = c[-1], nxp = c[1], nym = *(c - sy), nyp = c[sy];  // in-plane neighbours of plane z (pipelined)
+			gfloat_p c = zlen > 0 ? Ld + (size_t)x + (size_t)sy * (size_t)y + (size_t)sz * (size_t)(za - L.zoff) : centre;
+			float cm = *(c - sz), cc = *c, cp = c[sz];  // centre column at z-1, z, z+1
+			float nxm = c[-1], nxp = c[1], nym = *(c - sy), nyp = c[sy];  // in-plane neighbours of plane z
 			int dz = za - czi;
 			for (int step = 0; step < maxlen; step++) {
 				const bool in = step < zlen;
-				// next step's loads first: they stay in flight while this voxel is processed
-				const float *cn = (step + 1 < zlen) ? c + sz : c;
-				const float cp = c[sz];  // z+1 (z <= nz-2 by the window bounds)
+				// software pipeline: everything the NEXT step needs (its in-plane neighbours and its z+1 value) is requested
+				// now and consumed one step later; the clamped addresses stay inside the window's plane range
+				const bool more = step + 1 < zlen;
+				const gfloat_p cn = more ? c + sz : c;
+				const float cpn = cn[sz];  // plane z+2 (<= zb+1 <= nz-1), or z+1 again on the last step
 				const float nxm1 = cn[-1], nxp1 = cn[1], nym1 = *(cn - sy), nyp1 = cn[sy];
 				const float vzd = (float)dz * u;
 				float bx = px + R2 * vzd, by = py + R5 * vzd, bz = pz + R8 * vzd;
 				bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
 				bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
-				bool act = in && !(bx <= -0.5f || by <= -0.5f || bz <= -0.5f || bx >= 3.5f || by >= 3.5f || bz >= 3.5f);
+				// inside the 4x4x4 cube: the reference's !(b <= -0.5 || b >= 3.5) per axis (Src/cSIFT3D.cc:1299-1303); the
+				// coordinates are finite, so min/max over the three axes gives the same predicate in two v_min3/v_max3
+				bool act = in && fminf(fminf(bx, by), bz) > -0.5f && fmaxf(fmaxf(bx, by), bz) < 3.5f;
 				const float w = s_lut[in ? rr + dz * dz : 0];
 				float gx = 0.5f * (nxp - nxm);
 				float gy = 0.5f * (nyp - nym);
@@ -333,8 +361,8 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 				const float rz = R6 * gx + R7 * gy + R8 * gz;
 				const float g2 = rx * rx + ry * ry + rz * rz;
 				act = act && !(g2 < kBaryEps);
-				cm = cc; cc = cp; nxm = nxm1; nxp = nxp1; nym = nym1; nyp = nyp1;
-				c = cn; dz += (step + 1 < zlen) ? 1 : 0;
+				cm = cc; cc = cp; cp = cpn; nxm = nxm1; nxp = nxp1; nym = nym1; nyp = nyp1;
+				c = cn; dz += more ? 1 : 0;
 				// ---- push the active lanes into the wave's queue (compaction by ballot rank) ----
 				const unsigned long long m = __ballot(act);
 				if (m) {
@@ -351,6 +379,9 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 					                 s_predf, hist_rep);
 					qhead = (qhead + 64) & (kQCap - 1);
 					qcount -= 64;
+#if defined(S3D_EXP) && S3D_EXP == 5
+					exp_pops++;
+#endif
 				}
 			}
 		}
@@ -392,6 +423,14 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		}
 		float *out = d_desc + (size_t)slot * kDesc;
 		out[tid] = v0; out[tid + 256] = v1; out[tid + 512] = v2;
+#if defined(S3D_EXP) && S3D_EXP == 5
+		{
+			int tl = exp_lanes;
+			for (int o = 32; o > 0; o >>= 1) tl += __shfl_xor(tl, o, 64);
+			__syncthreads();
+			if (tid == 0) { out[0] = (float)exp_steps; out[1] = (float)tl; out[2] = (float)exp_pops; }
+		}
+#endif
 	}
 }
 

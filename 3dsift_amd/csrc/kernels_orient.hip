@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 		const int plane = (wx > 0 && wy > 0) ? wx * wy : 0;
 		const float inv_wx = 1.0f / (float)(wx > 0 ? wx : 1);
 		const size_t sy = (size_t)L.nx, sz = (size_t)L.nx * L.ny;
+		const gfloat_p Ld = as_global(L.d);  // global_load instead of flat_load (see sift3d_internal.h)
 		float t00 = 0.f, t01 = 0.f, t02 = 0.f, t11 = 0.f, t12 = 0.f, t22 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
 		for (int z = z0; z <= z1; z++) {
 			const int dz = z - czi;
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 				if (n >= lut.len) continue;
 				const float w = wtab[n];
 				if (w < 0.0f) continue;  // outside the sphere
-				const float *c = L.d + (size_t)x + sy * (size_t)y + sz * (size_t)(z - L.zoff);
+				const gfloat_p c = Ld + (size_t)x + sy * (size_t)y + sz * (size_t)(z - L.zoff);
 				float vx = 0.5f * (c[1] - c[-1]);
 				float vy = 0.5f * (c[sy] - *(c - sy));
 				float vz = 0.5f * (c[sz] - *(c - sz));

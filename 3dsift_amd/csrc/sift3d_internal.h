@@ -132,6 +132,14 @@ void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, co
                           const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st);
 
 // ---- kernels_orient.hip --------------------------------------------------------------------
+// Level pointers reach the keypoint kernels through a table in device memory, so the compiler cannot prove their address
+// space and would emit FLAT loads, which count on both vmcnt and lgkmcnt and force a full s_waitcnt after every load
+// group (no software pipelining).  Casting to the global address space gives global_load + in-order vmcnt.
+#ifdef __HIPCC__
+typedef const float __attribute__((address_space(1))) *gfloat_p;
+__device__ __forceinline__ gfloat_p as_global(const float *p) { return (gfloat_p)p; }
+#endif
+
 struct LevelRef {
 	const float *d;   // local plane 0 of the buffer
 	int nx, ny, nz;   // nz = GLOBAL number of planes (window clipping, Src/cSIFT3D.cc:951-955)
