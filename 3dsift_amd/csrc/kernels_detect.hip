@@ -41,24 +41,43 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	// the block's 16 rows x wpr words are dealt to its 4 waves word by word
 	const int y0 = yb * kRows;
 	const int nwords = min(kRows, ny - y0) * wpr;
-	for (int wi = wid; wi < nwords; wi += kThreads / 64) {
-		const int ry = wi / wpr, xw = wi - ry * wpr;
-		const int y = y0 + ry, x = xw * 64 + lane;
-		bool hit = false;
-		if (z_in && y >= 1 && y <= ny - 2 && x >= 1 && x <= nx - 2) {
-			const size_t i = (size_t)x + sy * (size_t)y + sz * (size_t)z;
-			const float val = cur[i];
-			if (val > thr || val < -thr) {
+	// kBatch words per pass: their centre values are requested together and only then examined, so a wave has kBatch
+	// independent HBM reads in flight instead of one (the scan is a pure streaming read; with one load per iteration it
+	// ran at the memory latency, not the bandwidth)
+	constexpr int kBatch = 8;
+	for (int w0 = wid * kBatch; w0 < nwords; w0 += (kThreads / 64) * kBatch) {
+		float val[kBatch];
+		size_t idx[kBatch];
+		bool in[kBatch];
+#pragma unroll
+		for (int b = 0; b < kBatch; b++) {
+			const int wi = w0 + b;
+			const int ry = wi / wpr, xw = wi - ry * wpr;
+			const int y = y0 + ry, x = xw * 64 + lane;
+			in[b] = wi < nwords && z_in && y >= 1 && y <= ny - 2 && x >= 1 && x <= nx - 2;
+			idx[b] = (size_t)x + sy * (size_t)y + sz * (size_t)z;
+			val[b] = cur[in[b] ? idx[b] : (sz * (size_t)z)];  // unconditional load, clamped address
+		}
+#pragma unroll
+		for (int b = 0; b < kBatch; b++) {
+			const int wi = w0 + b;
+			if (wi >= nwords) break;  // wave-uniform
+			const int ry = wi / wpr, xw = wi - ry * wpr;
+			const int y = y0 + ry;
+			bool hit = false;
+			const float v = val[b];
+			if (in[b] && (v > thr || v < -thr)) {
+				const size_t i = idx[b];
 				const float n0 = prev[i], n1 = cur[i - 1], n2 = cur[i + 1], n3 = cur[i + sy], n4 = cur[i - sy], n5 = cur[i + sz],
 				            n6 = cur[i - sz], n7 = next[i];
-				const bool mn = val < n0 && val < n1 && val < n2 && val < n3 && val < n4 && val < n5 && val < n6 && val < n7;
-				const bool mx = val > n0 && val > n1 && val > n2 && val > n3 && val > n4 && val > n5 && val > n6 && val > n7;
+				const bool mn = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 && v < n7;
+				const bool mx = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 && v > n7;
 				hit = mn || mx;
 			}
+			const unsigned long long m = __ballot(hit);
+			if (lane == 0) masks[((size_t)(lvl * nz + zi) * ny + y) * wpr + xw] = m;
+			cnt += (unsigned)__popcll(m);
 		}
-		const unsigned long long m = __ballot(hit);
-		if (lane == 0) masks[((size_t)(lvl * nz + zi) * ny + y) * wpr + xw] = m;
-		cnt += (unsigned)__popcll(m);
 	}
 	if (lane == 0) s_cnt[wid] = cnt;
 	__syncthreads();

@@ -199,11 +199,29 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 		float T6[6] = {wave_sum(t00), wave_sum(t01), wave_sum(t02), wave_sum(t11), wave_sum(t12), wave_sum(t22)};
 		float w3[3] = {wave_sum(g0), wave_sum(g1), wave_sum(g2)};
 		if (lane == 0) {
-			DevKp kp = kps[k];
-			kp.code = finish_orientation(kp, T6, w3, max_eig, corner);
-			kps[k] = kp;
-			codes[k] = kp.code;  // dense copy for the compaction scan
+			// window sums only: the eigen decomposition runs in k_orient_finish, one LANE per extremum (here it would
+			// occupy one lane of the wave and idle the other 63)
+			kps[k].st[0] = T6[0]; kps[k].st[1] = T6[1]; kps[k].st[2] = T6[2]; kps[k].st[4] = T6[3]; kps[k].st[5] = T6[4]; kps[k].st[8] = T6[5];
+			kps[k].win[0] = w3[0]; kps[k].win[1] = w3[1]; kps[k].win[2] = w3[2];
 		}
+	}
+}
+
+// second phase of Assign_Orientation_Imp (Src/cSIFT3D.cc:1000-1137): eigen decomposition, rejection tests, rotation
+// matrix; one thread per extremum
+__global__ void __launch_bounds__(64) k_orient_finish(DevKp *__restrict__ kps, int *__restrict__ codes, const unsigned *__restrict__ d_count,
+                                                      unsigned cap, float max_eig, float corner, int part_rank, int part_world) {
+	const unsigned count = min(d_count[0], cap);
+	const unsigned pw = part_world > 1 ? (unsigned)part_world : 1u, pr = part_world > 1 ? (unsigned)part_rank : 0u;
+	const unsigned owned = count > pr ? (count - pr + pw - 1) / pw : 0u;
+	for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < owned; j += gridDim.x * blockDim.x) {
+		const unsigned k = j * pw + pr;
+		DevKp kp = kps[k];
+		const float T6[6] = {kp.st[0], kp.st[1], kp.st[2], kp.st[4], kp.st[5], kp.st[8]};
+		const float w3[3] = {kp.win[0], kp.win[1], kp.win[2]};
+		kp.code = finish_orientation(kp, T6, w3, max_eig, corner);
+		kps[k] = kp;
+		codes[k] = kp.code;  // dense copy for the compaction scan
 	}
 }
 
@@ -211,6 +229,7 @@ void launch_orient(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap
                    const float *d_lutpool, float max_eig, float corner, int part_rank, int part_world, hipStream_t st) {
 	hipLaunchKernelGGL(k_orient, dim3(256 * 8), dim3(256), 0, st, kps, codes, d_count, cap, d_levels, d_luts, d_lutpool, max_eig, corner,
 	                   part_rank, part_world);
+	hipLaunchKernelGGL(k_orient_finish, dim3(256 * 8), dim3(64), 0, st, kps, codes, d_count, cap, max_eig, corner, part_rank, part_world);
 }
 
 // Orientation results as kOrientWords int32 words per extremum (code, then the bit patterns of win, eigvalue, eigvector,
