@@ -226,9 +226,11 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 	const unsigned nkp = min(d_nkp[0], kp_cap);
 	const unsigned pw = part_world > 1 ? (unsigned)part_world : 1u, pr = part_world > 1 ? (unsigned)part_rank : 0u;
 	if (pw > 1)
-		for (unsigned row = blockIdx.x; row < nkp; row += gridDim.x)
-			if (row % pw != pr)
-				for (int i = tid; i < kDesc; i += 256) d_desc[(size_t)row * kDesc + i] = 0.0f;
+		for (unsigned pos = blockIdx.x; pos < nkp; pos += gridDim.x)
+			if (pos % pw != pr) {
+				const size_t row = (size_t)kps[order[pos]].slot;
+				for (int i = tid; i < kDesc; i += 256) d_desc[row * kDesc + i] = 0.0f;
+			}
 	const unsigned nown = nkp > pr ? (nkp - pr + pw - 1) / pw : 0u;
 	for (;;) {
 		__syncthreads();
@@ -236,8 +238,8 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		__syncthreads();
 		const unsigned item = s_item;
 		if (item >= nown) break;  // block-uniform
-		const int slot = (int)(item * pw + pr);
-		const unsigned k = (unsigned)order[slot];
+		const unsigned k = (unsigned)order[item * pw + pr];  // processing order: big windows first (k_slots)
+		const int slot = kps[k].slot;                        // row of the keypoint in the results (reference order)
 		const int cxi = kps[k].x, cyi = kps[k].y, czi = kps[k].z;
 		const int li = kps[k].octave * 8 + kps[k].level;
 		const float scale = kps[k].scale;

@@ -274,36 +274,67 @@ void launch_orient_unpack(DevKp *kps, int *codes, const unsigned *d_count, unsig
 __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const int *__restrict__ codes,
                                                 const unsigned *__restrict__ d_count, unsigned cap, unsigned *__restrict__ d_nkp,
                                                 int *__restrict__ order, unsigned kp_cap) {
-	__shared__ unsigned s_wave[16];
+	// slot  = exclusive scan of (code == 1) in list order: the keypoint's row in the results (reference order)
+	// order = the accepted extrema sorted by keypoint level DESCENDING (stable): the descriptor window volume grows 4x
+	//         from level 1 to level 3, and handing out the big ones first (longest processing time first) keeps the
+	//         tail of the descriptor kernel short.  Deterministic (two scans, no atomics), so every rank of a
+	//         partitioned run derives the same list.
+	constexpr int kL = 6;  // levels 0..5 (kMaxKpLevels = 5)
+	__shared__ unsigned s_wave[16][kL + 1];
+	__shared__ unsigned s_base[kL];
 	const unsigned count = min(d_count[0], cap);
 	const unsigned t = threadIdx.x;
 	const unsigned chunk = (count + 1023u) / 1024u;
 	const unsigned lo = min(t * chunk, count), hi = min(lo + chunk, count);
-	unsigned sum = 0;
-	for (unsigned i = lo; i < hi; i++) sum += (codes[i] == 1);
-	unsigned v = sum;
-	const int lane = t & 63, wid = t >> 6;
+	unsigned sum[kL + 1];  // [0..kL-1] accepted per level, [kL] accepted total
 #pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		unsigned u = __shfl_up(v, o, 64);
-		if (lane >= o) v += u;
+	for (int l = 0; l <= kL; l++) sum[l] = 0;
+	for (unsigned i = lo; i < hi; i++)
+		if (codes[i] == 1) {
+			const int lv = min(max(kps[i].level, 0), kL - 1);
+#pragma unroll
+			for (int l = 0; l < kL; l++) sum[l] += (lv == l);
+			sum[kL]++;
+		}
+	const int lane = t & 63, wid = t >> 6;
+	unsigned v[kL + 1];
+#pragma unroll
+	for (int l = 0; l <= kL; l++) {
+		v[l] = sum[l];
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			unsigned u = __shfl_up(v[l], o, 64);
+			if (lane >= o) v[l] += u;
+		}
+		if (lane == 63) s_wave[wid][l] = v[l];
 	}
-	if (lane == 63) s_wave[wid] = v;
+	__syncthreads();
+	if (t <= kL) {
+		unsigned a = 0;
+		for (int w = 0; w < 16; w++) { unsigned c = s_wave[w][t]; s_wave[w][t] = a; a += c; }
+		if (t < kL) s_base[t] = a;  // total of level t (turned into the start position below)
+		else d_nkp[0] = a;
+	}
 	__syncthreads();
 	if (t == 0) {
 		unsigned a = 0;
-		for (int w = 0; w < 16; w++) { unsigned c = s_wave[w]; s_wave[w] = a; a += c; }
+		for (int l = kL - 1; l >= 0; l--) { unsigned c = s_base[l]; s_base[l] = a; a += c; }  // higher levels first
 	}
 	__syncthreads();
-	const unsigned incl = v + s_wave[wid];
-	unsigned run = incl - sum;
+	unsigned run[kL + 1];
+#pragma unroll
+	for (int l = 0; l <= kL; l++) run[l] = v[l] + s_wave[wid][l] - sum[l];
 	for (unsigned i = lo; i < hi; i++) {
 		if (codes[i] == 1) {
-			if (run < kp_cap) order[run] = (int)i;  // slot -> extremum: the descriptor kernel walks the accepted keypoints only
-			kps[i].slot = (int)run++;
+			const int lv = min(max(kps[i].level, 0), kL - 1);
+			unsigned pos = 0;
+#pragma unroll
+			for (int l = 0; l < kL; l++)
+				if (lv == l) pos = s_base[l] + run[l]++;
+			if (pos < kp_cap) order[pos] = (int)i;
+			kps[i].slot = (int)run[kL]++;
 		} else kps[i].slot = -1;
 	}
-	if (t == 1023) d_nkp[0] = incl;
 }
 
 void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigned cap, unsigned *d_nkp, int *order, unsigned kp_cap,

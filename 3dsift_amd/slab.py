@@ -78,6 +78,15 @@ def capi_words():
     return capi.ORIENT_WORDS
 
 
+def described_rows(levels, rank, world):
+    """Rows (keypoint slots, reference order) whose descriptor a partitioned handle computes: the library deals the
+    accepted keypoints in its processing order -- keypoint level descending, stable (longest windows first,
+    kernels_orient.hip k_slots) -- position p goes to rank p % world."""
+    levels = np.asarray(levels)
+    order = np.argsort(-levels, kind="stable")
+    return np.sort(order[rank::world])
+
+
 def merge_keypoints(parts_oct0, tail):
     """Reference order (octave, level, z, y, x) (Src/cSIFT3D.cc:373-416) from per-slab octave-0 lists plus the tail.
     parts_oct0: list of (kp, desc) per rank; tail: (kp, desc) of octaves >= 1.  Returns (kp, desc)."""
@@ -386,11 +395,15 @@ class SlabExtractor:
         ws = self._wl()
         parts = self.comm.gather_objects([w.ctx.GetKeypoints() for w in ws])
         if self.noct >= 2:
-            # tail keypoint records are complete everywhere; descriptor row i lives on rank i % world
-            rows = self.comm.gather_objects([w.tail.GetKeypoints()[1][w.rank::self.world] for w in ws])
+            # tail keypoint records are complete everywhere; the descriptor rows are dealt (see described_rows)
+            mine = []
+            for w in ws:
+                wkp, wds = w.tail.GetKeypoints()
+                mine.append(wds[described_rows(wkp["level"], w.rank, self.world)])
+            rows = self.comm.gather_objects(mine)
             tkp, tds = ws[0].tail.GetKeypoints()
             for r, part in enumerate(rows):
-                tds[r::self.world] = part
+                tds[described_rows(tkp["level"], r, self.world)] = part
             tail = (tkp, tds)
         else:
             kp, ds = parts[0]

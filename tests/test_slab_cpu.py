@@ -61,6 +61,14 @@ def test_halo_transfers_fill_exactly_the_halo(nz, world, h):
     assert slab.halo_transfers(b, nz, 1, 0, 5, 5) == []
 
 
+def test_described_rows_partition_everything_once():
+    lv = np.array([1, 1, 2, 3, 3, 1, 2, 2, 3, 1, 1, 2, 3])
+    parts = [slab.described_rows(lv, r, 3) for r in range(3)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(len(lv)))
+    # level-descending stable order: positions 0..3 are the four level-3 rows in index order -> ranks 0,1,2,0
+    assert parts[0].tolist() == [1, 3, 7, 10, 12] and 4 in parts[1] and 8 in parts[2]
+
+
 def test_merge_keypoints_restores_reference_order():
     rng = np.random.default_rng(0)
     n = 200
