@@ -139,10 +139,17 @@ __device__ int finish_orientation(DevKp &kp, const float T6[6], const float w3[3
 	return 1;
 }
 
+// LDS tiles of the orientation window: the default radius (3 * 1.5 * scale <= 11.43 voxels) gives <= 25 voxels per side,
+// + 2 for the central differences; larger windows (non-default sigma) take the global-load path
+constexpr int kTileW = 28, kTileH = 27, kTileLd = (27 * 27 + 63) / 64;
+constexpr int kOriLut = 256;  // squared-offset weight table of the orientation window (r^2 <= 131 by default)
+
 __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__restrict__ codes, const unsigned *__restrict__ d_count, unsigned cap,
                                                 const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                 const float *__restrict__ lutpool, float max_eig, float corner, int part_rank,
                                                 int part_world) {
+	__shared__ float s_tile[4 * 3 * kTileW * kTileH];  // per wave: planes z-1, z, z+1 of the window footprint
+	__shared__ float s_wlut[4 * kOriLut];
 	const unsigned count = min(d_count[0], cap);
 	const int lane = threadIdx.x & 63;
 	const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -171,6 +178,92 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 		const size_t sy = (size_t)L.nx, sz = (size_t)L.nx * L.ny;
 		const gfloat_p Ld = as_global(L.d);  // global_load instead of flat_load (see sift3d_internal.h)
 		float t00 = 0.f, t01 = 0.f, t02 = 0.f, t11 = 0.f, t12 = 0.f, t22 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+		const int tw = wx + 2, th = wy + 2;  // window footprint plus the central-difference border
+		if (plane > 0 && z1 >= z0 && tw <= kTileW && th <= kTileH && lut.len <= kOriLut) {
+			// ---- LDS path: three consecutive (tw x th) planes of the level live in this wave's LDS slots, so a window
+			// voxel costs one global load (plus border) instead of six; plane z+2 is requested into registers while plane
+			// z is processed and written to its slot one iteration later.  Same voxel -> lane mapping and accumulation
+			// order as the global path below.
+			float *tile = &s_tile[(threadIdx.x >> 6) * 3 * kTileW * kTileH];
+			float *wl = &s_wlut[(threadIdx.x >> 6) * kOriLut];   // this wave's copy of the window weights
+			for (int i = lane; i < lut.len && i < kOriLut; i += 64) wl[i] = wtab[i];
+			const int tn = tw * th;
+			const float inv_tw = 1.0f / (float)tw;
+			int toff[kTileLd];   // per-lane tile offsets of the pieces this lane moves (same for every plane)
+			int goff[kTileLd];
+#pragma unroll
+			for (int i = 0; i < kTileLd; i++) {
+				const int idx = lane + 64 * i;
+				const int ty = (int)(((float)idx + 0.5f) * inv_tw);
+				const int tx = idx - ty * tw;
+				const bool ok = idx < tn;
+				toff[i] = ok ? ty * kTileW + tx : -1;
+				goff[i] = ok ? (x0 - 1 + tx) + (int)sy * (y0 - 1 + ty) : (x0 - 1) + (int)sy * (y0 - 1);
+			}
+			const gfloat_p base = Ld - sz * (size_t)L.zoff;
+			float pf[kTileLd];
+			auto request = [&](int zp) {  // unconditional, clamped loads (planes z0-1 .. z1+1 are inside the level)
+				const gfloat_p pl = base + sz * (size_t)zp;
+#pragma unroll
+				for (int i = 0; i < kTileLd; i++) pf[i] = pl[goff[i]];
+			};
+			auto deposit = [&](int slot) {
+				float *dstp = tile + slot * (kTileW * kTileH);
+#pragma unroll
+				for (int i = 0; i < kTileLd; i++)
+					if (toff[i] >= 0) dstp[toff[i]] = pf[i];
+			};
+			request(z0 - 1); deposit(0);
+			request(z0);     deposit(1);
+			request(z0 + 1);
+			int sm = 0, sc = 1, sp = 2;  // slots of planes z-1, z, z+1
+			for (int z = z0; z <= z1; z++) {
+				deposit(sp);                       // plane z+1 (requested one iteration ago)
+				request(min(z + 2, z1 + 1));       // in flight while plane z is processed
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				const float *pm = tile + sm * (kTileW * kTileH), *pc = tile + sc * (kTileW * kTileH), *pp = tile + sp * (kTileW * kTileH);
+				const int dz = z - czi;
+				// kUn voxels per pass, all LDS reads (weights included) issued before the first use; inactive voxels read
+				// valid addresses and are masked, so the loop body is branch-free and pipelines
+				constexpr int kUn = 2;
+				for (int v0 = lane; v0 < plane; v0 += 64 * kUn) {
+					float nb[kUn][6], w[kUn];
+#pragma unroll
+					for (int q = 0; q < kUn; q++) {
+						const int v = v0 + 64 * q;
+						const int ly = (int)(((float)v + 0.5f) * inv_wx);
+						const int lx = v - ly * wx;
+						const int dx = x0 + lx - cxi, dy = y0 + ly - cyi;
+						const int n = dx * dx + dy * dy + dz * dz;
+						const bool ok = v < plane && n < lut.len;
+						w[q] = ok ? wl[n] : -1.0f;
+						const int o = ok ? (ly + 1) * kTileW + lx + 1 : kTileW + 1;
+						nb[q][0] = pc[o + 1]; nb[q][1] = pc[o - 1]; nb[q][2] = pc[o + kTileW]; nb[q][3] = pc[o - kTileW];
+						nb[q][4] = pp[o]; nb[q][5] = pm[o];
+					}
+#pragma unroll
+					for (int q = 0; q < kUn; q++) {
+						if (w[q] < 0.0f) continue;  // outside the sphere / past the end of the plane
+						float vx = 0.5f * (nb[q][0] - nb[q][1]);
+						float vy = 0.5f * (nb[q][2] - nb[q][3]);
+						float vz = 0.5f * (nb[q][4] - nb[q][5]);
+						vx = vx * inv_u; vy = vy * inv_u; vz = vz * inv_u;
+						const float ww = w[q];
+						t00 = t00 + vx * vx * ww;
+						t01 = t01 + vx * vy * ww;
+						t02 = t02 + vx * vz * ww;
+						t11 = t11 + vy * vy * ww;
+						t12 = t12 + vy * vz * ww;
+						t22 = t22 + vz * vz * ww;
+						g0 = g0 + vx * ww; g1 = g1 + vy * ww; g2 = g2 + vz * ww;
+					}
+				}
+				__builtin_amdgcn_wave_barrier();   // every lane is done with plane z-1 before its slot is overwritten
+				const int tmp = sm; sm = sc; sc = sp; sp = tmp;
+			}
+		} else
 		for (int z = z0; z <= z1; z++) {
 			const int dz = z - czi;
 			for (int v = lane; v < plane; v += 64) {
@@ -183,9 +276,14 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 				const float w = wtab[n];
 				if (w < 0.0f) continue;  // outside the sphere
 				const gfloat_p c = Ld + (size_t)x + sy * (size_t)y + sz * (size_t)(z - L.zoff);
+#if defined(S3D_EXP) && S3D_EXP == 10  // experiment: one load per voxel
+				const float c0 = c[0];
+				float vx = 0.5f * (c0 * 1.1f - c0), vy = 0.5f * (c0 * 1.2f - c0), vz = 0.5f * (c0 * 1.3f - c0);
+#else
 				float vx = 0.5f * (c[1] - c[-1]);
 				float vy = 0.5f * (c[sy] - *(c - sy));
 				float vz = 0.5f * (c[sz] - *(c - sz));
+#endif
 				vx = vx * inv_u; vy = vy * inv_u; vz = vz * inv_u;
 				t00 = t00 + vx * vx * w;
 				t01 = t01 + vx * vy * w;
@@ -277,37 +375,33 @@ __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const i
 	// slot  = exclusive scan of (code == 1) in list order: the keypoint's row in the results (reference order)
 	// order = the accepted extrema sorted by keypoint level DESCENDING (stable): the descriptor window volume grows 4x
 	//         from level 1 to level 3, and handing out the big ones first (longest processing time first) keeps the
-	//         tail of the descriptor kernel short.  Deterministic (two scans, no atomics), so every rank of a
+	//         tail of the descriptor kernel short.  Deterministic (ballot ranks, no atomics), so every rank of a
 	//         partitioned run derives the same list.
-	constexpr int kL = 6;  // levels 0..5 (kMaxKpLevels = 5)
+	// One workgroup; wave w owns the contiguous range [w*per, (w+1)*per) and walks it 64 entries at a time (coalesced),
+	// ranks inside a row of 64 come from ballots.
+	constexpr int kL = 6;  // levels 0..5 (kMaxKpLevels = 5); key kL = all accepted
 	__shared__ unsigned s_wave[16][kL + 1];
 	__shared__ unsigned s_base[kL];
 	const unsigned count = min(d_count[0], cap);
 	const unsigned t = threadIdx.x;
-	const unsigned chunk = (count + 1023u) / 1024u;
-	const unsigned lo = min(t * chunk, count), hi = min(lo + chunk, count);
-	unsigned sum[kL + 1];  // [0..kL-1] accepted per level, [kL] accepted total
-#pragma unroll
-	for (int l = 0; l <= kL; l++) sum[l] = 0;
-	for (unsigned i = lo; i < hi; i++)
-		if (codes[i] == 1) {
-			const int lv = min(max(kps[i].level, 0), kL - 1);
-#pragma unroll
-			for (int l = 0; l < kL; l++) sum[l] += (lv == l);
-			sum[kL]++;
-		}
 	const int lane = t & 63, wid = t >> 6;
-	unsigned v[kL + 1];
+	const unsigned per = ((count + 15u) / 16u + 63u) & ~63u;  // per-wave range, multiple of 64
+	const unsigned lo = min((unsigned)wid * per, count), hi = min(lo + per, count);
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	unsigned tot[kL + 1];
 #pragma unroll
-	for (int l = 0; l <= kL; l++) {
-		v[l] = sum[l];
+	for (int l = 0; l <= kL; l++) tot[l] = 0;
+	for (unsigned i0 = lo; i0 < hi; i0 += 64) {
+		const unsigned i = i0 + lane;
+		const bool acc = i < hi && codes[i] == 1;
+		const int lv = acc ? min(max(kps[i].level, 0), kL - 1) : -1;
 #pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			unsigned u = __shfl_up(v[l], o, 64);
-			if (lane >= o) v[l] += u;
-		}
-		if (lane == 63) s_wave[wid][l] = v[l];
+		for (int l = 0; l < kL; l++) tot[l] += (unsigned)__popcll(__ballot(lv == l));
+		tot[kL] += (unsigned)__popcll(__ballot(acc));
 	}
+	if (lane == 0)
+#pragma unroll
+		for (int l = 0; l <= kL; l++) s_wave[wid][l] = tot[l];
 	__syncthreads();
 	if (t <= kL) {
 		unsigned a = 0;
@@ -323,17 +417,25 @@ __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const i
 	__syncthreads();
 	unsigned run[kL + 1];
 #pragma unroll
-	for (int l = 0; l <= kL; l++) run[l] = v[l] + s_wave[wid][l] - sum[l];
-	for (unsigned i = lo; i < hi; i++) {
-		if (codes[i] == 1) {
-			const int lv = min(max(kps[i].level, 0), kL - 1);
-			unsigned pos = 0;
+	for (int l = 0; l < kL; l++) run[l] = s_base[l] + s_wave[wid][l];
+	run[kL] = s_wave[wid][kL];
+	for (unsigned i0 = lo; i0 < hi; i0 += 64) {
+		const unsigned i = i0 + lane;
+		const bool acc = i < hi && codes[i] == 1;
+		const int lv = acc ? min(max(kps[i].level, 0), kL - 1) : -1;
+		unsigned pos = 0;
 #pragma unroll
-			for (int l = 0; l < kL; l++)
-				if (lv == l) pos = s_base[l] + run[l]++;
+		for (int l = 0; l < kL; l++) {
+			const unsigned long long m = __ballot(lv == l);
+			if (lv == l) pos = run[l] + (unsigned)__popcll(m & lt);
+			run[l] += (unsigned)__popcll(m);
+		}
+		const unsigned long long ma = __ballot(acc);
+		if (acc) {
 			if (pos < kp_cap) order[pos] = (int)i;
-			kps[i].slot = (int)run[kL]++;
-		} else kps[i].slot = -1;
+			kps[i].slot = (int)(run[kL] + (unsigned)__popcll(ma & lt));
+		} else if (i < hi) kps[i].slot = -1;
+		run[kL] += (unsigned)__popcll(ma);
 	}
 }
 
