@@ -53,7 +53,7 @@ class Params(C.Structure):
 
 class SlabDesc(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("z0", C.c_int), ("z1", C.c_int), ("halo", C.c_int),
-                ("noct_total", C.c_int)]
+                ("noct_total", C.c_int), ("octave", C.c_int)]
 
 
 class Sift3dError(RuntimeError):
@@ -317,19 +317,20 @@ class SlabCSIFT3D(CSIFT3D):
     (caller-owned device memory of arena_floats(...) floats) so the caller's communication layer can address halo planes."""
 
     @staticmethod
-    def arena_floats(nx, ny, nz, z0, z1, halo, noct_total, **kw):
-        d = SlabDesc(nx, ny, nz, z0, z1, halo, noct_total); p = _params(kw); n = C.c_size_t(0)
+    def arena_floats(nx, ny, nz, z0, z1, halo, noct_total, octave=0, **kw):
+        d = SlabDesc(nx, ny, nz, z0, z1, halo, noct_total, octave); p = _params(kw); n = C.c_size_t(0)
         _check(lib().sift3d_slab_arena_floats(C.byref(d), C.byref(p), C.byref(n)))
         return n.value
 
-    def __init__(self, nx, ny, nz, z0, z1, halo, noct_total, arena_ptr, arena_floats, device=0, **kw):
+    def __init__(self, nx, ny, nz, z0, z1, halo, noct_total, arena_ptr, arena_floats, device=0, octave=0, **kw):
         self._h = C.c_void_p()
         p = _params(kw)
         self.levels = p.num_kp_levels
         self.dims = (nx, ny, nz)
         self.z0, self.z1, self.halo = z0, z1, halo
         self.shape = (z1 - z0 + 2 * halo, ny, nx)
-        d = SlabDesc(nx, ny, nz, z0, z1, halo, noct_total)
+        self.octave = octave
+        d = SlabDesc(nx, ny, nz, z0, z1, halo, noct_total, octave)
         _check(lib().sift3d_slab_create(C.byref(self._h), C.byref(d), C.byref(p), device, C.c_void_p(int(arena_ptr)), arena_floats))
 
     def buffer(self, kind, idx=0):

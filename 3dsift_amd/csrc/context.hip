@@ -896,8 +896,10 @@ static int slab_cfg(const sift3d_slab_desc *d, CreateCfg &cfg) {
 		set_last_error("bad slab description (owned range must be non-empty, start and end on even planes, inside the volume)");
 		return SIFT3D_ERR_ARG;
 	}
+	if (d->octave < 0 || d->octave > 20) { set_last_error("bad slab octave"); return SIFT3D_ERR_ARG; }
 	cfg.nx = d->nx; cfg.ny = d->ny; cfg.nz = d->nz; cfg.noct_total = d->noct_total; cfg.slab = true;
 	cfg.z0 = d->z0; cfg.z1 = d->z1; cfg.halo = d->halo;
+	cfg.octave_base = d->octave; cfg.seeded = d->octave > 0;
 	return SIFT3D_OK;
 }
 
@@ -909,8 +911,9 @@ extern "C" int sift3d_slab_arena_floats(const sift3d_slab_desc *d, const sift3d_
 	sift3d_ctx tmp;  // geometry only, no device work
 	if (params) tmp.p = *params; else sift3d_default_params(&tmp.p);
 	tmp.nx = cfg.nx; tmp.ny = cfg.ny; tmp.nz = cfg.nz; tmp.slab = true; tmp.own0 = cfg.z0; tmp.own1 = cfg.z1; tmp.halo = cfg.halo;
+	tmp.octave_base = cfg.octave_base; tmp.seeded = cfg.seeded;
 	plan_pyramid(&tmp, cfg.noct_total);
-	tmp.in.nx = cfg.nx; tmp.in.ny = cfg.ny; tmp.in.nz = cfg.nz; tmp.in.bz = cfg.z1 - cfg.z0 + 2 * cfg.halo;
+	tmp.in.nx = cfg.nx; tmp.in.ny = cfg.ny; tmp.in.nz = cfg.nz; tmp.in.bz = cfg.seeded ? 1 : cfg.z1 - cfg.z0 + 2 * cfg.halo;
 	*n = arena_floats_of(&tmp);
 	return SIFT3D_OK;
 }
@@ -927,7 +930,7 @@ extern "C" int sift3d_slab_create(sift3d_handle *out, const sift3d_slab_desc *d,
 	sift3d_ctx *c = *out;
 	if (c->noct < 1) { sift3d_destroy(c); *out = nullptr; set_last_error("volume too small for one octave"); return SIFT3D_ERR_ARG; }
 	// the fused level kernel is the only slab-aware Gaussian: default half widths and n >= 2*hw+2 along x and y
-	for (int i = 0; i < c->ng; i++) {
+	for (int i = c->seeded ? 1 : 0; i < c->ng; i++) {
 		const int hw = i == 0 ? c->base_taps.hw : c->taps[i].hw;
 		const bool inst = hw == 2 || hw == 3 || hw == 4 || hw == 5 || hw == 6 || hw == 8;
 		if (!inst || c->nx < 2 * hw + 2 || c->ny < 2 * hw + 2 || hw + 1 > c->halo) {
@@ -958,7 +961,7 @@ extern "C" int sift3d_slab_buffer(sift3d_handle c, int kind, int idx, size_t *of
 }
 
 extern "C" int sift3d_slab_upload(sift3d_handle c, const float *planes, int zg0, int zg1, int on_device) {
-	if (!c || !c->slab || !planes || zg0 < c->in.zoff || zg1 > c->in.zoff + c->in.planes() || zg0 < 0 || zg1 > c->nz || zg1 <= zg0)
+	if (!c || !c->slab || c->seeded || !planes || zg0 < c->in.zoff || zg1 > c->in.zoff + c->in.planes() || zg0 < 0 || zg1 > c->nz || zg1 <= zg0)
 		return SIFT3D_ERR_ARG;
 	int rc = set_device(c->device);
 	if (rc) return rc;
@@ -970,7 +973,7 @@ extern "C" int sift3d_slab_upload(sift3d_handle c, const float *planes, int zg0,
 }
 
 extern "C" int sift3d_slab_input_absmax(sift3d_handle c, float *local_max) {
-	if (!c || !c->slab || !local_max) return SIFT3D_ERR_ARG;
+	if (!c || !c->slab || c->seeded || !local_max) return SIFT3D_ERR_ARG;
 	int rc = set_device(c->device);
 	if (rc) return rc;
 	const size_t pl = (size_t)c->nx * c->ny;
@@ -983,7 +986,7 @@ extern "C" int sift3d_slab_input_absmax(sift3d_handle c, float *local_max) {
 }
 
 extern "C" int sift3d_slab_input_scale(sift3d_handle c, float global_max) {
-	if (!c || !c->slab) return SIFT3D_ERR_ARG;
+	if (!c || !c->slab || c->seeded) return SIFT3D_ERR_ARG;
 	int rc = set_device(c->device);
 	if (rc) return rc;
 	unsigned bits;
@@ -1018,7 +1021,8 @@ extern "C" int sift3d_slab_level(sift3d_handle c, int i) {
 	bool ok;
 	if (i == 0) {
 		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(c->nd + 4), c->stream));
-		ok = launch_fused_level(c->in.d, L.d, nullptr, nullptr, L.nx, L.ny, zr, c->base_taps, c->stream);
+		// octave > 0: level 0 is the decimated G[octave-1][num_kp_levels], written by the caller
+		ok = c->seeded ? true : launch_fused_level(c->in.d, L.d, nullptr, nullptr, L.nx, L.ny, zr, c->base_taps, c->stream);
 	} else {
 		ok = launch_fused_level(c->gss[i - 1].d, L.d, c->dog[i - 1].d, c->d_dogmax + (i - 1), L.nx, L.ny, zr, c->taps[i], c->stream);
 	}

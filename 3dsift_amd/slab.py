@@ -10,9 +10,12 @@ pipeline, with results equal to the single-GPU run (pyramid / extrema bit for bi
                DoG[1..3]         : 1 plane (extrema test reads z+-1; deferred)
              as point-to-point sends between z-neighbours (RCCL over xGMI), posted while the next level computes.
              The normalisation max and the 5 DoG maxima are all-reduced (MAX); x/y passes need no communication.
-  octaves>=1 G[1][0] = DownSample_3D(G[0][3]) is decimated slab-wise and all-gathered (1/8 of one level); the remaining
-             octaves (1/7 of the pyramid work) run replicated in a SEEDED context, only the descriptor work is dealt by
-             keypoint slot and the rows are all-reduced (SUM of disjoint rows = exact).
+  octave 1.. the first `sharded_octaves` octaves are sharded the same way: G[o+1][0] = DownSample_3D(G[o][3]) is
+             decimated slab-wise straight into the next octave's slab buffers (slab starts are multiples of
+             2^sharded_octaves, so plane 2k never leaves its slab); thin slabs simply take halo planes from several ranks.
+  tail       the level 0 of the first replicated octave is all-gathered (1/8^S of one level); the remaining octaves run
+             replicated in a SEEDED context; their orientation work is dealt by extremum index (integer all-reduce(SUM)
+             of zero-padded rows restores it exactly), their descriptor work by keypoint and stays distributed.
 
 The same lock-step driver runs over a communicator:
   DistComm  one worker per process, torch.distributed (backend "nccl" == RCCL); works with gloo on CPU tensors for tests
@@ -24,7 +27,8 @@ from collections import namedtuple
 
 import numpy as np
 
-Transfer = namedtuple("Transfer", "src dst kind idx zg0 zg1")  # global planes [zg0, zg1) of buffer (kind, idx): src -> dst
+# global planes [zg0, zg1) of buffer (kind, idx) of sharded octave `stage`: src -> dst
+Transfer = namedtuple("Transfer", "src dst kind idx zg0 zg1 stage", defaults=(0,))
 
 KIND_INPUT, KIND_GSS, KIND_DOG = 0, 1, 2
 
@@ -37,23 +41,29 @@ def octaves_total(nx, ny, nz):
     return max(0, int(np.log2(np.float32(min(nx, ny, nz)))) - 2)
 
 
-def slab_bounds(nz, world):
-    """Owned plane ranges [z0, z1) per rank: contiguous, even starts (DownSample_3D keeps plane 2k, so an even start keeps
-    the decimated planes of a slab inside it), as equal as possible; an odd last plane goes to the last rank."""
-    pairs = nz // 2
-    if pairs < world:
-        raise ValueError(f"{nz} planes cannot be split into {world} even-aligned slabs")
-    base, rem = divmod(pairs, world)
+def slab_bounds(nz, world, align=2):
+    """Owned plane ranges [z0, z1) per rank: contiguous, starts on multiples of `align` (DownSample_3D keeps plane 2k, so
+    an even start keeps the decimated planes of a slab inside it; 2^S when S octaves are sharded), as equal as possible;
+    the remainder planes go to the last rank."""
+    units = nz // align
+    if units < world:
+        raise ValueError(f"{nz} planes cannot be split into {world} slabs aligned to {align}")
+    base, rem = divmod(units, world)
     out, z = [], 0
     for r in range(world):
-        n = 2 * (base + (1 if r < rem else 0))
+        n = align * (base + (1 if r < rem else 0))
         out.append((z, z + n))
         z += n
     out[-1] = (out[-1][0], nz)
     return out
 
 
-def halo_transfers(bounds, nz, kind, idx, lo, hi):
+def halve_bounds(bounds, nz):
+    """owned ranges of the next octave: plane k of octave o+1 is plane 2k of octave o (Src/cSIFT3D.cc:321-344)"""
+    return [(z0 // 2, min(z1 // 2, nz // 2)) for z0, z1 in bounds]
+
+
+def halo_transfers(bounds, nz, kind, idx, lo, hi, stage=0):
     """Transfers that fill, for every rank, the global planes at distance (lo, hi] outside its owned range:
     [z0-hi, z0-lo) and [z1+lo, z1+hi), clipped to the volume, from whichever ranks own them.  Deterministic order
     (destination-major), identical on every rank, so matching sends and receives are posted in the same order."""
@@ -69,7 +79,7 @@ def halo_transfers(bounds, nz, kind, idx, lo, hi):
                     continue
                 s, e = max(a, q0), min(b, q1)
                 if e > s:
-                    out.append(Transfer(q, r, kind, idx, s, e))
+                    out.append(Transfer(q, r, kind, idx, s, e, stage))
     return out
 
 
@@ -115,7 +125,7 @@ class SimComm:
     def exchange(self, workers, transfers):
         import torch
         for t in transfers:
-            workers[t.dst].view(t.kind, t.idx, t.zg0, t.zg1).copy_(workers[t.src].view(t.kind, t.idx, t.zg0, t.zg1))
+            workers[t.dst].view(t.kind, t.idx, t.zg0, t.zg1, t.stage).copy_(workers[t.src].view(t.kind, t.idx, t.zg0, t.zg1, t.stage))
         return None
 
     def wait(self, handle):
@@ -174,9 +184,9 @@ class DistComm:
         ops = []
         for t in transfers:
             if t.src == self.rank:
-                ops.append(dist.P2POp(dist.isend, w.view(t.kind, t.idx, t.zg0, t.zg1), t.dst))
+                ops.append(dist.P2POp(dist.isend, w.view(t.kind, t.idx, t.zg0, t.zg1, t.stage), t.dst))
             elif t.dst == self.rank:
-                ops.append(dist.P2POp(dist.irecv, w.view(t.kind, t.idx, t.zg0, t.zg1), t.src))
+                ops.append(dist.P2POp(dist.irecv, w.view(t.kind, t.idx, t.zg0, t.zg1, t.stage), t.src))
         if not ops:
             return []
         return dist.batch_isend_irecv(ops)
@@ -227,37 +237,23 @@ class DistComm:
 # --------------------------------------------------------------------------------------------------------------------
 # one rank's device state
 # --------------------------------------------------------------------------------------------------------------------
-class SlabWorker:
-    """Slab context + seeded tail context + the torch-owned arena of one rank."""
+class SlabStage:
+    """one sharded octave of one rank: slab context + the torch-owned arena its level buffers live in"""
 
-    def __init__(self, rank, world, dims, device=0, halo=None, **params):
+    def __init__(self, rank, octave, dims, bounds, halo, noct, device, params):
         import torch
         from . import capi
         nx, ny, nz = dims
-        self.rank, self.world, self.dims, self.device = rank, world, dims, device
-        self.params = params
-        self.levels = params.get("num_kp_levels", 3)
-        self.bounds = slab_bounds(nz, world)
-        self.z0, self.z1 = self.bounds[rank]
-        self.halo = int(halo) if halo is not None else capi.slab_min_halo(**params)
-        self.noct = octaves_total(nx, ny, nz)
+        self.octave, self.dims, self.bounds = octave, dims, bounds
+        self.z0, self.z1 = bounds[rank]
+        self.plane = nx * ny
         dev = torch.device("cuda", device)
-        n = capi.SlabCSIFT3D.arena_floats(nx, ny, nz, self.z0, self.z1, self.halo, self.noct, **params)
+        n = capi.SlabCSIFT3D.arena_floats(nx, ny, nz, self.z0, self.z1, halo, noct, octave=octave, **params)
         self.arena = torch.zeros(n, dtype=torch.float32, device=dev)
         torch.cuda.synchronize(dev)
-        self.ctx = capi.SlabCSIFT3D(nx, ny, nz, self.z0, self.z1, self.halo, self.noct, self.arena.data_ptr(), n, device=device, **params)
-        self.plane = nx * ny
+        self.ctx = capi.SlabCSIFT3D(nx, ny, nz, self.z0, self.z1, halo, noct, self.arena.data_ptr(), n, device=device,
+                                    octave=octave, **params)
         self._buf = {}
-        # replicated tail (octaves >= 1)
-        self.tail = None
-        self.seed = self.seed_mine = None
-        if self.noct >= 2:
-            n2 = (nz // 2, ny // 2, nx // 2)
-            self.tail = capi.SeededCSIFT3D(n2, 1, self.noct, device=device, **params)
-            self.tail.set_partition(rank, world)
-            self.seed = torch.empty(n2, dtype=torch.float32, device=dev)
-            self.counts2 = [min(b[1] // 2, nz // 2) - b[0] // 2 for b in self.bounds]
-            self.seed_mine = torch.empty((max(self.counts2), ny // 2, nx // 2), dtype=torch.float32, device=dev)
 
     def view(self, kind, idx, zg0, zg1):
         """arena view of the global planes [zg0, zg1) of a level buffer (contiguous: buffers are plane-major)"""
@@ -268,10 +264,55 @@ class SlabWorker:
         assert zoff <= zg0 < zg1 <= zoff + planes, (kind, idx, zg0, zg1, zoff, planes)
         return self.arena[off + (zg0 - zoff) * self.plane: off + (zg1 - zoff) * self.plane]
 
+
+class SlabWorker:
+    """The sharded octaves (SlabStage each) + the seeded, replicated tail context of one rank."""
+
+    def __init__(self, rank, world, dims, device=0, halo=None, sharded_octaves=1, **params):
+        import torch
+        from . import capi
+        nx, ny, nz = dims
+        self.rank, self.world, self.dims, self.device = rank, world, dims, device
+        self.params = params
+        self.levels = params.get("num_kp_levels", 3)
+        self.halo = int(halo) if halo is not None else capi.slab_min_halo(**params)
+        self.noct = octaves_total(nx, ny, nz)
+        # octaves sharded as slabs: at most all but none below the fused kernel's minimum extent (18 voxels in x, y)
+        S = max(1, min(sharded_octaves, self.noct))
+        while S > 1 and (min(nx, ny) >> (S - 1) < 18 or (nz >> S) < world):
+            S -= 1
+        self.S = S
+        self.stages = []
+        b = slab_bounds(nz, world, align=1 << S)
+        d = (nx, ny, nz)
+        for o in range(S):
+            self.stages.append(SlabStage(rank, o, d, b, self.halo, self.noct, device, params))
+            b = halve_bounds(b, d[2])
+            d = (d[0] // 2, d[1] // 2, d[2] // 2)
+        self.bounds = self.stages[0].bounds
+        self.z0, self.z1 = self.bounds[rank]
+        self.ctx = self.stages[0].ctx
+        self.arena = self.stages[0].arena
+        dev = torch.device("cuda", device)
+        # replicated tail (octaves >= S): seeded with the all-gathered level 0 of octave S
+        self.tail = None
+        self.seed = self.seed_mine = None
+        if self.noct > S:
+            n2 = (d[2], d[1], d[0])
+            self.tail = capi.SeededCSIFT3D(n2, S, self.noct, device=device, **params)
+            self.tail.set_partition(rank, world)
+            self.seed = torch.empty(n2, dtype=torch.float32, device=dev)
+            self.counts2 = [z1 - z0 for z0, z1 in b]
+            self.seed_mine = torch.empty((max(max(self.counts2), 1), d[1], d[0]), dtype=torch.float32, device=dev)
+
+    def view(self, kind, idx, zg0, zg1, stage=0):
+        return self.stages[stage].view(kind, idx, zg0, zg1)
+
     def close(self):
         if self.tail is not None:
             self.tail.close()
-        self.ctx.close()
+        for st in self.stages:
+            st.ctx.close()
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -280,13 +321,14 @@ class SlabWorker:
 class SlabExtractor:
     """CSIFT3D for a volume sharded over `world` ranks.  `comm.local_ranks()` are the ranks living in this process."""
 
-    def __init__(self, dims, comm, device=0, halo=None, **params):
+    def __init__(self, dims, comm, device=0, halo=None, sharded_octaves=2, **params):
         self.dims, self.comm = dims, comm
         self.world = comm.world
         devs = device if isinstance(device, (list, tuple)) else [device] * len(comm.local_ranks())
-        self.workers = {r: SlabWorker(r, self.world, dims, device=d, halo=halo, **params) for r, d in zip(comm.local_ranks(), devs)}
+        self.workers = {r: SlabWorker(r, self.world, dims, device=d, halo=halo, sharded_octaves=sharded_octaves, **params)
+                        for r, d in zip(comm.local_ranks(), devs)}
         w0 = next(iter(self.workers.values()))
-        self.bounds, self.halo, self.levels, self.noct = w0.bounds, w0.halo, w0.levels, w0.noct
+        self.bounds, self.halo, self.levels, self.noct, self.S = w0.bounds, w0.halo, w0.levels, w0.noct, w0.S
         self.ng = self.levels + 3
         self.need = [w0.ctx.halo_planes(i) for i in range(self.ng)]   # planes of G[i] its consumers reach
         self.hws = [w0.ctx.level_hw(i) for i in range(self.ng)]       # half width of the Gaussian producing G[i]
@@ -321,50 +363,58 @@ class SlabExtractor:
         """CSIFT3D::KpSiftAlgorithm (Src/cSIFT3D.cc:165-235) over the slabs."""
         import time
         import torch
-        comm, ws, nz = self.comm, self._wl(), self.dims[2]
+        comm, ws = self.comm, self._wl()
         deferred = []
-        seed_pending = False
         t0 = time.perf_counter()
-        for i in range(self.ng):
-            for w in ws:
-                w.ctx.level_async(i)
-            for w in ws:
-                w.ctx.sync()
-            urgent_h = self.hws[i + 1] if i + 1 < self.ng else 0
-            # the planes level i+1 needs first, the wider keypoint-window halo and the DoG plane behind it
-            h_urgent = comm.exchange(ws, halo_transfers(self.bounds, nz, KIND_GSS, i, 0, urgent_h))
-            late = halo_transfers(self.bounds, nz, KIND_GSS, i, urgent_h, self.need[i])
-            if 1 <= i - 1 <= self.levels:
-                late += halo_transfers(self.bounds, nz, KIND_DOG, i - 1, 0, 1)
-            deferred.append(comm.exchange(ws, late))
-            if i == self.levels and self.noct >= 2:
-                # G[1][0] = DownSample_3D(G[0][levels]) (Src/cSIFT3D.cc:293-296, 321-344): owned planes only
-                for w in ws:
-                    w.ctx.decimate(w.seed_mine.data_ptr())
-                seed_pending = True
-            comm.wait(h_urgent)
-        # DoG[levels + 1] needs no halo; DoG maxima -> global (threshold of Detect_KeyPoints, Src/cSIFT3D.cc:379-384)
-        mx = comm.allreduce_max([w.ctx.get_dogmax() for w in ws])
-        for w, m in zip(ws, mx):
-            w.ctx.set_dogmax(m)
+        for s in range(self.S):
+            sts = [w.stages[s] for w in ws]
+            bounds, nzs = sts[0].bounds, sts[0].dims[2]
+            for i in range(self.ng):
+                for st in sts:
+                    st.ctx.level_async(i)          # level 0 of an octave > 0 was written by the decimation below
+                for st in sts:
+                    st.ctx.sync()
+                urgent_h = self.hws[i + 1] if i + 1 < self.ng else 0
+                # the planes level i+1 needs first, then the wider keypoint-window halo and the DoG plane behind it
+                h_urgent = comm.exchange(ws, halo_transfers(bounds, nzs, KIND_GSS, i, 0, urgent_h, s))
+                late = halo_transfers(bounds, nzs, KIND_GSS, i, urgent_h, self.need[i], s)
+                if 1 <= i - 1 <= self.levels:
+                    late += halo_transfers(bounds, nzs, KIND_DOG, i - 1, 0, 1, s)
+                deferred.append(comm.exchange(ws, late))
+                if i == self.levels and s + 1 < self.noct:
+                    # G[s+1][0] = DownSample_3D(G[s][levels]) (Src/cSIFT3D.cc:293-296, 321-344), owned planes only:
+                    # straight into the next sharded octave's level-0 buffer, or into the all-gather piece of the tail
+                    for w in ws:
+                        if s + 1 < self.S:
+                            nst = w.stages[s + 1]
+                            if nst.z1 > nst.z0:
+                                w.stages[s].ctx.decimate(nst.view(KIND_GSS, 0, nst.z0, nst.z1).data_ptr())
+                        else:
+                            w.stages[s].ctx.decimate(w.seed_mine.data_ptr())
+                comm.wait(h_urgent)
+            # DoG maxima -> global (threshold of Detect_KeyPoints, Src/cSIFT3D.cc:379-384)
+            mx = comm.allreduce_max([st.ctx.get_dogmax() for st in sts])
+            for st, m in zip(sts, mx):
+                st.ctx.set_dogmax(m)
         for h in deferred:
             comm.wait(h)
         self.times["pyramid"] = time.perf_counter() - t0
-        if seed_pending:
+        if self.noct > self.S:
             comm.allgather_planes([w.seed_mine for w in ws], [w.seed for w in ws], ws[0].counts2)
             for w in ws:
                 w.tail.seed(w.seed.data_ptr())
         t1 = time.perf_counter()
-        for w in ws:
-            w.ctx.detect()
-        for w in ws:
-            w.ctx.describe()
-        self.times["keypoints0"] = time.perf_counter() - t1
+        for s in range(self.S):
+            for w in ws:
+                w.stages[s].ctx.detect()
+            for w in ws:
+                w.stages[s].ctx.describe()
+        self.times["keypoints_sharded"] = time.perf_counter() - t1
         t2 = time.perf_counter()
-        if self.noct >= 2:
-            # replicated pyramid + extrema of octaves >= 1; orientation dealt by extremum index, results restored on every
-            # rank by an integer all-reduce(SUM) of zero-padded rows (exact); descriptors dealt by keypoint slot and LEFT
-            # distributed, like the octave-0 keypoints (GetKeypoints / the matcher's all-gather collect them)
+        if self.noct > self.S:
+            # replicated pyramid + extrema of the remaining octaves; orientation dealt by extremum index, results restored
+            # on every rank by an integer all-reduce(SUM) of zero-padded rows (exact); descriptors dealt by keypoint and
+            # LEFT distributed, like the sharded keypoints (GetKeypoints / the matcher's all-gather collect them)
             for w in ws:
                 w.tail.run_partial_orientation()
             bufs = []
@@ -383,18 +433,23 @@ class SlabExtractor:
         return self
 
     def num_local_keypoints(self):
-        """keypoints this process holds records for: octave-0 of its slabs (+ the replicated tail records once)"""
+        """keypoints this process holds records for: the sharded octaves of its slabs (+ the replicated tail records once)"""
         ws = self._wl()
-        n = sum(int(w.ctx.device_results()[2]) for w in ws)
-        if self.noct >= 2:
+        n = sum(int(st.ctx.device_results()[2]) for w in ws for st in w.stages)
+        if self.noct > self.S:
             n += int(ws[0].tail.device_results()[2])
         return n
 
     def GetKeypoints(self):
         """Global result in reference order on every rank (gathers through the host; not part of the timed path)."""
         ws = self._wl()
-        parts = self.comm.gather_objects([w.ctx.GetKeypoints() for w in ws])
-        if self.noct >= 2:
+        kps, dss = [], []
+        for s in range(self.S):
+            parts = self.comm.gather_objects([w.stages[s].ctx.GetKeypoints() for w in ws])
+            empty = (parts[0][0][:0], parts[0][1][:0])
+            k, d = merge_keypoints(parts, empty)
+            kps.append(k); dss.append(d)
+        if self.noct > self.S:
             # tail keypoint records are complete everywhere; the descriptor rows are dealt (see described_rows)
             mine = []
             for w in ws:
@@ -404,11 +459,8 @@ class SlabExtractor:
             tkp, tds = ws[0].tail.GetKeypoints()
             for r, part in enumerate(rows):
                 tds[described_rows(tkp["level"], r, self.world)] = part
-            tail = (tkp, tds)
-        else:
-            kp, ds = parts[0]
-            tail = (kp[:0], ds[:0])
-        return merge_keypoints(parts, tail)
+            kps.append(tkp); dss.append(tds)
+        return np.concatenate(kps), np.concatenate(dss)
 
     def close(self):
         for w in self.workers.values():

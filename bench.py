@@ -92,11 +92,11 @@ def run_slab(dims, world, rank, local, dev, steps, warmup, sim_ranks=0, seed=432
         step = ex.KpSiftAlgorithm
 
         def count():
-            n0 = sum(int(w.ctx.device_results()[2]) for w in ex._wl())
+            n0 = sum(int(st.ctx.device_results()[2]) for w in ex._wl() for st in w.stages)
             t = torch.tensor([n0], dtype=torch.int64, device=dev)
             if world > 1 and not sim_ranks:
                 dist.all_reduce(t)
-            nt = int(ex._wl()[0].tail.device_results()[2]) if ex.noct >= 2 else 0
+            nt = int(ex._wl()[0].tail.device_results()[2]) if ex.noct > ex.S else 0
             return int(t.item()) + nt
 
         detail = lambda: {k: round(v * 1e3, 3) for k, v in ex.times.items()}
@@ -114,6 +114,7 @@ def run_slab(dims, world, rank, local, dev, steps, warmup, sim_ranks=0, seed=432
            "keypoints": count(), "last_step_ms": detail()}
     if nranks > 1:
         res["halo_planes"] = ex.halo
+        res["sharded_octaves"] = ex.S
         res["slab_planes"] = [b[1] - b[0] for b in ex.bounds]
     ex.close()
     return res

@@ -134,7 +134,10 @@ typedef struct sift3d_slab_desc {
 	int nx, ny, nz;      /* GLOBAL dims of the volume */
 	int z0, z1;          /* owned global planes [z0, z1) of octave 0; z0 even, z1 even or == nz */
 	int halo;            /* margin planes per side; >= 38 for default parameters (descriptor window reach) */
-	int noct_total;      /* octaves of the whole volume: (int)log2f(min(nx,ny,nz)) - 2 */
+	int noct_total;      /* octaves of the ORIGINAL volume: (int)log2f(min dim) - 2 */
+	int octave;          /* absolute octave this context holds (0 = the input octave).  octave > 0: nx,ny,nz,z0,z1 are in
+	                      * that octave's voxels and G[octave][0] is provided by the caller (owned planes written by
+	                      * sift3d_slab_decimate of the octave above, halo planes exchanged); sift3d_slab_level(h, 0) is a no-op */
 } sift3d_slab_desc;
 
 /* smallest admissible halo for `params`: the z reach of a descriptor window in octave 0 (38 for the defaults) */
@@ -161,7 +164,8 @@ int sift3d_slab_get_dogmax(sift3d_handle h, float *max5);          /* local maxi
 int sift3d_slab_set_dogmax(sift3d_handle h, const float *max5);    /* global maxima after the all-reduce */
 int sift3d_slab_detect(sift3d_handle h);                            /* extrema of the owned planes (DoG halos of 1 plane exchanged) */
 int sift3d_slab_describe(sift3d_handle h);                          /* orientation + descriptors; results via sift3d_get_keypoints */
-/* DownSample_3D of the owned planes of G[0][num_kp_levels] -> d_dst = (nx/2) x (ny/2) x ((z1-z0)/2) floats (device) */
+/* DownSample_3D of the owned planes of G[octave][num_kp_levels] -> d_dst = (nx/2) x (ny/2) x ((z1-z0)/2) floats (device):
+ * the owned planes of level 0 of the next octave (a sharded slab context of octave+1, or the all-gather buffer of the tail) */
 int sift3d_slab_decimate(sift3d_handle h, float *d_dst);
 
 /* Seeded context: octaves octave_base.. of a volume whose G[octave_base][0] (dims nx,ny,nz) the caller provides */

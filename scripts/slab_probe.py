@@ -9,7 +9,8 @@ synth = importlib.import_module("3dsift_amd.synth")
 dims = (1024, 1024, 512)
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda", 0)
-ex = slab.SlabExtractor(dims, slab.SimComm(R))
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+ex = slab.SlabExtractor(dims, slab.SimComm(R), sharded_octaves=S)
 shape = (dims[2], dims[1], dims[0])
 slabs = {r: synth.blobs_torch(shape, dev, seed=4321, zrange=ex.bounds[r]) for r in range(R)}
 ex.load(device_slabs=slabs)
@@ -20,7 +21,7 @@ w = ex._wl()[0]
 print("tail timer", {k: round(v * 1e3, 3) for k, v in w.tail.m_timer.items()})
 kp, _ = w.tail.GetKeypoints(with_desc=False)
 print("tail keypoints", len(kp), "per octave", np.bincount(kp["octave"]).tolist(), "extrema", len(w.tail.extrema()))
-print("oct0 keypoints per rank", [int(x.ctx.device_results()[2]) for x in ex._wl()])
+print("sharded octaves", ex.S, "keypoints per rank", [[int(st.ctx.device_results()[2]) for st in x.stages] for x in ex._wl()])
 # per-call timings of one rank
 for name, fn in (("detect", w.ctx.detect), ("describe", w.ctx.describe), ("tail.run", w.tail.KpSiftAlgorithm)):
     torch.cuda.synchronize(); t = time.perf_counter(); fn(); torch.cuda.synchronize(); print(name, round((time.perf_counter() - t) * 1e3, 3), "ms")

@@ -23,37 +23,41 @@ def _single(vol):
     return s
 
 
-@pytest.mark.parametrize("shape,world", [((128, 128, 128), 2), ((128, 128, 128), 4), ((160, 80, 96), 3)])
-def test_slab_equals_single_volume(shape, world):
+@pytest.mark.parametrize("shape,world,sharded", [((128, 128, 128), 2, 1), ((128, 128, 128), 4, 2), ((160, 80, 96), 3, 2),
+                                                 ((128, 128, 128), 2, 2)])
+def test_slab_equals_single_volume(shape, world, sharded):
     vol = _volume(shape, seed=11 + world)
     nz, ny, nx = shape
     ref = _single(vol)
     kp_ref, ds_ref = ref.GetKeypoints()
     assert len(kp_ref) > 50
 
-    ex = slab.SlabExtractor((nx, ny, nz), slab.SimComm(world))
+    ex = slab.SlabExtractor((nx, ny, nz), slab.SimComm(world), sharded_octaves=sharded)
+    assert ex.S == sharded
     ex.load(volume=vol)
     ex.KpSiftAlgorithm()
 
-    # pyramid of octave 0: owned planes of every level, bit for bit
+    # pyramids of the sharded octaves: owned planes of every level, bit for bit
     ng, nd = ref.levels + 3, ref.levels + 2
-    for i in range(ng):
-        want = ref.gss(0, i)
-        for w in ex._wl():
-            got = w.ctx.held_level(0, i)[w.halo:w.halo + (w.z1 - w.z0)]
-            assert np.array_equal(got, want[w.z0:w.z1]), f"GSS level {i} rank {w.rank}"
-    for i in range(nd):
-        want = ref.dog(0, i)
-        for w in ex._wl():
-            got = w.ctx.held_level(1, i)[w.halo:w.halo + (w.z1 - w.z0)]
-            assert np.array_equal(got, want[w.z0:w.z1]), f"DoG level {i} rank {w.rank}"
-
-    # extrema of octave 0: union over the slabs == single-volume list
     ext_ref = ref.extrema()
-    e0 = ext_ref[ext_ref["octave"] == 0]
-    got = np.concatenate([w.ctx.extrema() for w in ex._wl()])
     key = lambda a: sorted(zip(a["level"].tolist(), a["z"].tolist(), a["y"].tolist(), a["x"].tolist()))
-    assert key(got) == key(e0)
+    for o in range(ex.S):
+        for i in range(ng):
+            want = ref.gss(o, i)
+            for w in ex._wl():
+                st = w.stages[o]
+                got = st.ctx.held_level(0, i)[w.halo:w.halo + (st.z1 - st.z0)]
+                assert np.array_equal(got, want[st.z0:st.z1]), f"octave {o} GSS level {i} rank {w.rank}"
+        for i in range(nd):
+            want = ref.dog(o, i)
+            for w in ex._wl():
+                st = w.stages[o]
+                got = st.ctx.held_level(1, i)[w.halo:w.halo + (st.z1 - st.z0)]
+                assert np.array_equal(got, want[st.z0:st.z1]), f"octave {o} DoG level {i} rank {w.rank}"
+        # extrema: union over the slabs == single-volume list of that octave
+        eo = ext_ref[ext_ref["octave"] == o]
+        got = np.concatenate([w.stages[o].ctx.extrema() for w in ex._wl()])
+        assert key(got) == key(eo)
 
     # keypoints + descriptors, in reference order
     kp, ds = ex.GetKeypoints()
@@ -68,7 +72,7 @@ def test_slab_equals_single_volume(shape, world):
 def test_slab_halo_too_small_is_refused():
     import torch
     nx = ny = nz = 64
-    n = capi.SlabCSIFT3D.arena_floats(nx, ny, nz, 0, 32, 4, 4)
+    n = capi.SlabCSIFT3D.arena_floats(nx, ny, nz, 0, 32, 40, 4)
     arena = torch.zeros(n, dtype=torch.float32, device="cuda")
     with pytest.raises(capi.Sift3dError):
         capi.SlabCSIFT3D(nx, ny, nz, 0, 32, 4, 4, arena.data_ptr(), n)   # halo 4 < widest Gaussian (hw 8)

@@ -44,6 +44,19 @@ def test_slab_bounds_refuses_too_many_ranks():
         slab.slab_bounds(14, 8)
 
 
+def test_bounds_for_two_sharded_octaves_stay_aligned():
+    b0 = slab.slab_bounds(512, 8, align=4)
+    assert all(z0 % 4 == 0 for z0, _ in b0) and b0[-1][1] == 512
+    b1 = slab.halve_bounds(b0, 512)
+    assert b1[0][0] == 0 and b1[-1][1] == 256 and all(z0 % 2 == 0 for z0, _ in b1)
+    for (a0, a1), (c0, c1) in zip(b1, b1[1:]):
+        assert a1 == c0
+    # odd depth: the last plane of octave 0 has no image in octave 1
+    b0 = slab.slab_bounds(161, 3, align=4)
+    b1 = slab.halve_bounds(b0, 161)
+    assert b0[-1][1] == 161 and b1[-1][1] == 80 and sum(z1 - z0 for z0, z1 in b1) == 80
+
+
 @pytest.mark.parametrize("nz,world,h", [(512, 8, 38), (128, 4, 38), (160, 3, 8), (64, 8, 38)])
 def test_halo_transfers_fill_exactly_the_halo(nz, world, h):
     b = slab.slab_bounds(nz, world)
@@ -111,7 +124,7 @@ WORKER = textwrap.dedent("""
                 for z in range(z0, z1):
                     t[z - self.zoff] = 1000.0 * key[0] + z
                 self.buf[key] = t.reshape(-1)
-        def view(self, kind, idx, a, b):
+        def view(self, kind, idx, a, b, stage=0):
             return self.buf[(kind, idx)][(a - self.zoff) * plane:(b - self.zoff) * plane]
 
     w = FakeWorker()
