@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(64) k_orient_finish(DevKp *__restrict__ kps, i
 		const float w3[3] = {kp.win[0], kp.win[1], kp.win[2]};
 		kp.code = finish_orientation(kp, T6, w3, max_eig, corner);
 		kps[k] = kp;
-		codes[k] = kp.code;  // dense copy for the compaction scan
+		codes[k] = kp.code == 1 ? ((kp.level << 4) | 1) : kp.code;  // dense copy for the compaction scan (level in the high bits)
 	}
 }
 
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) k_orient_unpack(DevKp *__restrict__ kps, 
 	for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
 		const unsigned k = i / kOrientWords, w = i - k * kOrientWords;
 		const int v = src[i];
-		if (w == 0) { kps[k].code = v; codes[k] = v; }
+		if (w == 0) { kps[k].code = v; codes[k] = v == 1 ? ((kps[k].level << 4) | 1) : v; }
 		else kps[k].win[w - 1] = __int_as_float(v);
 	}
 }
@@ -391,13 +391,20 @@ __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const i
 	unsigned tot[kL + 1];
 #pragma unroll
 	for (int l = 0; l <= kL; l++) tot[l] = 0;
-	for (unsigned i0 = lo; i0 < hi; i0 += 64) {
-		const unsigned i = i0 + lane;
-		const bool acc = i < hi && codes[i] == 1;
-		const int lv = acc ? min(max(kps[i].level, 0), kL - 1) : -1;
+	// codes[] carries (level << 4) | 1 for accepted extrema, the reject code (< 0) or 0 otherwise: one dense array to read
+	constexpr int kU = 4;  // rows of 64 requested together (the loop is a chain of dependent loads otherwise)
+	for (unsigned i0 = lo; i0 < hi; i0 += 64 * kU) {
+		int c[kU];
 #pragma unroll
-		for (int l = 0; l < kL; l++) tot[l] += (unsigned)__popcll(__ballot(lv == l));
-		tot[kL] += (unsigned)__popcll(__ballot(acc));
+		for (int q = 0; q < kU; q++) { const unsigned i = i0 + 64 * q + lane; c[q] = i < hi ? codes[i] : 0; }
+#pragma unroll
+		for (int q = 0; q < kU; q++) {
+			const bool acc = c[q] > 0 && (c[q] & 15) == 1;
+			const int lv = acc ? min(c[q] >> 4, kL - 1) : -1;
+#pragma unroll
+			for (int l = 0; l < kL; l++) tot[l] += (unsigned)__popcll(__ballot(lv == l));
+			tot[kL] += (unsigned)__popcll(__ballot(acc));
+		}
 	}
 	if (lane == 0)
 #pragma unroll
@@ -419,23 +426,29 @@ __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const i
 #pragma unroll
 	for (int l = 0; l < kL; l++) run[l] = s_base[l] + s_wave[wid][l];
 	run[kL] = s_wave[wid][kL];
-	for (unsigned i0 = lo; i0 < hi; i0 += 64) {
-		const unsigned i = i0 + lane;
-		const bool acc = i < hi && codes[i] == 1;
-		const int lv = acc ? min(max(kps[i].level, 0), kL - 1) : -1;
-		unsigned pos = 0;
+	for (unsigned i0 = lo; i0 < hi; i0 += 64 * kU) {
+		int c[kU];
 #pragma unroll
-		for (int l = 0; l < kL; l++) {
-			const unsigned long long m = __ballot(lv == l);
-			if (lv == l) pos = run[l] + (unsigned)__popcll(m & lt);
-			run[l] += (unsigned)__popcll(m);
+		for (int q = 0; q < kU; q++) { const unsigned i = i0 + 64 * q + lane; c[q] = i < hi ? codes[i] : 0; }
+#pragma unroll
+		for (int q = 0; q < kU; q++) {
+			const unsigned i = i0 + 64 * q + lane;
+			const bool acc = c[q] > 0 && (c[q] & 15) == 1;
+			const int lv = acc ? min(c[q] >> 4, kL - 1) : -1;
+			unsigned pos = 0;
+#pragma unroll
+			for (int l = 0; l < kL; l++) {
+				const unsigned long long m = __ballot(lv == l);
+				if (lv == l) pos = run[l] + (unsigned)__popcll(m & lt);
+				run[l] += (unsigned)__popcll(m);
+			}
+			const unsigned long long ma = __ballot(acc);
+			if (acc) {
+				if (pos < kp_cap) order[pos] = (int)i;
+				kps[i].slot = (int)(run[kL] + (unsigned)__popcll(ma & lt));
+			} else if (i < hi) kps[i].slot = -1;
+			run[kL] += (unsigned)__popcll(ma);
 		}
-		const unsigned long long ma = __ballot(acc);
-		if (acc) {
-			if (pos < kp_cap) order[pos] = (int)i;
-			kps[i].slot = (int)(run[kL] + (unsigned)__popcll(ma & lt));
-		} else if (i < hi) kps[i].slot = -1;
-		run[kL] += (unsigned)__popcll(ma);
 	}
 }
 
