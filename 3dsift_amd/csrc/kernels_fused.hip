@@ -40,6 +40,15 @@
 
 namespace s3d {
 
+// Packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two voxels per instruction at the issue cost of one scalar op, each lane an
+// ordinary IEEE multiply / add, so results stay bit-identical) is used where a thread has >= 4 independent accumulator
+// chains of pairs: the x-blur.  The y/z blurs keep scalar ops on 4 chains (with 2 packed chains they become bound by
+// dependent-issue latency).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef f2 __attribute__((aligned(4))) f2u;  // pair at an odd float offset (LDS)
+typedef const f2u __attribute__((address_space(3))) *lds_f2u_p;
+
 __device__ __forceinline__ float absmax_step_f(float m, float v) {
 	const float a = fabsf(v);
 	return (a > m) ? a : m;
@@ -50,7 +59,11 @@ struct FusedCfg {
 #ifndef S3D_TX
 #define S3D_TX 32
 #endif
-	static constexpr int TX = S3D_TX, TY = 1024 / S3D_TX, NT = 256;  // 4 outputs (consecutive y) per thread
+#ifndef S3D_TY
+#define S3D_TY (1024 / S3D_TX)
+#endif
+	static constexpr int TX = S3D_TX, TY = S3D_TY, NT = TX * TY / 4;  // 4 outputs (consecutive y) per thread
+	static constexpr int NW = NT / 64;                              // waves per workgroup
 	static constexpr int SEGS = TX / 8;                            // x-blur items per row (8 outputs each)
 	static constexpr int HXL = ((HW + 1 + 3) / 4) * 4;  // low-side x halo: the right-boundary rule reaches p-hw-1
 	static constexpr int HXH = ((HW + 3) / 4) * 4;
@@ -64,7 +77,19 @@ struct FusedCfg {
 	static constexpr int WN4 = (WOFF + 8 + 2 * HW + 3) / 4;
 	static constexpr int NLD = (ROWS * W4 + NT - 1) / NT;  // float4 tile loads per thread and plane
 	// workgroups per CU the register budget is set for; 3 at hw 8 costs a dozen spilled VGPRs and is still ahead of 2
-	static constexpr int OCC = HW <= 4 ? 4 : 3;
+#ifndef S3D_PKX_MASK
+#define S3D_PKX_MASK 0  /* bit HW set: packed x-blur for that half width.  Measured r01c: bit-exact, 40 % fewer x-blur
+                          instructions, no change of the kernel time at any half width (5.16 vs 5.18 ms per 512^3 pyramid
+                          with hw 2 and 5 packed, slower where the odd-pair registers spill) -> off */
+#endif
+	static constexpr bool PKX = ((S3D_PKX_MASK >> HW) & 1) != 0;
+#ifndef S3D_OCC_LO
+#define S3D_OCC_LO 4
+#endif
+#ifndef S3D_OCC_HI
+#define S3D_OCC_HI 3
+#endif
+	static constexpr int OCC = HW <= 4 ? S3D_OCC_LO : S3D_OCC_HI;
 };
 
 // reference boundary coordinate rule for output position p, tap offset d, axis length n
@@ -252,10 +277,42 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				__syncthreads();
 			}
 			// ---------------- x-blur: in_t rows 1..ROWS-1 -> xb (exactly one item per thread) ----------------
-			{
-				const int r = 1 + tid / C::SEGS, seg = tid % C::SEGS;
+#pragma unroll 1
+			for (int item = tid; item < (C::ROWS - 1) * C::SEGS; item += C::NT) {
+				const int r = 1 + item / C::SEGS, seg = item % C::SEGS;
 				const int gy = y0 - HW - 1 + r;
-				if (r < C::ROWS && gy >= 0 && gy < ny) {
+				if (gy >= 0 && gy < ny) {
+					if constexpr (C::PKX) {
+					const float *trow = &in_t[r * C::PITCH] + C::WSTART + seg * 8;
+					// register window as pairs: E[i] = (w[2i], w[2i+1]) from the 16-B loads, O[i] = (w[2i+1], w[2i+2]) read
+					// again from LDS at the odd offset (the LDS pointer is laundered so that the compiler issues ds_read2
+					// instead of assembling the odd pairs with v_mov from the even ones)
+					f2 E[C::WN4 * 2], O[C::WN4 * 2 - 1];
+#pragma unroll
+					for (int k = 0; k < C::WN4; k++) {
+						const f4 f = *reinterpret_cast<const f4 *>(trow + 4 * k);
+						E[2 * k] = f.xy; E[2 * k + 1] = f.zw;
+					}
+					lds_f2u_p trow_o = (lds_f2u_p)(trow + 1);  // stays an LDS (address space 3) pointer: ds_read, not flat_load
+					asm volatile("" : "+v"(trow_o));
+#pragma unroll
+					for (int k = 0; k < C::WN4 * 2 - 1; k++) O[k] = trow_o[k];
+					f2 o[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+#pragma unroll
+					for (int d = -HW; d <= HW; d++) {  // tap-major: four independent packed accumulator chains
+						f2 pr[4];
+#pragma unroll
+						for (int pp = 0; pp < 4; pp++) {
+							const int i0 = C::WOFF + 2 * pp + HW - d;  // window index of the pair's first element (compile time)
+							pr[pp] = ((i0 & 1) ? O[(i0 - 1) / 2] : E[i0 / 2]) * t.w[d + HW];
+						}
+#pragma unroll
+						for (int pp = 0; pp < 4; pp++) o[pp] = o[pp] + pr[pp];
+					}
+					f4 *xo = reinterpret_cast<f4 *>(&xb[r * C::TX + seg * 8]);
+					xo[0] = f4{o[0].x, o[0].y, o[1].x, o[1].y};
+					xo[1] = f4{o[2].x, o[2].y, o[3].x, o[3].y};
+					} else {
 					const float *trow = &in_t[r * C::PITCH];
 					float win[C::WN4 * 4];
 #pragma unroll
@@ -274,6 +331,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 					float4 *xo = reinterpret_cast<float4 *>(&xb[r * C::TX + seg * 8]);
 					xo[0] = make_float4(o[0], o[1], o[2], o[3]);
 					xo[1] = make_float4(o[4], o[5], o[6], o[7]);
+					}
 				}
 			}
 			if (need_row0) {
@@ -395,21 +453,23 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		if (wlane == 0) s_red[wid] = mx;
 		__syncthreads();
 		if (tid == 0) {
-			const float r = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+			float r = s_red[0];
+#pragma unroll
+			for (int w = 1; w < C::NW; w++) r = fmaxf(r, s_red[w]);
 			if (r > 0.0f) atomicMax(dogmax, __float_as_uint(r));
 		}
 	}
 }
 
 template <int HW, bool DOG>
-__global__ void __launch_bounds__(256, FusedCfg<HW>::OCC) k_fused_level(const float *__restrict__ src, float *__restrict__ dst,
+__global__ void __launch_bounds__(FusedCfg<HW>::NT, (FusedCfg<HW>::OCC * 4 + FusedCfg<HW>::NW - 1) / FusedCfg<HW>::NW) k_fused_level(const float *__restrict__ src, float *__restrict__ dst,
                                                                        float *__restrict__ dog, unsigned *__restrict__ dogmax,
                                                                        int nx, int ny, ZRange zr, Taps t, EdgeFrac ef, int ntx, int nty,
                                                                        int cz) {
 	using C = FusedCfg<HW>;
 	__shared__ __attribute__((aligned(16))) float in_t[C::ROWS * C::PITCH];
 	__shared__ __attribute__((aligned(16))) float xb[C::ROWS * C::TX];
-	__shared__ float s_red[4];
+	__shared__ float s_red[C::NW];
 	if ((nx & 3) == 0) fused_level_body<HW, DOG, true>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red);
 	else fused_level_body<HW, DOG, false>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red);
 }
@@ -436,7 +496,7 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 	const int ntiles = ntx * nty;
 	// z chunking: pick the chunk count that minimises (residency rounds) x (planes marched per workgroup);
 	// every chunk pays a ramp of 2*HW+1 planes, every partially filled round leaves CUs idle
-	const int slots = 256 * C::OCC;
+	const int slots = 256 * ((C::OCC * 4 + C::NW - 1) / C::NW);  // OCC counts 4-wave units per CU
 	const int ramp = 2 * HW + 1;
 	int best_cz = nz;
 	double best_cost = 1e300;
@@ -455,7 +515,7 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 	edge_fractions(nx, HW, ef.f[0]);
 	edge_fractions(ny, HW, ef.f[1]);
 	edge_fractions(zr.nzg, HW, ef.f[2]);
-	dim3 grid((unsigned)(ntiles * nchunks)), block(256);
+	dim3 grid((unsigned)(ntiles * nchunks)), block(C::NT);
 	if (dog) hipLaunchKernelGGL((k_fused_level<HW, true>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
 	else hipLaunchKernelGGL((k_fused_level<HW, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
 }
