@@ -38,45 +38,45 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
 	unsigned cnt = 0;
 	const bool z_in = (zg >= 1 && zg <= zr.nzg - 2);
-	// the block's 16 rows x wpr words are dealt to its 4 waves word by word
 	const int y0 = yb * kRows;
-	const int nwords = min(kRows, ny - y0) * wpr;
-	// kBatch words per pass: their centre values are requested together and only then examined, so a wave has kBatch
-	// independent HBM reads in flight instead of one (the scan is a pure streaming read; with one load per iteration it
-	// ran at the memory latency, not the bandwidth)
+	// The block's 16 rows are dealt to its 4 waves 4 rows each; a wave walks a row kBatch ballot words at a time: the
+	// centre values of the kBatch words are requested together and only then examined, so a wave has kBatch independent
+	// HBM reads in flight (the scan is a pure streaming read; with one load per iteration it ran at the memory latency).
+	// Row / word indices are wave-uniform loop counters: no per-lane integer divisions.
 	constexpr int kBatch = 8;
-	for (int w0 = wid * kBatch; w0 < nwords; w0 += (kThreads / 64) * kBatch) {
-		float val[kBatch];
-		size_t idx[kBatch];
-		bool in[kBatch];
+	const int nrows = min(kRows, ny - y0);
+	const int swid = __builtin_amdgcn_readfirstlane(wid);
+	for (int ry = swid * (kRows / 4); ry < min(nrows, (swid + 1) * (kRows / 4)); ry++) {
+		const int y = y0 + ry;
+		const bool y_in = z_in && y >= 1 && y <= ny - 2;
+		const size_t rowbase = sy * (size_t)y + sz * (size_t)z;
+		unsigned long long *mrow = masks + ((size_t)(lvl * nz + zi) * ny + y) * wpr;
+		for (int xw0 = 0; xw0 < wpr; xw0 += kBatch) {
+			float val[kBatch];
+			bool in[kBatch];
 #pragma unroll
-		for (int b = 0; b < kBatch; b++) {
-			const int wi = w0 + b;
-			const int ry = wi / wpr, xw = wi - ry * wpr;
-			const int y = y0 + ry, x = xw * 64 + lane;
-			in[b] = wi < nwords && z_in && y >= 1 && y <= ny - 2 && x >= 1 && x <= nx - 2;
-			idx[b] = (size_t)x + sy * (size_t)y + sz * (size_t)z;
-			val[b] = cur[in[b] ? idx[b] : (sz * (size_t)z)];  // unconditional load, clamped address
-		}
-#pragma unroll
-		for (int b = 0; b < kBatch; b++) {
-			const int wi = w0 + b;
-			if (wi >= nwords) break;  // wave-uniform
-			const int ry = wi / wpr, xw = wi - ry * wpr;
-			const int y = y0 + ry;
-			bool hit = false;
-			const float v = val[b];
-			if (in[b] && (v > thr || v < -thr)) {
-				const size_t i = idx[b];
-				const float n0 = prev[i], n1 = cur[i - 1], n2 = cur[i + 1], n3 = cur[i + sy], n4 = cur[i - sy], n5 = cur[i + sz],
-				            n6 = cur[i - sz], n7 = next[i];
-				const bool mn = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 && v < n7;
-				const bool mx = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 && v > n7;
-				hit = mn || mx;
+			for (int b = 0; b < kBatch; b++) {
+				const int x = (xw0 + b) * 64 + lane;
+				in[b] = y_in && x >= 1 && x <= nx - 2;  // implies xw0 + b < wpr
+				val[b] = cur[in[b] ? rowbase + (size_t)x : sz * (size_t)z];  // unconditional load, clamped address
 			}
-			const unsigned long long m = __ballot(hit);
-			if (lane == 0) masks[((size_t)(lvl * nz + zi) * ny + y) * wpr + xw] = m;
-			cnt += (unsigned)__popcll(m);
+#pragma unroll
+			for (int b = 0; b < kBatch; b++) {
+				if (xw0 + b >= wpr) break;  // wave-uniform
+				bool hit = false;
+				const float v = val[b];
+				if (in[b] && (v > thr || v < -thr)) {
+					const size_t i = rowbase + (size_t)((xw0 + b) * 64 + lane);
+					const float n0 = prev[i], n1 = cur[i - 1], n2 = cur[i + 1], n3 = cur[i + sy], n4 = cur[i - sy], n5 = cur[i + sz],
+					            n6 = cur[i - sz], n7 = next[i];
+					const bool mn = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 && v < n7;
+					const bool mx = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 && v > n7;
+					hit = mn || mx;
+				}
+				const unsigned long long m = __ballot(hit);
+				if (lane == 0) mrow[xw0 + b] = m;
+				cnt += (unsigned)__popcll(m);
+			}
 		}
 	}
 	if (lane == 0) s_cnt[wid] = cnt;
