@@ -1000,7 +1000,9 @@ extern "C" int sift3d_slab_input_scale(sift3d_handle c, float global_max) {
 extern "C" int sift3d_slab_halo_planes(sift3d_handle c, int i, int *planes) {
 	if (!c || !c->slab || !planes || i < 0 || i >= c->ng) return SIFT3D_ERR_ARG;
 	int need = 0;
-	if (i + 1 < c->ng) need = c->taps[i + 1].hw;               // input reach of the next Gaussian level
+	// input reach of the next Gaussian level: its z-march loads planes p-hw-1 .. p+hw (the extra low plane feeds the
+	// right-boundary lerp of the last planes of the volume, Src/cSIFT3D.cc:751-760)
+	if (i + 1 < c->ng) need = c->taps[i + 1].hw + 1;
 	if (i >= 1 && i <= c->p.num_kp_levels) need = c->halo;       // orientation / descriptor windows on G[1..levels]
 	*planes = std::min(need, c->halo);
 	return SIFT3D_OK;

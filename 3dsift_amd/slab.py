@@ -5,7 +5,7 @@ pipeline, with results equal to the single-GPU run (pyramid / extrema bit for bi
 
   octave 0   rank r owns the global planes [z0_r, z1_r) of every level; level buffers carry `halo` extra planes per
              side.  Per Gaussian level the ranks exchange the planes the NEXT consumer reaches:
-               G[i] -> level i+1 : hw_{i+1} planes per side           (urgent, awaited before level i+1 starts)
+               G[i] -> level i+1 : hw_{i+1}+1 planes per side         (urgent, awaited before level i+1 starts)
                G[1..3]           : up to `halo` planes (orientation + descriptor windows reach +-37 planes; deferred)
                DoG[1..3]         : 1 plane (extrema test reads z+-1; deferred)
              as point-to-point sends between z-neighbours (RCCL over xGMI), posted while the next level computes.
@@ -356,7 +356,7 @@ class SlabExtractor:
         for w, m in zip(ws, mx):
             w.ctx.input_scale(float(m[0]))
         nz = self.dims[2]
-        hw0 = self.hws[0]
+        hw0 = self.hws[0] + 1
         self.comm.wait(self.comm.exchange(ws, halo_transfers(self.bounds, nz, KIND_INPUT, 0, 0, hw0)))
 
     def KpSiftAlgorithm(self):
@@ -374,7 +374,7 @@ class SlabExtractor:
                     st.ctx.level_async(i)          # level 0 of an octave > 0 was written by the decimation below
                 for st in sts:
                     st.ctx.sync()
-                urgent_h = self.hws[i + 1] if i + 1 < self.ng else 0
+                urgent_h = self.hws[i + 1] + 1 if i + 1 < self.ng else 0   # planes p-hw-1 .. p+hw of the next level's z-march
                 # the planes level i+1 needs first, then the wider keypoint-window halo and the DoG plane behind it
                 h_urgent = comm.exchange(ws, halo_transfers(bounds, nzs, KIND_GSS, i, 0, urgent_h, s))
                 late = halo_transfers(bounds, nzs, KIND_GSS, i, urgent_h, self.need[i], s)

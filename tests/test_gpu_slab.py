@@ -24,13 +24,13 @@ def _single(vol):
 
 
 @pytest.mark.parametrize("shape,world,sharded", [((128, 128, 128), 2, 1), ((128, 128, 128), 4, 2), ((160, 80, 96), 3, 2),
-                                                 ((128, 128, 128), 2, 2)])
+                                                 ((128, 128, 128), 2, 2), ((64, 64, 64), 8, 2), ((64, 64, 64), 8, 1)])
 def test_slab_equals_single_volume(shape, world, sharded):
     vol = _volume(shape, seed=11 + world)
     nz, ny, nx = shape
     ref = _single(vol)
     kp_ref, ds_ref = ref.GetKeypoints()
-    assert len(kp_ref) > 50
+    assert len(kp_ref) > 10
 
     ex = slab.SlabExtractor((nx, ny, nz), slab.SimComm(world), sharded_octaves=sharded)
     assert ex.S == sharded
