@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # same guide: dense f32-input MFMA peak (= the f32 vector peak; no xf32/TF32 on gfx950)
 
 
 def pyramid_voxels(shape, levels=3):
@@ -149,6 +150,7 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="cubic volume edge (BASELINE metric: 512)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU-baseline sample crop (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-match", action="store_true", help="skip the configs[2] matcher leg")
     ap.add_argument("--allpairs", action="store_true", help="N>1: all-gather descriptors + all-pairs enhancedMatch (configs[4])")
     ap.add_argument("--workload", choices=["volumes", "slab"], default="volumes")
     ap.add_argument("--slab-dims", default="1024x1024x512", help="nx x ny x nz of the sharded volume (configs[3])")
@@ -272,6 +274,29 @@ def main():
         rms = float(np.sqrt(np.mean((gdesc.astype(np.float64) - odesc) ** 2))) if same and len(okp) else None
         out["parity"] = {"sample_keypoints_gpu": len(gkp), "sample_keypoints_cpu": len(okp), "same_keypoint_set": bool(same),
                          "descriptor_rms": rms}
+    if rank == 0 and world == 1 and not args.no_match:
+        # ---- BASELINE configs[2] leg (not part of `value`): second volume = the same blobs shifted by one voxel in x,
+        # extract, then muBruteMatcher::enhancedMatch on the device-resident descriptors; the score GEMM is the one MFMA
+        # kernel of the path (v_mfma_f32_32x32x2_f32), priced against the dense f32 matrix peak
+        vol2 = synth.blobs_torch(shape, dev, seed=1234 + rank, shift=(1.0, 0.0, 0.0))
+        torch.cuda.synchronize()
+        ex2 = capi.CSIFT3D(None, device=local, device_ptr=vol2.data_ptr(), shape=shape)
+        del vol2
+        ex2.KpSiftAlgorithm()
+        (da, xa, na), (db, xb, nb) = ex.device_results(), ex2.device_results()
+        mt = capi.muBruteMatcher(device=local)
+        secs = []
+        for _ in range(3):
+            r = mt.enhancedMatch(da, xa, db, xb, 0.85, on_device=True, n=na, m=nb)
+            secs.append(mt.totalTime)
+        tm = min(secs)
+        flop = 2.0 * 2.0 * na * nb * 768  # both directions of enhancedMatch
+        out["matcher"] = {"workload": f"enhancedMatch of {na} x {nb} descriptors (two {n}^3 volumes, second shifted 1 voxel)",
+                          "seconds": tm, "matched_pairs": int(len(r["pairs"])),
+                          "roofline": {"bound": "mfma", "kernel": "k_scores_topk (A.B^T on v_mfma_f32_32x32x2_f32, fused top-4) + k_rescore",
+                                       "achieved": flop / tm / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                       "frac": flop / tm / 1e12 / MFMA_F32_PEAK_TF, "traffic": None}}
+        ex2.close()
     if args.allpairs and world > 1:
         # BASELINE configs[4] matching leg (not part of `value`): all-gather the device-resident descriptors
         # over RCCL, then every rank runs enhancedMatch on its share of the ordered volume pairs
