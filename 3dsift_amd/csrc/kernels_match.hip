@@ -14,87 +14,181 @@
 //                   would be needed to break this).
 // gfx950 only: 64-lane waves, MFMA C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include <float.h>
+#include <stdio.h>
+
+#include <algorithm>
 
 #include "sift3d_internal.h"
 
 namespace s3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, BK = 32, PITCH = BK + 1, KD = kDesc, TOPK = 4;
+constexpr int KD = kDesc, TOPK = 4;
+// score kernel tiling: a 256-thread workgroup owns 128 rows x 128 columns per tile; wave w owns rows 32w..32w+31 across all
+// 128 columns (four 32x32 accumulators), so every row's running top-4 belongs to exactly one wave and lives in registers
+constexpr int BM = 128, BN = 128, BK = 32, PITCH = BK + 4;  // +16 B: the 16-B reads of 8 consecutive rows hit distinct banks
+constexpr int kMaxSplits = 16;
+constexpr int SP = BN + 1;  // pitch of the score tile in LDS (row-per-lane scans: conflict-free)
 
-__global__ void __launch_bounds__(256) k_scores_topk(const float *__restrict__ A, const int *__restrict__ row_ids, int nrows,
-                                                     const float *__restrict__ B, int m, int *__restrict__ cand /*[nrows][TOPK]*/) {
-	__shared__ float As[BM * PITCH];
-	__shared__ float Bs[BN * PITCH];
-	__shared__ float Ss[BM * (BN + 1)];
+struct Cand { float s; int j; };  // partial top-4 entry (score, column); j < 0 = empty
+
+// insert (s, j) into a list ordered by (score desc, column asc): same order the reference's strict '>' scan in ascending j
+// produces, independent of the order in which candidates arrive
+__device__ __forceinline__ void top4_insert(float (&bs)[TOPK], int (&bj)[TOPK], float s, int j) {
+	int pos = TOPK;
+#pragma unroll
+	for (int t = TOPK - 1; t >= 0; t--)
+		if (bj[t] < 0 || s > bs[t] || (s == bs[t] && j < bj[t])) pos = t;
+#pragma unroll
+	for (int t = TOPK - 1; t > 0; t--)
+		if (t > pos) { bs[t] = bs[t - 1]; bj[t] = bj[t - 1]; }
+#pragma unroll
+	for (int t = 0; t < TOPK; t++)
+		if (t == pos) { bs[t] = s; bj[t] = j; }
+}
+
+// S = A * B^T on v_mfma_f32_32x32x2_f32 with a fused running top-4 per row.  grid = (row blocks, column splits); each
+// workgroup streams the tiles of its column range, double-buffered through LDS.  An MFMA step multiplies two k indices:
+// lanes 0-31 feed k = s, lanes 32-63 feed k = s + 16 of the 32-wide chunk, so a lane's operands for four consecutive steps
+// are four consecutive floats of a plain row-major LDS tile (one ds_read_b128).  The summation order over k is free here:
+// the scores only SELECT candidates, k_rescore recomputes them exactly.
+__global__ void __launch_bounds__(256, 2) k_scores_top4(const float *__restrict__ A, const int *__restrict__ row_ids, int nrows,
+                                                        const float *__restrict__ B, int m, int tiles_per_split,
+                                                        Cand *__restrict__ part /*[nrows][gridDim.y][TOPK]*/) {
+	// [A buf0 | A buf1 | B buf0 | B buf1]; after the MFMAs of a tile the same memory holds the tile's 128 x 128 scores
+	__shared__ __attribute__((aligned(16))) float smem[4 * BM * PITCH];
+	float(*As)[BM * PITCH] = reinterpret_cast<float(*)[BM * PITCH]>(smem);
+	float(*Bs)[BN * PITCH] = reinterpret_cast<float(*)[BN * PITCH]>(smem + 2 * BM * PITCH);
+	static_assert(4 * 32 * SP <= 4 * BM * PITCH, "score tile must fit the staging buffers");
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-	const int wr = wid >> 1, wc = wid & 1;  // 2x2 waves, 32x32 each
+	const int li = lane & 31, lh = lane >> 5;
 	const int row0 = blockIdx.x * BM;
+	const int ntiles = (m + BN - 1) / BN;
+	const int tile_lo = blockIdx.y * tiles_per_split, tile_hi = min(ntiles, tile_lo + tiles_per_split);
 
-	// staging coordinates: 4 threads per row, 8 consecutive floats each
-	const int srow = tid >> 2, scol = (tid & 3) * 8;
-	int arow = row0 + srow;
-	const bool a_ok = arow < nrows;
-	const float *Ap = a_ok ? A + (size_t)(row_ids ? row_ids[arow] : arow) * KD : nullptr;
+	// staging: 8 consecutive lanes load one 128-B row piece (32 floats) as float4s; 32 rows per pass, 4 passes
+	const int srow = tid >> 3, spiece = (tid & 7) * 4;
+	const float *Ap[4];
+#pragma unroll
+	for (int p = 0; p < 4; p++) {
+		const int r = row0 + srow + 32 * p;
+		Ap[p] = r < nrows ? A + (size_t)(row_ids ? row_ids[r] : r) * KD + spiece : nullptr;
+	}
+	float bs[TOPK];
+	int bj[TOPK];
+#pragma unroll
+	for (int t = 0; t < TOPK; t++) { bs[t] = -FLT_MAX; bj[t] = -1; }
+	// selection: lane (li, lh) scans columns lh*64 .. lh*64+63 of row li of this wave's band, in ascending column order
+	const bool my_row_ok = (row0 + wid * 32 + li) < nrows;
 
-	float best_s[TOPK];
-	int best_j[TOPK];
+	for (int tile = tile_lo; tile < tile_hi; tile++) {
+		const int col0 = tile * BN;
+		const float *Bp[4];
 #pragma unroll
-	for (int t = 0; t < TOPK; t++) { best_s[t] = -FLT_MAX; best_j[t] = -1; }
-
-	for (int col0 = 0; col0 < m; col0 += BN) {
-		f32x16 acc;
-#pragma unroll
-		for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-		const int brow = col0 + srow;
-		const float *Bp = brow < m ? B + (size_t)brow * KD : nullptr;
-		for (int k0 = 0; k0 < KD; k0 += BK) {
-			float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
-			if (Ap) { a0 = *reinterpret_cast<const float4 *>(Ap + k0 + scol); a1 = *reinterpret_cast<const float4 *>(Ap + k0 + scol + 4); }
-			if (Bp) { b0 = *reinterpret_cast<const float4 *>(Bp + k0 + scol); b1 = *reinterpret_cast<const float4 *>(Bp + k0 + scol + 4); }
-			__syncthreads();  // previous chunk fully consumed
-			float *as = As + srow * PITCH + scol, *bs = Bs + srow * PITCH + scol;
-			as[0] = a0.x; as[1] = a0.y; as[2] = a0.z; as[3] = a0.w; as[4] = a1.x; as[5] = a1.y; as[6] = a1.z; as[7] = a1.w;
-			bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
-			__syncthreads();
-			const float *ar = As + (wr * 32 + (lane & 31)) * PITCH + (lane >> 5);
-			const float *br = Bs + (wc * 32 + (lane & 31)) * PITCH + (lane >> 5);
-#pragma unroll
-			for (int kk = 0; kk < BK; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[kk], br[kk], acc, 0, 0, 0);
+		for (int p = 0; p < 4; p++) {
+			const int c = col0 + srow + 32 * p;
+			Bp[p] = c < m ? B + (size_t)c * KD + spiece : nullptr;
 		}
-		// scores -> LDS tile
+		f32x16 acc[4];
 #pragma unroll
-		for (int r = 0; r < 16; r++) {
-			const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-			Ss[(wr * 32 + row) * (BN + 1) + wc * 32 + (lane & 31)] = acc[r];
-		}
+		for (int nb = 0; nb < 4; nb++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) acc[nb][r] = 0.0f;
+		f32x4 pa[4], pb[4];
+		auto fetch = [&](int k0) {
+#pragma unroll
+			for (int p = 0; p < 4; p++) {
+				pa[p] = Ap[p] ? *reinterpret_cast<const f32x4 *>(Ap[p] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+				pb[p] = Bp[p] ? *reinterpret_cast<const f32x4 *>(Bp[p] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+			}
+		};
+		auto stash = [&](int buf) {
+#pragma unroll
+			for (int p = 0; p < 4; p++) {
+				*reinterpret_cast<f32x4 *>(&As[buf][(srow + 32 * p) * PITCH + spiece]) = pa[p];
+				*reinterpret_cast<f32x4 *>(&Bs[buf][(srow + 32 * p) * PITCH + spiece]) = pb[p];
+			}
+		};
+		fetch(0);
+		__syncthreads();  // every wave is done with both buffers of the previous tile
+		stash(0);
 		__syncthreads();
-		// running top-4 of each row, columns in ascending j (strict '>' keeps the lower j on ties)
-		if (tid < BM) {
-			const int jmax = min(BN, m - col0);
-			for (int j = 0; j < jmax; j++) {
-				const float s = Ss[tid * (BN + 1) + j];
-				if (s > best_s[TOPK - 1]) {
-					int pos = TOPK - 1;
+		constexpr int NCH = KD / BK;
+		for (int ch = 0; ch < NCH; ch++) {
+			const int buf = ch & 1;
+			if (ch + 1 < NCH) fetch((ch + 1) * BK);  // in flight during the MFMAs of this chunk
+			const float *ar = &As[buf][(wid * 32 + li) * PITCH + lh * 16];
+			const float *br = &Bs[buf][li * PITCH + lh * 16];
 #pragma unroll
-					for (int t = TOPK - 2; t >= 0; t--)
-						if (s > best_s[t]) pos = t;
+			for (int q = 0; q < 4; q++) {
+				const f32x4 a4 = *reinterpret_cast<const f32x4 *>(ar + 4 * q);
+				f32x4 b4[4];
 #pragma unroll
-					for (int t = TOPK - 1; t > 0; t--)
-						if (t > pos) { best_s[t] = best_s[t - 1]; best_j[t] = best_j[t - 1]; }
+				for (int nb = 0; nb < 4; nb++) b4[nb] = *reinterpret_cast<const f32x4 *>(br + nb * 32 * PITCH + 4 * q);
 #pragma unroll
-					for (int t = 0; t < TOPK; t++)
-						if (t == pos) { best_s[t] = s; best_j[t] = col0 + j; }
-				}
+				for (int e = 0; e < 4; e++)
+#pragma unroll
+					for (int nb = 0; nb < 4; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[nb][e], acc[nb], 0, 0, 0);
+			}
+			if (ch + 1 < NCH) {
+				stash(buf ^ 1);   // the other buffer was last read in chunk ch-1, a barrier ago
+				__syncthreads();
 			}
 		}
-		__syncthreads();
-	}
-	if (tid < BM && row0 + tid < nrows) {
+		// ---- fused selection.  The staging buffers are dead now: every wave dumps its 32 x 128 score band there (C layout
+		// of a 32x32 block: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) and each lane scans half a
+		// row in ascending column order with the reference's strict '>' rule; one compare per score, inserts are rare.
+		__syncthreads();  // all waves finished reading As / Bs
+		float *S = smem + wid * 32 * SP;
 #pragma unroll
-		for (int t = 0; t < TOPK; t++) cand[(size_t)(row0 + tid) * TOPK + t] = best_j[t];
+		for (int nb = 0; nb < 4; nb++)
+#pragma unroll
+			for (int r = 0; r < 16; r++) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * SP + nb * 32 + li] = acc[nb][r];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (my_row_ok) {
+			const float *srow_p = S + li * SP + lh * 64;
+			const int cbase = col0 + lh * 64;
+			const int ncol = min(64, m - cbase);
+#pragma unroll 4
+			for (int jj = 0; jj < ncol; jj++) {
+				const float sv = srow_p[jj];
+				if (sv > bs[TOPK - 1] || bj[TOPK - 1] < 0) top4_insert(bs, bj, sv, cbase + jj);
+			}
+		}
 	}
+	// the two half-row lists of a row -> one (lanes 32..63 hand theirs to lanes 0..31)
+#pragma unroll
+	for (int t = 0; t < TOPK; t++) {
+		const float os = __shfl(bs[t], li + 32, 64);
+		const int oj = __shfl(bj[t], li + 32, 64);
+		if (lane < 32 && oj >= 0) top4_insert(bs, bj, os, oj);
+	}
+	if (lane < 32 && my_row_ok) {
+		Cand *o = part + ((size_t)(row0 + wid * 32 + lane) * gridDim.y + blockIdx.y) * TOPK;
+#pragma unroll
+		for (int t = 0; t < TOPK; t++) o[t] = Cand{bs[t], bj[t]};
+	}
+}
+
+// merge the per-split partial lists of a row into its global top-4 (score desc, column asc)
+__global__ void __launch_bounds__(256) k_merge_top4(const Cand *__restrict__ part, int nrows, int splits, int *__restrict__ cand) {
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= nrows) return;
+	float bs[TOPK];
+	int bj[TOPK];
+#pragma unroll
+	for (int t = 0; t < TOPK; t++) { bs[t] = -FLT_MAX; bj[t] = -1; }
+	for (int s = 0; s < splits; s++)
+		for (int t = 0; t < TOPK; t++) {
+			const Cand c = part[((size_t)r * splits + s) * TOPK + t];
+			if (c.j >= 0) top4_insert(bs, bj, c.s, c.j);
+		}
+#pragma unroll
+	for (int t = 0; t < TOPK; t++) cand[(size_t)r * TOPK + t] = bj[t];
 }
 
 // exact re-score + replay of the reference update rule (Src/cMatcher.cc:52-77)
@@ -144,10 +238,16 @@ __global__ void __launch_bounds__(256) k_rescore(const float *__restrict__ A, co
 }
 
 // rows: optional list of row indices into A (reverse pass over the masked targets only)
-int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const float *d_b, int m, int *d_cand, float *d_gd,
-                      float *d_sd, int *d_gi, int *d_si, hipStream_t st) {
+int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const float *d_b, int m, int *d_cand, void *d_part,
+                      float *d_gd, float *d_sd, int *d_gi, int *d_si, hipStream_t st) {
 	if (nrows <= 0) return SIFT3D_OK;
-	hipLaunchKernelGGL(k_scores_topk, dim3((nrows + BM - 1) / BM), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, d_cand);
+	// column splits: as many workgroups as fit ONE residency round (two per CU), never more than the tiles there are
+	const int rb = (nrows + BM - 1) / BM, ntiles = (m + BN - 1) / BN;
+	int splits = std::min(std::min(kMaxSplits, ntiles), std::max(1, (2 * 256) / rb));
+	const int tps = (ntiles + splits - 1) / splits;
+	splits = (ntiles + tps - 1) / tps;
+	hipLaunchKernelGGL(k_scores_top4, dim3(rb, splits), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, tps, (Cand *)d_part);
+	hipLaunchKernelGGL(k_merge_top4, dim3((nrows + 255) / 256), dim3(256), 0, st, (const Cand *)d_part, nrows, splits, d_cand);
 	hipLaunchKernelGGL(k_rescore, dim3((nrows + 3) / 4), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, d_cand, d_gd, d_sd, d_gi, d_si);
 	return SIFT3D_OK;
 }
@@ -192,6 +292,7 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 	const float *rx = ref_xyz, *tx = tar_xyz;
 
 	float *d_a = nullptr, *d_b = nullptr, *d_f = nullptr;
+	void *d_part = nullptr;
 	int *d_i = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	int rc = SIFT3D_OK;
@@ -212,6 +313,7 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 		}
 		MCHK(hipMalloc(&d_f, sizeof(float) * 2 * big));
 		MCHK(hipMalloc(&d_i, sizeof(int) * (2 + TOPK + 1) * big));
+		MCHK(hipMalloc(&d_part, sizeof(Cand) * TOPK * kMaxSplits * big));
 		float *d_gd = d_f, *d_sd = d_f + big;
 		int *d_gi = d_i, *d_si = d_i + big, *d_cand = d_i + 2 * big, *d_rows = d_i + (2 + TOPK) * big;
 		MCHK(hipEventCreate(&e0));
@@ -220,7 +322,7 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 
 		// ---- ref -> tar ----
 		if (n > 0 && m > 0) {
-			match_rows_device(d_a, nullptr, n, d_b, m, d_cand, d_gd, d_sd, d_gi, d_si, nullptr);
+			match_rows_device(d_a, nullptr, n, d_b, m, d_cand, d_part, d_gd, d_sd, d_gi, d_si, nullptr);
 			MCHK(hipMemcpy(gd.data(), d_gd, sizeof(float) * n, hipMemcpyDeviceToHost));
 			MCHK(hipMemcpy(sd.data(), d_sd, sizeof(float) * n, hipMemcpyDeviceToHost));
 			MCHK(hipMemcpy(gi.data(), d_gi, sizeof(int) * n, hipMemcpyDeviceToHost));
@@ -240,7 +342,7 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 			// ---- tar -> ref over the masked targets only (masked-out rows keep gIdx2 = -1) ----
 			if (!rows.empty() && n > 0) {
 				MCHK(hipMemcpy(d_rows, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
-				match_rows_device(d_b, d_rows, (int)rows.size(), d_a, n, d_cand, d_gd, d_sd, d_gi, d_si, nullptr);
+				match_rows_device(d_b, d_rows, (int)rows.size(), d_a, n, d_cand, d_part, d_gd, d_sd, d_gi, d_si, nullptr);
 				std::vector<float> tg(m), ts(m);
 				std::vector<int> ti(m), tsi(m);
 				MCHK(hipMemcpy(tg.data(), d_gd, sizeof(float) * m, hipMemcpyDeviceToHost));
@@ -286,5 +388,6 @@ done:
 	if (!on_device) { hipFree(d_a); hipFree(d_b); }
 	hipFree(d_f);
 	hipFree(d_i);
+	hipFree(d_part);
 	return rc;
 }

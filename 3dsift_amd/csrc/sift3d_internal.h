@@ -171,8 +171,9 @@ void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, in
 // ---- kernels_match.hip ---------------------------------------------------------------------
 // best / second-best dot of every listed row of A against all m rows of B (calMatches);
 // d_row_ids == nullptr means rows 0..nrows-1; outputs are indexed by the ORIGINAL row id.
+// d_part: scratch for the per-column-split partial top-4 lists, 8 B * 4 * 16 * nrows
 int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const float *d_b, int m, int *d_cand /*nrows*4*/,
-                      float *d_gd, float *d_sd, int *d_gi, int *d_si, hipStream_t st);
+                      void *d_part, float *d_gd, float *d_sd, int *d_gi, int *d_si, hipStream_t st);
 
 // error plumbing
 void set_last_error(const std::string &s);

@@ -285,15 +285,17 @@ def main():
         ex2.KpSiftAlgorithm()
         (da, xa, na), (db, xb, nb) = ex.device_results(), ex2.device_results()
         mt = capi.muBruteMatcher(device=local)
-        secs = []
+        secs, secs_e = [], []
         for _ in range(3):
-            r = mt.enhancedMatch(da, xa, db, xb, 0.85, on_device=True, n=na, m=nb)
+            mt.injectMatch(da, xa, db, xb, 0.85, on_device=True, n=na, m=nb)   # one full N x M pass: exact flop count
             secs.append(mt.totalTime)
+            r = mt.enhancedMatch(da, xa, db, xb, 0.85, on_device=True, n=na, m=nb)
+            secs_e.append(mt.totalTime)
         tm = min(secs)
-        flop = 2.0 * 2.0 * na * nb * 768  # both directions of enhancedMatch
-        out["matcher"] = {"workload": f"enhancedMatch of {na} x {nb} descriptors (two {n}^3 volumes, second shifted 1 voxel)",
-                          "seconds": tm, "matched_pairs": int(len(r["pairs"])),
-                          "roofline": {"bound": "mfma", "kernel": "k_scores_topk (A.B^T on v_mfma_f32_32x32x2_f32, fused top-4) + k_rescore",
+        flop = 2.0 * na * nb * 768
+        out["matcher"] = {"workload": f"injectMatch (one full pass) of {na} x {nb} descriptors (two {n}^3 volumes, second shifted 1 voxel)",
+                          "seconds": tm, "enhancedMatch_seconds": min(secs_e), "matched_pairs": int(len(r["pairs"])),
+                          "roofline": {"bound": "mfma", "kernel": "k_scores_top4 (A.B^T on v_mfma_f32_32x32x2_f32, fused top-4) + k_merge_top4 + k_rescore",
                                        "achieved": flop / tm / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                        "frac": flop / tm / 1e12 / MFMA_F32_PEAK_TF, "traffic": None}}
         ex2.close()
