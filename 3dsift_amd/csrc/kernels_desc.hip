@@ -284,12 +284,16 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		// Columns are dealt to the waves as 8x8 tiles of the window's (x, y) footprint: chord lengths (and the cube clip)
 		// vary slowly across a tile, so the lanes of a wave finish their z-march together (a 64x1 row segment spans
 		// the circle from rim to centre and leaves ~40 % of the lane-steps idle)
-		const int tiles_x = (wx + 7) >> 3, tiles_y = (wy + 7) >> 3;
+#ifndef S3D_DESC_TW
+#define S3D_DESC_TW 8
+#endif
+		constexpr int kTW = S3D_DESC_TW, kTH = 64 / kTW;  // (x, y) footprint of a wave's column tile
+		const int tiles_x = (wx + kTW - 1) / kTW, tiles_y = (wy + kTH - 1) / kTH;
 		const int ntiles = ncol > 0 ? tiles_x * tiles_y : 0;
 		for (int t0 = 0; t0 < ntiles; t0 += 4) {
 			const int tile = t0 + wid;                 // wave-uniform
 			const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-			const int lx = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+			const int lx = tx * kTW + (lane % kTW), ly = ty * kTH + (lane / kTW);
 			const int x = x0 + lx, y = y0 + ly;
 			const int dx = x - cxi, dy = y - cyi;
 			const int rr = dx * dx + dy * dy;

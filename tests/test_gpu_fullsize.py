@@ -1,0 +1,98 @@
+"""Full-size (512^3, BASELINE.json configs[1]/[2] scale) checks of the HIP path through size-independent properties: the
+CPU oracle needs ~5 s per 512^3 volume and is exercised at this size by bench.py's parity block; here the properties
+need no reference run."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+capi = importlib.import_module("3dsift_amd.capi")
+slab = importlib.import_module("3dsift_amd.slab")
+synth = importlib.import_module("3dsift_amd.synth")
+
+N = 512
+
+
+@pytest.fixture(scope="module")
+def run512():
+    import torch
+    vol = synth.blobs_torch((N, N, N), "cuda", seed=1234)
+    torch.cuda.synchronize()
+    ex = capi.CSIFT3D(None, device_ptr=vol.data_ptr(), shape=(N, N, N))
+    ex.KpSiftAlgorithm()
+    kp, ds = ex.GetKeypoints()
+    yield vol, ex, kp, ds
+    ex.close()
+
+
+def test_reference_order_and_ranges(run512):
+    _, ex, kp, ds = run512
+    assert ex.num_octaves == 7 and len(kp) > 5000
+    key = np.stack([kp["octave"], kp["level"], kp["z"], kp["y"], kp["x"]], 1).astype(np.int64)
+    order = np.lexsort(key.T[::-1])
+    assert np.array_equal(order, np.arange(len(kp)))            # (octave, level, z, y, x) scan order, no duplicates
+    assert len(np.unique(key, axis=0)) == len(kp)
+    for ax, f in (("x", "rx"), ("y", "ry"), ("z", "rz")):
+        assert np.array_equal(kp[f], kp[ax] * (2.0 ** kp["octave"]).astype(np.float32))   # Src/cSIFT3D.cc:1377-1379
+        dim = (N >> kp["octave"]).astype(np.float32)
+        assert (kp[ax] >= 1).all() and (kp[ax] <= dim - 2).all()                           # IMG_BORDER
+    assert set(np.unique(kp["level"])) <= {1, 2, 3}
+
+
+def test_descriptors_are_normalised_and_clamped(run512):
+    _, _, kp, ds = run512
+    assert ds.shape == (len(kp), 768) and np.isfinite(ds).all() and (ds >= 0).all()
+    nrm = np.sqrt((ds.astype(np.float64) ** 2).sum(1))
+    # second normalisation, Src/cSIFT3D.cc:1356-1358; a keypoint of the last tiny octaves whose whole window falls on the
+    # 1-voxel border has an empty histogram and an all-zero descriptor (0 / (0 + DBL_EPSILON)), like the reference
+    empty = nrm == 0
+    assert np.abs(nrm[~empty] - 1.0).max() < 1e-5 and empty.sum() < 0.01 * len(kp) and (kp["octave"][empty] >= 3).all()
+    assert ds.max() <= 1.0
+
+
+def test_rotation_is_orthonormal(run512):
+    _, _, kp, _ = run512
+    R = kp["Rotation"].reshape(-1, 3, 3).astype(np.float64)
+    eye = np.einsum("nij,nkj->nik", R, R)
+    assert np.abs(eye - np.eye(3)).max() < 1e-5
+    assert np.abs(np.linalg.det(R) - 1.0).max() < 1e-5           # v3 = v1 x v2, Src/cSIFT3D.cc:1120-1131
+
+
+def test_run_is_deterministic_and_scale_invariant(run512):
+    import torch
+    vol, ex, kp, ds = run512
+    ex.KpSiftAlgorithm()
+    kp2, ds2 = ex.GetKeypoints()
+    assert np.array_equal(kp2, kp) and np.array_equal(ds2, ds)   # integer LDS histograms: bit-reproducible
+    # max-abs normalisation makes the result invariant under an exact (power of two) rescale of the input
+    v4 = vol * 4.0
+    torch.cuda.synchronize()
+    e4 = capi.CSIFT3D(None, device_ptr=v4.data_ptr(), shape=(N, N, N))
+    e4.KpSiftAlgorithm()
+    kp4, ds4 = e4.GetKeypoints()
+    e4.close()
+    assert np.array_equal(kp4, kp) and np.array_equal(ds4, ds)
+
+
+def test_two_simulated_slabs_equal_the_whole(run512):
+    """z-slab sharding at full size: 2 simulated ranks, 2 sharded octaves == the single-volume result, bit for bit"""
+    vol, _, kp, ds = run512
+    exs = slab.SlabExtractor((N, N, N), slab.SimComm(2), sharded_octaves=2)
+    exs.load(device_slabs={r: vol[b0:b1].contiguous() for r, (b0, b1) in enumerate(exs.bounds)})
+    exs.KpSiftAlgorithm()
+    kps, dss = exs.GetKeypoints()
+    exs.close()
+    assert np.array_equal(kps, kp) and np.array_equal(dss, ds)
+
+
+def test_matcher_identity_and_shift(run512):
+    import torch
+    vol, ex, kp, ds = run512
+    d, x, n = ex.device_results()
+    m = capi.muBruteMatcher()
+    r = m.enhancedMatch(d, x, d, x, 0.85, on_device=True, n=n, m=n)   # a set against itself: every survivor pairs with itself
+    assert len(r["pairs"]) > 0.9 * n
+    assert np.array_equal(r["pairs"][:, :3], r["pairs"][:, 3:])
+    assert (r["gDist"][r["gIdx"] >= 0] < 1e-5).all()
