@@ -35,10 +35,19 @@
 // boundary planes per volume use wave-uniform ring selects.  Levels with a dimension < 2*hw+2 use the generic
 // separable kernels of kernels_pyramid.hip.
 #include <string.h>
+#include <stdio.h>
 
 #include "sift3d_internal.h"
 
 namespace s3d {
+
+#if defined(S3D_EXP) && S3D_EXP == 20
+// in-kernel stamps (development): cycles per phase of a workgroup-plane, summed per wave, for a few workgroups
+__device__ unsigned long long g_stamp[64][4][8];
+#define S3D_STAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; }
+#else
+#define S3D_STAMP(i)
+#endif
 
 // Packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two voxels per instruction at the issue cost of one scalar op, each lane an
 // ordinary IEEE multiply / add, so results stay bit-identical) is used where a thread has >= 4 independent accumulator
@@ -219,7 +228,30 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	const int out_off = gx_out + (y0 + yq * 4) * sy;  // plane-relative offset of this thread's first output
 	const bool col_ok = gx_out < nx;
 
+#if defined(S3D_EXP) && S3D_EXP == 20
+	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#endif
 	const int q_begin = zc0 - HW - 1, q_end = zc1 - 1 + HW;  // inclusive
+	// DoG centre values G[i-1](p): requested one whole plane ahead (at the END of the previous iteration, after its
+	// stores).  vmcnt retires in order, so requesting them before the tile prefetch of the same plane -- or consuming them in
+	// the plane that requested them -- makes the DoG wait for the prefetch as well and exposes the HBM latency every plane
+	// (in-kernel stamps, r01c: 1 800 of 7 400 cycles per plane at hw 8 sat in "DoG + stores").
+	float cen[4] = {0.f, 0.f, 0.f, 0.f};
+	auto request_centres = [&](int pn) {
+		if (!DOG) return;
+		if (full_tile) {
+			// unconditional (plane clamped): no branch around the loads
+			const float *cp = src + (size_t)sz * (size_t)min(max(pn, 0), nz - 1) + out_off;
+#pragma unroll
+			for (int j = 0; j < 4; j++) cen[j] = cp[j * sy];
+		} else if (pn >= zc0 && pn < zc1 && col_ok) {
+			const float *cp = src + (size_t)sz * (size_t)pn + out_off;
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+				if (y0 + yq * 4 + j < ny) cen[j] = cp[j * sy];
+		}
+	};
+	request_centres(q_begin - HW);
 	issue_plane_loads(q_begin);
 	for (int q = q_begin; q <= q_end; q++) {
 		const bool have_plane = (q >= 0 && q < nz) && (q + zoff >= 0) && (q + zoff < nzg);
@@ -235,24 +267,13 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 					*reinterpret_cast<float4 *>(&in_t[ld_lds[i]]) = w4;
 				}
 		}
+		S3D_STAMP(0)  // tile registers -> LDS
 		issue_plane_loads(q + 1);
-		float cen[4] = {0.f, 0.f, 0.f, 0.f};
-		if (DOG && full_tile) {
-			// unconditional (plane clamped) so that the loads stay in flight across the x/y phases
-			const float *cp = src + (size_t)sz * (size_t)min(max(p, 0), nz - 1) + out_off;
-#pragma unroll
-			for (int j = 0; j < 4; j++) cen[j] = cp[j * sy];
-		} else if (DOG && emit) {
-			if (col_ok) {
-				const float *cp = src + (size_t)sz * (size_t)p + out_off;
-#pragma unroll
-				for (int j = 0; j < 4; j++)
-					if (y0 + yq * 4 + j < ny) cen[j] = cp[j * sy];
-			}
-		}
 		float v[4] = {0.f, 0.f, 0.f, 0.f};
 		if (have_plane) {
+			S3D_STAMP(1)  // issue of the prefetch + DoG centre loads
 			__syncthreads();  // barrier A: tile visible (and every thread is done with the previous xb)
+			S3D_STAMP(2)  // wait at barrier A
 			if (edge_x) {
 				// x extension columns of the LDS tile (see header), every row of the tile
 				const int xend = nx - 1;
@@ -367,7 +388,9 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 					}
 				}
 			}
+			S3D_STAMP(3)  // x-blur
 			__syncthreads();  // barrier B: xb visible, in_t free for the next plane
+			S3D_STAMP(4)  // wait at barrier B
 			// ---------------- y-blur: xb -> registers (4 consecutive y of column x0+lane) ----------------
 			{
 				float yw[4 + 2 * HW];
@@ -382,6 +405,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				}
 			}
 		}
+		S3D_STAMP(5)  // y-blur
 		// ---------------- ring insert (slot q mod RING) + z-blur of plane p = q - HW ----------------
 		const int pg = p + zoff;  // global plane
 		const bool z_interior = emit && (pg >= HW) && (pg <= nzg - 2 - HW);
@@ -394,6 +418,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		default: break;
 		}
 #undef S3D_CASE
+		S3D_STAMP(6)  // z-blur
 		if (emit) {
 			if (!z_interior) {
 				// wave-uniform tap sources; plane s sits in slot s mod RING
@@ -445,7 +470,13 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				}
 			}
 		}
+		S3D_STAMP(7)  // DoG + stores
+		request_centres(p + 1);  // for the next iteration, in flight during its x / y / z phases
 	}
+#if defined(S3D_EXP) && S3D_EXP == 20
+	if (HW == S3D_STAMP_HW && blockIdx.x < 64 && wlane == 0)
+		for (int i = 0; i < 8; i++) g_stamp[blockIdx.x][wid][i] = st_acc[i];
+#endif
 	if (DOG) {
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -516,6 +547,23 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 	edge_fractions(ny, HW, ef.f[1]);
 	edge_fractions(zr.nzg, HW, ef.f[2]);
 	dim3 grid((unsigned)(ntiles * nchunks)), block(C::NT);
+#if defined(S3D_EXP) && S3D_EXP == 20
+	if (HW == S3D_STAMP_HW && nx >= 512 && dog) {
+		hipLaunchKernelGGL((k_fused_level<HW, true>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
+		hipStreamSynchronize(st);
+		static unsigned long long h[64][4][8];
+		hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h));
+		const char *nm[8] = {"tile->LDS", "issue loads", "wait bar A", "x-blur", "wait bar B", "y-blur", "z-blur", "DoG+stores"};
+		const int planes = cz + 2 * HW + 1;
+		for (int w = 0; w < 4; w++) {
+			fprintf(stderr, "STAMP hw %d wave %d (cycles per plane, mean of 64 WGs, %d planes):", HW, w, planes);
+			double tot = 0;
+			for (int i = 0; i < 8; i++) { double a = 0; for (int b = 0; b < 64; b++) a += (double)h[b][w][i]; a /= 64.0 * planes; tot += a; fprintf(stderr, " %s %.0f", nm[i], a); }
+			fprintf(stderr, " | total %.0f\n", tot);
+		}
+		return;
+	}
+#endif
 	if (dog) hipLaunchKernelGGL((k_fused_level<HW, true>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
 	else hipLaunchKernelGGL((k_fused_level<HW, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
 }
