@@ -58,6 +58,18 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef f2 __attribute__((aligned(4))) f2u;  // pair at an odd float offset (LDS)
 typedef const f2u __attribute__((address_space(3))) *lds_f2u_p;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence over ALL memory: hipcc puts
+// s_waitcnt vmcnt(0) in front of s_barrier whenever global stores are pending, which made every plane wait for the stores
+// it had just issued (in-kernel stamps: 1 600 cycles per plane).  The global stores of this kernel are never read by the
+// workgroup, so waiting for the LDS queue is sufficient.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void store_f4_untracked(float *p, float4 v) {
+	typedef float f4v __attribute__((ext_vector_type(4)));
+	const f4v d = {v.x, v.y, v.z, v.w};
+	asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" ::"v"(p), "v"(d) : "memory");
+}
+
 __device__ __forceinline__ float absmax_step_f(float m, float v) {
 	const float a = fabsf(v);
 	return (a > m) ? a : m;
@@ -71,8 +83,9 @@ struct FusedCfg {
 #ifndef S3D_TY
 #define S3D_TY (1024 / S3D_TX)
 #endif
-	static constexpr int TX = S3D_TX, TY = S3D_TY, NT = TX * TY / 4;  // 4 outputs (consecutive y) per thread
+	static constexpr int TX = S3D_TX, TY = S3D_TY, NT = TX * TY / 4;  // 4 outputs (consecutive x, one 16-B piece) per thread
 	static constexpr int NW = NT / 64;                              // waves per workgroup
+	static constexpr int XP = TX + 16;                             // xb row pitch: 16-B column reads of 8 consecutive rows use every bank once per 4 rows
 	static constexpr int SEGS = TX / 8;                            // x-blur items per row (8 outputs each)
 	static constexpr int HXL = ((HW + 1 + 3) / 4) * 4;  // low-side x halo: the right-boundary rule reaches p-hw-1
 	static constexpr int HXH = ((HW + 3) / 4) * 4;
@@ -165,7 +178,9 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	const int nz = zr.nz, zoff = zr.zoff, nzg = zr.nzg;  // local planes, global z of local plane 0, global planes
 	const int zc0 = zr.zo0 + chunk * cz, zc1 = min(zr.zo1, zc0 + cz);
 
-	const int tid = threadIdx.x, lane = tid % C::TX, yq = tid / C::TX, wlane = tid & 63, wid = tid >> 6;
+	// output mapping: thread (xq, ty) owns the 16-B piece x = 4*xq .. 4*xq+3 of tile row ty: one dwordx4 load (DoG centre) and
+	// two dwordx4 stores per plane instead of 12 scalar VMEM instructions (VMEM issue, not bytes, was the cost)
+	const int tid = threadIdx.x, xq = tid % (C::TX / 4), ty = tid / (C::TX / 4), wlane = tid & 63, wid = tid >> 6;
 	const bool edge_x = (x0 < HW) || (x0 + C::TX - 1 > nx - 2 - HW);
 	const bool edge_y = (y0 < HW) || (y0 + C::TY - 1 > ny - 2 - HW);
 	const bool need_row0 = (y0 + C::TY - 1 > ny - 2 - HW);  // tile holds right-boundary y outputs (they reach y-hw-1)
@@ -182,7 +197,9 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		bool ok = item < C::ROWS * C::W4 && gy >= 0 && gy < ny && (r > 0 || need_row0);
 		if (VEC) ok = ok && gx >= 0 && gx + 3 < nx;
 		ld_goff[i] = ok ? gy * sy + gx : -1;
-		ld_lds[i] = item < C::ROWS * C::W4 ? r * C::PITCH + 4 * c4 : -1;
+		// items past the end of the tile write a dump slot behind it: the LDS writes stay branch-free, so the compiler can wait for
+		// exactly the load it needs (vmcnt(k)) instead of draining everything at the join of an exec-masked block
+		ld_lds[i] = item < C::ROWS * C::W4 ? r * C::PITCH + 4 * c4 : C::ROWS * C::PITCH;
 	}
 	float4 pf[C::NLD];  // prefetched tile pieces of the NEXT plane
 #pragma unroll
@@ -224,9 +241,9 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		for (int k = 0; k < C::RING; k++) ring[j][k] = 0.0f;
 	float mx = 0.0f;
 
-	const int gx_out = x0 + lane;
-	const int out_off = gx_out + (y0 + yq * 4) * sy;  // plane-relative offset of this thread's first output
-	const bool col_ok = gx_out < nx;
+	const int gx_out = x0 + 4 * xq;
+	const int out_off = gx_out + (y0 + ty) * sy;  // plane-relative offset of this thread's first output
+	const bool row_ok = y0 + ty < ny;
 
 #if defined(S3D_EXP) && S3D_EXP == 20
 	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
@@ -237,42 +254,65 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	// the plane that requested them -- makes the DoG wait for the prefetch as well and exposes the HBM latency every plane
 	// (in-kernel stamps, r01c: 1 800 of 7 400 cycles per plane at hw 8 sat in "DoG + stores").
 	float cen[4] = {0.f, 0.f, 0.f, 0.f};
+	// branch-free (a branch around a load makes hipcc drain it at the join): addresses of outputs outside the volume are
+	// clamped to the tile's first valid element, their values are never used
+	int cen_off[4];
+	bool cen_vec = false;
+	{
+		const int safe = min(x0, nx - 1) + min(y0, ny - 1) * sy;
+		if (VEC) {
+			cen_vec = true;
+			cen_off[0] = (row_ok && gx_out + 3 < nx) ? out_off : (safe & ~3);
+			cen_off[1] = cen_off[2] = cen_off[3] = 0;
+		} else {
+#pragma unroll
+			for (int j = 0; j < 4; j++) cen_off[j] = (row_ok && gx_out + j < nx) ? out_off + j : safe;
+		}
+	}
 	auto request_centres = [&](int pn) {
 		if (!DOG) return;
-		if (full_tile) {
-			// unconditional (plane clamped): no branch around the loads
-			const float *cp = src + (size_t)sz * (size_t)min(max(pn, 0), nz - 1) + out_off;
+		const float *cp = src + (size_t)sz * (size_t)min(max(pn, 0), nz - 1);
+		if (VEC) {
+			const float4 c4 = *reinterpret_cast<const float4 *>(cp + cen_off[0]);
+			cen[0] = c4.x; cen[1] = c4.y; cen[2] = c4.z; cen[3] = c4.w;
+		} else {
 #pragma unroll
-			for (int j = 0; j < 4; j++) cen[j] = cp[j * sy];
-		} else if (pn >= zc0 && pn < zc1 && col_ok) {
-			const float *cp = src + (size_t)sz * (size_t)pn + out_off;
-#pragma unroll
-			for (int j = 0; j < 4; j++)
-				if (y0 + yq * 4 + j < ny) cen[j] = cp[j * sy];
+			for (int j = 0; j < 4; j++) cen[j] = cp[cen_off[j]];
 		}
 	};
-	request_centres(q_begin - HW);
+	(void)cen_vec;
+	auto plane_valid = [&](int qq) { return (qq >= 0 && qq < nz) && (qq + zoff >= 0) && (qq + zoff < nzg); };
+	auto deposit_tile = [&](int qq) {  // prefetched registers of plane qq -> LDS tile
+		if (!plane_valid(qq)) return;
+#pragma unroll
+		for (int i = 0; i < C::NLD; i++) {
+			float4 w4 = pf[i];
+			if (VEC) {  // selects, not branches
+				const bool outside = ld_goff[i] < 0;
+				w4.x = outside ? 0.f : w4.x; w4.y = outside ? 0.f : w4.y; w4.z = outside ? 0.f : w4.z; w4.w = outside ? 0.f : w4.w;
+			}
+			*reinterpret_cast<float4 *>(&in_t[ld_lds[i]]) = w4;
+		}
+	};
+	// Schedule of the global memory operations (hipcc waits with vmcnt(0), i.e. for EVERYTHING outstanding, wherever a
+	// prefetched register is consumed in this loop): the tile of plane q+1 is deposited in LDS AFTER the z-blur of plane q
+	// (in_t is free since barrier B), immediately followed by the DoG and the stores, and only then are the tile of plane q+2
+	// and the DoG centres of plane p+1 requested.  At the single wait per plane every outstanding load and store is one whole
+	// plane old; nothing young is ever waited for.
 	issue_plane_loads(q_begin);
+	deposit_tile(q_begin);
 	for (int q = q_begin; q <= q_end; q++) {
 		const bool have_plane = (q >= 0 && q < nz) && (q + zoff >= 0) && (q + zoff < nzg);
 		const int p = q - HW;
 		const bool emit = (p >= zc0 && p < zc1);
-		// ---------------- regs -> LDS tile of plane q; then prefetch plane q+1 and the DoG centres of plane p ----------------
-		if (have_plane) {
-#pragma unroll
-			for (int i = 0; i < C::NLD; i++)
-				if (ld_lds[i] >= 0) {
-					float4 w4 = pf[i];
-					if (VEC && ld_goff[i] < 0) w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-					*reinterpret_cast<float4 *>(&in_t[ld_lds[i]]) = w4;
-				}
-		}
-		S3D_STAMP(0)  // tile registers -> LDS
-		issue_plane_loads(q + 1);
+		// DoG centre values of THIS plane: the first memory operation of the iteration, consumed after the z-blur together with
+		// the tile prefetch (one wait, everything it covers is most of a plane old).  Not carried across the back-edge: hipcc
+		// copies a loop-carried load result there and waits for it.
+		request_centres(p);
+		issue_plane_loads(q + 1);  // tile of the next plane: consumed (deposited in LDS) after this plane's z-blur
 		float v[4] = {0.f, 0.f, 0.f, 0.f};
 		if (have_plane) {
-			S3D_STAMP(1)  // issue of the prefetch + DoG centre loads
-			__syncthreads();  // barrier A: tile visible (and every thread is done with the previous xb)
+			lds_barrier();  // barrier A: tile visible (and every thread is done with the previous xb)
 			S3D_STAMP(2)  // wait at barrier A
 			if (edge_x) {
 				// x extension columns of the LDS tile (see header), every row of the tile
@@ -295,7 +335,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 						}
 					}
 				}
-				__syncthreads();
+				lds_barrier();
 			}
 			// ---------------- x-blur: in_t rows 1..ROWS-1 -> xb (exactly one item per thread) ----------------
 #pragma unroll 1
@@ -330,7 +370,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 #pragma unroll
 						for (int pp = 0; pp < 4; pp++) o[pp] = o[pp] + pr[pp];
 					}
-					f4 *xo = reinterpret_cast<f4 *>(&xb[r * C::TX + seg * 8]);
+					f4 *xo = reinterpret_cast<f4 *>(&xb[r * C::XP + seg * 8]);
 					xo[0] = f4{o[0].x, o[0].y, o[1].x, o[1].y};
 					xo[1] = f4{o[2].x, o[2].y, o[3].x, o[3].y};
 					} else {
@@ -349,7 +389,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 						for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * win[C::WOFF + j + HW - d];
 						o[j] = acc;
 					}
-					float4 *xo = reinterpret_cast<float4 *>(&xb[r * C::TX + seg * 8]);
+					float4 *xo = reinterpret_cast<float4 *>(&xb[r * C::XP + seg * 8]);
 					xo[0] = make_float4(o[0], o[1], o[2], o[3]);
 					xo[1] = make_float4(o[4], o[5], o[6], o[7]);
 					}
@@ -368,7 +408,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 			}
 			if (edge_y) {
 				// y extension rows of xb (see header): mirror above row 0, lerp rows from dim_end on
-				__syncthreads();
+				lds_barrier();
 				const int yend = ny - 1;
 				const int ntop = (y0 < HW) ? HW : 0;                       // y0 < HW  =>  y0 == 0
 				const int nbot = need_row0 ? (HW + 1) : 0;
@@ -376,32 +416,47 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 					const int e = item / C::TX, xx = item % C::TX;
 					if (e < ntop) {
 						const int k = e + 1;                                // E[-k] = row k
-						xb[(HW + 1 - k - y0) * C::TX + xx] = xb[(HW + 1 + k - y0) * C::TX + xx];
+						xb[(HW + 1 - k - y0) * C::XP + xx] = xb[(HW + 1 + k - y0) * C::XP + xx];
 					} else {
 						const int k = e - ntop, m = yend - k;               // E[yend+k] = (1-f)*row[m-1] + f*row[m]
 						const int rd = yend + k - (y0 - HW - 1);
 						if (rd < C::ROWS) {
 							const float f = ef.f[1][k];
-							const float a = xb[(m - 1 - (y0 - HW - 1)) * C::TX + xx], b = xb[(m - (y0 - HW - 1)) * C::TX + xx];
-							xb[rd * C::TX + xx] = (1.0f - f) * a + f * b;
+							const float a = xb[(m - 1 - (y0 - HW - 1)) * C::XP + xx], b = xb[(m - (y0 - HW - 1)) * C::XP + xx];
+							xb[rd * C::XP + xx] = (1.0f - f) * a + f * b;
 						}
 					}
 				}
 			}
 			S3D_STAMP(3)  // x-blur
-			__syncthreads();  // barrier B: xb visible, in_t free for the next plane
+			lds_barrier();  // barrier B: xb visible, in_t free for the next plane
 			S3D_STAMP(4)  // wait at barrier B
-			// ---------------- y-blur: xb -> registers (4 consecutive y of column x0+lane) ----------------
+			// ---------------- y-blur: xb -> registers (the 4 x-neighbours of row ty: four independent chains) ----------------
 			{
-				float yw[4 + 2 * HW];
+				// rows are consumed in tap order from LDS in groups of kG, the next group requested before the current one is used
+				// (a full register window of 2*HW+1 float4 would cost 68 VGPRs at hw 8; one row at a time exposes the LDS latency
+				// 2*HW+1 times)
+				constexpr int kG = 4, NT_ = 2 * HW + 1;
+				const float *ycol = &xb[(ty + 1) * C::XP + 4 * xq];
+				// step s = d + HW = 0 .. 2*HW in the reference's order; it reads row (2*HW - s)
+				float4 cur[kG], nxt[kG];
 #pragma unroll
-				for (int k = 0; k < 4 + 2 * HW; k++) yw[k] = xb[(yq * 4 + 1 + k) * C::TX + lane];
+				for (int i = 0; i < kG; i++) cur[i] = *reinterpret_cast<const float4 *>(ycol + (i < NT_ ? 2 * HW - i : 0) * C::XP);
 #pragma unroll
-				for (int j = 0; j < 4; j++) {
-					float acc = 0.0f;
+				for (int g0 = 0; g0 < NT_; g0 += kG) {
 #pragma unroll
-					for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * yw[j + HW - d];
-					v[j] = acc;
+					for (int i = 0; i < kG; i++)
+						if (g0 + kG + i < NT_) nxt[i] = *reinterpret_cast<const float4 *>(ycol + (2 * HW - (g0 + kG + i)) * C::XP);
+#pragma unroll
+					for (int i = 0; i < kG; i++) {
+						const int st = g0 + i;
+						if (st < NT_) {
+							const float tap = t.w[st];
+							v[0] = v[0] + tap * cur[i].x; v[1] = v[1] + tap * cur[i].y; v[2] = v[2] + tap * cur[i].z; v[3] = v[3] + tap * cur[i].w;
+						}
+					}
+#pragma unroll
+					for (int i = 0; i < kG; i++) cur[i] = nxt[i];
 				}
 			}
 		}
@@ -419,6 +474,8 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		}
 #undef S3D_CASE
 		S3D_STAMP(6)  // z-blur
+		deposit_tile(q + 1);
+		S3D_STAMP(0)  // wait for the prefetch + tile registers -> LDS
 		if (emit) {
 			if (!z_interior) {
 				// wave-uniform tap sources; plane s sits in slot s mod RING
@@ -444,34 +501,37 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 #pragma unroll
 				for (int j = 0; j < 4; j++) out[j] = acc[j];
 			}
-			if (full_tile) {
-				const size_t base = (size_t)sz * (size_t)p + (size_t)out_off;
+		}
+		float dg[4];
 #pragma unroll
-				for (int j = 0; j < 4; j++) {
-					dst[base + (size_t)(j * sy)] = out[j];
-					if (DOG) {
-						const float dg = (out[j] - cen[j]) * (-1.0f);
-						dog[base + (size_t)(j * sy)] = dg;
-						mx = absmax_step_f(mx, dg);
-					}
+		for (int j = 0; j < 4; j++) dg[j] = (out[j] - cen[j]) * (-1.0f);
+		// loads BEFORE the stores: a load that re-uses a register a pending store still reads makes hipcc wait for the
+		// store to complete (vmcnt(0)); this way nothing is written that an older memory operation reads
+		S3D_STAMP(7)  // DoG + issue of the prefetch + DoG centre loads
+		if (emit) {
+			const size_t base = (size_t)sz * (size_t)p + (size_t)out_off;
+			if (full_tile && VEC) {
+				// The hot-path stores are issued through inline asm so that hipcc does not track them: it would otherwise make
+				// the next loads that re-use the stores' data registers wait for the stores to COMPLETE (s_waitcnt vmcnt).  The
+				// hardware only needs the data registers to be read, which the wait states below cover; nothing in this kernel
+				// reads dst / dog back.
+				store_f4_untracked(dst + base, make_float4(out[0], out[1], out[2], out[3]));
+				if (DOG) {
+					store_f4_untracked(dog + base, make_float4(dg[0], dg[1], dg[2], dg[3]));
+#pragma unroll
+					for (int j = 0; j < 4; j++) mx = absmax_step_f(mx, dg[j]);
 				}
-			} else if (col_ok) {
-				const size_t base = (size_t)sz * (size_t)p + (size_t)out_off;
+			} else if (row_ok) {
 #pragma unroll
 				for (int j = 0; j < 4; j++) {
-					if (y0 + yq * 4 + j < ny) {
-						dst[base + (size_t)(j * sy)] = out[j];
-						if (DOG) {
-							const float dg = (out[j] - cen[j]) * (-1.0f);
-							dog[base + (size_t)(j * sy)] = dg;
-							mx = absmax_step_f(mx, dg);
-						}
+					if (gx_out + j < nx) {
+						dst[base + j] = out[j];
+						if (DOG) { dog[base + j] = dg[j]; mx = absmax_step_f(mx, dg[j]); }
 					}
 				}
 			}
 		}
-		S3D_STAMP(7)  // DoG + stores
-		request_centres(p + 1);  // for the next iteration, in flight during its x / y / z phases
+		S3D_STAMP(1)  // stores
 	}
 #if defined(S3D_EXP) && S3D_EXP == 20
 	if (HW == S3D_STAMP_HW && blockIdx.x < 64 && wlane == 0)
@@ -498,8 +558,8 @@ __global__ void __launch_bounds__(FusedCfg<HW>::NT, (FusedCfg<HW>::OCC * 4 + Fus
                                                                        int nx, int ny, ZRange zr, Taps t, EdgeFrac ef, int ntx, int nty,
                                                                        int cz) {
 	using C = FusedCfg<HW>;
-	__shared__ __attribute__((aligned(16))) float in_t[C::ROWS * C::PITCH];
-	__shared__ __attribute__((aligned(16))) float xb[C::ROWS * C::TX];
+	__shared__ __attribute__((aligned(16))) float in_t[C::ROWS * C::PITCH + 4];  // + dump slot, see ld_lds
+	__shared__ __attribute__((aligned(16))) float xb[C::ROWS * C::XP];
 	__shared__ float s_red[C::NW];
 	if ((nx & 3) == 0) fused_level_body<HW, DOG, true>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red);
 	else fused_level_body<HW, DOG, false>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red);
@@ -553,7 +613,7 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 		hipStreamSynchronize(st);
 		static unsigned long long h[64][4][8];
 		hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h));
-		const char *nm[8] = {"tile->LDS", "issue loads", "wait bar A", "x-blur", "wait bar B", "y-blur", "z-blur", "DoG+stores"};
+		const char *nm[8] = {"wait+tile->LDS", "stores", "wait bar A", "x-blur", "wait bar B", "y-blur", "z-blur", "DoG+issue loads"};
 		const int planes = cz + 2 * HW + 1;
 		for (int w = 0; w < 4; w++) {
 			fprintf(stderr, "STAMP hw %d wave %d (cycles per plane, mean of 64 WGs, %d planes):", HW, w, planes);
