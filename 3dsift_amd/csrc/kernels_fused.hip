@@ -67,7 +67,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ void store_f4_untracked(float *p, float4 v) {
 	typedef float f4v __attribute__((ext_vector_type(4)));
 	const f4v d = {v.x, v.y, v.z, v.w};
-	asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" ::"v"(p), "v"(d) : "memory");
+	asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" ::"v"(p), "v"(d));
 }
 
 __device__ __forceinline__ float absmax_step_f(float m, float v) {
@@ -160,8 +160,13 @@ template <int HW, bool DOG, bool VEC>
 __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                  unsigned *__restrict__ dogmax, int nx, int ny, const ZRange zr, const Taps &t,
                                                  const EdgeFrac &ef, int ntx, int nty, int cz, float *in_t, float *xb,
-                                                 float *s_red) {
+                                                 float *s_red, float *s_ef) {
 	using C = FusedCfg<HW>;
+	// the boundary fractions are read through LDS: indexed dynamically out of the kernel-argument struct they would be global
+	// loads whose s_waitcnt vmcnt(0) makes EDGE tiles drain the tile prefetch every plane (and the slowest workgroup sets the
+	// kernel time)
+	if (threadIdx.x < 2 * (kMaxHW + 1)) s_ef[threadIdx.x] = ef.f[threadIdx.x / (kMaxHW + 1)][threadIdx.x % (kMaxHW + 1)];
+	__syncthreads();
 
 	// ---- XCD-aware, bijective block -> (chunk, tile) mapping: blocks b, b+8, ... share an XCD ----
 	const int nblocks = gridDim.x;
@@ -283,7 +288,9 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	(void)cen_vec;
 	auto plane_valid = [&](int qq) { return (qq >= 0 && qq < nz) && (qq + zoff >= 0) && (qq + zoff < nzg); };
 	auto deposit_tile = [&](int qq) {  // prefetched registers of plane qq -> LDS tile
-		if (!plane_valid(qq)) return;
+		// unconditional: a plane outside the volume goes to the dump slot.  If the registers were not consumed on every path,
+		// hipcc would make the NEXT request wait (write-after-write) -- with vmcnt(0), i.e. also for the stores just issued.
+		const bool valid = plane_valid(qq);
 #pragma unroll
 		for (int i = 0; i < C::NLD; i++) {
 			float4 w4 = pf[i];
@@ -291,7 +298,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				const bool outside = ld_goff[i] < 0;
 				w4.x = outside ? 0.f : w4.x; w4.y = outside ? 0.f : w4.y; w4.z = outside ? 0.f : w4.z; w4.w = outside ? 0.f : w4.w;
 			}
-			*reinterpret_cast<float4 *>(&in_t[ld_lds[i]]) = w4;
+			*reinterpret_cast<float4 *>(&in_t[valid ? ld_lds[i] : C::ROWS * C::PITCH]) = w4;
 		}
 	};
 	// Schedule of the global memory operations (hipcc waits with vmcnt(0), i.e. for EVERYTHING outstanding, wherever a
@@ -329,7 +336,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 					} else {
 						const int k = e - nleft, m = xend - k;
 						if (xend + k - x0 < C::TX + C::HXH) {
-							const float f = ef.f[0][k];
+							const float f = s_ef[k];                 // x fractions
 							const float a = trow[m - 1], b = trow[m];
 							trow[xend + k] = (1.0f - f) * a + f * b;
 						}
@@ -421,7 +428,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 						const int k = e - ntop, m = yend - k;               // E[yend+k] = (1-f)*row[m-1] + f*row[m]
 						const int rd = yend + k - (y0 - HW - 1);
 						if (rd < C::ROWS) {
-							const float f = ef.f[1][k];
+							const float f = s_ef[kMaxHW + 1 + k];    // y fractions
 							const float a = xb[(m - 1 - (y0 - HW - 1)) * C::XP + xx], b = xb[(m - (y0 - HW - 1)) * C::XP + xx];
 							xb[rd * C::XP + xx] = (1.0f - f) * a + f * b;
 						}
@@ -561,8 +568,9 @@ __global__ void __launch_bounds__(FusedCfg<HW>::NT, (FusedCfg<HW>::OCC * 4 + Fus
 	__shared__ __attribute__((aligned(16))) float in_t[C::ROWS * C::PITCH + 4];  // + dump slot, see ld_lds
 	__shared__ __attribute__((aligned(16))) float xb[C::ROWS * C::XP];
 	__shared__ float s_red[C::NW];
-	if ((nx & 3) == 0) fused_level_body<HW, DOG, true>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red);
-	else fused_level_body<HW, DOG, false>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red);
+	__shared__ float s_ef[2 * (kMaxHW + 1)];
+	if ((nx & 3) == 0) fused_level_body<HW, DOG, true>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef);
+	else fused_level_body<HW, DOG, false>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef);
 }
 
 // fp32 fractions of the reference's right-boundary rule for an axis of length n (see file header):
