@@ -35,6 +35,8 @@
 // histogram additions differs, i.e. ~1e-7 relative -- tolerance 1e-4 RMS (BASELINE.json).
 #include <float.h>
 
+#include <stdio.h>
+
 #include "sift3d_internal.h"
 
 namespace s3d {
@@ -181,6 +183,13 @@ __device__ __forceinline__ void accumulate_voxel(bool valid, float bx, float by,
 	}
 }
 
+#if defined(S3D_EXP) && S3D_EXP == 21
+// in-kernel stamps (development): cycles per phase, summed per wave over the whole kernel, for the first 64 workgroups
+__device__ unsigned long long g_dstamp[64][4][8];
+#define S3D_DSTAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; }
+#else
+#define S3D_DSTAMP(i)
+#endif
 constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <= 64, a pop removes exactly 64
 
 __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
@@ -216,6 +225,9 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 	if (tid < 12) s_predn[tid] = c_pred.n[tid / 3][tid % 3];
 	if (tid < 32) s_predf[tid] = c_pred.face[tid];
 	int cur_lut = -1;
+#if defined(S3D_EXP) && S3D_EXP == 21
+	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+#endif
 	float(*q)[kQCap] = s_q[wid];
 	unsigned long long *hist_rep = &hist[lane & (kRep - 1)];
 
@@ -278,6 +290,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 #if defined(S3D_EXP) && S3D_EXP == 5
 		int exp_steps = 0, exp_lanes = 0, exp_pops = 0;
 #endif
+		S3D_DSTAMP(0)  // keypoint fetch, histogram clear, barriers
 		int qhead = 0, qcount = 0;  // wave-uniform (every lane executes every push / pop below)
 		// All control flow from here to the drain is wave-uniform: lanes without work are predicated, never branched
 		// away, because the queue bookkeeping must see every ballot.
@@ -332,6 +345,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
 			maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+			S3D_DSTAMP(1)  // batch setup (chord, cube clip)
 			if (maxlen == 0) continue;  // wave-uniform
 #if defined(S3D_EXP) && S3D_EXP == 5
 			exp_steps += maxlen; exp_lanes += zlen;
@@ -349,6 +363,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 				const gfloat_p cn = more ? c + sz : c;
 				const float cpn = cn[sz];  // plane z+2 (<= zb+1 <= nz-1), or z+1 again on the last step
 				const float nxm1 = cn[-1], nxp1 = cn[1], nym1 = *(cn - sy), nyp1 = cn[sy];
+				S3D_DSTAMP(2)  // back-edge + issue of the next step's loads
 				const float vzd = (float)dz * u;
 				float bx = px + R2 * vzd, by = py + R5 * vzd, bz = pz + R8 * vzd;
 				bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
@@ -369,6 +384,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 				act = act && !(g2 < kBaryEps);
 				cm = cc; cc = cp; cp = cpn; nxm = nxm1; nxp = nxp1; nym = nym1; nyp = nyp1;
 				c = cn; dz += more ? 1 : 0;
+				S3D_DSTAMP(3)  // step arithmetic
 				// ---- push the active lanes into the wave's queue (compaction by ballot rank) ----
 				const unsigned long long m = __ballot(act);
 				if (m) {
@@ -378,6 +394,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 					}
 					qcount += (int)__popcll(m);
 				}
+				S3D_DSTAMP(4)  // push
 				// ---- a full wave of active voxels is ready: run the heavy part on all 64 lanes ----
 				if (qcount >= 64) {
 					const int pos = (qhead + lane) & (kQCap - 1);
@@ -389,6 +406,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 					exp_pops++;
 #endif
 				}
+				S3D_DSTAMP(5)  // pop (accumulate 64 voxels)
 			}
 		}
 		if (qcount > 0) {  // drain (wave-uniform)
@@ -397,6 +415,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 			accumulate_voxel(valid, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], s_face, s_fidx, s_predn, s_predf,
 			                 hist_rep);
 		}
+		S3D_DSTAMP(6)  // drain
 		__syncthreads();
 
 		// normalise -> clamp -> normalise (Src/cSIFT3D.cc:1350-1358, 1639-1656)
@@ -429,6 +448,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		}
 		float *out = d_desc + (size_t)slot * kDesc;
 		out[tid] = v0; out[tid + 256] = v1; out[tid + 512] = v2;
+		S3D_DSTAMP(7)  // normalise + store
 #if defined(S3D_EXP) && S3D_EXP == 5
 		{
 			int tl = exp_lanes;
@@ -438,6 +458,10 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		}
 #endif
 	}
+#if defined(S3D_EXP) && S3D_EXP == 21
+	if (blockIdx.x < 64 && lane == 0)
+		for (int i = 0; i < 8; i++) g_dstamp[blockIdx.x][wid][i] = st_acc[i];
+#endif
 }
 
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels, const WinLut *d_luts,
@@ -446,6 +470,19 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
 	(void)hipMemsetAsync(d_work, 0, sizeof(unsigned), st);
 	hipLaunchKernelGGL(k_describe, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
 	                   part_rank, part_world, order, d_nkp, d_work);
+#if defined(S3D_EXP) && S3D_EXP == 21
+	{
+		hipStreamSynchronize(st);
+		static unsigned long long h[64][4][8];
+		hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dstamp), sizeof(h));
+		const char *nm[8] = {"kp setup", "batch setup", "backedge+loads", "step math", "push", "pop", "drain", "normalise"};
+		double tot = 0, a[8] = {0};
+		for (int i = 0; i < 8; i++) { for (int b = 0; b < 64; b++) for (int w = 0; w < 4; w++) a[i] += (double)h[b][w][i]; tot += a[i]; }
+		fprintf(stderr, "DSTAMP share of wave time:");
+		for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * a[i] / tot);
+		fprintf(stderr, " | cycles per wave %.0f\n", tot / 256.0);
+	}
+#endif
 }
 
 // final keypoint records (Keypoint fields incl. rx,ry,rz = x*2^octave, Src/cSIFT3D.cc:1377-1379)
