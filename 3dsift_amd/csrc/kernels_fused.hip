@@ -85,6 +85,11 @@ struct FusedCfg {
 #endif
 	static constexpr int TX = S3D_TX, TY = S3D_TY, NT = TX * TY / 4;  // 4 outputs (consecutive x, one 16-B piece) per thread
 	static constexpr int NW = NT / 64;                              // waves per workgroup
+	// DoG centre values G[i-1](p), p = q - HW: the raw tile of plane q holds them, so each thread parks its 16-B piece in a
+	// private LDS ring of HW+1 planes instead of re-reading G[i-1] from memory (3.1 GB of 16.7 GB per 512^3 pyramid).  The
+	// ring does not fit beside three resident workgroups at hw 8; that level keeps the global re-read.
+	static constexpr bool CRING = HW <= 6;
+	static constexpr int CR = HW + 1;
 	static constexpr int XP = TX + 16;                             // xb row pitch: 16-B column reads of 8 consecutive rows use every bank once per 4 rows
 	static constexpr int SEGS = TX / 8;                            // x-blur items per row (8 outputs each)
 	static constexpr int HXL = ((HW + 1 + 3) / 4) * 4;  // low-side x halo: the right-boundary rule reaches p-hw-1
@@ -160,7 +165,7 @@ template <int HW, bool DOG, bool VEC>
 __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                  unsigned *__restrict__ dogmax, int nx, int ny, const ZRange zr, const Taps &t,
                                                  const EdgeFrac &ef, int ntx, int nty, int cz, float *in_t, float *xb,
-                                                 float *s_red, float *s_ef) {
+                                                 float *s_red, float *s_ef, float4 *cring) {
 	using C = FusedCfg<HW>;
 	// the boundary fractions are read through LDS: indexed dynamically out of the kernel-argument struct they would be global
 	// loads whose s_waitcnt vmcnt(0) makes EDGE tiles drain the tile prefetch every plane (and the slowest workgroup sets the
@@ -308,6 +313,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	// plane old; nothing young is ever waited for.
 	issue_plane_loads(q_begin);
 	deposit_tile(q_begin);
+	int cslot_w = 0;  // ring slot of plane q (planes enter one per iteration, so slot = iteration index mod CR)
 	for (int q = q_begin; q <= q_end; q++) {
 		const bool have_plane = (q >= 0 && q < nz) && (q + zoff >= 0) && (q + zoff < nzg);
 		const int p = q - HW;
@@ -315,12 +321,14 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		// DoG centre values of THIS plane: the first memory operation of the iteration, consumed after the z-blur together with
 		// the tile prefetch (one wait, everything it covers is most of a plane old).  Not carried across the back-edge: hipcc
 		// copies a loop-carried load result there and waits for it.
-		request_centres(p);
+		if (!(DOG && C::CRING)) request_centres(p);
 		issue_plane_loads(q + 1);  // tile of the next plane: consumed (deposited in LDS) after this plane's z-blur
 		float v[4] = {0.f, 0.f, 0.f, 0.f};
 		if (have_plane) {
 			lds_barrier();  // barrier A: tile visible (and every thread is done with the previous xb)
 			S3D_STAMP(2)  // wait at barrier A
+			if (DOG && C::CRING)  // this thread's piece of the raw plane q -> its private ring slot
+				cring[(cslot_w)*C::NT + tid] = *reinterpret_cast<const float4 *>(&in_t[(ty + HW + 1) * C::PITCH + C::HXL + 4 * xq]);
 			if (edge_x) {
 				// x extension columns of the LDS tile (see header), every row of the tile
 				const int xend = nx - 1;
@@ -509,6 +517,11 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				for (int j = 0; j < 4; j++) out[j] = acc[j];
 			}
 		}
+		if (DOG && C::CRING) {
+			// plane p = q - HW sits HW slots behind the one written in this iteration: (cslot_w + 1) mod CR
+			const float4 c4 = cring[(cslot_w + 1 == C::CR ? 0 : cslot_w + 1) * C::NT + tid];
+			cen[0] = c4.x; cen[1] = c4.y; cen[2] = c4.z; cen[3] = c4.w;
+		}
 		float dg[4];
 #pragma unroll
 		for (int j = 0; j < 4; j++) dg[j] = (out[j] - cen[j]) * (-1.0f);
@@ -539,6 +552,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 			}
 		}
 		S3D_STAMP(1)  // stores
+		cslot_w = cslot_w + 1 == C::CR ? 0 : cslot_w + 1;
 	}
 #if defined(S3D_EXP) && S3D_EXP == 20
 	if (HW == S3D_STAMP_HW && blockIdx.x < 64 && wlane == 0)
@@ -569,8 +583,9 @@ __global__ void __launch_bounds__(FusedCfg<HW>::NT, (FusedCfg<HW>::OCC * 4 + Fus
 	__shared__ __attribute__((aligned(16))) float xb[C::ROWS * C::XP];
 	__shared__ float s_red[C::NW];
 	__shared__ float s_ef[2 * (kMaxHW + 1)];
-	if ((nx & 3) == 0) fused_level_body<HW, DOG, true>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef);
-	else fused_level_body<HW, DOG, false>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef);
+	__shared__ __attribute__((aligned(16))) float4 cring[(DOG && C::CRING) ? C::CR * C::NT : 1];
+	if ((nx & 3) == 0) fused_level_body<HW, DOG, true>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef, cring);
+	else fused_level_body<HW, DOG, false>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef, cring);
 }
 
 // fp32 fractions of the reference's right-boundary rule for an axis of length n (see file header):
