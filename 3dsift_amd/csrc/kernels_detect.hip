@@ -21,9 +21,19 @@ constexpr int kRows = 16;   // rows per block
 constexpr int kThreads = 256;
 
 // masks layout: word index = ((lvl * nz + z) * ny + y) * wpr + xw, wpr = ceil(nx / 64): scan order
+//
+// Two-phase per wave: (1) stream the centre values, kBatch ballot words per pass, and push the voxels that pass the peak
+// threshold (a few per cent) into a wave-private LDS queue by ballot rank; (2) whenever 64 candidates are queued, all 64
+// lanes fetch the 8 neighbours of one candidate each and OR their verdict into the wave's LDS copy of the mask words.
+// A per-word `if (candidate) { 8 loads }` issues those 8 load instructions for nearly every word (some lane usually is a
+// candidate) and the compiler drains them at each join: one memory round trip per word.
+constexpr int kQueue = 640;  // >= 63 left over + 8 words x 64 lanes pushed before the next drain
 __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int ny, ZRange zr, int nyb, float peak_thresh,
                                                    unsigned long long *__restrict__ masks, unsigned *__restrict__ block_counts) {
 	__shared__ unsigned s_cnt[kThreads / 64];
+	__shared__ float s_qv[kThreads / 64][kQueue];
+	__shared__ unsigned short s_qi[kThreads / 64][kQueue];
+	__shared__ unsigned long long s_mask[kThreads / 64][(kRows / 4) * 64];  // [row of the wave][word], wpr <= 64
 	const int b = blockIdx.x;
 	const int nz = zr.zo1 - zr.zo0;                              // planes scanned by this launch (local range [zo0, zo1))
 	const int yb = b % nyb, zi = (b / nyb) % nz, lvl = b / (nyb * nz);
@@ -36,49 +46,87 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	const int wpr = (nx + 63) >> 6;
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
-	unsigned cnt = 0;
 	const bool z_in = (zg >= 1 && zg <= zr.nzg - 2);
 	const int y0 = yb * kRows;
-	// The block's 16 rows are dealt to its 4 waves 4 rows each; a wave walks a row kBatch ballot words at a time: the
-	// centre values of the kBatch words are requested together and only then examined, so a wave has kBatch independent
-	// HBM reads in flight (the scan is a pure streaming read; with one load per iteration it ran at the memory latency).
-	// Row / word indices are wave-uniform loop counters: no per-lane integer divisions.
 	constexpr int kBatch = 8;
 	const int nrows = min(kRows, ny - y0);
 	const int swid = __builtin_amdgcn_readfirstlane(wid);
-	for (int ry = swid * (kRows / 4); ry < min(nrows, (swid + 1) * (kRows / 4)); ry++) {
-		const int y = y0 + ry;
-		const bool y_in = z_in && y >= 1 && y <= ny - 2;
-		const size_t rowbase = sy * (size_t)y + sz * (size_t)z;
-		unsigned long long *mrow = masks + ((size_t)(lvl * nz + zi) * ny + y) * wpr;
-		for (int xw0 = 0; xw0 < wpr; xw0 += kBatch) {
-			float val[kBatch];
-			bool in[kBatch];
+	const int r_lo = swid * (kRows / 4), r_hi = min(nrows, (swid + 1) * (kRows / 4));
+	float *qv = s_qv[swid];
+	unsigned short *qi = s_qi[swid];
+	unsigned long long *mloc = s_mask[swid];
+	for (int i = lane; i < (kRows / 4) * 64; i += 64) mloc[i] = 0ull;
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	const size_t plane0 = sz * (size_t)z + sy * (size_t)y0;
+	int qn = 0;  // wave-uniform
+	// evaluate `n` queued candidates starting at entry `first` (n <= 64)
+	auto evaluate = [&](int first, int n, int seg0) {
+		const bool act = lane < n;
+		const int e = first + (act ? lane : 0);
+		const float v = qv[e];
+		const unsigned id = qi[e];                       // (row within the wave) << 12 | word << 6 | lane bit
+		const int rr = (int)(id >> 12), xw = (int)((id >> 6) & 63), bit = (int)(id & 63);
+		const size_t i = plane0 + sy * (size_t)(r_lo + rr) + (size_t)((seg0 + xw) * 64 + bit);
+		// idle lanes read voxel (1, 1) of the plane: candidates only exist on interior planes of volumes with ny, nx >= 3, so all
+		// eight neighbour addresses of that voxel are inside the level
+		const size_t ic = act ? i : sz * (size_t)z + sy + 1;
+		const float n0 = prev[ic], n1 = cur[ic - 1], n2 = cur[ic + 1], n3 = cur[ic + sy], n4 = cur[ic - sy], n5 = cur[ic + sz],
+		            n6 = cur[ic - sz], n7 = next[ic];
+		const bool mn = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 && v < n7;
+		const bool mx = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 && v > n7;
+		if (act && (mn || mx)) atomicOr(&mloc[rr * 64 + xw], 1ull << bit);
+	};
+	unsigned cnt = 0;
+	// rows wider than 64 ballot words (nx > 4096) are handled in segments of 64 words: the local mask copy holds one segment
+	for (int seg0 = 0; seg0 < wpr; seg0 += 64) {
+		const int seg1 = min(wpr, seg0 + 64);
+		for (int ry = r_lo; ry < r_hi; ry++) {
+			const int y = y0 + ry;
+			const bool y_in = z_in && y >= 1 && y <= ny - 2;
+			const size_t rowbase = sy * (size_t)y + sz * (size_t)z;
+			for (int xw0 = seg0; xw0 < seg1; xw0 += kBatch) {
+				float val[kBatch];
+				bool in[kBatch];
 #pragma unroll
-			for (int b = 0; b < kBatch; b++) {
-				const int x = (xw0 + b) * 64 + lane;
-				in[b] = y_in && x >= 1 && x <= nx - 2;  // implies xw0 + b < wpr
-				val[b] = cur[in[b] ? rowbase + (size_t)x : sz * (size_t)z];  // unconditional load, clamped address
-			}
-#pragma unroll
-			for (int b = 0; b < kBatch; b++) {
-				if (xw0 + b >= wpr) break;  // wave-uniform
-				bool hit = false;
-				const float v = val[b];
-				if (in[b] && (v > thr || v < -thr)) {
-					const size_t i = rowbase + (size_t)((xw0 + b) * 64 + lane);
-					const float n0 = prev[i], n1 = cur[i - 1], n2 = cur[i + 1], n3 = cur[i + sy], n4 = cur[i - sy], n5 = cur[i + sz],
-					            n6 = cur[i - sz], n7 = next[i];
-					const bool mn = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 && v < n7;
-					const bool mx = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 && v > n7;
-					hit = mn || mx;
+				for (int bb = 0; bb < kBatch; bb++) {
+					const int x = (xw0 + bb) * 64 + lane;
+					in[bb] = y_in && xw0 + bb < seg1 && x >= 1 && x <= nx - 2;
+					val[bb] = cur[in[bb] ? rowbase + (size_t)x : sz * (size_t)z];  // unconditional load, clamped address
 				}
-				const unsigned long long m = __ballot(hit);
-				if (lane == 0) mrow[xw0 + b] = m;
+#pragma unroll
+				for (int bb = 0; bb < kBatch; bb++) {
+					const float v = val[bb];
+					const bool c = in[bb] && (v > thr || v < -thr);
+					const unsigned long long m = __ballot(c);
+					if (c) {
+						const int pos = qn + (int)__popcll(m & lt);
+						qv[pos] = v;
+						qi[pos] = (unsigned short)(((ry - r_lo) << 12) | ((xw0 + bb - seg0) << 6) | lane);
+					}
+					qn += (int)__popcll(m);
+				}
+				// drain full waves of candidates (entries are consumed from the END so the front stays in place)
+				while (qn >= 64) {
+					qn -= 64;
+					evaluate(qn, 64, seg0);
+				}
+			}
+		}
+		if (qn > 0) evaluate(0, qn, seg0);
+		qn = 0;
+		// masks + count of this wave's rows, then clear the local copy for the next segment
+		for (int ry = r_lo; ry < r_hi; ry++) {
+			unsigned long long *mrow = masks + ((size_t)(lvl * nz + zi) * ny + (y0 + ry)) * wpr;
+			for (int xw = seg0 + lane; xw < seg1; xw += 64) {
+				const unsigned long long m = mloc[(ry - r_lo) * 64 + xw - seg0];
+				mrow[xw] = m;
 				cnt += (unsigned)__popcll(m);
+				mloc[(ry - r_lo) * 64 + xw - seg0] = 0ull;
 			}
 		}
 	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
 	if (lane == 0) s_cnt[wid] = cnt;
 	__syncthreads();
 	if (threadIdx.x == 0) block_counts[b] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
