@@ -71,6 +71,8 @@ def test_g4_g6_golden_keypoints(capi, synth, tag):
     ((40, 56, 72), 5, 0.01),        # ragged, 3 octaves
     ((17, 33, 20), 23, 0.05),       # one octave, everything is boundary
     ((128, 96, 80), 9, 0.0),        # 4 octaves, non-cubic
+    ((48, 50, 45), 3, 0.01),        # odd width: scalar (non 16-byte) load/store path of the fused kernel
+    ((40, 37, 54), 4, 0.0),         # nx % 4 == 2, odd ny
 ])
 def test_full_pipeline_vs_oracle(capi, orc, synth, shape, seed, noise):
     vol = synth.blobs(shape, seed=seed, noise=noise)
