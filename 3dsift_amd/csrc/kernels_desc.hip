@@ -67,7 +67,7 @@ constexpr int kFaceStride = 16;  // floats per face in the LDS table
 #ifndef S3D_DESC_REP
 #define S3D_DESC_REP 4
 #endif
-constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = bin*kRep + (lane & (kRep-1)))
+constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = bin*kRep + lane % kRep)
 
 // reference Moller-Trumbore for ONE face whose constants sit at F[0..15]:
 // e1(0..2) e2(3..5) t(6..8) q(9..11) qe2(12); returns pass/fail exactly like Check_intersect_faces' body
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
 #endif
 	float(*q)[kQCap] = s_q[wid];
-	unsigned long long *hist_rep = &hist[lane & (kRep - 1)];
+	unsigned long long *hist_rep = &hist[lane % kRep];
 
 	// The accepted keypoints (slot -> extremum list from k_slots) are handed out one at a time through a global counter:
 	// window sizes differ 4x between keypoint levels, so a static deal leaves a long tail.  A partitioned run (multi-GPU
@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		long long a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
 		for (int r = 0; r < kRep; r++) {
-			const int rr2 = (r + tid) & (kRep - 1);  // stagger the replica order across lanes
+			const int rr2 = (r + tid) % kRep;  // stagger the replica order across lanes
 			a0 += (long long)hist[tid * kRep + rr2];
 			a1 += (long long)hist[(tid + 256) * kRep + rr2];
 			a2 += (long long)hist[(tid + 512) * kRep + rr2];
