@@ -330,9 +330,9 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 			if (DOG && C::CRING)  // this thread's piece of the raw plane q -> its private ring slot
 				cring[(cslot_w)*C::NT + tid] = *reinterpret_cast<const float4 *>(&in_t[(ty + HW + 1) * C::PITCH + C::HXL + 4 * xq]);
 			if (edge_x) {
-				// the extension below overwrites column nx-1 of the tile with E[dim_end]: every thread must have parked its RAW
-				// centre piece first
-				if (DOG && C::CRING) lds_barrier();
+				// the right-edge extension below overwrites column nx-1 of the tile with E[dim_end]: every thread must have parked
+				// its RAW centre piece first (the left-edge mirror only writes halo columns)
+				if (DOG && C::CRING && x0 + C::TX - 1 > nx - 2 - HW) lds_barrier();
 				// x extension columns of the LDS tile (see header), every row of the tile
 				const int xend = nx - 1;
 				const int nleft = (x0 < HW) ? HW : 0;                       // x0 < HW  =>  x0 == 0
