@@ -67,6 +67,7 @@ def run_slab(dims, world, rank, local, dev, steps, warmup, sim_ranks=0, seed=432
     s3d_dist = importlib.import_module("3dsift_amd.dist")
     nx, ny, nz = dims
     shape = (nz, ny, nx)
+    torch.cuda.set_device(local)  # the current device is per thread, and the N>1 leg runs in a watchdog thread
 
     def barrier():
         torch.cuda.synchronize()
