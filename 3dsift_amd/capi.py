@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsift3d_hip.so")
+LIB_PATH = os.environ.get("S3D_LIB") or os.path.join(HERE, "libsift3d_hip.so")  # S3D_LIB: kernel-variant A/B builds (scripts/ab_pyramid.py)
 DESC = 768
 
 KP_DTYPE = np.dtype(

@@ -262,7 +262,7 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	for (auto &e : c->ev_seed) if (e) hipEventDestroy(e);
 	for (auto &e : c->ev_done) if (e) hipEventDestroy(e);
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
-	for (size_t o = 1; o < c->ostream.size(); o++) if (c->ostream[o]) hipStreamDestroy(c->ostream[o]);
+	for (size_t o = 1; o < c->ostream.size(); o++) if (c->ostream[o] && c->ostream[o] != c->stream) hipStreamDestroy(c->ostream[o]);
 	if (c->stream) hipStreamDestroy(c->stream);
 	delete c;
 	return SIFT3D_OK;
@@ -399,8 +399,11 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	c->ev_seed.assign(c->ostream.size(), nullptr);
 	c->ev_done.assign(c->ostream.size(), nullptr);
 	c->ostream[0] = c->stream;
+	// S3D_ONE_STREAM=1 (profiling): every octave on the main stream, so a kernel trace shows isolated launch durations
+	const bool one_stream = [] { const char *e = getenv("S3D_ONE_STREAM"); return e && e[0] == '1'; }();
 	for (size_t o = 0; o < c->ostream.size(); o++) {
-		if (o > 0) CHECKED(hipStreamCreateWithFlags(&c->ostream[o], hipStreamNonBlocking));
+		if (o > 0 && one_stream) c->ostream[o] = c->stream;
+		else if (o > 0) CHECKED(hipStreamCreateWithFlags(&c->ostream[o], hipStreamNonBlocking));
 		CHECKED(hipEventCreateWithFlags(&c->ev_seed[o], hipEventDisableTiming));
 		CHECKED(hipEventCreateWithFlags(&c->ev_done[o], hipEventDisableTiming));
 	}
