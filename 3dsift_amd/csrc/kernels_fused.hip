@@ -89,6 +89,17 @@ __device__ __forceinline__ void store_f4_untracked(float *p, float4 v) {
 #endif
 }
 
+// LDS-DMA (gfx950 global_load_lds_dwordx4): each lane's 16 bytes at `base + voff` go straight to LDS at lds_dst + 16*lane --
+// no destination registers, no ds_write pass.  M0 carries the wave-uniform LDS byte address and is restored (compiler-reserved).
+// Not tracked by hipcc: completion is awaited with explicit counted s_waitcnt vmcnt (see the plane loop).
+__device__ __forceinline__ void glds16(const float *base, unsigned voff, unsigned lds_dst) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 __device__ __forceinline__ float absmax_step_f(float m, float v) {
 	const float a = fabsf(v);
 	return (a > m) ? a : m;
@@ -108,6 +119,7 @@ struct FusedCfg {
 	// private LDS ring of HW+1 planes instead of re-reading G[i-1] from memory (3.1 GB of 16.7 GB per 512^3 pyramid).  The
 	// ring does not fit beside three resident workgroups at hw 8; that level keeps the global re-read.
 	static constexpr bool CRING = HW <= 6;
+	static constexpr bool CRING_DMA = HW <= 4;  // beside the double-buffered DMA tile the ring only fits three workgroups per CU up to hw 4
 	static constexpr int CR = HW + 1;
 	static constexpr int XP = TX + 16;                             // xb row pitch: 16-B column reads of 8 consecutive rows use every bank once per 4 rows
 	static constexpr int SEGS = TX / 8;                            // x-blur items per row (8 outputs each)
@@ -208,12 +220,18 @@ __device__ __forceinline__ void zblur_static(f2 (&ring)[2][2 * HW + 2], const f2
 // VEC: nx % 4 == 0, so every 16-B tile piece is either fully inside the volume or fully outside and all
 // tile loads are branch-free (clamped address + select) -- essential: a branch around a load makes hipcc wait
 // for it at the join, which serialises the prefetch.  !VEC (odd widths, small volumes) keeps guarded scalar loads.
-template <int HW, bool DOG, bool VEC>
+// DMA (with VEC): the tile of plane q+1 travels global -> LDS by LDS-DMA into the other half of a double-buffered, lane-linear
+// tile (row pitch W, piece i of the plane at float offset 4*i) while plane q is processed: no prefetch registers, no deposit
+// pass, and the wave never waits for the load it has just issued.
+template <int HW, bool DOG, bool VEC, bool DMA, bool CR_ON>
 __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                  unsigned *__restrict__ dogmax, int nx, int ny, const ZRange zr, const Taps &t,
                                                  const EdgeFrac &ef, int ntx, int nty, int cz, float *in_t, float *xb,
                                                  float *s_red, float *s_ef, float4 *cring) {
 	using C = FusedCfg<HW>;
+	static_assert(!DMA || VEC, "LDS-DMA tiles need 16-byte pieces");
+	constexpr int IP = DMA ? C::W : C::PITCH;            // row pitch of the LDS tile
+	constexpr int BUF = C::NLD * C::NT * 4;              // floats per DMA tile buffer (whole wave-instructions: 1 KiB each)
 	// the boundary fractions are read through LDS: indexed dynamically out of the kernel-argument struct they would be global
 	// loads whose s_waitcnt vmcnt(0) makes EDGE tiles drain the tile prefetch every plane (and the slowest workgroup sets the
 	// kernel time)
@@ -253,17 +271,27 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		const int gy = y0 - HW - 1 + r, gx = x0 - C::HXL + 4 * c4;
 		bool ok = item < C::ROWS * C::W4 && gy >= 0 && gy < ny && (r > 0 || need_row0);
 		if (VEC) ok = ok && gx >= 0 && gx + 3 < nx;
-		ld_goff[i] = ok ? gy * sy + gx : -1;
+		ld_goff[i] = ok ? gy * sy + gx : (DMA ? 0 : -1);  // DMA: clamped to a valid piece (its LDS image is never used: halo patches
+		                                                   // overwrite what edge outputs read, everything else feeds discarded outputs)
 		// items past the end of the tile write a dump slot behind it: the LDS writes stay branch-free, so the compiler can wait for
 		// exactly the load it needs (vmcnt(k)) instead of draining everything at the join of an exec-masked block
 		ld_lds[i] = item < C::ROWS * C::W4 ? r * C::PITCH + 4 * c4 : C::ROWS * C::PITCH;
 	}
+	const unsigned lds_tile = (unsigned)(unsigned long long)in_t;  // LDS byte address (low 32 bits of the flat address)
+	const unsigned lds_wave = lds_tile + (unsigned)__builtin_amdgcn_readfirstlane(wid) * 1024u;
+	auto issue_plane_dma = [&](int q) {  // plane q -> buffer q & 1
+		const float *plane = src + (size_t)sz * (size_t)min(max(q, 0), nz - 1);
+		const unsigned dstb = lds_wave + (unsigned)(q & 1) * (unsigned)(BUF * 4);
+#pragma unroll
+		for (int i = 0; i < C::NLD; i++) glds16(plane, (unsigned)ld_goff[i] * 4u, dstb + (unsigned)(i * C::NT * 16));
+	};
 	float4 pf[C::NLD];  // prefetched tile pieces of the NEXT plane
 #pragma unroll
 	for (int i = 0; i < C::NLD; i++) pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
 	auto issue_plane_loads = [&](int q) {
 		if (S3D_DIAG & 1) return;
+		if (DMA) { issue_plane_dma(q); return; }
 		// no branch around the loads (a join would make the compiler drain them): planes outside [0, nz) are
 		// clamped to a valid plane and simply never used
 		if (!VEC && (q < 0 || q >= nz)) return;
@@ -341,6 +369,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	(void)cen_vec;
 	auto plane_valid = [&](int qq) { return (qq >= 0 && qq < nz) && (qq + zoff >= 0) && (qq + zoff < nzg); };
 	auto deposit_tile = [&](int qq) {  // prefetched registers of plane qq -> LDS tile
+		if (DMA) return;
 		// unconditional: a plane outside the volume goes to the dump slot.  If the registers were not consumed on every path,
 		// hipcc would make the NEXT request wait (write-after-write) -- with vmcnt(0), i.e. also for the stores just issued.
 		const bool valid = plane_valid(qq);
@@ -361,6 +390,11 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	// plane old; nothing young is ever waited for.
 	issue_plane_loads(q_begin);
 	deposit_tile(q_begin);
+	if (DMA) wait_vmcnt<0>();  // the first plane: one exposed latency per workgroup
+	// DMA bookkeeping: VMEM operations this wave issued AFTER the DMA of the plane it is about to read (vmcnt retires in order):
+	// the asm stores of the previous plane (0 in the ramp, 1 or 2 on the fast path), this plane's DoG centre request and the DMA
+	// of the next plane.  2 = the previous plane stored through compiler-tracked stores (partial tiles): wait for everything.
+	int prev_stores = 0;
 	int cslot_w = 0;  // ring slot of plane q (planes enter one per iteration, so slot = iteration index mod CR)
 	for (int q = q_begin; q <= q_end; q++) {
 		const bool have_plane = (q >= 0 && q < nz) && (q + zoff >= 0) && (q + zoff < nzg);
@@ -369,18 +403,25 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		// DoG centre values of THIS plane: the first memory operation of the iteration, consumed after the z-blur together with
 		// the tile prefetch (one wait, everything it covers is most of a plane old).  Not carried across the back-edge: hipcc
 		// copies a loop-carried load result there and waits for it.
-		if (!(DOG && C::CRING)) request_centres(p);
+		if (!CR_ON) request_centres(p);
 		issue_plane_loads(q + 1);  // tile of the next plane: consumed (deposited in LDS) after this plane's z-blur
+		float *const tin = DMA ? in_t + (q & 1) * BUF : in_t;  // tile of plane q
 		f2 v[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
 		if (have_plane) {
+			if (DMA) {
+				constexpr int kAfter = C::NLD + ((DOG && !CR_ON) ? 1 : 0), kSt = DOG ? 2 : 1;
+				if (prev_stores == 1) wait_vmcnt<kAfter + kSt>();
+				else if (prev_stores == 0) wait_vmcnt<kAfter>();
+				else wait_vmcnt<0>();
+			}
 			lds_barrier();  // barrier A: tile visible (and every thread is done with the previous xb)
 			S3D_STAMP(2)  // wait at barrier A
-			if (DOG && C::CRING)  // this thread's piece of the raw plane q -> its private ring slot
-				cring[(cslot_w)*C::NT + tid] = *reinterpret_cast<const float4 *>(&in_t[(ty + HW + 1) * C::PITCH + C::HXL + 4 * xq]);
+			if (CR_ON)  // this thread's piece of the raw plane q -> its private ring slot
+				cring[(cslot_w)*C::NT + tid] = *reinterpret_cast<const float4 *>(&tin[(ty + HW + 1) * IP + C::HXL + 4 * xq]);
 			if (edge_x) {
 				// the right-edge extension below overwrites column nx-1 of the tile with E[dim_end]: every thread must have parked
 				// its RAW centre piece first (the left-edge mirror only writes halo columns)
-				if (DOG && C::CRING && x0 + C::TX - 1 > nx - 2 - HW) lds_barrier();
+				if (CR_ON && x0 + C::TX - 1 > nx - 2 - HW) lds_barrier();
 				// x extension columns of the LDS tile (see header), every row of the tile
 				const int xend = nx - 1;
 				const int nleft = (x0 < HW) ? HW : 0;                       // x0 < HW  =>  x0 == 0
@@ -390,7 +431,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				const unsigned ne_magic = 65536u / (unsigned)ne + 1u;
 				for (int item = tid; item < C::ROWS * ne; item += C::NT) {
 					const int r = (int)(((unsigned)item * ne_magic) >> 16), e = item - r * ne;
-					float *trow = &in_t[r * C::PITCH] + (C::HXL - x0);  // trow[gx] addresses volume column gx
+					float *trow = &tin[r * IP] + (C::HXL - x0);  // trow[gx] addresses volume column gx
 					if (e < nleft) {
 						const int k = e + 1;
 						trow[-k] = trow[k];
@@ -420,7 +461,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				const int gy = y0 - HW - 1 + r;
 				if (gy >= 0 && gy < ny) {
 					if constexpr (C::PKX) {
-					const float *trow = &in_t[r * C::PITCH] + C::WSTART + seg * 8;
+					const float *trow = &tin[r * IP] + C::WSTART + seg * 8;
 					// register window as pairs: E[i] = (w[2i], w[2i+1]) from the 16-B loads, O[i] = (w[2i+1], w[2i+2]) read
 					// again from LDS at the odd offset (the LDS pointer is laundered so that the compiler issues ds_read2
 					// instead of assembling the odd pairs with v_mov from the even ones)
@@ -450,7 +491,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 					xo[0] = f4{o[0].x, o[0].y, o[1].x, o[1].y};
 					xo[1] = f4{o[2].x, o[2].y, o[3].x, o[3].y};
 					} else {
-					const float *trow = &in_t[r * C::PITCH];
+					const float *trow = &tin[r * IP];
 					float win[C::WN4 * 4];
 #pragma unroll
 					for (int k = 0; k < C::WN4; k++) {
@@ -475,7 +516,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				// bottom tiles only: the extra low halo row (one wave's worth of work, plain loop)
 				const int gy = y0 - HW - 1;
 				if (gy >= 0 && tid < C::TX) {
-					const float *trow = &in_t[0];
+					const float *trow = &tin[0];
 					float acc = 0.0f;
 #pragma unroll
 					for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * trow[C::HXL + tid - d];  // unrolled: the LDS reads go out together
@@ -600,7 +641,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				for (int j = 0; j < 4; j++) out[j] = acc[j];
 			}
 		}
-		if (DOG && C::CRING) {
+		if (CR_ON) {
 			// plane p = q - HW sits HW slots behind the one written in this iteration: (cslot_w + 1) mod CR
 			const float4 c4 = cring[(cslot_w + 1 == C::CR ? 0 : cslot_w + 1) * C::NT + tid];
 			cen[0] = c4.x; cen[1] = c4.y; cen[2] = c4.z; cen[3] = c4.w;
@@ -611,6 +652,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		// loads BEFORE the stores: a load that re-uses a register a pending store still reads makes hipcc wait for the
 		// store to complete (vmcnt(0)); this way nothing is written that an older memory operation reads
 		S3D_STAMP(7)  // DoG + issue of the prefetch + DoG centre loads
+		prev_stores = emit ? ((full_tile && VEC && !(S3D_DIAG & 2)) ? 1 : 2) : 0;
 		if (emit) {
 			const size_t base = (size_t)sz * (size_t)p + (size_t)out_off;
 			if ((S3D_DIAG & 2) && !(out[0] == 12345.678f && dg[1] == 3.25f)) {
@@ -657,19 +699,27 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	}
 }
 
+#ifndef S3D_DMA_MASK
+#define S3D_DMA_MASK 0  /* bit HW set: LDS-DMA tile path for that half width (widths that are multiples of 4).  Measured r02: bit-exact,
+                          frees the 12 prefetch registers (no spills at hw 8) and the deposit pass, hw 6 / 8 levels 5-8 % faster in
+                          isolation, hw 3 8 % slower, whole pyramid unchanged (4.05 vs 4.03 ms) -> off */
+#endif
 template <int HW, bool DOG>
 __global__ void __launch_bounds__(FusedCfg<HW>::NT, (FusedCfg<HW>::OCC * 4 + FusedCfg<HW>::NW - 1) / FusedCfg<HW>::NW) k_fused_level(const float *__restrict__ src, float *__restrict__ dst,
                                                                        float *__restrict__ dog, unsigned *__restrict__ dogmax,
                                                                        int nx, int ny, ZRange zr, Taps t, EdgeFrac ef, int ntx, int nty,
                                                                        int cz) {
 	using C = FusedCfg<HW>;
-	__shared__ __attribute__((aligned(16))) float in_t[C::ROWS * C::PITCH + 4];  // + dump slot, see ld_lds
+	constexpr bool DMA = ((S3D_DMA_MASK >> HW) & 1) != 0;
+	constexpr int kTile = C::ROWS * C::PITCH + 4, kTileDma = 2 * C::NLD * C::NT * 4;
+	constexpr bool CR = DOG && (DMA ? C::CRING_DMA : C::CRING);  // DoG centre ring in LDS (both bodies of this kernel follow it)
+	__shared__ __attribute__((aligned(16))) float in_t[(DMA && kTileDma > kTile) ? kTileDma : kTile];  // + dump slot, see ld_lds
 	__shared__ __attribute__((aligned(16))) float xb[C::ROWS * C::XP];
 	__shared__ float s_red[C::NW];
 	__shared__ float s_ef[2 * (kMaxHW + 1)];
-	__shared__ __attribute__((aligned(16))) float4 cring[(DOG && C::CRING) ? C::CR * C::NT : 1];
-	if ((nx & 3) == 0) fused_level_body<HW, DOG, true>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef, cring);
-	else fused_level_body<HW, DOG, false>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef, cring);
+	__shared__ __attribute__((aligned(16))) float4 cring[CR ? C::CR * C::NT : 1];
+	if ((nx & 3) == 0) fused_level_body<HW, DOG, true, DMA, CR>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef, cring);
+	else fused_level_body<HW, DOG, false, false, CR>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef, cring);
 }
 
 // fp32 fractions of the reference's right-boundary rule for an axis of length n (see file header):
