@@ -145,6 +145,8 @@ struct sift3d_ctx {
 	// holds planes [own0-halo, own1+halo); halo planes are filled by the caller (neighbour exchange)
 	bool slab = false;
 	int own0 = 0, own1 = 0, halo = 0;
+	// single-volume path: DoG[o][0] and DoG[o][nd-1] are not written by the pyramid (see DetectLevels); copy_level forms them
+	bool dog_elide = false;
 	bool ext_arena = false;         // level buffers live in memory owned by the caller
 	int part_rank = 0, part_world = 1;  // descriptor work split of replicated octaves
 
@@ -501,11 +503,28 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 }
 
 // GaussianSmooth_3D (Src/cSIFT3D.cc:535-622) on device buffers: X -> Y -> Z(+DoG)
+#ifndef S3D_FUSED_MIN_DEFAULT
+#define S3D_FUSED_MIN_DEFAULT 33  /* levels with a dimension <= 32 (octaves 4+ of a 512^3 volume) take the generic separable kernels: 3.88 vs 4.02 ms */
+#endif
+#ifndef S3D_O0_TAIL_SLOTS_DEFAULT
+#define S3D_O0_TAIL_SLOTS_DEFAULT 0
+#endif
+#ifndef S3D_BG_SLOTS_DEFAULT
+#define S3D_BG_SLOTS_DEFAULT 0
+#endif
 static void smooth_level(sift3d_ctx *c, int o, const float *src, const Level &dst, const Taps &t, const float *prev, float *dog,
-                         unsigned *dogmax) {
+                         unsigned *dogmax, int level = 0) {
 	hipStream_t st = c->ostream[o];
+	// Slot planning across the octave streams (single-round launches keep every slot they take until they end): the levels of
+	// octave 0 behind the seed level G[0][num_kp_levels] leave a third of the machine to the chains of the smaller octaves, which
+	// are planned for that third; otherwise those chains starve and run as a tail after octave 0 has finished.
+	static const int tail_slots = [] { const char *e = getenv("S3D_O0_TAIL_SLOTS"); return e ? atoi(e) : S3D_O0_TAIL_SLOTS_DEFAULT; }();
+	static const int bg_slots = [] { const char *e = getenv("S3D_BG_SLOTS"); return e ? atoi(e) : S3D_BG_SLOTS_DEFAULT; }();
+	const int plan_slots = c->noct > 1 ? (o == 0 ? (level > c->p.num_kp_levels ? tail_slots : 0) : bg_slots) : 0;
 	// hot path: one fused pass (x, y, z blur + DoG + abs-max); prev == src for every DoG-producing level
-	if (c->use_fused && (prev == nullptr || prev == src) && launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.zr_all(), t, st))
+	static const int fused_min = [] { const char *e = getenv("S3D_FUSED_MIN"); return e ? atoi(e) : S3D_FUSED_MIN_DEFAULT; }();
+	if (c->use_fused && (prev == nullptr || prev == src) && std::min(dst.nx, std::min(dst.ny, dst.nz)) >= fused_min &&
+	    launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.zr_all(), t, st, plan_slots))
 		return;
 	launch_conv_axis(0, src, c->tmpA[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
 	launch_conv_axis(1, c->tmpA[o], c->tmpB[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
@@ -519,6 +538,9 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 	if (upto < 1) upto = 1;
 	if (upto > 5) upto = 5;
 	hipStream_t st = c->stream;
+	// S3D_DOG_EAGER=1: write every DoG level (A/B; the z-slab path always does)
+	static const bool dog_eager = [] { const char *e = getenv("S3D_DOG_EAGER"); return e && e[0] == '1'; }();
+	c->dog_elide = !dog_eager && c->nd >= 3;
 	for (int attempt = 0; attempt < 4; attempt++) {
 		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(std::max(1, c->noct * c->nd) + 4), st));
 		S3D_HIP(hipEventRecord(c->ev[0], st));
@@ -543,7 +565,8 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 				} else {
 					const Level &P = c->gss[(size_t)o * c->ng + i - 1];
 					const Level &D = c->dog[(size_t)o * c->nd + i - 1];
-					smooth_level(c, o, P.d, L, c->taps[i], P.d, D.d, c->d_dogmax + (size_t)o * c->nd + i - 1);
+					if (c->dog_elide && (i - 1 == 0 || i - 1 == c->nd - 1)) smooth_level(c, o, P.d, L, c->taps[i], nullptr, nullptr, nullptr, i);
+					else smooth_level(c, o, P.d, L, c->taps[i], P.d, D.d, c->d_dogmax + (size_t)o * c->nd + i - 1, i);
 				}
 				if (i == c->p.num_kp_levels) S3D_HIP(hipEventRecord(c->ev_seed[o], so));
 			}
@@ -565,6 +588,11 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 					DL.absmax_bits[i - 1] = c->d_dogmax + (size_t)o * c->nd + i;
 					DL.level_id[i - 1] = i;
 					DL.scale[i - 1] = c->dog[(size_t)o * c->nd + i].scale;
+				}
+				if (c->dog_elide) {
+					DL.prev0_hi = c->gss[(size_t)o * c->ng + 1].d; DL.prev0_lo = c->gss[(size_t)o * c->ng].d;
+					DL.nextl_hi = c->gss[(size_t)o * c->ng + c->nd].d; DL.nextl_lo = c->gss[(size_t)o * c->ng + c->nd - 1].d;
+					DL.nextl_slot = nl - 1;
 				}
 				const Level &C = c->dog[(size_t)o * c->nd + 1];
 				launch_detect_octave(DL, nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, c->det, c->d_ext, c->ext_cap, st);
@@ -682,6 +710,12 @@ extern "C" int sift3d_copy_level(sift3d_handle c, int is_dog, int idx, float *ou
 	if (!L) return SIFT3D_ERR_ARG;
 	int rc = set_device(c->device);
 	if (rc) return rc;
+	if (is_dog && c->dog_elide && (idx % c->nd == 0 || idx % c->nd == c->nd - 1)) {
+		// an elided DoG level (never written by the pipeline): form it now, exactly like Sub, into its arena slot
+		const int o = idx / c->nd, i = idx % c->nd;
+		launch_dog_from_gss(c->gss[(size_t)o * c->ng + i + 1].d, c->gss[(size_t)o * c->ng + i].d, L->d, L->n(), c->stream);
+		S3D_HIP(hipStreamSynchronize(c->stream));
+	}
 	S3D_HIP(hipMemcpy(out, L->d, sizeof(float) * L->n(), hipMemcpyDeviceToHost));
 	return SIFT3D_OK;
 }

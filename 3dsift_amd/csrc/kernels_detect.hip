@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	const float *__restrict__ cur = L.cur[lvl];
 	const float *__restrict__ prev = L.prev[lvl];
 	const float *__restrict__ next = L.next[lvl];
+	const bool lazy_prev = lvl == 0 && L.prev0_hi != nullptr, lazy_next = lvl == L.nextl_slot && L.nextl_hi != nullptr;
 	const float thr = peak_thresh * __uint_as_float(*L.absmax_bits[lvl]);
 	const int wpr = (nx + 63) >> 6;
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -70,8 +71,10 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 		// idle lanes read voxel (1, 1) of the plane: candidates only exist on interior planes of volumes with ny, nx >= 3, so all
 		// eight neighbour addresses of that voxel are inside the level
 		const size_t ic = act ? i : sz * (size_t)z + sy + 1;
-		const float n0 = prev[ic], n1 = cur[ic - 1], n2 = cur[ic + 1], n3 = cur[ic + sy], n4 = cur[ic - sy], n5 = cur[ic + sz],
-		            n6 = cur[ic - sz], n7 = next[ic];
+		// elided first / last DoG level: formed from the two Gaussian levels like Sub does (block-uniform choice)
+		const float n0 = lazy_prev ? (L.prev0_hi[ic] - L.prev0_lo[ic]) * (-1.0f) : prev[ic];
+		const float n7 = lazy_next ? (L.nextl_hi[ic] - L.nextl_lo[ic]) * (-1.0f) : next[ic];
+		const float n1 = cur[ic - 1], n2 = cur[ic + 1], n3 = cur[ic + sy], n4 = cur[ic - sy], n5 = cur[ic + sz], n6 = cur[ic - sz];
 		const bool mn = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 && v < n7;
 		const bool mx = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 && v > n7;
 		if (act && (mn || mx)) atomicOr(&mloc[rr * 64 + xw], 1ull << bit);

@@ -36,6 +36,11 @@
 // separable kernels of kernels_pyramid.hip.
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#ifndef S3D_BG_K_DEFAULT
+#define S3D_BG_K_DEFAULT 0.0
+#endif
 
 #include "sift3d_internal.h"
 
@@ -736,7 +741,7 @@ static void edge_fractions(int n, int hw, float *f) {
 
 template <int HW>
 static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
-                      hipStream_t st) {
+                      hipStream_t st, int plan_slots) {
 	const int nz = zr.zo1 - zr.zo0;  // planes to produce
 	if (nz <= 0) return;
 	using C = FusedCfg<HW>;
@@ -744,12 +749,20 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 	const int ntiles = ntx * nty;
 	// z chunking: pick the chunk count that minimises (residency rounds) x (planes marched per workgroup);
 	// every chunk pays a ramp of 2*HW+1 planes, every partially filled round leaves CUs idle
-	const int slots = 256 * ((C::OCC * 4 + C::NW - 1) / C::NW);  // OCC counts 4-wave units per CU
+	// workgroup slots the chunking is planned for: the whole machine by default; the caller passes fewer when other octaves'
+	// launches are meant to run beside this one (a single-round launch holds every slot it takes for its whole duration)
+	const int full_slots = 256 * ((C::OCC * 4 + C::NW - 1) / C::NW);  // OCC counts 4-wave units per CU
+	const int slots = plan_slots > 0 ? std::min(plan_slots, full_slots) : full_slots;
 	const int ramp = 2 * HW + 1;
 	int best_cz = nz;
 	double best_cost = 1e300;
+	// Levels with few tiles (octaves >= 1) run beside the big octave-0 launches on their own streams: what they cost the
+	// machine is their total work (workgroup-planes), not their latency, so their chunks are kept >= bg_k ramps long
+	static const double bg_k = [] { const char *e = getenv("S3D_BG_K"); return e ? atof(e) : S3D_BG_K_DEFAULT; }();
+	const bool background = ntiles * 4 <= slots;
 	for (int n = 1; n <= nz && n <= 64; n++) {
 		const int czn = (nz + n - 1) / n;
+		if (background && n > 1 && czn < bg_k * ramp) break;
 		const int nch = (nz + czn - 1) / czn;
 		const long wgs = (long)ntiles * nch;
 		const long rounds = (wgs + slots - 1) / slots;
@@ -788,16 +801,16 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 // returns false when no fused instantiation exists for this half width (caller uses the generic
 // separable kernels of kernels_pyramid.hip instead -- still the HIP path)
 bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr,
-                        const Taps &t, hipStream_t st) {
+                        const Taps &t, hipStream_t st, int plan_slots) {
 	// the halo-extension form of the boundary rule needs n >= 2*hw+2 along x and y (see header)
 	if (nx < 2 * t.hw + 2 || ny < 2 * t.hw + 2) return false;
 	switch (t.hw) {
-	case 2: launch_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
-	case 3: launch_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
-	case 4: launch_hw<4>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
-	case 5: launch_hw<5>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
-	case 6: launch_hw<6>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
-	case 8: launch_hw<8>(src, dst, dog, dogmax, nx, ny, zr, t, st); return true;
+	case 2: launch_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 3: launch_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 4: launch_hw<4>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 5: launch_hw<5>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 6: launch_hw<6>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 8: launch_hw<8>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
 	default: return false;
 	}
 }

@@ -85,6 +85,14 @@ void launch_absmax(const float *src, size_t n, unsigned *d_max_bits, hipStream_t
 	hipLaunchKernelGGL(k_absmax, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, src, n, d_max_bits);
 }
 
+// Sub (Src/cSIFT3D.cc:849-882) for a DoG level the pipeline did not materialise (checking accessor only): dog = (hi - lo) * (-1)
+__global__ void __launch_bounds__(256) k_dog_from_gss(const float *__restrict__ hi, const float *__restrict__ lo, float *__restrict__ dog, size_t n) {
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dog[i] = (hi[i] - lo[i]) * (-1.0f);
+}
+void launch_dog_from_gss(const float *hi, const float *lo, float *dog, size_t n, hipStream_t st) {
+	hipLaunchKernelGGL(k_dog_from_gss, dim3(grid_for(n, 256)), dim3(256), 0, st, hi, lo, dog, n);
+}
+
 void launch_scale_by_max(float *data, size_t n, const unsigned *d_max_bits, hipStream_t st) {
 	hipLaunchKernelGGL(k_scale, dim3(grid_for(n, 256, 4)), dim3(256), 0, st, data, n, d_max_bits);
 }

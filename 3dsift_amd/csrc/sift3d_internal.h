@@ -104,13 +104,14 @@ struct FacePredict {
 // ---- kernels_pyramid.hip -------------------------------------------------------------------
 void launch_absmax(const float *src, size_t n, unsigned *d_max_bits, hipStream_t st);
 void launch_scale_by_max(float *data, size_t n, const unsigned *d_max_bits, hipStream_t st);
+void launch_dog_from_gss(const float *hi, const float *lo, float *dog, size_t n, hipStream_t st);  // dog = (hi - lo) * (-1)
 // separable pass along AXIS (0 x, 1 y, 2 z); for AXIS==2 optionally also emits
 // dog = -(dst - prev) and accumulates max|dog| (bits) into d_dogmax.
 void launch_conv_axis(int axis, const float *src, float *dst, int nx, int ny, int nz, const Taps &t,
                       const float *prev, float *dog, unsigned *d_dogmax, hipStream_t st);
 // fused single-pass level kernel (kernels_fused.hip); false => no instantiation for this half width
 bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr,
-                        const Taps &t, hipStream_t st);
+                        const Taps &t, hipStream_t st, int plan_slots = 0);
 void launch_downsample(const float *src, int snx, int sny, float *dst, int nx, int ny, int nz, hipStream_t st);
 
 // ---- kernels_detect.hip --------------------------------------------------------------------
@@ -124,6 +125,12 @@ struct DetectBufs {
 constexpr int kMaxKpLevels = 5;
 struct DetectLevels {
 	const float *cur[kMaxKpLevels], *prev[kMaxKpLevels], *next[kMaxKpLevels];
+	// Elided DoG levels: the first and the last DoG level of an octave are read ONLY as the centre-voxel neighbour of extremum
+	// candidates (Src/cSIFT3D.cc:889-896), so the single-volume path does not materialise them; the candidate test forms the
+	// value from the two Gaussian levels exactly like Sub does, (hi - lo) * (-1) (Src/cSIFT3D.cc:875).  Null = materialised.
+	const float *prev0_hi, *prev0_lo;        // prev of level slot 0 = DoG[0] = (G[1] - G[0]) * (-1)
+	const float *nextl_hi, *nextl_lo;        // next of level slot nextl_slot = DoG[nd-1] = (G[nd] - G[nd-1]) * (-1)
+	int nextl_slot;
 	const unsigned *absmax_bits[kMaxKpLevels];
 	int level_id[kMaxKpLevels];
 	float scale[kMaxKpLevels];

@@ -247,7 +247,10 @@ def main():
         "descriptor_keypoints_per_s": (nkp / stage["d_Extraction"]) if stage["d_Extraction"] > 0 else None,
         "roofline": {"bound": "hbm", "kernel": "pyramid build (all Gaussian/DoG level kernels of one KpSiftAlgorithm)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "algorithmic_bytes": alg_bytes, "seconds": t_pyr, "traffic": traffic},
+                     "algorithmic_bytes": alg_bytes, "seconds": t_pyr, "traffic": traffic,
+                     # the first and last DoG level of every octave are no longer written (only candidate voxels ever read them;
+                     # the extrema test forms those values from the two Gaussian levels): 60 of SURVEY's 68 B/voxel are moved
+                     "algorithmic_bytes_moved": 60.0 * pv, "frac_moved": 60.0 * pv / t_pyr / 1e9 / HBM_PEAK_GBS},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:

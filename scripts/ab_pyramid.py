@@ -23,7 +23,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     for _ in range(12):
         ex.run_stages(1); t.append(ex.m_timer["d_BuildGSS"] * 1e3)
     t = np.array(t[2:])
-    print("%-40s pyramid ms median %.3f min %.3f   hash %s" % (os.path.basename(os.environ.get("S3D_LIB", "default")), np.median(t), t.min(), h.hexdigest()[:12]), flush=True)
+    print("%-40s pyramid ms median %.3f min %.3f   hash %s" % (os.path.basename(os.environ.get("S3D_LIB", "default")) + " " + os.environ.get("S3D_TAG", ""), np.median(t), t.min(), h.hexdigest()[:12]), flush=True)
     sys.exit(0)
 for lib in [None] + sys.argv[1:]:
     env = dict(os.environ)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# start/end (us, relative to the first launch) of every pyramid kernel of the last run, octaves on their own streams
+cd /tmp && export TMPDIR=/tmp
+[ -n "$2" ] && export S3D_LIB=$(realpath /root/repo/$2)
+rm -rf /tmp/p_tl; rocprofv3 --kernel-trace -d /tmp/p_tl --output-format csv -- python3 /root/repo/scripts/prof_pyramid.py ${1:-512} 3 1 > /dev/null 2>&1
+f=$(find /tmp/p_tl -name "*kernel_trace.csv" | head -1)
+python3 - "$f" <<'PY'
+import csv,sys
+rows=[r for r in csv.DictReader(open(sys.argv[1])) if 's3d::' in r['Kernel_Name']]
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+per=len(rows)//3
+last=rows[-per:]
+t0=int(last[0]['Start_Timestamp'])
+for r in last:
+    n=r['Kernel_Name'].split('(')[0].replace('void ','').replace('s3d::','')
+    s=(int(r['Start_Timestamp'])-t0)/1e3; e=(int(r['End_Timestamp'])-t0)/1e3
+    g=int(r['Grid_Size_X'])//max(int(r['Workgroup_Size_X']),1)
+    print(f"{n:26s} wgs {g:5d} q {r.get('Queue_Id','?'):>3s}  {s:8.1f} -> {e:8.1f}  ({e-s:7.1f} us)")
+PY
