@@ -48,7 +48,7 @@ namespace s3d {
 
 #if defined(S3D_EXP) && S3D_EXP == 20
 // in-kernel stamps (development): cycles per phase of a workgroup-plane, summed per wave, for a few workgroups
-__device__ unsigned long long g_stamp[64][4][8];
+__device__ unsigned long long g_stamp[64][4][10];
 #define S3D_STAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; }
 #else
 #define S3D_STAMP(i)
@@ -58,6 +58,12 @@ __device__ unsigned long long g_stamp[64][4][8];
 #ifndef S3D_DIAG
 #define S3D_DIAG 0
 #endif
+
+// Kernel-argument forms of Taps / EdgeFrac sized for the fused instantiations (hw <= 8): the general structs hold 65 taps
+// for the separable path, and a larger argument block costs this kernel 1-2 % (scalar loads / SGPR pressure).
+constexpr int kFusedMaxHW = 8;
+struct FTaps { float w[2 * kFusedMaxHW + 1]; };
+struct FEdge { float f[3][kFusedMaxHW + 1]; };
 
 // Packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two voxels per instruction at the issue cost of one scalar op, each lane an
 // ordinary IEEE multiply / add, so results stay bit-identical) is used where a thread has >= 4 independent accumulator
@@ -190,7 +196,7 @@ __device__ __forceinline__ int ring_slot(int s) {
 // ring insert + interior z-blur with the ring in place: plane s lives in slot s mod RING; K = q mod RING
 // is a compile-time constant inside each case of the caller's switch, so every ring index is static
 template <int HW, int K>
-__device__ __forceinline__ void zblur_static(f2 (&ring)[2][2 * HW + 2], const f2 (&v)[2], const Taps &t, bool interior,
+__device__ __forceinline__ void zblur_static(f2 (&ring)[2][2 * HW + 2], const f2 (&v)[2], const FTaps &t, bool interior,
                                              f2 (&out)[2]) {
 	constexpr int RING = 2 * HW + 2;
 #pragma unroll
@@ -230,8 +236,8 @@ __device__ __forceinline__ void zblur_static(f2 (&ring)[2][2 * HW + 2], const f2
 // pass, and the wave never waits for the load it has just issued.
 template <int HW, bool DOG, bool VEC, bool DMA, bool CR_ON>
 __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
-                                                 unsigned *__restrict__ dogmax, int nx, int ny, const ZRange zr, const Taps &t,
-                                                 const EdgeFrac &ef, int ntx, int nty, int cz, float *in_t, float *xb,
+                                                 unsigned *__restrict__ dogmax, int nx, int ny, const ZRange zr, const FTaps &t,
+                                                 const FEdge &ef, int ntx, int nty, int cz, float *in_t, float *xb,
                                                  float *s_red, float *s_ef, float4 *cring) {
 	using C = FusedCfg<HW>;
 	static_assert(!DMA || VEC, "LDS-DMA tiles need 16-byte pieces");
@@ -240,7 +246,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	// the boundary fractions are read through LDS: indexed dynamically out of the kernel-argument struct they would be global
 	// loads whose s_waitcnt vmcnt(0) makes EDGE tiles drain the tile prefetch every plane (and the slowest workgroup sets the
 	// kernel time)
-	if (threadIdx.x < 2 * (kMaxHW + 1)) s_ef[threadIdx.x] = ef.f[threadIdx.x / (kMaxHW + 1)][threadIdx.x % (kMaxHW + 1)];
+	if (threadIdx.x < 2 * (kFusedMaxHW + 1)) s_ef[threadIdx.x] = ef.f[threadIdx.x / (kFusedMaxHW + 1)][threadIdx.x % (kFusedMaxHW + 1)];
 	__syncthreads();
 
 	// ---- XCD-aware, bijective block -> (chunk, tile) mapping: blocks b, b+8, ... share an XCD ----
@@ -337,7 +343,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	const bool row_ok = y0 + ty < ny;
 
 #if defined(S3D_EXP) && S3D_EXP == 20
-	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+	unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
 #endif
 	const int q_begin = zc0 - HW - 1, q_end = zc1 - 1 + HW;  // inclusive
 	// DoG centre values G[i-1](p): requested one whole plane ahead (at the END of the previous iteration, after its
@@ -409,12 +415,16 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		// the tile prefetch (one wait, everything it covers is most of a plane old).  Not carried across the back-edge: hipcc
 		// copies a loop-carried load result there and waits for it.
 		if (!CR_ON) request_centres(p);
-		issue_plane_loads(q + 1);  // tile of the next plane: consumed (deposited in LDS) after this plane's z-blur
+#ifndef S3D_DMA_LATE
+#define S3D_DMA_LATE 0  /* 1: the LDS-DMA of the next plane is issued after barrier B (mid-plane) instead of at the top */
+#endif
+		if (!(DMA && S3D_DMA_LATE)) issue_plane_loads(q + 1);  // tile of the next plane: consumed (deposited in LDS) after this plane's z-blur
+		S3D_STAMP(8)  // issue of the centre + tile loads
 		float *const tin = DMA ? in_t + (q & 1) * BUF : in_t;  // tile of plane q
 		f2 v[2] = {f2{0.f, 0.f}, f2{0.f, 0.f}};
 		if (have_plane) {
 			if (DMA) {
-				constexpr int kAfter = C::NLD + ((DOG && !CR_ON) ? 1 : 0), kSt = DOG ? 2 : 1;
+				constexpr int kAfter = (S3D_DMA_LATE ? 0 : C::NLD) + ((DOG && !CR_ON) ? 1 : 0), kSt = DOG ? 2 : 1;
 				if (prev_stores == 1) wait_vmcnt<kAfter + kSt>();
 				else if (prev_stores == 0) wait_vmcnt<kAfter>();
 				else wait_vmcnt<0>();
@@ -543,7 +553,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 						const int k = e - ntop, m = yend - k;               // E[yend+k] = (1-f)*row[m-1] + f*row[m]
 						const int rd = yend + k - (y0 - HW - 1);
 						if (rd < C::ROWS) {
-							const float f = s_ef[kMaxHW + 1 + k];    // y fractions
+							const float f = s_ef[kFusedMaxHW + 1 + k];    // y fractions
 							const float a = xb[(m - 1 - (y0 - HW - 1)) * C::XP + xx], b = xb[(m - (y0 - HW - 1)) * C::XP + xx];
 							xb[rd * C::XP + xx] = (1.0f - f) * a + f * b;
 						}
@@ -552,6 +562,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 			}
 			S3D_STAMP(3)  // x-blur
 			lds_barrier();  // barrier B: xb visible, in_t free for the next plane
+			if (DMA && S3D_DMA_LATE) issue_plane_loads(q + 1);
 			S3D_STAMP(4)  // wait at barrier B
 			// ---------------- y-blur: xb -> registers (the 4 x-neighbours of row ty: four independent chains) ----------------
 			if (S3D_DIAG & 8) {
@@ -590,6 +601,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 				}
 			}
 		}
+		if (DMA && S3D_DMA_LATE && !have_plane) issue_plane_loads(q + 1);
 		S3D_STAMP(5)  // y-blur
 		// ---------------- ring insert (slot q mod RING) + z-blur of plane p = q - HW ----------------
 		const int pg = p + zoff;  // global plane
@@ -687,7 +699,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	}
 #if defined(S3D_EXP) && S3D_EXP == 20
 	if (HW == S3D_STAMP_HW && blockIdx.x < 64 && wlane == 0)
-		for (int i = 0; i < 8; i++) g_stamp[blockIdx.x][wid][i] = st_acc[i];
+		for (int i = 0; i < 10; i++) g_stamp[blockIdx.x][wid][i] = st_acc[i];
 #endif
 	if (DOG) {
 #pragma unroll
@@ -712,7 +724,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 template <int HW, bool DOG>
 __global__ void __launch_bounds__(FusedCfg<HW>::NT, (FusedCfg<HW>::OCC * 4 + FusedCfg<HW>::NW - 1) / FusedCfg<HW>::NW) k_fused_level(const float *__restrict__ src, float *__restrict__ dst,
                                                                        float *__restrict__ dog, unsigned *__restrict__ dogmax,
-                                                                       int nx, int ny, ZRange zr, Taps t, EdgeFrac ef, int ntx, int nty,
+                                                                       int nx, int ny, ZRange zr, FTaps t, FEdge ef, int ntx, int nty,
                                                                        int cz) {
 	using C = FusedCfg<HW>;
 	constexpr bool DMA = ((S3D_DMA_MASK >> HW) & 1) != 0;
@@ -721,7 +733,7 @@ __global__ void __launch_bounds__(FusedCfg<HW>::NT, (FusedCfg<HW>::OCC * 4 + Fus
 	__shared__ __attribute__((aligned(16))) float in_t[(DMA && kTileDma > kTile) ? kTileDma : kTile];  // + dump slot, see ld_lds
 	__shared__ __attribute__((aligned(16))) float xb[C::ROWS * C::XP];
 	__shared__ float s_red[C::NW];
-	__shared__ float s_ef[2 * (kMaxHW + 1)];
+	__shared__ float s_ef[2 * (kFusedMaxHW + 1)];
 	__shared__ __attribute__((aligned(16))) float4 cring[CR ? C::CR * C::NT : 1];
 	if ((nx & 3) == 0) fused_level_body<HW, DOG, true, DMA, CR>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef, cring);
 	else fused_level_body<HW, DOG, false, false, CR>(src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, in_t, xb, s_red, s_ef, cring);
@@ -740,8 +752,11 @@ static void edge_fractions(int n, int hw, float *f) {
 }
 
 template <int HW>
-static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
+static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &tg,
                       hipStream_t st, int plan_slots) {
+	static_assert(HW <= kFusedMaxHW, "argument structs");
+	FTaps t;
+	for (int i = 0; i < 2 * kFusedMaxHW + 1; i++) t.w[i] = i < 2 * HW + 1 ? tg.w[i] : 0.0f;
 	const int nz = zr.zo1 - zr.zo0;  // planes to produce
 	if (nz <= 0) return;
 	using C = FusedCfg<HW>;
@@ -771,7 +786,7 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 	}
 	const int cz = best_cz;
 	const int nchunks = (nz + cz - 1) / cz;
-	EdgeFrac ef;
+	FEdge ef;
 	memset(&ef, 0, sizeof(ef));
 	edge_fractions(nx, HW, ef.f[0]);
 	edge_fractions(ny, HW, ef.f[1]);
@@ -781,14 +796,14 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 	if (HW == S3D_STAMP_HW && nx >= 512 && dog) {
 		hipLaunchKernelGGL((k_fused_level<HW, true>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
 		hipStreamSynchronize(st);
-		static unsigned long long h[64][4][8];
+		static unsigned long long h[64][4][10];
 		hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h));
-		const char *nm[8] = {"wait+tile->LDS", "stores", "wait bar A", "x-blur", "wait bar B", "y-blur", "z-blur", "DoG+issue loads"};
+		const char *nm[10] = {"wait+tile->LDS", "stores", "wait bar A", "x-blur", "wait bar B", "y-blur", "z-blur", "DoG", "issue loads", "-"};
 		const int planes = cz + 2 * HW + 1;
 		for (int w = 0; w < 4; w++) {
 			fprintf(stderr, "STAMP hw %d wave %d (cycles per plane, mean of 64 WGs, %d planes):", HW, w, planes);
 			double tot = 0;
-			for (int i = 0; i < 8; i++) { double a = 0; for (int b = 0; b < 64; b++) a += (double)h[b][w][i]; a /= 64.0 * planes; tot += a; fprintf(stderr, " %s %.0f", nm[i], a); }
+			for (int i = 0; i < 9; i++) { double a = 0; for (int b = 0; b < 64; b++) a += (double)h[b][w][i]; a /= 64.0 * planes; tot += a; fprintf(stderr, " %s %.0f", nm[i], a); }
 			fprintf(stderr, " | total %.0f\n", tot);
 		}
 		return;

@@ -16,7 +16,10 @@
 
 namespace s3d {
 
-constexpr int kMaxHW = 16;              // largest Gaussian half width supported (33 taps)
+#ifndef S3D_MAX_HW
+#define S3D_MAX_HW 32
+#endif
+constexpr int kMaxHW = S3D_MAX_HW;              // largest Gaussian half width supported (65 taps; num_kp_levels = 1 needs 17)
 constexpr int kMaxTaps = 2 * kMaxHW + 1;
 constexpr int kDesc = SIFT3D_DESC_NUMEL;
 constexpr int kFaces = 20;

@@ -173,3 +173,22 @@ def test_matcher_vs_oracle_random(capi, orc):
     got = mt.enhancedMatch(a, ax, e, ex); want = orc.match(a, ax, e, ex, 0.85, 3)
     for k in want:
         assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("levels", [1, 2, 4])
+def test_nondefault_num_kp_levels(capi, orc, synth, levels):
+    """CreateCSIFT3D(..., num_kp_levels) != 3 (Include/cSIFT3D.h:184): other sigma schedule / half widths (levels without a fused
+    instantiation take the separable kernels), other count of DoG levels -- the first and the last one are formed on request."""
+    vol = synth.blobs((72, 64, 80), seed=11, noise=0.01)
+    g = capi.CreateCSIFT3D(vol, num_kp_levels=levels).KpSiftAlgorithm()
+    o = orc.extractor(vol, num_kp_levels=levels).run(5)
+    assert g.num_octaves == o.num_octaves
+    for oc in range(g.num_octaves):
+        for i in range(levels + 3):
+            assert np.array_equal(bits(g.gss(oc, i)), bits(o.gss(oc, i))), ("gss", oc, i)
+        for i in range(levels + 2):
+            assert np.array_equal(bits(g.dog(oc, i)), bits(o.dog(oc, i))), ("dog", oc, i)
+    assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema()))
+    kp, desc = g.GetKeypoints()
+    okp, odesc = o.keypoints()
+    compare_keypoints(kp, desc, okp, odesc)
