@@ -147,6 +147,7 @@ struct sift3d_ctx {
 	int own0 = 0, own1 = 0, halo = 0;
 	// single-volume path: DoG[o][0] and DoG[o][nd-1] are not written by the pyramid (see DetectLevels); copy_level forms them
 	bool dog_elide = false;
+	bool desc_lut_lds = true;       // every descriptor window weight table fits the LDS copy (kMaxDescLut)
 	bool ext_arena = false;         // level buffers live in memory owned by the caller
 	int part_rank = 0, part_world = 1;  // descriptor work split of replicated octaves
 
@@ -321,7 +322,7 @@ static int build_luts(sift3d_ctx *c) {
 				const int len = (int)floor((double)r2 / (double)uu) + 2;
 				WinLut &L = luts[((size_t)(o + c->octave_base) * 8 + lv) * 2 + which];
 				L.off = (int)pool.size(); L.len = len; L.nin = -1; L.radius = radius; L.sigma = sigma;
-				if (which == 1 && len > kMaxDescLut) { set_last_error("descriptor window larger than the LDS weight table"); return SIFT3D_ERR_ARG; }
+				if (which == 1 && len > kMaxDescLut) c->desc_lut_lds = false;  // k_describe<false>: table read from global memory
 				for (int n = 0; n < len; n++) {
 					const float sq = (float)n * uu;  // exact: equals the reference's fp32 sum of squares
 					float w;
@@ -608,7 +609,7 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		// ---- Extract_Description (Src/cSIFT3D.cc:484-502) ----
 		if (upto >= 5) {
 			launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, c->part_rank,
-			                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st);
+			                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st, c->desc_lut_lds);
 		}
 		if (upto >= 4) launch_finalize(c->d_ext, c->d_total, c->ext_cap, upto >= 5, c->d_kpout, c->d_xyz, c->kp_cap, st);
 		S3D_HIP(hipEventRecord(c->ev[5], st));
@@ -910,7 +911,7 @@ extern "C" int sift3d_run_describe(sift3d_handle c) {
 	S3D_HIP(hipEventRecord(c->ev[6], st));
 	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, st);
 	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, c->part_rank,
-	                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st);
+	                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st, c->desc_lut_lds);
 	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
 	S3D_HIP(hipEventRecord(c->ev[7], st));
 	unsigned host_words[3] = {0, 0, 0};
@@ -1154,7 +1155,7 @@ extern "C" int sift3d_slab_describe(sift3d_handle c) {
 	              c->p.corner_thresh, 0, 1, st);
 	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, st);
 	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, 0, 1, c->d_order, c->d_nkp,
-	                c->d_nkp + 1, st);
+	                c->d_nkp + 1, st, c->desc_lut_lds);
 	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
 	bool again;
 	rc = slab_count_and_regrow(c, again);

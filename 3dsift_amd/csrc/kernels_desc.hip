@@ -192,6 +192,9 @@ __device__ unsigned long long g_dstamp[64][4][8];
 #endif
 constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <= 64, a pop removes exactly 64
 
+// LUT_LDS: the window's weight table is staged in LDS (default parameters: 1293 entries).  Larger windows (sigma_default well
+// above 1.6) read the table from global memory instead (L2-resident, a few KB): slower, but no size limit.
+template <bool LUT_LDS>
 __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
                                                   const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap,
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
                                                   const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work) {
 	__shared__ unsigned s_item;
 	__shared__ unsigned long long hist[kDesc * kRep];  // [bin][replica], two's-complement fixed point, 2^-29 units
-	__shared__ float s_lut[kMaxDescLut];
+	__shared__ float s_lut[LUT_LDS ? kMaxDescLut : 1];
 	__shared__ float s_q[4][6][kQCap];                 // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
 	__shared__ float s_predn[12];
 	__shared__ int s_predf[32];
@@ -281,10 +284,11 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 
 		__syncthreads();  // previous keypoint finished with hist / s_lut
 		for (int i = tid; i < kDesc * kRep; i += 256) hist[i] = 0ull;
-		if (cur_lut != li) {
+		if (LUT_LDS && cur_lut != li) {
 			for (int i = tid; i < lut.len && i < kMaxDescLut; i += 256) s_lut[i] = lutpool[lut.off + i];
 			cur_lut = li;
 		}
+		const gfloat_p lut_g = as_global(lutpool) + lut.off;
 		__syncthreads();
 
 #if defined(S3D_EXP) && S3D_EXP == 5
@@ -371,7 +375,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 				// inside the 4x4x4 cube: the reference's !(b <= -0.5 || b >= 3.5) per axis (Src/cSIFT3D.cc:1299-1303); the
 				// coordinates are finite, so min/max over the three axes gives the same predicate in two v_min3/v_max3
 				bool act = in && fminf(fminf(bx, by), bz) > -0.5f && fmaxf(fmaxf(bx, by), bz) < 3.5f;
-				const float w = s_lut[in ? rr + dz * dz : 0];
+				const float w = LUT_LDS ? s_lut[in ? rr + dz * dz : 0] : lut_g[in ? rr + dz * dz : 0];
 				float gx = 0.5f * (nxp - nxm);
 				float gy = 0.5f * (nyp - nym);
 				float gz = 0.5f * (cp - cm);
@@ -466,10 +470,14 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels, const WinLut *d_luts,
                      const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world, const int *order,
-                     const unsigned *d_nkp, unsigned *d_work, hipStream_t st) {
+                     const unsigned *d_nkp, unsigned *d_work, hipStream_t st, bool lut_in_lds) {
 	(void)hipMemsetAsync(d_work, 0, sizeof(unsigned), st);
-	hipLaunchKernelGGL(k_describe, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-	                   part_rank, part_world, order, d_nkp, d_work);
+	if (lut_in_lds)
+		hipLaunchKernelGGL(k_describe<true>, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
+		                   part_rank, part_world, order, d_nkp, d_work);
+	else
+		hipLaunchKernelGGL(k_describe<false>, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
+		                   part_rank, part_world, order, d_nkp, d_work);
 #if defined(S3D_EXP) && S3D_EXP == 21
 	{
 		hipStreamSynchronize(st);

@@ -174,7 +174,7 @@ void upload_faces(const FaceConst *faces, const FacePredict *pred);  // into __c
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels,
                      const WinLut *d_luts, const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world,
                      const int *order, const unsigned *d_nkp, unsigned *d_work /* device counter, zeroed by the launch */,
-                     hipStream_t st);
+                     hipStream_t st, bool lut_in_lds = true);
 void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, int transposed,
                      sift3d_keypoint *d_out, float *d_xyz, unsigned kp_cap, hipStream_t st);
 

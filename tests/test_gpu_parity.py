@@ -192,3 +192,28 @@ def test_nondefault_num_kp_levels(capi, orc, synth, levels):
     kp, desc = g.GetKeypoints()
     okp, odesc = o.keypoints()
     compare_keypoints(kp, desc, okp, odesc)
+
+
+@pytest.mark.parametrize("params", [
+    dict(sigma_default=2.0),                          # wider kernels: half widths without a fused instantiation
+    dict(sigma_default=1.3, sigma_n_default=0.9),     # narrower base blur
+    dict(peak_thresh=0.05),                           # many more extrema
+    dict(peak_thresh=0.3, max_eig_thres=0.95, corner_thresh=0.2),
+    dict(num_kp_levels=2, sigma_default=2.4, peak_thresh=0.08),
+])
+def test_nondefault_parameters(capi, orc, synth, params):
+    """Every CreateCSIFT3D parameter (Include/cSIFT3D.h:184-194) away from its default, against the oracle."""
+    vol = synth.blobs((64, 72, 56), seed=21, noise=0.01)
+    g = capi.CreateCSIFT3D(vol, **params).KpSiftAlgorithm()
+    o = orc.extractor(vol, **params).run(5)
+    levels = params.get("num_kp_levels", 3)
+    assert g.num_octaves == o.num_octaves
+    for oc in range(g.num_octaves):
+        for i in range(levels + 3):
+            assert np.array_equal(bits(g.gss(oc, i)), bits(o.gss(oc, i))), ("gss", oc, i)
+        for i in range(levels + 2):
+            assert np.array_equal(bits(g.dog(oc, i)), bits(o.dog(oc, i))), ("dog", oc, i)
+    assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema()))
+    kp, desc = g.GetKeypoints()
+    okp, odesc = o.keypoints()
+    compare_keypoints(kp, desc, okp, odesc)
