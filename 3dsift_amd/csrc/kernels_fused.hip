@@ -267,9 +267,28 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 	// output mapping: thread (xq, ty) owns the 16-B piece x = 4*xq .. 4*xq+3 of tile row ty: one dwordx4 load (DoG centre) and
 	// two dwordx4 stores per plane instead of 12 scalar VMEM instructions (VMEM issue, not bytes, was the cost)
 	const int tid = threadIdx.x, xq = tid % (C::TX / 4), ty = tid / (C::TX / 4), wlane = tid & 63, wid = tid >> 6;
-	const bool edge_x = !(S3D_DIAG & 64) && ((x0 < HW) || (x0 + C::TX - 1 > nx - 2 - HW));
-	const bool edge_y = !(S3D_DIAG & 64) && ((y0 < HW) || (y0 + C::TY - 1 > ny - 2 - HW));
-	const bool need_row0 = !(S3D_DIAG & 64) && (y0 + C::TY - 1 > ny - 2 - HW);  // tile holds right-boundary y outputs (they reach y-hw-1)
+	// Edge tiles, fast form (volumes whose width and height are multiples of the tile; S3D_EDGE_FAST): the halo extension is
+	// produced where its source values already sit in registers, so edge tiles run the same two barriers per plane as interior
+	// tiles (a launch is one residency round: it lasts as long as its slowest tile).
+	//   left   E[-k] = src[k] and right E[xend+k] = (1-f_k) src[xend-k-1] + f_k src[xend-k]: formed in the register window of the
+	//          x-blur items that read them (first / last segment of a row; static window indices because xend = x0 + 31); the
+	//          LDS tile keeps the raw values, so the DoG centre ring needs no care
+	//   top    E[-k] = xb[k]: the x-blur item of row k stores its result a second time in row -k
+	//   bottom E[yend+k] = (1-f_k) xb[yend-k-1] + f_k xb[yend-k]: the fourth wave (it holds no x-blur item) blurs rows
+	//          yend-hw-1 .. yend again, one row per lane group, and combines neighbouring rows through a wave shuffle; it also
+	//          takes the extra low halo row the bottom tiles need
+	// Other shapes keep the patch loops below (two to three extra barriers per plane on edge tiles).
+#ifndef S3D_EDGE_FAST
+#define S3D_EDGE_FAST 1
+#endif
+	constexpr bool kFastOK = S3D_EDGE_FAST && VEC && !DMA && !C::PKX && C::NT == 256 && C::TX == 32 && C::TY == 32 && !(S3D_DIAG & 64);
+	const bool fast = kFastOK && (nx % C::TX == 0) && (ny % C::TY == 0);
+	const bool left_f = fast && !(S3D_DIAG & 256) && x0 == 0, right_f = fast && !(S3D_DIAG & 256) && x0 + C::TX == nx;
+	const bool top_f = fast && !(S3D_DIAG & 512) && y0 == 0, bottom_f = fast && !(S3D_DIAG & 1024) && y0 + C::TY == ny;
+	const bool edge_x = !fast && !(S3D_DIAG & 64) && ((x0 < HW) || (x0 + C::TX - 1 > nx - 2 - HW));
+	const bool edge_y = !fast && !(S3D_DIAG & 64) && ((y0 < HW) || (y0 + C::TY - 1 > ny - 2 - HW));
+	const bool load_row0 = !(S3D_DIAG & 64) && (y0 + C::TY - 1 > ny - 2 - HW);  // tile holds right-boundary y outputs (they reach y-hw-1)
+	const bool need_row0 = load_row0 && !fast;                                 // ... blurred by the loop below (fast: by wave 3)
 	const int sy = nx, sz = nx * ny;                         // levels are < 2^31 voxels (checked at create)
 	const bool full_tile = (x0 + C::TX <= nx) && (y0 + C::TY <= ny);  // every output of the tile is inside the volume
 
@@ -280,7 +299,7 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 		const int item = tid + i * C::NT;
 		const int r = item / C::W4, c4 = item - r * C::W4;
 		const int gy = y0 - HW - 1 + r, gx = x0 - C::HXL + 4 * c4;
-		bool ok = item < C::ROWS * C::W4 && gy >= 0 && gy < ny && (r > 0 || need_row0);
+		bool ok = item < C::ROWS * C::W4 && gy >= 0 && gy < ny && (r > 0 || load_row0);
 		if (VEC) ok = ok && gx >= 0 && gx + 3 < nx;
 		ld_goff[i] = ok ? gy * sy + gx : (DMA ? 0 : -1);  // DMA: clamped to a valid piece (its LDS image is never used: halo patches
 		                                                   // overwrite what edge outputs read, everything else feeds discarded outputs)
@@ -431,8 +450,10 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 			}
 			lds_barrier();  // barrier A: tile visible (and every thread is done with the previous xb)
 			S3D_STAMP(2)  // wait at barrier A
-			if (CR_ON)  // this thread's piece of the raw plane q -> its private ring slot
-				cring[(cslot_w)*C::NT + tid] = *reinterpret_cast<const float4 *>(&tin[(ty + HW + 1) * IP + C::HXL + 4 * xq]);
+			if (CR_ON) {  // this thread's piece of the raw plane q -> its private ring slot
+				float4 c4v = *reinterpret_cast<const float4 *>(&tin[(ty + HW + 1) * IP + C::HXL + 4 * xq]);
+				cring[(cslot_w)*C::NT + tid] = c4v;
+			}
 			if (edge_x) {
 				// the right-edge extension below overwrites column nx-1 of the tile with E[dim_end]: every thread must have parked
 				// its RAW centre piece first (the left-edge mirror only writes halo columns)
@@ -470,11 +491,19 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 #else
 			const int xitem0 = tid;
 #endif
-#pragma unroll 1
-			for (int item = xitem0; item < ((S3D_DIAG & 4) ? 0 : (C::ROWS - 1) * C::SEGS); item += C::NT) {
-				const int r = 1 + item / C::SEGS, seg = item % C::SEGS;
-				const int gy = y0 - HW - 1 + r;
-				if (gy >= 0 && gy < ny) {
+			// one item (8 outputs of one tile row) per thread; the fourth wave holds none and serves the bottom tiles (see `fast`)
+			int r = 1 + xitem0 / C::SEGS, seg = xitem0 % C::SEGS, xmode = 0;  // xmode 1: bottom helper row, 2: extra low halo row
+			bool xact = !(S3D_DIAG & 4) && xitem0 < (C::ROWS - 1) * C::SEGS;
+			if (bottom_f && tid >= 192) {  // wave-uniform
+				const int l = tid - 192;
+				if (l < (HW + 2) * 4) { xmode = 1; r = C::TY - 1 + (l >> 2); seg = l & 3; xact = true; }        // rows yend-hw-1 .. yend
+				else if (l < (HW + 3) * 4) { xmode = 2; r = 0; seg = l & 3; xact = true; }                  // row y0-hw-1
+			}
+			const int gy = y0 - HW - 1 + r;
+			xact = xact && gy >= 0 && gy < ny && !(bottom_f && xmode == 0 && gy == ny - 1);  // row yend of a bottom tile receives E[yend]
+			float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+			{
+				if (xact) {
 					if constexpr (C::PKX) {
 					const float *trow = &tin[r * IP] + C::WSTART + seg * 8;
 					// register window as pairs: E[i] = (w[2i], w[2i+1]) from the 16-B loads, O[i] = (w[2i+1], w[2i+2]) read
@@ -513,7 +542,25 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 						const float4 f = *reinterpret_cast<const float4 *>(trow + C::WSTART + seg * 8 + 4 * k);
 						win[4 * k] = f.x; win[4 * k + 1] = f.y; win[4 * k + 2] = f.z; win[4 * k + 3] = f.w;
 					}
-					float o[8];
+					// window index of tile column c for segment s: C::WOFF + HW + c - 8*s
+					if (left_f && seg == 0) {
+#pragma unroll
+						for (int k = 1; k <= HW; k++) win[C::WOFF + HW - k] = win[C::WOFF + HW + k];
+					}
+					if (right_f && seg == C::SEGS - 1) {
+						float e[HW + 1];
+#pragma unroll
+						for (int k = 0; k <= HW; k++) {
+							const float f = s_ef[k];  // x fractions
+							e[k] = (1.0f - f) * win[C::WOFF + HW + 6 - k] + f * win[C::WOFF + HW + 7 - k];
+						}
+#pragma unroll
+						for (int k = 0; k <= HW; k++) win[C::WOFF + HW + 7 + k] = e[k];
+					}
+					if (HW == 8 && right_f && seg == C::SEGS - 2) {  // the window of segment 2 ends on column xend = E[xend]
+						const float f = s_ef[0];
+						win[C::WOFF + HW + 15] = (1.0f - f) * win[C::WOFF + HW + 14] + f * win[C::WOFF + HW + 15];
+					}
 #pragma unroll
 					for (int j = 0; j < 8; j++) {
 						float acc = 0.0f;
@@ -521,9 +568,33 @@ __device__ __forceinline__ void fused_level_body(const float *__restrict__ src, 
 						for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * win[C::WOFF + j + HW - d];
 						o[j] = acc;
 					}
+					}
+				}
+			}
+			if constexpr (!C::PKX) {
+				if (xact && xmode != 1) {
 					float4 *xo = reinterpret_cast<float4 *>(&xb[r * C::XP + seg * 8]);
 					xo[0] = make_float4(o[0], o[1], o[2], o[3]);
 					xo[1] = make_float4(o[4], o[5], o[6], o[7]);
+					if (top_f && gy >= 1 && gy <= HW) {  // E[-k] = row k: second copy in the mirror row (those rows hold no item)
+						float4 *xm = reinterpret_cast<float4 *>(&xb[(HW + 1 - gy) * C::XP + seg * 8]);
+						xm[0] = make_float4(o[0], o[1], o[2], o[3]);
+						xm[1] = make_float4(o[4], o[5], o[6], o[7]);
+					}
+				}
+				if (bottom_f && tid >= 192) {  // wave-uniform: every lane of the fourth wave takes part in the shuffles
+					float a[8];
+#pragma unroll
+					for (int j = 0; j < 8; j++) a[j] = __shfl_up(o[j], 4, 64);  // the row below (same segment)
+					const int jr = (tid - 192) >> 2;                            // this lane holds xb row yend-hw-1+jr
+					if (xmode == 1 && jr >= 1) {
+						const int k = HW + 1 - jr;                                  // E[yend+k] = (1-f_k) xb[yend-k-1] + f_k xb[yend-k]
+						const float f = s_ef[kFusedMaxHW + 1 + k];                  // y fractions
+						float4 *xe = reinterpret_cast<float4 *>(&xb[(C::TY + HW + k) * C::XP + seg * 8]);
+						xe[0] = make_float4((1.0f - f) * a[0] + f * o[0], (1.0f - f) * a[1] + f * o[1], (1.0f - f) * a[2] + f * o[2],
+						                    (1.0f - f) * a[3] + f * o[3]);
+						xe[1] = make_float4((1.0f - f) * a[4] + f * o[4], (1.0f - f) * a[5] + f * o[5], (1.0f - f) * a[6] + f * o[6],
+						                    (1.0f - f) * a[7] + f * o[7]);
 					}
 				}
 			}
