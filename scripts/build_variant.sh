@@ -1,14 +1,16 @@
 #!/bin/bash
-# build a kernel-variant library for A/B timing: scripts/build_variant.sh NAME "-DS3D_...=..."  ->  variants/libsift3d_hip_NAME.so
+# build a kernel-variant library for A/B timing:
+#   scripts/build_variant.sh NAME "-DS3D_...=..." [source=kernels_fused]   ->  variants/libsift3d_hip_NAME.so
 set -e
 cd "$(dirname "$0")/.."
-name=$1; extra=$2
+name=$1; extra=$2; src=${3:-kernels_fused}
 mkdir -p variants 3dsift_amd/csrc/build_$name
 cd 3dsift_amd/csrc
-for f in context kernels_pyramid kernels_detect kernels_orient kernels_desc kernels_match; do
-  [ -f build/$f.o ] && cp -u build/$f.o build_$name/$f.o
+for f in context kernels_pyramid kernels_fused kernels_detect kernels_orient kernels_desc kernels_match; do
+  [ "$f" != "$src" ] && [ -f build/$f.o ] && cp -u build/$f.o build_$name/$f.o
 done
 FL="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value"
-/opt/rocm/bin/hipcc $extra $FL -fno-slp-vectorize -c kernels_fused.hip -o build_$name/kernels_fused.o
+[ "$src" = kernels_fused ] && FL="$FL -fno-slp-vectorize"
+/opt/rocm/bin/hipcc $extra $FL -c $src.hip -o build_$name/$src.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libsift3d_hip_$name.so build_$name/*.o
 echo built variants/libsift3d_hip_$name.so
