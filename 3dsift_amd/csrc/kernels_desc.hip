@@ -194,6 +194,8 @@ __device__ unsigned long long g_dstamp[64][4][8];
 #define S3D_DESC_X3 1
 #endif
 typedef float f3g __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f4g __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2g __attribute__((ext_vector_type(2), aligned(4)));
 constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <= 64, a pop removes exactly 64
 
 // LUT_LDS: the window's weight table is staged in LDS (default parameters: 1293 entries).  Larger windows (sigma_default well
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap,
                                                   int part_rank, int part_world, const int *__restrict__ order,
                                                   const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work) {
-	__shared__ unsigned s_item;
+	__shared__ unsigned s_item, s_tile;
 	__shared__ unsigned long long hist[kDesc * kRep];  // [bin][replica], two's-complement fixed point, 2^-29 units
 	__shared__ float s_lut[LUT_LDS ? kMaxDescLut : 1];
 	__shared__ float s_q[4][6][kQCap];                 // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
@@ -288,6 +290,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 
 		__syncthreads();  // previous keypoint finished with hist / s_lut
 		for (int i = tid; i < kDesc * kRep; i += 256) hist[i] = 0ull;
+		if (tid == 0) s_tile = 0u;
 		if (LUT_LDS && cur_lut != li) {
 			for (int i = tid; i < lut.len && i < kMaxDescLut; i += 256) s_lut[i] = lutpool[lut.off + i];
 			cur_lut = li;
@@ -305,6 +308,152 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		// Columns are dealt to the waves as 8x8 tiles of the window's (x, y) footprint: chord lengths (and the cube clip)
 		// vary slowly across a tile, so the lanes of a wave finish their z-march together (a 64x1 row segment spans
 		// the circle from rim to centre and leaves ~40 % of the lane-steps idle)
+#ifndef S3D_DESC_C2
+#define S3D_DESC_C2 1
+#endif
+#if S3D_DESC_C2
+		// Two adjacent columns (x, x+1) per lane, 8 lanes x 8 rows per wave = a 16 x 8 footprint.  The march is bound by the ISSUE
+		// of its vector-memory instructions, so the stencil of both columns comes from three loads per step: one 16-byte row
+		// piece (x-1 .. x+2) that also carries the centre values, requested two planes ahead, and two 8-byte pieces of the rows
+		// y-1 and y+1 -- 1.5 instructions per voxel instead of 4.  Queue order differs from the one-column form, the integer
+		// histogram sums do not.
+		constexpr int kLX = 8, kTH = 8;
+		const int tiles_x = (wx + 2 * kLX - 1) / (2 * kLX), tiles_y = (wy + kTH - 1) / kTH;
+		const int ntiles = ncol > 0 ? tiles_x * tiles_y : 0;
+		// tiles are handed to the four waves through an LDS counter: rim and centre tiles differ several-fold in work and a
+		// window only has 15-50 of them, so a static deal leaves waves idle at the barrier that closes the keypoint
+		for (;;) {
+			int tile = 0;
+			if (lane == 0) tile = (int)atomicAdd(&s_tile, 1u);
+			tile = __builtin_amdgcn_readfirstlane(tile);  // wave-uniform
+			if (tile >= ntiles) break;
+			const int ty = tile / tiles_x, tx = tile - ty * tiles_x;  // (a centre-out order, longest chords first, measured no better)
+			const int lxa = tx * 2 * kLX + 2 * (lane % kLX), ly = ty * kTH + (lane / kLX);
+			const int xa = x0 + lxa, y = y0 + ly;
+			const int dy = y - cyi;
+			const float vyd = (float)dy * u;
+			int rr[2], za[2], zb[2];
+			float px[2], py[2], pz[2];
+			bool colok[2];
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				const int dx = xa + k - cxi;
+				rr[k] = dx * dx + dy * dy;
+				colok[k] = tile < ntiles && lxa + k < wx && ly < wy && rr[k] <= nin;
+				const float vxd = (float)dx * u;
+				// partial rotations: (R0*vx + R1*vy) is evaluated first in the reference's left-to-right sums
+				px[k] = R0 * vxd + R1 * vyd; py[k] = R3 * vxd + R4 * vyd; pz[k] = R6 * vxd + R7 * vyd;
+				za[k] = 0; zb[k] = -1;
+				if (colok[k]) {
+					// in-sphere chord: dz^2 <= nin - rr
+					int h = (int)__fsqrt_rn((float)(nin - rr[k]));
+					while ((h + 1) * (h + 1) <= nin - rr[k]) h++;
+					while (h * h > nin - rr[k]) h--;
+					za[k] = max(z0, czi - h); zb[k] = min(z1, czi + h);
+					// clip the z range to the rotated 4x4x4 cube (iteration-count optimisation only, widened by 2 voxels: the
+					// reference's exact fp32 test still runs on every visited voxel)
+					float lo = (float)(za[k] - czi), hi = (float)(zb[k] - czi);
+					const float pr[3] = {px[k], py[k], pz[k]}, rr3[3] = {R2 * u, R5 * u, R8 * u};
+#pragma unroll
+					for (int r = 0; r < 3; r++) {
+						if (fabsf(rr3[r]) > 1e-6f * desc_hw) {
+							const float inv = __frcp_rn(rr3[r]);
+							const float t0 = (-desc_hw - pr[r]) * inv, t1 = (desc_hw - pr[r]) * inv;
+							lo = fmaxf(lo, fminf(t0, t1) - 2.0f);
+							hi = fminf(hi, fmaxf(t0, t1) + 2.0f);
+						} else if (fabsf(pr[r]) > desc_hw * 1.001f + 1.0f) {
+							hi = lo - 1.0f;  // this row never enters the cube
+						}
+					}
+					if (lo <= hi) { za[k] = max(za[k], czi + (int)floorf(lo)); zb[k] = min(zb[k], czi + (int)ceilf(hi)); }
+					else zb[k] = za[k] - 1;
+				}
+				if (!(colok[k] && zb[k] >= za[k])) { colok[k] = false; za[k] = 1 << 28; zb[k] = -(1 << 28); }  // empty column
+			}
+			const bool anycol = colok[0] || colok[1];
+			const int zA = min(za[0], za[1]), zB = max(zb[0], zb[1]);  // the lane marches the union of its two chords
+			const int zlen = anycol ? zB - zA + 1 : 0;
+			int maxlen = zlen;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+			maxlen = __builtin_amdgcn_readfirstlane(maxlen);
+			S3D_DSTAMP(1)  // batch setup (chord, cube clip)
+			if (maxlen == 0) continue;  // wave-uniform
+			// lanes without a column march on the keypoint's own column (always in bounds) and are masked.  Column a of a lane
+			// satisfies 1 <= x <= nx-2 whenever one of its columns is valid, so x-1 .. x+2 stays inside the level (x+2 = nx is the
+			// first element of the next row, and y <= ny-2).
+			gfloat_p c = zlen > 0 ? Ld + (size_t)xa + (size_t)sy * (size_t)y + (size_t)sz * (size_t)(zA - L.zoff) : centre;
+			typedef const f4g __attribute__((address_space(1))) *g4p;
+			typedef const f2g __attribute__((address_space(1))) *g2p;
+			f4g rowC = *reinterpret_cast<g4p>(c - 1);         // plane z:   x-1, a, b, x+2
+			f4g rowN = *reinterpret_cast<g4p>(c + sz - 1);    // plane z+1 (centres of both columns in .y .z)
+			f2g cmv = *reinterpret_cast<g2p>(c - sz);         // centres of plane z-1
+			f2g ymC = *reinterpret_cast<g2p>(c - sy), ypC = *reinterpret_cast<g2p>(c + sy);
+			int z = zA;
+			for (int step = 0; step < maxlen; step++) {
+				// software pipeline: the row piece of plane z+2 and the y rows of plane z+1 are requested now; clamped addresses stay
+				// inside the planes zA-1 .. zB+1 of the window
+				const bool more = step + 1 < zlen;
+				const gfloat_p cn = more ? c + sz : c;
+				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
+				const f2g ymN = *reinterpret_cast<g2p>(cn - sy), ypN = *reinterpret_cast<g2p>(cn + sy);
+				S3D_DSTAMP(2)  // back-edge + issue of the next step's loads
+				const int dz = z - czi;
+				const float vzd = (float)dz * u;
+				float bxk[2], byk[2], bzk[2], rxk[2], ryk[2], rzk[2];
+				bool actk[2];
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					const bool in = step < zlen && z >= za[k] && z <= zb[k];
+					float bx = px[k] + R2 * vzd, by = py[k] + R5 * vzd, bz = pz[k] + R8 * vzd;
+					bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
+					bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
+					// inside the 4x4x4 cube: the reference's !(b <= -0.5 || b >= 3.5) per axis (Src/cSIFT3D.cc:1299-1303)
+					bool act = in && fminf(fminf(bx, by), bz) > -0.5f && fmaxf(fmaxf(bx, by), bz) < 3.5f;
+					const float w = LUT_LDS ? s_lut[in ? rr[k] + dz * dz : 0] : lut_g[in ? rr[k] + dz * dz : 0];
+					const float nxm = k ? rowC.y : rowC.x, nxp = k ? rowC.w : rowC.z;
+					const float nym = k ? ymC.y : ymC.x, nyp = k ? ypC.y : ypC.x;
+					const float cp = k ? rowN.z : rowN.y, cm = k ? cmv.y : cmv.x;
+					float gx = 0.5f * (nxp - nxm);
+					float gy = 0.5f * (nyp - nym);
+					float gz = 0.5f * (cp - cm);
+					gx = gx * inv_u; gy = gy * inv_u; gz = gz * inv_u;
+					gx = gx * w; gy = gy * w; gz = gz * w;
+					const float rx = R0 * gx + R1 * gy + R2 * gz;
+					const float ry = R3 * gx + R4 * gy + R5 * gz;
+					const float rz = R6 * gx + R7 * gy + R8 * gz;
+					const float g2 = rx * rx + ry * ry + rz * rz;
+					actk[k] = act && !(g2 < kBaryEps);
+					bxk[k] = bx; byk[k] = by; bzk[k] = bz; rxk[k] = rx; ryk[k] = ry; rzk[k] = rz;
+				}
+				cmv = f2g{rowC.y, rowC.z}; rowC = rowN; rowN = rowNN; ymC = ymN; ypC = ypN;
+				c = cn; z += more ? 1 : 0;
+				S3D_DSTAMP(3)  // step arithmetic
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					// ---- push the active lanes into the wave's queue (compaction by ballot rank) ----
+					const unsigned long long m = __ballot(actk[k]);
+					if (m) {
+						if (actk[k]) {
+							const int pos = (qhead + qcount + (int)__popcll(m & ((1ull << lane) - 1ull))) & (kQCap - 1);
+							q[0][pos] = bxk[k]; q[1][pos] = byk[k]; q[2][pos] = bzk[k]; q[3][pos] = rxk[k]; q[4][pos] = ryk[k]; q[5][pos] = rzk[k];
+						}
+						qcount += (int)__popcll(m);
+					}
+					S3D_DSTAMP(4)  // push
+					// ---- a full wave of active voxels is ready: run the heavy part on all 64 lanes ----
+					if (qcount >= 64) {
+						const int pos = (qhead + lane) & (kQCap - 1);
+						accumulate_voxel(true, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], s_face, s_fidx, s_predn,
+						                 s_predf, hist_rep);
+						qhead = (qhead + 64) & (kQCap - 1);
+						qcount -= 64;
+					}
+					S3D_DSTAMP(5)  // pop (accumulate 64 voxels)
+				}
+			}
+		}
+#else
 #ifndef S3D_DESC_TW
 #define S3D_DESC_TW 8
 #endif
@@ -424,6 +573,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 				S3D_DSTAMP(5)  // pop (accumulate 64 voxels)
 			}
 		}
+#endif
 		if (qcount > 0) {  // drain (wave-uniform)
 			const int pos = (qhead + lane) & (kQCap - 1);
 			const bool valid = lane < qcount;
