@@ -141,14 +141,16 @@ __device__ int finish_orientation(DevKp &kp, const float T6[6], const float w3[3
 
 // LDS tiles of the orientation window: the default radius (3 * 1.5 * scale <= 11.43 voxels) gives <= 25 voxels per side,
 // + 2 for the central differences; larger windows (non-default sigma) take the global-load path
-constexpr int kTileW = 28, kTileH = 27, kTileLd = (27 * 27 + 63) / 64;
+constexpr int kTileW = 28, kTileH = 27;
+constexpr int kTilePc = ((kTileW / 4) * kTileH + 63) / 64;  // 16-byte pieces of a tile plane per lane (3)
+typedef float f4o __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte global piece at dword alignment
 constexpr int kOriLut = 256;  // squared-offset weight table of the orientation window (r^2 <= 131 by default)
 
 __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__restrict__ codes, const unsigned *__restrict__ d_count, unsigned cap,
                                                 const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                 const float *__restrict__ lutpool, float max_eig, float corner, int part_rank,
                                                 int part_world) {
-	__shared__ float s_tile[4 * 3 * kTileW * kTileH];  // per wave: planes z-1, z, z+1 of the window footprint
+	__shared__ __attribute__((aligned(16))) float s_tile[4 * 3 * kTileW * kTileH];  // per wave: planes z-1, z, z+1 of the window footprint
 	__shared__ float s_wlut[4 * kOriLut];
 	const unsigned count = min(d_count[0], cap);
 	const int lane = threadIdx.x & 63;
@@ -187,31 +189,36 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 			float *tile = &s_tile[(threadIdx.x >> 6) * 3 * kTileW * kTileH];
 			float *wl = &s_wlut[(threadIdx.x >> 6) * kOriLut];   // this wave's copy of the window weights
 			for (int i = lane; i < lut.len && i < kOriLut; i += 64) wl[i] = wtab[i];
-			const int tn = tw * th;
-			const float inv_tw = 1.0f / (float)tw;
-			int toff[kTileLd];   // per-lane tile offsets of the pieces this lane moves (same for every plane)
-			int goff[kTileLd];
+			// The tile planes travel as 16-byte pieces (dword-aligned global_load_dwordx4, ds_write_b128): 3 vector-memory
+			// instructions per lane and plane instead of 12 -- their ISSUE is what costs.  The last piece of a row may reach up to
+			// 3 floats past column tw-1: inside the level row, or in the next row / plane; only for a window in the far corner
+			// of a level these are the first bytes of the NEXT Gaussian level of the arena (levels 1..3 are never the last).
+			const int npx = (tw + 3) >> 2;   // pieces per tile row
+			const int tnp = npx * th;
+			const float inv_npx = 1.0f / (float)npx;
+			int toff[kTilePc];   // per-lane tile offsets of the pieces this lane moves (same for every plane)
+			int goff[kTilePc];
 #pragma unroll
-			for (int i = 0; i < kTileLd; i++) {
+			for (int i = 0; i < kTilePc; i++) {
 				const int idx = lane + 64 * i;
-				const int ty = (int)(((float)idx + 0.5f) * inv_tw);
-				const int tx = idx - ty * tw;
-				const bool ok = idx < tn;
-				toff[i] = ok ? ty * kTileW + tx : -1;
-				goff[i] = ok ? (x0 - 1 + tx) + (int)sy * (y0 - 1 + ty) : (x0 - 1) + (int)sy * (y0 - 1);
+				const int ty = (int)(((float)idx + 0.5f) * inv_npx);
+				const int px = idx - ty * npx;
+				const bool ok = idx < tnp;
+				toff[i] = ok ? ty * kTileW + 4 * px : -1;
+				goff[i] = ok ? (x0 - 1 + 4 * px) + (int)sy * (y0 - 1 + ty) : (x0 - 1) + (int)sy * (y0 - 1);
 			}
 			const gfloat_p base = Ld - sz * (size_t)L.zoff;
-			float pf[kTileLd];
+			f4o pf[kTilePc];
 			auto request = [&](int zp) {  // unconditional, clamped loads (planes z0-1 .. z1+1 are inside the level)
 				const gfloat_p pl = base + sz * (size_t)zp;
 #pragma unroll
-				for (int i = 0; i < kTileLd; i++) pf[i] = pl[goff[i]];
+				for (int i = 0; i < kTilePc; i++) pf[i] = *reinterpret_cast<const f4o __attribute__((address_space(1))) *>(pl + goff[i]);
 			};
 			auto deposit = [&](int slot) {
 				float *dstp = tile + slot * (kTileW * kTileH);
 #pragma unroll
-				for (int i = 0; i < kTileLd; i++)
-					if (toff[i] >= 0) dstp[toff[i]] = pf[i];
+				for (int i = 0; i < kTilePc; i++)
+					if (toff[i] >= 0) *reinterpret_cast<float4 *>(dstp + toff[i]) = make_float4(pf[i].x, pf[i].y, pf[i].z, pf[i].w);
 			};
 			request(z0 - 1); deposit(0);
 			request(z0);     deposit(1);
