@@ -172,9 +172,27 @@ __global__ void __launch_bounds__(256) k_downsample(const float *__restrict__ sr
 	}
 }
 
+// widths that are multiples of 4: one thread makes 4 consecutive outputs from two 16-byte loads and one 16-byte store
+// (0.75 vector-memory instructions per output instead of 2; this launch heads every octave's chain)
+typedef float f4d __attribute__((ext_vector_type(4), aligned(4)));
+__global__ void __launch_bounds__(256) k_downsample4(const float *__restrict__ src, int snx, int sny, float *__restrict__ dst,
+                                                     int nx4, int ny, int nz) {
+	const size_t total = (size_t)nx4 * ny * nz;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+		const int x4 = (int)(i % nx4);
+		const size_t r = i / nx4;
+		const int y = (int)(r % ny), z = (int)(r / ny);
+		const float *s = src + (size_t)(8 * x4) + (size_t)snx * ((size_t)(2 * y) + (size_t)sny * (size_t)(2 * z));
+		const f4d a = *reinterpret_cast<const f4d *>(s), b = *reinterpret_cast<const f4d *>(s + 4);
+		*reinterpret_cast<f4d *>(dst + 4 * i) = f4d{a.x, a.z, b.x, b.z};
+	}
+}
+
 void launch_downsample(const float *src, int snx, int sny, float *dst, int nx, int ny, int nz, hipStream_t st) {
 	const size_t total = (size_t)nx * ny * nz;
-	hipLaunchKernelGGL(k_downsample, dim3(grid_for(total, 256)), dim3(256), 0, st, src, snx, sny, dst, nx, ny, nz);
+	// 8*x4+7 <= 2*nx-1 <= snx-1: the two pieces stay inside the source row
+	if ((nx & 3) == 0) hipLaunchKernelGGL(k_downsample4, dim3(grid_for(total / 4, 256)), dim3(256), 0, st, src, snx, sny, dst, nx / 4, ny, nz);
+	else hipLaunchKernelGGL(k_downsample, dim3(grid_for(total, 256)), dim3(256), 0, st, src, snx, sny, dst, nx, ny, nz);
 }
 
 }  // namespace s3d
