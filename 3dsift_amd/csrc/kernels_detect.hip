@@ -17,7 +17,10 @@
 
 namespace s3d {
 
-constexpr int kRows = 16;   // rows per block
+#ifndef S3D_DET_ROWS
+#define S3D_DET_ROWS 32  /* rows per block: 32 measured best (detect 0.93 -> 0.84 ms at 512^3; 64: 1.01) */
+#endif
+constexpr int kRows = S3D_DET_ROWS;   // rows per block
 constexpr int kThreads = 256;
 
 // masks layout: word index = ((lvl * nz + z) * ny + y) * wpr + xw, wpr = ceil(nx / 64): scan order
