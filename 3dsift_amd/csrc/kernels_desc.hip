@@ -71,7 +71,17 @@ constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = 
 
 // reference Moller-Trumbore for ONE face whose constants sit at F[0..15]:
 // e1(0..2) e2(3..5) t(6..8) q(9..11) qe2(12); returns pass/fail exactly like Check_intersect_faces' body
-__device__ __forceinline__ bool face_test(const float *F, float gx, float gy, float gz, float &b0, float &b1, float &b2) {
+#ifndef S3D_FACE_T
+#define S3D_FACE_T 1  /* face constants transposed in LDS ([constant][face]): lanes with different faces read different banks */
+#endif
+#if S3D_FACE_T
+#define FC(i) Fb[(i) * kFaceT]
+#else
+#define FC(i) Fb[i]
+#endif
+constexpr int kFaceT = 20;  // faces per constant row of the transposed table
+__device__ __forceinline__ bool face_test(const float *Fb, float gx, float gy, float gz, float &b0, float &b1, float &b2) {
+	const float F[13] = {FC(0), FC(1), FC(2), FC(3), FC(4), FC(5), FC(6), FC(7), FC(8), FC(9), FC(10), FC(11), FC(12)};
 	const float px = gy * F[5] - gz * F[4];
 	const float py = gz * F[3] - gx * F[5];
 	const float pz = gx * F[4] - gy * F[3];
@@ -129,7 +139,11 @@ __device__ __forceinline__ void accumulate_voxel(bool valid, float bx, float by,
 		}
 		const int bits = (rx < 0.f ? 1 : 0) | (ry < 0.f ? 2 : 0) | (rz < 0.f ? 4 : 0);
 		f = s_predf[kb * 8 + bits];
+#if S3D_FACE_T
+		const bool ok = face_test(&s_face[f], rx, ry, rz, b0, b1, b2);
+#else
 		const bool ok = face_test(&s_face[f * kFaceStride], rx, ry, rz, b0, b1, b2);
+#endif
 		slow = !(ok && b0 >= kFastMargin && b1 >= kFastMargin && b2 >= kFastMargin);
 	}
 	if (__any(slow)) {
@@ -228,7 +242,11 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		else if (j < 9) v = F.t[j - 6];
 		else if (j < 12) v = F.q[j - 9];
 		else if (j == 12) v = F.qe2;
+#if S3D_FACE_T
+		s_face[j * kFaceT + f] = v;  // j < 16 rows of 20 faces: same 320 floats
+#else
 		s_face[i] = v;
+#endif
 	}
 	for (int i = tid; i < kFaces * 4; i += 256) s_fidx[i] = (i & 3) < 3 ? c_faces[i >> 2].idx[i & 3] : 0;
 	if (tid < 12) s_predn[tid] = c_pred.n[tid / 3][tid % 3];
