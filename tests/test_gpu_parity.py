@@ -73,6 +73,9 @@ def test_g4_g6_golden_keypoints(capi, synth, tag):
     ((128, 96, 80), 9, 0.0),        # 4 octaves, non-cubic
     ((48, 50, 45), 3, 0.01),        # odd width: scalar (non 16-byte) load/store path of the fused kernel
     ((40, 37, 54), 4, 0.0),         # nx % 4 == 2, odd ny
+    ((96, 64, 32), 6, 0.01),        # nx = 32: ONE tile column (left and right edge in the same tile), two tile rows; edge fast path
+    ((40, 32, 64), 8, 0.0),         # ny = 32: one tile row (top and bottom edge in the same tile), two tile columns
+    ((33, 96, 96), 10, 0.01),       # 3 x 3 tiles: every edge class and an interior tile, odd depth
 ])
 def test_full_pipeline_vs_oracle(capi, orc, synth, shape, seed, noise):
     vol = synth.blobs(shape, seed=seed, noise=noise)
