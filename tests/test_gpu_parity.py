@@ -220,3 +220,26 @@ def test_nondefault_parameters(capi, orc, synth, params):
     kp, desc = g.GetKeypoints()
     okp, odesc = o.keypoints()
     compare_keypoints(kp, desc, okp, odesc)
+
+
+def test_dog_elision_matches_eager_build(capi, synth, tmp_path):
+    """The single-volume path does not write the first / last DoG level of an octave (the extrema test forms those values from
+    the Gaussian levels).  A fresh process with S3D_DOG_EAGER=1 (every DoG level written, as the z-slab path does) must give
+    the same keypoints and the same DoG levels bit for bit."""
+    import subprocess, sys, hashlib, os
+    code = (
+        "import importlib,hashlib,sys,numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "capi=importlib.import_module('3dsift_amd.capi'); synth=importlib.import_module('3dsift_amd.synth')\n"
+        "ex=capi.CreateCSIFT3D(synth.blobs((72,96,64),seed=3,noise=0.01)).KpSiftAlgorithm()\n"
+        "h=hashlib.sha1(); kp,d=ex.GetKeypoints(); h.update(kp.tobytes()); h.update(d.tobytes())\n"
+        "[h.update(ex.dog(o,i).tobytes()) for o in range(ex.num_octaves) for i in range(5)]\n"
+        "print('HASH',h.hexdigest(),len(kp))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    )
+    outs = []
+    for eager in ("0", "1"):
+        env = dict(os.environ, S3D_DOG_EAGER=eager)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
+    assert outs[0] == outs[1] and int(outs[0].split()[2]) > 20
