@@ -790,6 +790,7 @@ bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogm
                         const Taps &t, hipStream_t st, int plan_slots) {
 	// the halo-extension form of the boundary rule needs n >= 2*hw+2 along x and y (see header)
 	if (nx < 2 * t.hw + 2 || ny < 2 * t.hw + 2) return false;
+	if (launch_march_level(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots)) return true;  // tile-aligned shapes (kernels_march.hip)
 	switch (t.hw) {
 	case 2: launch_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
 	case 3: launch_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;

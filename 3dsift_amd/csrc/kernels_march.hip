@@ -1,0 +1,398 @@
+// kernels_march.hip -- the pyramid hot kernel for tile-aligned levels (nx, ny multiples of 32): ONE pass over HBM per level,
+// one workgroup barrier per plane, no register ring.
+//
+//   G[i] = gauss_z(gauss_y(gauss_x(G[i-1])))   and   DoG[i-1] = (G[i] - G[i-1]) * (-1)   and   max|DoG[i-1]|
+//
+// replaces, per level, GaussianSmooth_3D + Im_permute + Sub + im_max_abs (Src/cSIFT3D.cc:535-882, Src/cUtil.cc:587-605) exactly
+// like kernels_fused.hip (which stays the path for every other shape); the arithmetic contract is the same: every output is the
+// literal chain acc = acc + tap[d+hw]*term for d = -hw..+hw with separate IEEE multiply and add (-ffp-contract=off), boundary terms
+// through the extended line E[] of kernels_fused.hip's header (E[-k] = src[k]; E[dim_end+k] = (1-f_k) src[dim_end-k-1] + f_k src[dim_end-k]).
+//
+// What is different (r02; the old kernel issued 230 lane-instructions per voxel at hw 8 against 102 of blur arithmetic, had 41-52 %
+// LDS bank-conflict cycles and two barriers per plane):
+//   * the z-blur is a SCATTER into 2*hw running sums instead of a gather from a ring of 2*hw+2 planes.  The reference adds the terms
+//     of output p in the order src[p+hw], src[p+hw-1], ... src[p-hw] (d = -hw..+hw), so a workgroup that marches DOWN in z sees the
+//     terms of every pending output in exactly that order: with v the xy-blurred value of the plane just processed,
+//         out   = A[2hw-1] + tap[2hw]*v        (output p = plane + hw is complete)
+//         A[s]  = A[s-1]   + tap[s]  *v        s = 2hw-1 .. 1
+//         A[0]  = 0        + tap[0]  *v
+//     -- the shift of the pending sums is the destination register of the add: no ring, no moves, static register indices.
+//   * z boundaries are a FEED ORDER, not a slow path: the chunk that ends at the top of the volume first walks up the planes
+//     dim_end-hw-1 .. dim_end, feeding the lerps E[dim_end+hw] .. E[dim_end] of consecutive xy-blurred planes, then down through the
+//     real planes; the chunk that ends at plane 0 goes on with planes 1 .. hw again (E[-k] = plane k).
+//   * the tile of the next plane travels global -> LDS by LDS-DMA (global_load_lds_dwordx4) into the other half of a double buffer;
+//     the x-blurred tile is double buffered too and the y/z work runs one plane behind the x-blur, so a plane costs ONE barrier.
+//   * LDS layouts are conflict-free for the 16-byte accesses of gfx950 (ds_read_b128 is served in the lane groups {0-3,12-15,20-27},
+//     {4-11,16-19,28-31}, +32; 64 banks): tile row pitch = W4 pieces with piece c of row r stored at piece c ^ (r & 1), x-blur work items
+//     dealt to lanes so that the four rows of a lane group differ in (r & 1) and in bit 3 of r * W4; x-blurred tile pitch 32 floats.
+//   * global stores and DMA loads take an SGPR base + 32-bit VGPR offset (no 64-bit vector address arithmetic in the loop).
+#include <string.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#include "sift3d_internal.h"
+
+namespace s3d {
+
+constexpr int kMarchMaxHW = 8;
+struct MTaps { float w[2 * kMarchMaxHW + 1]; };
+struct MEdge { float f[3][kMarchMaxHW + 1]; };  // x, y, z fractions of the right-boundary rule
+typedef float mf4 __attribute__((ext_vector_type(4)));
+
+template <int HW>
+struct MCfg {
+	static constexpr int TX = 32, TY = 32, NT = 256;
+	static constexpr int HX = ((HW + 3) / 4) * 4;          // x halo per side (floats, whole 16-byte pieces)
+	static constexpr int W = TX + 2 * HX, W4 = W / 4;      // tile row: 12 pieces (hw >= 5) or 10 (hw <= 4)
+	static constexpr int ROWS = TY + 2 * HW;               // row r <-> y = y0 - HW + r
+	static constexpr int NITEMS = ROWS * W4;               // 16-byte pieces per plane
+	static constexpr int NWI = (NITEMS + 63) / 64;         // DMA wave-instructions per plane (1 KiB each)
+	static constexpr int NDMA = (NWI + 3) / 4;             // ... per wave (wave w takes instructions w, w+4, ...)
+	static constexpr int TILE_F = NWI * 256;               // floats per tile buffer
+	static constexpr int XP = 32, XB_F = ROWS * XP;        // x-blurred tile
+	static constexpr int WOFF = HX - HW;                   // window index of input x-hw of output 0 (the window starts at piece 2*seg)
+	static constexpr int WN4 = (WOFF + 8 + 2 * HW + 3) / 4;
+	static constexpr int CRN = HW + 1;                     // DoG centre ring: plane p is needed HW steps after it was loaded
+	static_assert(W4 % 2 == 0 && 6 + WN4 <= W4, "tile geometry");
+	static_assert(ROWS <= 48, "x-blur items of waves 0..2; wave 3 serves the bottom tiles");
+};
+
+__device__ __forceinline__ void m_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void m_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// LDS-DMA: lane l's 16 bytes at base + voff land at lds_dst + 16*l.  M0 carries the wave-uniform LDS byte address (restored).
+__device__ __forceinline__ void m_dma16(const float *base, unsigned voff, unsigned lds_dst) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+// untracked store (hipcc would make later loads that re-use the data registers wait for the store to COMPLETE); nothing reads
+// dst / dog back in this kernel.  The wait states cover the hardware's read of the four data registers.
+__device__ __forceinline__ void m_store16(float *base, unsigned voff, mf4 d) {
+	asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 2" ::"v"(voff), "v"(d), "s"(base));
+}
+
+__device__ __forceinline__ float m_absmax(float m, float v) {
+	const float a = fabsf(v);
+	return (a > m) ? a : m;
+}
+
+#ifndef S3D_MARCH_OCC
+#define S3D_MARCH_OCC 3
+#endif
+
+template <int HW, bool DOG, bool CR>
+__global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
+                                                        unsigned *__restrict__ dogmax, int nx, int ny, ZRange zr, MTaps t, MEdge ef, int ntx,
+                                                        int nty, int cz) {
+	using C = MCfg<HW>;
+	__shared__ __attribute__((aligned(1024))) float tile[2 * C::TILE_F];
+	__shared__ __attribute__((aligned(16))) float xb[2 * C::XB_F];
+	__shared__ __attribute__((aligned(16))) mf4 cring[CR ? C::CRN * C::NT : 1];
+	__shared__ float s_ef[3 * (kMarchMaxHW + 1)];
+	__shared__ float s_red[4];
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+	if (tid < 3 * (kMarchMaxHW + 1)) s_ef[tid] = ef.f[tid / (kMarchMaxHW + 1)][tid % (kMarchMaxHW + 1)];
+
+	// ---- XCD-aware, bijective block -> (chunk, tile): blocks b, b+8, ... share an XCD and get neighbouring tiles ----
+	int lb;
+	{
+		const int nblocks = gridDim.x, b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+		const int per = nblocks >> 3, rem = nblocks & 7;
+		lb = xcd * per + min(xcd, rem) + idx;
+	}
+	const int tile_x = lb % ntx, tile_y = (lb / ntx) % nty, chunk = lb / (ntx * nty);
+	const int x0 = tile_x * C::TX, y0 = tile_y * C::TY;
+	const int nz = zr.nz, zoff = zr.zoff, dim_end = zr.nzg - 1;
+	const int zc0 = zr.zo0 + chunk * cz, zc1 = min(zr.zo1, zc0 + cz);
+	const int sy = nx, sz = nx * ny;
+	const bool left_f = x0 == 0, right_f = x0 + C::TX == nx, top_f = y0 == 0, bottom_f = y0 + C::TY == ny;
+
+	// ---- DMA items of this lane: LDS piece i of the tile buffer holds (row r = i / W4, piece (i % W4) ^ (r & 1)) ----
+	unsigned goffb[C::NDMA];
+#pragma unroll
+	for (int i = 0; i < C::NDMA; i++) {
+		const int item = (wid + 4 * i) * 64 + lane;
+		const int r = item / C::W4, cs = item - r * C::W4, c = cs ^ (r & 1);
+		const int gy = y0 - HW + r, gx = x0 - C::HX + 4 * c;
+		const bool ok = item < C::NITEMS && gy >= 0 && gy < ny && gx >= 0 && gx + 3 < nx;
+		// pieces outside the volume: any valid address (their LDS image is replaced in registers by the edge rules or never read)
+		goffb[i] = (unsigned)(ok ? gy * sy + gx : y0 * sy + x0) * 4u;
+	}
+	const unsigned lds_tile = (unsigned)(unsigned long long)tile + (unsigned)wid * 1024u;
+
+	// ---- x-blur item of this lane: 8 outputs of one tile row; rows dealt so that every ds_read_b128 lane group is conflict-free ----
+	int xr, xseg;
+	{
+		const int l5 = lane & 31;
+		int g, jj;  // lane group (of 16) and index inside it, in the hardware's service order
+		if (l5 < 4) { g = 0; jj = l5; }
+		else if (l5 < 12) { g = 1; jj = l5 - 4; }
+		else if (l5 < 16) { g = 0; jj = l5 - 8; }
+		else if (l5 < 20) { g = 1; jj = l5 - 8; }
+		else if (l5 < 28) { g = 0; jj = l5 - 12; }
+		else { g = 1; jj = l5 - 16; }
+		g += (lane >> 5) * 2;
+		const int q = jj >> 2;
+		// W4 = 12: four consecutive rows (r*12 mod 16 = 0,12,8,4; odd rows swizzled);  W4 = 10: rows {r, r+4, r+1, r+5}
+		const int rs = C::W4 == 12 ? 4 * g + q : ((g & 1) * 2 + (g >> 1) * 8 + (q & 1) * 4 + (q >> 1));
+		xr = 16 * wid + rs;
+		xseg = jj & 3;
+	}
+	bool xact = xr < C::ROWS, xhelp = false;
+	if (bottom_f && wid == 3) {  // wave 3 holds no item: it re-blurs rows yend-hw-1 .. yend for the bottom extension E[yend+k]
+		if (lane < (HW + 2) * 4) { xr = C::TY - 2 + (lane >> 2); xseg = lane & 3; xact = true; xhelp = true; }
+	}
+	{
+		const int gy = y0 - HW + xr;
+		xact = xact && gy >= 0 && gy < ny && (xhelp || !(bottom_f && gy == ny - 1));  // row yend of a bottom tile receives E[yend]
+	}
+	const int xgy = y0 - HW + xr;
+	const int xsw = xr & 1;
+	const int xbase_e = (xr * C::W4 + 2 * xseg + xsw) * 4, xbase_o = (xr * C::W4 + 2 * xseg - xsw) * 4;  // float offsets of even / odd window pieces
+	const int xout = xr * C::XP + xseg * 8;
+	const bool xmirror = top_f && !xhelp && xgy >= 1 && xgy <= HW;   // E[-k] = row k: second copy in the mirror row
+	const int xout_m = (HW - xgy) * C::XP + xseg * 8;
+
+	// ---- y/z work: thread (xq, ty) owns the 16-byte piece x = x0 + 4*xq .. +3 of row y0 + ty ----
+	const int xq = tid & 7, ty = tid >> 3;
+	const int ycol = ty * C::XP + 4 * xq;
+	const unsigned out_voff = (unsigned)((y0 + ty) * sy + x0 + 4 * xq) * 4u;
+	const int park_off = ((ty + HW) * C::W4 + ((C::HX / 4 + xq) ^ ((ty + HW) & 1))) * 4;  // raw centre piece in the tile
+
+	float A[2 * HW][4];
+#pragma unroll
+	for (int s = 0; s < 2 * HW; s++)
+#pragma unroll
+		for (int c = 0; c < 4; c++) A[s][c] = 0.0f;
+	float prevx[4] = {0.f, 0.f, 0.f, 0.f};
+	float mx = 0.0f;
+
+	// feed order (global E index e, descending): e_top = highest term of the chunk's top output
+	const int e_top = zc1 - 1 + zoff + HW, e_bot = zc0 + zoff - HW;
+	const int e_start = e_top + (e_top >= dim_end ? 1 : 0);  // +1: priming step (loads plane dim_end-hw-1, feeds nothing that is kept)
+	const int nsteps = e_start - e_bot + 1;
+	auto plane_ptr = [&](int e) {
+		const int L = e < 0 ? -e : (e > dim_end ? 2 * dim_end - e : e);
+		return src + (size_t)sz * (size_t)min(max(L - zoff, 0), nz - 1);
+	};
+	auto issue_dma = [&](int jn) {
+		const float *pl = plane_ptr(e_start - jn);
+		const unsigned dstb = lds_tile + (unsigned)(jn & 1) * (unsigned)(C::TILE_F * 4);
+#pragma unroll
+		for (int i = 0; i < C::NDMA; i++)
+			if (wid + 4 * i < C::NWI) m_dma16(pl, goffb[i], dstb + (unsigned)(i * 4096));
+	};
+	if (zc0 >= zc1) return;  // uniform (never for a planned grid)
+	issue_dma(0);
+	m_wait_vmcnt<0>();
+	__syncthreads();  // also publishes s_ef
+
+#pragma unroll 1
+	for (int j = 0; j <= nsteps; j++) {
+		const int buf = j & 1;
+		// DoG centre values of the output this step completes, without a centre ring: requested before anything else of the step
+		const int e_out = e_start - (j - 1);            // feed consumed by the y/z stage of this step
+		const int p_loc = e_out + HW - zoff;            // output plane it completes (local)
+		const bool emit = j >= 1 && p_loc >= zc0 && p_loc < zc1;
+		mf4 cen = {0.f, 0.f, 0.f, 0.f};
+		if (DOG && !CR) cen = *reinterpret_cast<const mf4 *>(reinterpret_cast<const char *>(src + (size_t)sz * (size_t)min(max(p_loc, 0), nz - 1)) + out_voff);
+		if (j + 1 < nsteps) issue_dma(j + 1);
+
+		// ---------------- x-blur of feed j: tile[buf] -> xb[buf] ----------------
+		if (j < nsteps) {
+			float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+			if (xact) {
+				const float *tb = tile + buf * C::TILE_F;
+				float win[C::WN4 * 4];
+#pragma unroll
+				for (int k = 0; k < C::WN4; k++) {
+					const mf4 f = *reinterpret_cast<const mf4 *>(tb + ((k & 1) ? xbase_o : xbase_e) + 4 * k);
+					win[4 * k] = f.x; win[4 * k + 1] = f.y; win[4 * k + 2] = f.z; win[4 * k + 3] = f.w;
+				}
+				// window index of tile column c (0 = x0) for segment s: WOFF + HW + c - 8*s
+				if (left_f && xseg == 0) {
+#pragma unroll
+					for (int k = 1; k <= HW; k++) win[C::WOFF + HW - k] = win[C::WOFF + HW + k];
+				}
+				if (right_f && xseg == 3) {
+					float e[HW + 1];
+#pragma unroll
+					for (int k = 0; k <= HW; k++) {
+						const float f = s_ef[k];
+						e[k] = (1.0f - f) * win[C::WOFF + HW + 6 - k] + f * win[C::WOFF + HW + 7 - k];
+					}
+#pragma unroll
+					for (int k = 0; k <= HW; k++) win[C::WOFF + HW + 7 + k] = e[k];
+				}
+				if (HW == 8 && right_f && xseg == 2) {  // the window of segment 2 ends on column xend = E[xend]
+					const float f = s_ef[0];
+					win[C::WOFF + HW + 15] = (1.0f - f) * win[C::WOFF + HW + 14] + f * win[C::WOFF + HW + 15];
+				}
+#pragma unroll
+				for (int jo = 0; jo < 8; jo++) {
+					float acc = 0.0f;
+#pragma unroll
+					for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * win[C::WOFF + jo + HW - d];
+					o[jo] = acc;
+				}
+				if (!xhelp) {
+					float *xo = xb + buf * C::XB_F;
+					*reinterpret_cast<mf4 *>(xo + xout) = mf4{o[0], o[1], o[2], o[3]};
+					*reinterpret_cast<mf4 *>(xo + xout + 4) = mf4{o[4], o[5], o[6], o[7]};
+					if (xmirror) {
+						*reinterpret_cast<mf4 *>(xo + xout_m) = mf4{o[0], o[1], o[2], o[3]};
+						*reinterpret_cast<mf4 *>(xo + xout_m + 4) = mf4{o[4], o[5], o[6], o[7]};
+					}
+				}
+			}
+			if (bottom_f && wid == 3) {  // wave-uniform: every lane takes part in the shuffles
+				float a[8];
+#pragma unroll
+				for (int jo = 0; jo < 8; jo++) a[jo] = __shfl_up(o[jo], 4, 64);  // the row below (same segment)
+				const int jr = lane >> 2;                                       // this lane holds x-blurred row yend-hw-1+jr
+				if (xhelp && jr >= 1) {
+					const int k = HW + 1 - jr;                                  // E[yend+k] = (1-f_k) xb[yend-k-1] + f_k xb[yend-k]
+					const float f = s_ef[kMarchMaxHW + 1 + k];
+					float *xe = xb + buf * C::XB_F + (C::TY - 1 + HW + k) * C::XP + xseg * 8;
+					*reinterpret_cast<mf4 *>(xe) = mf4{(1.0f - f) * a[0] + f * o[0], (1.0f - f) * a[1] + f * o[1], (1.0f - f) * a[2] + f * o[2],
+					                                   (1.0f - f) * a[3] + f * o[3]};
+					*reinterpret_cast<mf4 *>(xe + 4) = mf4{(1.0f - f) * a[4] + f * o[4], (1.0f - f) * a[5] + f * o[5], (1.0f - f) * a[6] + f * o[6],
+					                                       (1.0f - f) * a[7] + f * o[7]};
+				}
+			}
+		}
+
+		// ---------------- y-blur, feed and z-scatter of feed j-1: xb[buf ^ 1] ----------------
+		int nst = 0;
+		if (j >= 1) {
+			const float *yc = xb + (buf ^ 1) * C::XB_F + ycol;
+			float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+			for (int s = 0; s <= 2 * HW; s++) {  // step s = d + HW reads row ty + 2*HW - s
+				const mf4 rv = *reinterpret_cast<const mf4 *>(yc + (2 * HW - s) * C::XP);
+				const float tap = t.w[s];
+				v[0] = v[0] + tap * rv.x; v[1] = v[1] + tap * rv.y; v[2] = v[2] + tap * rv.z; v[3] = v[3] + tap * rv.w;
+			}
+			if (e_out >= dim_end) {  // wave-uniform, top chunk only: E[dim_end+k] = (1-f_k) X[dim_end-k-1] + f_k X[dim_end-k]
+				const float f = s_ef[2 * (kMarchMaxHW + 1) + min(e_out - dim_end, HW)];
+#pragma unroll
+				for (int c = 0; c < 4; c++) {
+					const float xn = v[c];
+					v[c] = (1.0f - f) * prevx[c] + f * xn;
+					prevx[c] = xn;
+				}
+			}
+			float out[4];
+#pragma unroll
+			for (int c = 0; c < 4; c++) out[c] = A[2 * HW - 1][c] + t.w[2 * HW] * v[c];
+#pragma unroll
+			for (int s = 2 * HW - 1; s >= 1; s--)
+#pragma unroll
+				for (int c = 0; c < 4; c++) A[s][c] = A[s - 1][c] + t.w[s] * v[c];
+#pragma unroll
+			for (int c = 0; c < 4; c++) A[0][c] = 0.0f + t.w[0] * v[c];
+
+			if (DOG && CR) cen = cring[(j % C::CRN) * C::NT + tid];  // parked HW+1 steps ago (read before this step's park below)
+			if (emit) {
+				float *gb = dst + (size_t)sz * (size_t)p_loc;
+				m_store16(gb, out_voff, mf4{out[0], out[1], out[2], out[3]});
+				nst = 1;
+				if (DOG) {
+					float dg[4];
+					dg[0] = (out[0] - cen.x) * (-1.0f); dg[1] = (out[1] - cen.y) * (-1.0f);
+					dg[2] = (out[2] - cen.z) * (-1.0f); dg[3] = (out[3] - cen.w) * (-1.0f);
+					m_store16(dog + (size_t)sz * (size_t)p_loc, out_voff, mf4{dg[0], dg[1], dg[2], dg[3]});
+					nst = 2;
+#pragma unroll
+					for (int c = 0; c < 4; c++) mx = m_absmax(mx, dg[c]);
+				}
+			}
+		}
+		if (DOG && CR && j < nsteps) cring[(j % C::CRN) * C::NT + tid] = *reinterpret_cast<const mf4 *>(tile + buf * C::TILE_F + park_off);
+
+		// the DMA of the next tile was issued before this step's stores (vmcnt retires in order)
+		if (nst == 2) m_wait_vmcnt<2>();
+		else if (nst == 1) m_wait_vmcnt<1>();
+		else m_wait_vmcnt<0>();
+		m_barrier();
+	}
+
+	if (DOG) {
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+		if (lane == 0) s_red[wid] = mx;
+		__syncthreads();
+		if (tid == 0) {
+			const float r = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+			if (r > 0.0f) atomicMax(dogmax, __float_as_uint(r));
+		}
+	}
+}
+
+static void march_edge_fractions(int n, int hw, float *f) {  // Src/cSIFT3D.cc:751-760, see kernels_fused.hip
+	const int dim_end = n - 1;
+	for (int k = 0; k <= hw; k++) {
+		const float c = (float)(dim_end + k);
+		const float cc = (float)(2 * dim_end) - c - 0.1f;
+		const int lo = (int)cc;
+		f[k] = cc - (float)lo;
+	}
+}
+
+template <int HW>
+static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &tg,
+                            hipStream_t st, int plan_slots) {
+	using C = MCfg<HW>;
+	MTaps t;
+	for (int i = 0; i < 2 * kMarchMaxHW + 1; i++) t.w[i] = i < 2 * HW + 1 ? tg.w[i] : 0.0f;
+	const int nzo = zr.zo1 - zr.zo0;
+	if (nzo <= 0) return;
+	const int ntx = nx / C::TX, nty = ny / C::TY, ntiles = ntx * nty;
+	// z chunking: the chunk count that minimises (residency rounds) x (planes marched per workgroup); a chunk pays a ramp of 2*HW (+1) planes
+	const int full_slots = 256 * S3D_MARCH_OCC;
+	const int slots = plan_slots > 0 ? std::min(plan_slots, full_slots) : full_slots;
+	const int ramp = 2 * HW + 1;
+	int best_cz = nzo;
+	double best_cost = 1e300;
+	for (int n = 1; n <= nzo && n <= 64; n++) {
+		const int czn = (nzo + n - 1) / n, nch = (nzo + czn - 1) / czn;
+		const long wgs = (long)ntiles * nch, rounds = (wgs + slots - 1) / slots;
+		const double cost = (double)rounds * (czn + ramp);
+		if (cost < best_cost - 1e-9) { best_cost = cost; best_cz = czn; }
+	}
+	const int cz = best_cz, nchunks = (nzo + cz - 1) / cz;
+	MEdge ef;
+	memset(&ef, 0, sizeof(ef));
+	march_edge_fractions(nx, HW, ef.f[0]);
+	march_edge_fractions(ny, HW, ef.f[1]);
+	march_edge_fractions(zr.nzg, HW, ef.f[2]);
+	const dim3 grid((unsigned)(ntiles * nchunks)), block(C::NT);
+	// DoG centre ring in LDS where three workgroups per CU still fit (hw <= 5); wider levels re-read the centre plane (L2)
+	constexpr bool CR = HW <= 5;
+	if (dog) hipLaunchKernelGGL((k_march_level<HW, true, CR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
+	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
+}
+
+// false => not applicable (shape not tile aligned, level too small for the extended-line boundary form, half width without an
+// instantiation): the caller falls through to kernels_fused.hip / kernels_pyramid.hip
+bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
+                        hipStream_t st, int plan_slots) {
+	static const bool off = [] { const char *e = getenv("S3D_MARCH"); return e && e[0] == '0'; }();
+	if (off) return false;
+	if ((nx % 32) || (ny % 32) || nx < 2 * t.hw + 2 || ny < 2 * t.hw + 2 || zr.nzg < 2 * t.hw + 2) return false;
+	switch (t.hw) {
+	case 2: launch_march_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 3: launch_march_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 4: launch_march_hw<4>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 5: launch_march_hw<5>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 6: launch_march_hw<6>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 8: launch_march_hw<8>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	default: return false;
+	}
+}
+
+}  // namespace s3d
