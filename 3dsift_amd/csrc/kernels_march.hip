@@ -57,7 +57,15 @@ struct MCfg {
 	static_assert(ROWS <= 48, "x-blur items of waves 0..2; wave 3 serves the bottom tiles");
 };
 
-__device__ __forceinline__ void m_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// development diagnostics, timing only (never set in the product build; results are wrong by construction): 1 no tile DMA, 2 no stores,
+// 4 no wait for the DMA, 8 no barriers, 16 / 32 / 64 no x / y / z blur arithmetic (the LDS traffic stays)
+#ifndef S3D_MDIAG
+#define S3D_MDIAG 0
+#endif
+__device__ __forceinline__ void m_barrier() {
+	if (S3D_MDIAG & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 template <int N>
 __device__ __forceinline__ void m_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -78,12 +86,37 @@ __device__ __forceinline__ float m_absmax(float m, float v) {
 	return (a > m) ? a : m;
 }
 
-#ifndef S3D_MARCH_OCC
-#define S3D_MARCH_OCC 3
+// workgroups per CU the register budget and the chunk planning are set for, per half width (DOG instantiations with the centre
+// ring in LDS fit three)
+#ifndef S3D_MARCH_SCHEDB
+#define S3D_MARCH_SCHEDB 0
 #endif
+#ifndef S3D_MARCH_ROT
+#define S3D_MARCH_ROT 1
+#endif
+#ifndef S3D_MARCH_YG
+#define S3D_MARCH_YG 6  /* y-blur rows requested per group */
+#endif
+#ifndef S3D_MARCH_CR_MAXHW
+#define S3D_MARCH_CR_MAXHW 5  /* DoG centre ring in LDS up to this half width (three workgroups per CU still fit); wider levels re-read the centre plane */
+#endif
+#ifndef S3D_MOCC_LO
+#define S3D_MOCC_LO 3
+#endif
+#ifndef S3D_MOCC_5
+#define S3D_MOCC_5 3
+#endif
+#ifndef S3D_MOCC_6
+#define S3D_MOCC_6 3
+#endif
+#ifndef S3D_MOCC_8
+#define S3D_MOCC_8 3
+#endif
+template <int HW, bool CR>
+constexpr int march_occ() { return CR ? 3 : (HW <= 4 ? S3D_MOCC_LO : (HW == 5 ? S3D_MOCC_5 : (HW == 6 ? S3D_MOCC_6 : S3D_MOCC_8))); }
 
 template <int HW, bool DOG, bool CR>
-__global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
+__global__ void __launch_bounds__(256, (march_occ<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                         unsigned *__restrict__ dogmax, int nx, int ny, ZRange zr, MTaps t, MEdge ef, int ntx,
                                                         int nty, int cz) {
 	using C = MCfg<HW>;
@@ -125,7 +158,11 @@ __global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float 
 	const unsigned lds_tile = (unsigned)(unsigned long long)tile + (unsigned)wid * 1024u;
 
 	// ---- x-blur item of this lane: 8 outputs of one tile row; rows dealt so that every ds_read_b128 lane group is conflict-free ----
-	int xr, xseg;
+	// The x-blur holds 3 waves' worth of items (ROWS <= 48 rows x 4 segments); the wave without items is the one with role 3, and the
+	// roles rotate with the step (role = (wave + step) & 3): co-resident workgroups place their waves on the SIMDs in a fixed pattern
+	// (hwid_probe: three workgroups put their fourth waves on three different SIMDs, the remaining SIMD carries three item waves), so
+	// a fixed role assignment leaves one SIMD with 13 % more vector work than the average.
+	int rs, xseg_r;
 	{
 		const int l5 = lane & 31;
 		int g, jj;  // lane group (of 16) and index inside it, in the hardware's service order
@@ -138,24 +175,26 @@ __global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float 
 		g += (lane >> 5) * 2;
 		const int q = jj >> 2;
 		// W4 = 12: four consecutive rows (r*12 mod 16 = 0,12,8,4; odd rows swizzled);  W4 = 10: rows {r, r+4, r+1, r+5}
-		const int rs = C::W4 == 12 ? 4 * g + q : ((g & 1) * 2 + (g >> 1) * 8 + (q & 1) * 4 + (q >> 1));
-		xr = 16 * wid + rs;
-		xseg = jj & 3;
+		rs = C::W4 == 12 ? 4 * g + q : ((g & 1) * 2 + (g >> 1) * 8 + (q & 1) * 4 + (q >> 1));
+		xseg_r = jj & 3;
 	}
-	bool xact = xr < C::ROWS, xhelp = false;
-	if (bottom_f && wid == 3) {  // wave 3 holds no item: it re-blurs rows yend-hw-1 .. yend for the bottom extension E[yend+k]
-		if (lane < (HW + 2) * 4) { xr = C::TY - 2 + (lane >> 2); xseg = lane & 3; xact = true; xhelp = true; }
+	// per-role activity / mirror bits of the regular items (role r: tile row 16*r + rs)
+	int amask = 0, mmask = 0;
+#pragma unroll
+	for (int r = 0; r < 3; r++) {
+		const int row = 16 * r + rs, gy = y0 - HW + row;
+		const bool act = row < C::ROWS && gy >= 0 && gy < ny && !(bottom_f && gy == ny - 1);  // row yend of a bottom tile receives E[yend]
+		amask |= (act ? 1 : 0) << r;
+		mmask |= ((act && top_f && gy >= 1 && gy <= HW) ? 1 : 0) << r;  // E[-k] = row k: second copy in the mirror row
 	}
-	{
-		const int gy = y0 - HW + xr;
-		xact = xact && gy >= 0 && gy < ny && (xhelp || !(bottom_f && gy == ny - 1));  // row yend of a bottom tile receives E[yend]
-	}
-	const int xgy = y0 - HW + xr;
-	const int xsw = xr & 1;
-	const int xbase_e = (xr * C::W4 + 2 * xseg + xsw) * 4, xbase_o = (xr * C::W4 + 2 * xseg - xsw) * 4;  // float offsets of even / odd window pieces
-	const int xout = xr * C::XP + xseg * 8;
-	const bool xmirror = top_f && !xhelp && xgy >= 1 && xgy <= HW;   // E[-k] = row k: second copy in the mirror row
-	const int xout_m = (HW - xgy) * C::XP + xseg * 8;
+	const int sw_r = rs & 1;  // 16*role is even: the swizzle bit does not depend on the role
+	const int xbe_r = (rs * C::W4 + 2 * xseg_r + sw_r) * 4, xbo_r = (rs * C::W4 + 2 * xseg_r - sw_r) * 4;  // float offsets of even / odd window pieces
+	const int xout_r = rs * C::XP + xseg_r * 8;
+	const int xoutm_r = (HW - (y0 - HW + rs)) * C::XP + xseg_r * 8;
+	// bottom tiles: the wave with role 3 re-blurs rows yend-hw-1 .. yend (one row per 4 lanes) for the bottom extension E[yend+k]
+	const int row_h = C::TY - 2 + (lane >> 2), xseg_h = lane & 3, sw_h = row_h & 1;
+	const bool act_h = bottom_f && lane < (HW + 2) * 4;
+	const int xbe_h = (row_h * C::W4 + 2 * xseg_h + sw_h) * 4, xbo_h = (row_h * C::W4 + 2 * xseg_h - sw_h) * 4;
 
 	// ---- y/z work: thread (xq, ty) owns the 16-byte piece x = x0 + 4*xq .. +3 of row y0 + ty ----
 	const int xq = tid & 7, ty = tid >> 3;
@@ -184,7 +223,7 @@ __global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float 
 		const unsigned dstb = lds_tile + (unsigned)(jn & 1) * (unsigned)(C::TILE_F * 4);
 #pragma unroll
 		for (int i = 0; i < C::NDMA; i++)
-			if (wid + 4 * i < C::NWI) m_dma16(pl, goffb[i], dstb + (unsigned)(i * 4096));
+			if (!(S3D_MDIAG & 1) && wid + 4 * i < C::NWI) m_dma16(pl, goffb[i], dstb + (unsigned)(i * 4096));
 	};
 	if (zc0 >= zc1) return;  // uniform (never for a planned grid)
 	issue_dma(0);
@@ -204,6 +243,13 @@ __global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float 
 
 		// ---------------- x-blur of feed j: tile[buf] -> xb[buf] ----------------
 		if (j < nsteps) {
+			const int role = S3D_MARCH_ROT ? ((wid + j) & 3) : wid;  // wave-uniform
+			const bool xhelp = role == 3;
+			const bool xact = xhelp ? act_h : (((amask >> role) & 1) != 0);
+			const bool xmirror = !xhelp && (((mmask >> role) & 1) != 0);
+			const int xseg = xhelp ? xseg_h : xseg_r;
+			const int xbase_e = xhelp ? xbe_h : xbe_r + role * (16 * C::W4 * 4), xbase_o = xhelp ? xbo_h : xbo_r + role * (16 * C::W4 * 4);
+			const int xout = xout_r + role * (16 * C::XP), xout_m = xoutm_r - role * (16 * C::XP);
 			float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 			if (xact) {
 				const float *tb = tile + buf * C::TILE_F;
@@ -232,12 +278,12 @@ __global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float 
 					const float f = s_ef[0];
 					win[C::WOFF + HW + 15] = (1.0f - f) * win[C::WOFF + HW + 14] + f * win[C::WOFF + HW + 15];
 				}
+				// tap-major: the eight outputs are eight independent chains (one dependent chain issues at half the rate)
 #pragma unroll
-				for (int jo = 0; jo < 8; jo++) {
-					float acc = 0.0f;
+				for (int d = -HW; d <= HW; d++) {
+					if ((S3D_MDIAG & 16) && d != 0) continue;
 #pragma unroll
-					for (int d = -HW; d <= HW; d++) acc = acc + t.w[d + HW] * win[C::WOFF + jo + HW - d];
-					o[jo] = acc;
+					for (int jo = 0; jo < 8; jo++) o[jo] = o[jo] + t.w[d + HW] * win[C::WOFF + jo + HW - d];
 				}
 				if (!xhelp) {
 					float *xo = xb + buf * C::XB_F;
@@ -249,12 +295,12 @@ __global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float 
 					}
 				}
 			}
-			if (bottom_f && wid == 3) {  // wave-uniform: every lane takes part in the shuffles
+			if (bottom_f && xhelp) {  // wave-uniform: every lane takes part in the shuffles
 				float a[8];
 #pragma unroll
 				for (int jo = 0; jo < 8; jo++) a[jo] = __shfl_up(o[jo], 4, 64);  // the row below (same segment)
 				const int jr = lane >> 2;                                       // this lane holds x-blurred row yend-hw-1+jr
-				if (xhelp && jr >= 1) {
+				if (xact && jr >= 1) {
 					const int k = HW + 1 - jr;                                  // E[yend+k] = (1-f_k) xb[yend-k-1] + f_k xb[yend-k]
 					const float f = s_ef[kMarchMaxHW + 1 + k];
 					float *xe = xb + buf * C::XB_F + (C::TY - 1 + HW + k) * C::XP + xseg * 8;
@@ -271,11 +317,27 @@ __global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float 
 		if (j >= 1) {
 			const float *yc = xb + (buf ^ 1) * C::XB_F + ycol;
 			float v[4] = {0.f, 0.f, 0.f, 0.f};
+			{
+				// step s = d + HW reads row ty + 2*HW - s; rows are requested a group ahead of their use (hipcc keeps only two reads
+				// in flight on its own and exposes the LDS latency nine times per plane)
+				constexpr int KG = S3D_MARCH_YG, NTAP = 2 * HW + 1;
+				mf4 cur[KG], nxt[KG];
 #pragma unroll
-			for (int s = 0; s <= 2 * HW; s++) {  // step s = d + HW reads row ty + 2*HW - s
-				const mf4 rv = *reinterpret_cast<const mf4 *>(yc + (2 * HW - s) * C::XP);
-				const float tap = t.w[s];
-				v[0] = v[0] + tap * rv.x; v[1] = v[1] + tap * rv.y; v[2] = v[2] + tap * rv.z; v[3] = v[3] + tap * rv.w;
+				for (int i = 0; i < KG; i++) cur[i] = *reinterpret_cast<const mf4 *>(yc + (i < NTAP ? 2 * HW - i : 0) * C::XP);
+#pragma unroll
+				for (int g0 = 0; g0 < NTAP; g0 += KG) {
+#pragma unroll
+					for (int i = 0; i < KG; i++)
+						if (g0 + KG + i < NTAP) nxt[i] = *reinterpret_cast<const mf4 *>(yc + (2 * HW - (g0 + KG + i)) * C::XP);
+#pragma unroll
+					for (int i = 0; i < KG; i++)
+						if (g0 + i < NTAP && !((S3D_MDIAG & 32) && (g0 + i) % 4 != 0)) {
+							const float tap = t.w[g0 + i];
+							v[0] = v[0] + tap * cur[i].x; v[1] = v[1] + tap * cur[i].y; v[2] = v[2] + tap * cur[i].z; v[3] = v[3] + tap * cur[i].w;
+						}
+#pragma unroll
+					for (int i = 0; i < KG; i++) cur[i] = nxt[i];
+				}
 			}
 			if (e_out >= dim_end) {  // wave-uniform, top chunk only: E[dim_end+k] = (1-f_k) X[dim_end-k-1] + f_k X[dim_end-k]
 				const float f = s_ef[2 * (kMarchMaxHW + 1) + min(e_out - dim_end, HW)];
@@ -290,14 +352,19 @@ __global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float 
 #pragma unroll
 			for (int c = 0; c < 4; c++) out[c] = A[2 * HW - 1][c] + t.w[2 * HW] * v[c];
 #pragma unroll
-			for (int s = 2 * HW - 1; s >= 1; s--)
+			for (int s = 2 * HW - 1; s >= 1; s--) {
+				if ((S3D_MDIAG & 64) && s != HW) continue;
 #pragma unroll
 				for (int c = 0; c < 4; c++) A[s][c] = A[s - 1][c] + t.w[s] * v[c];
+			}
 #pragma unroll
 			for (int c = 0; c < 4; c++) A[0][c] = 0.0f + t.w[0] * v[c];
 
 			if (DOG && CR) cen = cring[(j % C::CRN) * C::NT + tid];  // parked HW+1 steps ago (read before this step's park below)
-			if (emit) {
+#if S3D_MARCH_SCHEDB
+			__builtin_amdgcn_sched_barrier(0);  // keep the accumulator updates in front of the stores and of the wait for the DMA
+#endif
+			if (emit && !((S3D_MDIAG & 2) && out[0] != 12345.678f)) {
 				float *gb = dst + (size_t)sz * (size_t)p_loc;
 				m_store16(gb, out_voff, mf4{out[0], out[1], out[2], out[3]});
 				nst = 1;
@@ -315,7 +382,8 @@ __global__ void __launch_bounds__(256, S3D_MARCH_OCC) k_march_level(const float 
 		if (DOG && CR && j < nsteps) cring[(j % C::CRN) * C::NT + tid] = *reinterpret_cast<const mf4 *>(tile + buf * C::TILE_F + park_off);
 
 		// the DMA of the next tile was issued before this step's stores (vmcnt retires in order)
-		if (nst == 2) m_wait_vmcnt<2>();
+		if (S3D_MDIAG & 4) {}
+		else if (nst == 2) m_wait_vmcnt<2>();
 		else if (nst == 1) m_wait_vmcnt<1>();
 		else m_wait_vmcnt<0>();
 		m_barrier();
@@ -353,7 +421,7 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	if (nzo <= 0) return;
 	const int ntx = nx / C::TX, nty = ny / C::TY, ntiles = ntx * nty;
 	// z chunking: the chunk count that minimises (residency rounds) x (planes marched per workgroup); a chunk pays a ramp of 2*HW (+1) planes
-	const int full_slots = 256 * S3D_MARCH_OCC;
+	const int full_slots = 256 * (dog ? march_occ<HW, (HW <= S3D_MARCH_CR_MAXHW)>() : march_occ<HW, false>());
 	const int slots = plan_slots > 0 ? std::min(plan_slots, full_slots) : full_slots;
 	const int ramp = 2 * HW + 1;
 	int best_cz = nzo;
@@ -372,7 +440,7 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	march_edge_fractions(zr.nzg, HW, ef.f[2]);
 	const dim3 grid((unsigned)(ntiles * nchunks)), block(C::NT);
 	// DoG centre ring in LDS where three workgroups per CU still fit (hw <= 5); wider levels re-read the centre plane (L2)
-	constexpr bool CR = HW <= 5;
+	constexpr bool CR = HW <= S3D_MARCH_CR_MAXHW;
 	if (dog) hipLaunchKernelGGL((k_march_level<HW, true, CR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
 	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
 }
