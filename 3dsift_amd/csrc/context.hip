@@ -309,7 +309,7 @@ static void plan_pyramid(sift3d_ctx *c, int noct_total) {
 static int build_luts(sift3d_ctx *c) {
 	std::vector<WinLut> luts((size_t)std::max(1, c->noct + c->octave_base) * 8 * 2);
 	std::vector<float> pool;
-	for (auto &l : luts) { l.off = 0; l.len = 0; l.nin = -1; l.radius = 0; l.sigma = 0; }
+	for (auto &l : luts) { l.off = 0; l.len = 0; l.nin = -1; l.radius = 0; l.sigma = 0; l.fix_scale = 1.0f; l.wsum = 1.0f; }
 	for (int o = 0; o < c->noct; o++)
 		for (int lv = 1; lv <= c->p.num_kp_levels && lv < 8; lv++) {
 			const Level &D = c->dog[(size_t)o * c->nd + lv];  // keypoint scale = DoG level scale (Src/cSIFT3D.cc:407)
@@ -321,7 +321,16 @@ static int build_luts(sift3d_ctx *c) {
 				const float r2 = radius * radius, uu = u * u;
 				const int len = (int)floor((double)r2 / (double)uu) + 2;
 				WinLut &L = luts[((size_t)(o + c->octave_base) * 8 + lv) * 2 + which];
-				L.off = (int)pool.size(); L.len = len; L.nin = -1; L.radius = radius; L.sigma = sigma;
+				L.off = (int)pool.size(); L.len = len; L.nin = -1; L.radius = radius; L.sigma = sigma; L.fix_scale = 1.0f;
+				if (which == 1) {
+					// 32-bit histogram bins: a bin (cell, vertex) collects wgt * |g| * bary over the voxels within one cell of its centre;
+					// the trilinear weights of those voxels sum to at most (cw + 2)^3 (cw = cell width in voxels = desc_width / (4u) =
+					// 5 scale / u), |g| <= sqrt(3) (normalised data, |0.5 (a - b) / u| <= 1 per axis, weight <= 1), bary <= 1 + 2e-6
+					const double cw = 5.0 * (double)scale / (double)u, bound = (cw + 2.0) * (cw + 2.0) * (cw + 2.0) * 1.7321 * 1.001;
+					int k = (int)floor(log2(2147483647.0 / bound));
+					k = std::max(0, std::min(k, 29));
+					L.fix_scale = (float)ldexp(1.0, k);
+				}
 				if (which == 1 && len > kMaxDescLut) c->desc_lut_lds = false;  // k_describe<false>: table read from global memory
 				for (int n = 0; n < len; n++) {
 					const float sq = (float)n * uu;  // exact: equals the reference's fp32 sum of squares
@@ -329,8 +338,20 @@ static int build_luts(sift3d_ctx *c) {
 					if (!(sq > r2)) L.nin = n;
 					if (sq > r2) w = -1.0f;
 					else if (which == 0) w = expf((float)(-0.5 * (double)sq / (double)(sigma * sigma)));
-					else w = expf(-0.5f * sq / (sigma * sigma));
+					else w = expf(-0.5f * sq / (sigma * sigma)) * (0.5f / u);  // exact scaling (u = 2^octave), see WinLut
 					pool.push_back(w);
+				}
+				{
+					// sum of the weights over the lattice points of the sphere (k_describe's first guess of the gradient mass)
+					const int R = (int)floor(sqrt((double)std::max(L.nin, 0)));
+					double ws = 0.0;
+					for (int dz = -R; dz <= R; dz++)
+						for (int dy = -R; dy <= R; dy++)
+							for (int dx = -R; dx <= R; dx++) {
+								const int n = dx * dx + dy * dy + dz * dz;
+								if (n <= L.nin) ws += (double)pool[(size_t)L.off + n] * (which == 1 ? (double)u / 0.5 : 1.0);
+							}
+					L.wsum = (float)std::max(ws, 1.0);
 				}
 			}
 		}

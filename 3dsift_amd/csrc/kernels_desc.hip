@@ -19,13 +19,15 @@
 //     the reference's exact Moller-Trumbore arithmetic for that face and accepted only when all three
 //     barycentrics clear a 1e-4 margin (then no other face can pass the reference's -1.19e-6 test, so
 //     "first passing face in mesh order" is this face); otherwise the literal 20-face ordered scan runs
-//   * the 24 products of a voxel go straight to an LDS histogram kept in 64-BIT FIXED POINT (2^-29 units) and
-//     are added with ds_add_u64: on gfx950 an LDS float atomic (ds_add_f32) costs ~190 cycles per wave
-//     instruction, the integer forms 4-6 (scripts/microbench/lds_atomics.hip), and integer sums are order
-//     independent, so descriptors are bitwise reproducible run to run.  The fp32 product mag*w*bary is formed
-//     exactly like the reference, then converted with the 1.5*2^52 magic-add (one cvt, one f64 fma, one 64-bit
-//     subtract).  R replicas (replica = lane & (R-1), bin-major) keep neighbouring lanes that hit the same
-//     bin on different addresses; they are summed once per keypoint
+//   * the 24 products of a voxel go straight to an LDS histogram kept in 32-BIT FIXED POINT and are added with ds_add_u32: on gfx950
+//     an LDS float atomic (ds_add_f32) costs ~190 cycles per wave instruction, ds_add_u32 4.3 + 3.8 per extra lane on the same
+//     address, ds_add_u64 6.4 + 7.5 (scripts/microbench/lds_atomics.hip), and integer sums are order independent, so descriptors
+//     are bitwise reproducible run to run.  The unit 2^-k is chosen per (octave, level) on the host so that no bin can leave the
+//     int32 range for that window size (WinLut::fix_scale; 2^-17 .. 2^-20 for the default scales: the rounding of a contribution
+//     is < 4e-6 absolute, ~1e-5 of a bin sum and far inside the 1e-4 RMS bar).  The fp32 product mag*w*bary is formed exactly like
+//     the reference, scaled by the power of two and converted with one v_cvt_i32_f32 (round to nearest even).  R replicas
+//     (replica = lane & (R-1), bin-major) keep neighbouring lanes that hit the same bin on different addresses; they are summed
+//     once per keypoint
 //   * the four in-plane neighbour loads of the next z step are issued unconditionally one step ahead
 //     (software pipelining; a load behind the activity branch would be waited for at the join)
 //   * lane compaction: chords are ragged and many voxels are inactive, so each wave pushes its ACTIVE voxels
@@ -58,16 +60,38 @@ __device__ __forceinline__ void win_bounds_d(float c, float rad, float u, int n,
 
 constexpr float kBaryEps = (float)(FLT_EPSILON * 1E1);  // Src/cSIFT3D.cc:23
 
-// Histogram bins are 64-bit two's-complement fixed point in 2^-29 units: integer LDS atomics are ~40x faster than
-// ds_add_f32 on gfx950 (scripts/microbench/lds_atomics.hip) and make the sums order-independent (deterministic).
-constexpr float kFixedScaleF = 536870912.0f;              // 2^29
-constexpr double kFixedInv = 1.0 / 536870912.0;
+// Histogram bins are 32-bit two's-complement fixed point in units of 1 / WinLut::fix_scale (see the header).
 constexpr float kFastMargin = 1.0e-4f;
 constexpr int kFaceStride = 16;  // floats per face in the LDS table
 #ifndef S3D_DESC_REP
 #define S3D_DESC_REP 4
 #endif
+// (no waves-per-SIMD hint in __launch_bounds__: any value >= 2 makes hipcc schedule for occupancy and the kernel 10 % slower)
+#ifndef S3D_DESC_SPREAD
+#define S3D_DESC_SPREAD 1
+#endif
+#ifndef S3D_DESC_BIN64
+#define S3D_DESC_BIN64 0
+#endif
+#if S3D_DESC_BIN64
+typedef unsigned long long bin_t;   // A/B: 64-bit bins in 2^-29 units (never overflow, twice the LDS atomic cost)
+typedef long long sbin_t;
+#else
+typedef unsigned bin_t;
+typedef int sbin_t;
+#endif
 constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = bin*kRep + lane % kRep)
+// Bank spreading (r02).  The voxels of a 64-lane batch are spatial neighbours: most of them share the cell AND the face, so every
+// one of the 24 adds sent all lanes to the SAME bin -- R replicas = R banks, 64/R lanes queued on each (an LDS atomic costs ~1.9
+// cycles per lane on the busiest bank; measured 16 cycles per ds_add with 8 replicas).  Now lane l walks the 8 cells of its voxel in
+// the order d ^ r, r = (l >> 2) & 7, so the lanes of a batch hit 8 different cells at every step, and the bin layout gives the three
+// cell strides the residues 1, 2, 4 modulo 8: 8 cells x 4 replicas = all 32 banks.  idx(ix, iy, iz, v) = 17 ix + 74 iy + 300 iz + v.
+constexpr int kSX = 17, kSY = 74, kSZ = 300, kBins = S3D_DESC_SPREAD ? 4 * kSZ : kDesc;
+__device__ __forceinline__ int bin_index(int j) {  // descriptor element j = (ix + 4 iy + 16 iz) * 12 + v  ->  histogram index
+	if (!S3D_DESC_SPREAD) return j;
+	const int c = j / 12, v = j - c * 12;
+	return (c & 3) * kSX + ((c >> 2) & 3) * kSY + (c >> 4) * kSZ + v;
+}
 
 // reference Moller-Trumbore for ONE face whose constants sit at F[0..15]:
 // e1(0..2) e2(3..5) t(6..8) q(9..11) qe2(12); returns pass/fail exactly like Check_intersect_faces' body
@@ -121,9 +145,25 @@ __device__ __forceinline__ int intersect_scan(float gx, float gy, float gz, floa
 
 // heavy part of one ACTIVE voxel (inside sphere and cube, |g|^2 >= eps): face lookup, trilinear weights,
 // 24 fixed-point adds.  Runs on compacted full waves (see the queue in k_describe).
-__device__ __forceinline__ void accumulate_voxel(bool valid, float bx, float by, float bz, float rx, float ry, float rz,
-                                                 const float *s_face, const int *s_fidx, const float *s_predn, const int *s_predf,
-                                                 unsigned long long *hist_rep) {
+// fp32 -> int32, round to nearest (ties up): ONE instruction (__float2int_rn is v_rndne_f32 + v_cvt_i32_f32)
+__device__ __forceinline__ int cvt_rpi(float x) {
+	int r;
+	asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+	return r;
+}
+
+// R = the transposed rotation (rows R0..R8), fix_scale = 2^k of the histogram's fixed point.  The queue holds the WEIGHTED, NOT YET
+// ROTATED gradient of voxels that passed a slightly relaxed magnitude test; the rotation and the reference's exact test
+// (Src/cSIFT3D.cc:1323-1325, 1468) run here, on the compacted voxels only.
+__device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by, float bz, float gx, float gy, float gz,
+                                                 float R0, float R1, float R2, float R3, float R4, float R5, float R6, float R7, float R8,
+                                                 float fix_scale, const float *s_face, const int *s_fidx, const float *s_predn,
+                                                 const int *s_predf, bin_t *hist_rep, int spread /* lane constant: bits 0..2 = r */) {
+	const float rx = R0 * gx + R1 * gy + R2 * gz;
+	const float ry = R3 * gx + R4 * gy + R5 * gz;
+	const float rz = R6 * gx + R7 * gy + R8 * gz;
+	const float g2 = rx * rx + ry * ry + rz * rz;
+	valid = valid && !(g2 < kBaryEps);
 	float b0 = 0.f, b1 = 0.f, b2 = 0.f;
 	int f = -1;
 	bool slow = false;
@@ -149,52 +189,59 @@ __device__ __forceinline__ void accumulate_voxel(bool valid, float bx, float by,
 	if (__any(slow)) {
 		if (slow) f = intersect_scan(rx, ry, rz, b0, b1, b2);
 	}
-	if (!valid || f < 0) return;
-	const float g2 = rx * rx + ry * ry + rz * rz;
+	if (!valid || f < 0) return 0.0f;
 	const float mag = __fsqrt_rn(g2);
 	const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
 	const int ix = (int)bx, iy = (int)by, iz = (int)bz;  // truncation toward zero, like the reference: 0..3
 	// Trilinear weights (Src/cSIFT3D.cc:1510-1512 forms them as double products rounded to fp32; fp32 products differ
-	// from that by <= 1.5 ulp, far inside the descriptor tolerance) and 2^-29 fixed-point contributions: |value| <= sqrt(3)
-	// < 4 because the normalised, Gaussian-smoothed data is bounded by 1, so value * 2^29 fits an int32.
+	// from that by <= 1.5 ulp, far inside the descriptor tolerance)
 	const float wx0 = 1.0f - fx, wy0 = 1.0f - fy, wz0 = 1.0f - fz;
-	const float pxy[4] = {wx0 * wy0, wx0 * fy, fx * wy0, fx * fy};  // index ddx*2 + ddy
-	const float ms = mag * kFixedScaleF;                            // exact (power of two)
+	const float ms = mag * fix_scale;                               // exact (power of two)
 	const float m0 = ms * b0, m1 = ms * b1, m2 = ms * b2;
 	// cells ix+ddx etc. are >= 0 by construction; only the upper bound can fail (skip cells outside [0,3])
 	const bool okx = ix < 3, oky = iy < 3, okz = iz < 3;
-	const int base = (ix + iy * 4 + iz * 16) * 12;
-	unsigned long long *h0 = hist_rep + (base + s_fidx[f * 4]) * kRep;
-	unsigned long long *h1 = hist_rep + (base + s_fidx[f * 4 + 1]) * kRep;
-	unsigned long long *h2 = hist_rep + (base + s_fidx[f * 4 + 2]) * kRep;
-	// a barycentric coordinate can be negative by at most bary_eps (only after the exact face scan): then the
-	// contribution needs its sign extended to 64 bits; otherwise the high word is a constant zero (wave-uniform choice)
-	const bool neg = b0 < 0.0f || b1 < 0.0f || b2 < 0.0f;
-	if (__any(neg)) {
-#pragma unroll
-		for (int d = 0; d < 8; d++) {
-			const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;  // dx outer, dz inner (Src/cSIFT3D.cc:1492-1496)
-			if ((ddx && !okx) || (ddy && !oky) || (ddz && !okz)) continue;
-			const float wgt = pxy[ddx * 2 + ddy] * (ddz ? fz : wz0);
-			constexpr int kCell = 12 * kRep;
-			const int off = (ddx + ddy * 4 + ddz * 16) * kCell;
-			atomicAdd(h0 + off, (unsigned long long)(long long)__float2int_rn(wgt * m0));
-			atomicAdd(h1 + off, (unsigned long long)(long long)__float2int_rn(wgt * m1));
-			atomicAdd(h2 + off, (unsigned long long)(long long)__float2int_rn(wgt * m2));
-		}
-		return;
-	}
+#if S3D_DESC_SPREAD
+	// step d of this lane is the cell offset d ^ r: weights and cell strides swap roles per axis where the bit of r is set
+	const bool qx = spread & 1, qy = spread & 2, qz = spread & 4;
+	const float ax[2] = {qx ? fx : wx0, qx ? wx0 : fx}, ay[2] = {qy ? fy : wy0, qy ? wy0 : fy}, az[2] = {qz ? fz : wz0, qz ? wz0 : fz};
+	const bool badx[2] = {qx && !okx, !qx && !okx}, bady[2] = {qy && !oky, !qy && !oky}, badz[2] = {qz && !okz, !qz && !okz};
+	const int stx = qx ? -kSX * kRep : kSX * kRep, sty = qy ? -kSY * kRep : kSY * kRep, stz = qz ? -kSZ * kRep : kSZ * kRep;
+	const int base = ((ix + (qx ? 1 : 0)) * kSX + (iy + (qy ? 1 : 0)) * kSY + (iz + (qz ? 1 : 0)) * kSZ) * kRep;
+	const float pxy[4] = {ax[0] * ay[0], ax[0] * ay[1], ax[1] * ay[0], ax[1] * ay[1]};  // index ddx*2 + ddy
+	bin_t *h0 = hist_rep + base + s_fidx[f * 4] * kRep;
+	bin_t *h1 = hist_rep + base + s_fidx[f * 4 + 1] * kRep;
+	bin_t *h2 = hist_rep + base + s_fidx[f * 4 + 2] * kRep;
 #pragma unroll
 	for (int d = 0; d < 8; d++) {
 		const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;
+		if (badx[ddx] || bady[ddy] || badz[ddz]) continue;
+		const float wgt = pxy[ddx * 2 + ddy] * az[ddz];
+		const int off = (ddx ? stx : 0) + (ddy ? sty : 0) + (ddz ? stz : 0);
+		atomicAdd(h0 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m0));
+		atomicAdd(h1 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m1));
+		atomicAdd(h2 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m2));
+	}
+#else
+	const float pxy[4] = {wx0 * wy0, wx0 * fy, fx * wy0, fx * fy};  // index ddx*2 + ddy
+	const int base = (ix + iy * 4 + iz * 16) * 12;
+	bin_t *h0 = hist_rep + (base + s_fidx[f * 4]) * kRep;
+	bin_t *h1 = hist_rep + (base + s_fidx[f * 4 + 1]) * kRep;
+	bin_t *h2 = hist_rep + (base + s_fidx[f * 4 + 2]) * kRep;
+	// a barycentric coordinate can be negative by at most bary_eps (only after the exact face scan): the two's-complement add
+	// handles the sign
+#pragma unroll
+	for (int d = 0; d < 8; d++) {
+		const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;  // dx outer, dz inner (Src/cSIFT3D.cc:1492-1496)
 		if ((ddx && !okx) || (ddy && !oky) || (ddz && !okz)) continue;
 		const float wgt = pxy[ddx * 2 + ddy] * (ddz ? fz : wz0);
 		constexpr int kCell = 12 * kRep;
 		const int off = (ddx + ddy * 4 + ddz * 16) * kCell;  // compile-time: becomes the ds_add immediate offset
-		atomicAdd(h0 + off, (unsigned long long)(unsigned)__float2int_rn(wgt * m0));
-		atomicAdd(h1 + off, (unsigned long long)(unsigned)__float2int_rn(wgt * m1));
-		atomicAdd(h2 + off, (unsigned long long)(unsigned)__float2int_rn(wgt * m2));
+		atomicAdd(h0 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m0));
+		atomicAdd(h1 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m1));
+		atomicAdd(h2 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m2));
 	}
+#endif
+	return mag;
 }
 
 #if defined(S3D_EXP) && S3D_EXP == 21
@@ -221,7 +268,7 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
                                                   int part_rank, int part_world, const int *__restrict__ order,
                                                   const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work) {
 	__shared__ unsigned s_item, s_tile;
-	__shared__ unsigned long long hist[kDesc * kRep];  // [bin][replica], two's-complement fixed point, 2^-29 units
+	__shared__ bin_t hist[kBins * kRep];  // [bin][replica], two's-complement fixed point, units of 1 / lut.fix_scale
 	__shared__ float s_lut[LUT_LDS ? kMaxDescLut : 1];
 	__shared__ float s_q[4][6][kQCap];                 // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
 	__shared__ float s_predn[12];
@@ -256,7 +303,8 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
 #endif
 	float(*q)[kQCap] = s_q[wid];
-	unsigned long long *hist_rep = &hist[lane % kRep];
+	bin_t *hist_rep = &hist[lane % kRep];
+	const int spread = (lane / kRep) & 7;
 
 	// The accepted keypoints (slot -> extremum list from k_slots) are handed out one at a time through a global counter:
 	// window sizes differ 4x between keypoint levels, so a static deal leaves a long tail.  A partitioned run (multi-GPU
@@ -294,7 +342,21 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		const float desc_hw = (float)((double)win_radius / sqrt(2.0));
 		const float desc_width = 2.0f * desc_hw;
 		const float bin_fctr = __fdiv_rn(4.0f, desc_width);
-		const float u = L.unit, inv_u = __fdiv_rn(1.0f, u);
+		const float u = L.unit;
+		// Fixed-point unit of the 32-bit histogram, per keypoint: every bin sum is bounded by the gradient mass M = sum of |g| w over
+		// the window, so a unit 2^-k with M 2^k < 2^31 cannot overflow.  M is not known yet: the first pass uses an estimate (rms
+		// gradient of the orientation window, from the structure tensor, times the descriptor window's weight sum, with 4x head
+		// room), sums the true M on the way and, should the estimate have been too small, the keypoint is redone once with the
+		// exact bound.  WinLut::fix_scale (provable for ANY data of this window size) is the coarsest unit ever used.
+		const WinLut lut_o = luts[li * 2];
+		const float st_tr = fmaxf(kps[k].st[0] + kps[k].st[4] + kps[k].st[8], 0.0f);
+		const float m_est = __fsqrt_rn(__fdiv_rn(st_tr, lut_o.wsum)) * lut.wsum;
+		auto pick_scale = [&](float mass) {  // largest power of two <= 2^31 / mass, clamped to [provable, 2^29]
+			const float q = __fdiv_rn(2147483648.0f * 0.98f, fmaxf(mass, 1e-30f));
+			const float p2 = __uint_as_float(__float_as_uint(q) & 0xFF800000u);
+			return fminf(fmaxf(p2, lut.fix_scale), 536870912.0f);
+		};
+		float fix_scale = S3D_DESC_BIN64 ? 536870912.0f : pick_scale(m_est * 4.0f);
 		int x0, x1, y0, y1, z0, z1;
 		win_bounds_d((float)cxi, win_radius, u, L.nx, x0, x1);
 		win_bounds_d((float)cyi, win_radius, u, L.ny, y0, y1);
@@ -306,8 +368,13 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		const gfloat_p Ld = as_global(L.d);  // global_load instead of flat_load: in-order vmcnt, loads stay in flight
 		const gfloat_p centre = Ld + (size_t)cxi + (size_t)sy * (size_t)cyi + (size_t)sz * (size_t)(czi - L.zoff);  // always valid
 
-		__syncthreads();  // previous keypoint finished with hist / s_lut
-		for (int i = tid; i < kDesc * kRep; i += 256) hist[i] = 0ull;
+#if defined(S3D_EXP) && S3D_EXP == 6
+		float exp_mass = 0.f; int exp_attempts = 0;
+#endif
+		for (int attempt = 0;; attempt++) {  // block-uniform; a second pass only when the first unit was too fine
+		float msum = 0.0f;  // this lane's share of the gradient mass
+		__syncthreads();  // previous keypoint / pass finished with hist / s_lut
+		for (int i = tid; i < kBins * kRep; i += 256) hist[i] = 0;
 		if (tid == 0) s_tile = 0u;
 		if (LUT_LDS && cur_lut != li) {
 			for (int i = tid; i < lut.len && i < kMaxDescLut; i += 256) s_lut[i] = lutpool[lut.off + i];
@@ -432,17 +499,15 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 					const float nxm = k ? rowC.y : rowC.x, nxp = k ? rowC.w : rowC.z;
 					const float nym = k ? ymC.y : ymC.x, nyp = k ? ypC.y : ypC.x;
 					const float cp = k ? rowN.z : rowN.y, cm = k ? cmv.y : cmv.x;
-					float gx = 0.5f * (nxp - nxm);
-					float gy = 0.5f * (nyp - nym);
-					float gz = 0.5f * (cp - cm);
-					gx = gx * inv_u; gy = gy * inv_u; gz = gz * inv_u;
+					float gx = nxp - nxm;
+					float gy = nyp - nym;
+					float gz = cp - cm;
+					// w carries the reference's 0.5 and 1/u (exact power-of-two scalings, WinLut).  The rotation of the gradient and the
+					// exact |R g|^2 >= eps test run on the compacted voxels; here a voxel is only dropped when it fails by a margin
 					gx = gx * w; gy = gy * w; gz = gz * w;
-					const float rx = R0 * gx + R1 * gy + R2 * gz;
-					const float ry = R3 * gx + R4 * gy + R5 * gz;
-					const float rz = R6 * gx + R7 * gy + R8 * gz;
-					const float g2 = rx * rx + ry * ry + rz * rz;
-					actk[k] = act && !(g2 < kBaryEps);
-					bxk[k] = bx; byk[k] = by; bzk[k] = bz; rxk[k] = rx; ryk[k] = ry; rzk[k] = rz;
+					const float g2 = gx * gx + gy * gy + gz * gz;
+					actk[k] = act && !(g2 < kBaryEps * 0.99f);
+					bxk[k] = bx; byk[k] = by; bzk[k] = bz; rxk[k] = gx; ryk[k] = gy; rzk[k] = gz;
 				}
 				cmv = f2g{rowC.y, rowC.z}; rowC = rowN; rowN = rowNN; ymC = ymN; ypC = ypN;
 				c = cn; z += more ? 1 : 0;
@@ -462,8 +527,8 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 					// ---- a full wave of active voxels is ready: run the heavy part on all 64 lanes ----
 					if (qcount >= 64) {
 						const int pos = (qhead + lane) & (kQCap - 1);
-						accumulate_voxel(true, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], s_face, s_fidx, s_predn,
-						                 s_predf, hist_rep);
+						msum += accumulate_voxel(true, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale,
+						                 s_face, s_fidx, s_predn, s_predf, hist_rep, spread);
 						qhead = (qhead + 64) & (kQCap - 1);
 						qcount -= 64;
 					}
@@ -554,16 +619,13 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 				// coordinates are finite, so min/max over the three axes gives the same predicate in two v_min3/v_max3
 				bool act = in && fminf(fminf(bx, by), bz) > -0.5f && fmaxf(fmaxf(bx, by), bz) < 3.5f;
 				const float w = LUT_LDS ? s_lut[in ? rr + dz * dz : 0] : lut_g[in ? rr + dz * dz : 0];
-				float gx = 0.5f * (nxp - nxm);
-				float gy = 0.5f * (nyp - nym);
-				float gz = 0.5f * (cp - cm);
-				gx = gx * inv_u; gy = gy * inv_u; gz = gz * inv_u;
+				float gx = nxp - nxm;
+				float gy = nyp - nym;
+				float gz = cp - cm;
 				gx = gx * w; gy = gy * w; gz = gz * w;
-				const float rx = R0 * gx + R1 * gy + R2 * gz;
-				const float ry = R3 * gx + R4 * gy + R5 * gz;
-				const float rz = R6 * gx + R7 * gy + R8 * gz;
-				const float g2 = rx * rx + ry * ry + rz * rz;
-				act = act && !(g2 < kBaryEps);
+				const float rx = gx, ry = gy, rz = gz;  // rotated on the compacted voxels (accumulate_voxel)
+				const float g2 = gx * gx + gy * gy + gz * gz;
+				act = act && !(g2 < kBaryEps * 0.99f);
 				cm = cc; cc = cp; cp = cpn; nxm = nxm1; nxp = nxp1; nym = nym1; nyp = nyp1;
 				c = cn; dz += more ? 1 : 0;
 				S3D_DSTAMP(3)  // step arithmetic
@@ -580,8 +642,8 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 				// ---- a full wave of active voxels is ready: run the heavy part on all 64 lanes ----
 				if (qcount >= 64) {
 					const int pos = (qhead + lane) & (kQCap - 1);
-					accumulate_voxel(true, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], s_face, s_fidx, s_predn,
-					                 s_predf, hist_rep);
+					msum += accumulate_voxel(true, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale,
+					                 s_face, s_fidx, s_predn, s_predf, hist_rep, spread);
 					qhead = (qhead + 64) & (kQCap - 1);
 					qcount -= 64;
 #if defined(S3D_EXP) && S3D_EXP == 5
@@ -595,10 +657,27 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		if (qcount > 0) {  // drain (wave-uniform)
 			const int pos = (qhead + lane) & (kQCap - 1);
 			const bool valid = lane < qcount;
-			accumulate_voxel(valid, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], s_face, s_fidx, s_predn, s_predf,
-			                 hist_rep);
+			msum += accumulate_voxel(valid, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale,
+			                 s_face, s_fidx, s_predn, s_predf, hist_rep, spread);
 		}
 		S3D_DSTAMP(6)  // drain
+		// gradient mass of the window (block sum; fp32 sums of non-negative terms, 1e-4 relative at worst: covered by the margins)
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) msum = msum + __shfl_xor(msum, o, 64);
+		__syncthreads();
+		if (lane == 0) red[wid] = msum;
+		__syncthreads();
+		const float mass = ((red[0] + red[1]) + (red[2] + red[3])) * 1.001f;
+		// every bin (and replica) sum is <= mass * fix_scale + half a unit per contribution (< 2^20 contributions)
+		if (S3D_DESC_BIN64 || attempt == 1 || mass * fix_scale + 1048576.0f < 2147483648.0f) {
+#if defined(S3D_EXP) && S3D_EXP == 6
+			exp_mass = mass; exp_attempts = attempt + 1;
+#endif
+			break;
+		}
+		fix_scale = pick_scale(mass);  // exact bound: this pass cannot overflow
+		}
+		const double fix_inv = 1.0 / (double)fix_scale;
 		__syncthreads();
 
 		// normalise -> clamp -> normalise (Src/cSIFT3D.cc:1350-1358, 1639-1656)
@@ -607,11 +686,11 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 #pragma unroll
 		for (int r = 0; r < kRep; r++) {
 			const int rr2 = (r + tid) % kRep;  // stagger the replica order across lanes
-			a0 += (long long)hist[tid * kRep + rr2];
-			a1 += (long long)hist[(tid + 256) * kRep + rr2];
-			a2 += (long long)hist[(tid + 512) * kRep + rr2];
+			a0 += (long long)(sbin_t)hist[bin_index(tid) * kRep + rr2];
+			a1 += (long long)(sbin_t)hist[bin_index(tid + 256) * kRep + rr2];
+			a2 += (long long)(sbin_t)hist[bin_index(tid + 512) * kRep + rr2];
 		}
-		float v0 = (float)((double)a0 * kFixedInv), v1 = (float)((double)a1 * kFixedInv), v2 = (float)((double)a2 * kFixedInv);
+		float v0 = (float)((double)a0 * fix_inv), v1 = (float)((double)a1 * fix_inv), v2 = (float)((double)a2 * fix_inv);
 		for (int pass = 0; pass < 2; pass++) {
 			float s = v0 * v0 + v1 * v1 + v2 * v2;
 #pragma unroll
@@ -632,6 +711,10 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 		float *out = d_desc + (size_t)slot * kDesc;
 		out[tid] = v0; out[tid + 256] = v1; out[tid + 512] = v2;
 		S3D_DSTAMP(7)  // normalise + store
+#if defined(S3D_EXP) && S3D_EXP == 6
+		__syncthreads();
+		if (tid == 0) { out[0] = exp_mass; out[1] = m_est; out[2] = (float)exp_attempts; out[3] = fix_scale; }
+#endif
 #if defined(S3D_EXP) && S3D_EXP == 5
 		{
 			int tl = exp_lanes;

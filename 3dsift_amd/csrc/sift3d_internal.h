@@ -93,6 +93,11 @@ struct WinLut {
 	int nin;      // largest n that is still inside the sphere (tables are monotone)
 	float radius; // win_radius (fp32) for the box bounds
 	float sigma;
+	// descriptor tables only: the entries are weight * 0.5 / unit (exact: the unit is a power of two, so the reference's
+	// ((0.5*d) * (1/u)) * w rounds like d * (w * 0.5/u)), and the histogram bins of k_describe are 32-bit fixed point in units of
+	// 1/fix_scale (a power of two chosen so that no bin can overflow an int32 for this window size, see build_luts)
+	float fix_scale;
+	float wsum;  // sum of the (unscaled) Gaussian weights over the lattice points of the window sphere (gradient-mass estimate)
 };
 constexpr int kMaxDescLut = 1536;  // descriptor window table entries staged in LDS (default params: 1293)
 

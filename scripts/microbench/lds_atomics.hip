@@ -50,5 +50,11 @@ int main() {
 	run<1, 4>("ds_add_u32 4 lanes/address");
 	run<2, 0>("ds_add_u64 conflict-free");
 	run<2, 4>("ds_add_u64 4 lanes/address");
+	run<1, 2>("ds_add_u32 2 lanes/address");
+	run<1, 8>("ds_add_u32 8 lanes/address");
+	run<1, 16>("ds_add_u32 16 lanes/address");
+	run<2, 2>("ds_add_u64 2 lanes/address");
+	run<2, 8>("ds_add_u64 8 lanes/address");
+	run<2, 16>("ds_add_u64 16 lanes/address");
 	return 0;
 }
