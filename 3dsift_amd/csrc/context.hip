@@ -489,7 +489,7 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	build_faces(faces);
 	FacePredict pred;
 	build_predict(faces, &pred);
-	upload_faces(faces, &pred);
+	CHECKED(upload_faces(faces, &pred));
 
 	// keypoint lists: synthetic blob volumes give ~6e-4*V extrema; leave 8x headroom, regrow on overflow
 	const size_t V0 = (size_t)cfg.nx * cfg.ny * scan_planes;

@@ -46,9 +46,11 @@ namespace s3d {
 __constant__ FaceConst c_faces[kFaces];
 __constant__ FacePredict c_pred;
 
-void upload_faces(const FaceConst *faces, const FacePredict *pred) {
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_faces), faces, sizeof(FaceConst) * kFaces);
-	(void)hipMemcpyToSymbol(HIP_SYMBOL(c_pred), pred, sizeof(FacePredict));
+// __constant__ symbols live per device: called by every create on its own device (set by the caller)
+hipError_t upload_faces(const FaceConst *faces, const FacePredict *pred) {
+	hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_faces), faces, sizeof(FaceConst) * kFaces);
+	if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_pred), pred, sizeof(FacePredict));
+	return e;
 }
 
 __device__ __forceinline__ void win_bounds_d(float c, float rad, float u, int n, int &lo, int &hi) {
@@ -67,6 +69,12 @@ constexpr int kFaceStride = 16;  // floats per face in the LDS table
 #define S3D_DESC_REP 4
 #endif
 // (no waves-per-SIMD hint in __launch_bounds__: any value >= 2 makes hipcc schedule for occupancy and the kernel 10 % slower)
+#ifndef S3D_DESC_FASTMATH
+#define S3D_DESC_FASTMATH 0
+#endif
+#ifndef S3D_DESC_CLIPM
+#define S3D_DESC_CLIPM 2.0f  /* widening of the cube clip of a column's z range, voxels */
+#endif
 #ifndef S3D_DESC_SPREAD
 #define S3D_DESC_SPREAD 1
 #endif
@@ -113,7 +121,11 @@ __device__ __forceinline__ bool face_test(const float *Fb, float gx, float gy, f
 	if (fabsf(det) < kBaryEps) return false;
 	// reference: (float)(1.0 / (double)det).  A correctly rounded fp32 division gives the same value: double
 	// rounding is innocuous for division when the wide format has >= 2p+2 = 50 bits (binary64 has 53)
+#if S3D_DESC_FASTMATH
+	const float det_inv = __builtin_amdgcn_rcpf(det);  // 1 ulp; decisions keep their 1e-4 margin, values move by <= 1e-7 relative
+#else
 	const float det_inv = __fdiv_rn(1.0f, det);
+#endif
 	b1 = det_inv * (px * F[6] + py * F[7] + pz * F[8]);
 	b2 = det_inv * (gx * F[9] + gy * F[10] + gz * F[11]);
 	b0 = 1.0f - b1 - b2;
@@ -190,7 +202,11 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 		if (slow) f = intersect_scan(rx, ry, rz, b0, b1, b2);
 	}
 	if (!valid || f < 0) return 0.0f;
+#if S3D_DESC_FASTMATH
+	const float mag = __builtin_amdgcn_sqrtf(g2);  // 1 ulp
+#else
 	const float mag = __fsqrt_rn(g2);
+#endif
 	const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
 	const int ix = (int)bx, iy = (int)by, iz = (int)bz;  // truncation toward zero, like the reference: 0..3
 	// Trilinear weights (Src/cSIFT3D.cc:1510-1512 forms them as double products rounded to fp32; fp32 products differ
@@ -444,8 +460,8 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 						if (fabsf(rr3[r]) > 1e-6f * desc_hw) {
 							const float inv = __frcp_rn(rr3[r]);
 							const float t0 = (-desc_hw - pr[r]) * inv, t1 = (desc_hw - pr[r]) * inv;
-							lo = fmaxf(lo, fminf(t0, t1) - 2.0f);
-							hi = fminf(hi, fmaxf(t0, t1) + 2.0f);
+							lo = fmaxf(lo, fminf(t0, t1) - S3D_DESC_CLIPM);
+							hi = fminf(hi, fmaxf(t0, t1) + S3D_DESC_CLIPM);
 						} else if (fabsf(pr[r]) > desc_hw * 1.001f + 1.0f) {
 							hi = lo - 1.0f;  // this row never enters the cube
 						}
@@ -571,8 +587,8 @@ __global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps,
 					if (fabsf(rr3[r]) > 1e-6f * desc_hw) {
 						const float inv = __frcp_rn(rr3[r]);
 						const float t0 = (-desc_hw - pr[r]) * inv, t1 = (desc_hw - pr[r]) * inv;
-						lo = fmaxf(lo, fminf(t0, t1) - 2.0f);
-						hi = fminf(hi, fmaxf(t0, t1) + 2.0f);
+						lo = fmaxf(lo, fminf(t0, t1) - S3D_DESC_CLIPM);
+						hi = fminf(hi, fmaxf(t0, t1) + S3D_DESC_CLIPM);
 					} else if (fabsf(pr[r]) > desc_hw * 1.001f + 1.0f) {
 						hi = lo - 1.0f;  // this row never enters the cube
 					}

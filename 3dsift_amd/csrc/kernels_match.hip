@@ -10,8 +10,12 @@
 //   k_rescore     : the 4 candidates of each row are re-scored exactly like the reference
 //                   (fp32 product, fp64 accumulate, k ascending) and the reference's update rule is
 //                   replayed over them in ascending j -- bit-identical d1, d2, i1, i2 as long as the
-//                   true top-2 are among the fp32 top-4 (score gaps < 1e-6 relative among >= 3 rows
-//                   would be needed to break this).
+//                   true top-2 are among the fp32 top-4
+//   guard (r02)   : that condition is CHECKED per row: every column outside the list has an fp32 score <= the list's 4th
+//                   score s4, and an fp32 chain of 768 products is within E = 768 * 2^-23 * |a| * max|b| of the exact value, so
+//                   the list is complete whenever s4 + E < exact second-best score.  Rows that fail the test (near-duplicate
+//                   targets) are re-done by k_exact_rows: exact scores of ALL columns, top-2 by (score desc, column asc) --
+//                   which is what the reference's strict-'>' scan in ascending j yields.
 // gfx950 only: 64-lane waves, MFMA C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include <float.h>
 #include <stdio.h>
@@ -25,7 +29,10 @@ namespace s3d {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KD = kDesc, TOPK = 4;
+#ifndef S3D_MATCH_TOPK
+#define S3D_MATCH_TOPK 6  /* candidates kept per row by the fp32 selection (r02, two similar 512^3 volumes, one full pass: 4 -> 3.6 ms because ~10 % of the rows fail the guard and are re-done exactly, 6 -> 2.6 ms, 8 -> 2.9 ms) */
+#endif
+constexpr int KD = kDesc, TOPK = S3D_MATCH_TOPK;
 // score kernel tiling: a 256-thread workgroup owns 128 rows x 128 columns per tile; wave w owns rows 32w..32w+31 across all
 // 128 columns (four 32x32 accumulators), so every row's running top-4 belongs to exactly one wave and lives in registers
 constexpr int BM = 128, BN = 128, BK = 32, PITCH = BK + 4;  // +16 B: the 16-B reads of 8 consecutive rows hit distinct banks
@@ -175,7 +182,8 @@ __global__ void __launch_bounds__(256, 2) k_scores_top4(const float *__restrict_
 }
 
 // merge the per-split partial lists of a row into its global top-4 (score desc, column asc)
-__global__ void __launch_bounds__(256) k_merge_top4(const Cand *__restrict__ part, int nrows, int splits, int *__restrict__ cand) {
+__global__ void __launch_bounds__(256) k_merge_top4(const Cand *__restrict__ part, int nrows, int splits, int *__restrict__ cand,
+                                                    float *__restrict__ s4 /* 4th fp32 score of the row, -FLT_MAX if the list is short */) {
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
 	if (r >= nrows) return;
 	float bs[TOPK];
@@ -189,12 +197,32 @@ __global__ void __launch_bounds__(256) k_merge_top4(const Cand *__restrict__ par
 		}
 #pragma unroll
 	for (int t = 0; t < TOPK; t++) cand[(size_t)r * TOPK + t] = bj[t];
+	s4[r] = bj[TOPK - 1] >= 0 ? bs[TOPK - 1] : -FLT_MAX;
+}
+
+// squared norms of the rows of X (one wave per row), and their maximum (bits of a non-negative float)
+__global__ void __launch_bounds__(256) k_row_norm2(const float *__restrict__ X, int nrows, float *__restrict__ n2, unsigned *__restrict__ n2max) {
+	const int lane = threadIdx.x & 63;
+	const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (r >= nrows) return;
+	const float *x = X + (size_t)r * KD;
+	float a = 0.f;
+	for (int k = lane; k < KD; k += 64) a = a + x[k] * x[k];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) a = a + __shfl_xor(a, o, 64);
+	if (lane == 0) {
+		a = a * 1.0001f;  // fp32 summation error of 768 non-negative terms
+		if (n2) n2[r] = a;
+		if (n2max) atomicMax(n2max, __float_as_uint(a));
+	}
 }
 
 // exact re-score + replay of the reference update rule (Src/cMatcher.cc:52-77)
 __global__ void __launch_bounds__(256) k_rescore(const float *__restrict__ A, const int *__restrict__ row_ids, int nrows,
                                                  const float *__restrict__ B, const int *__restrict__ cand, float *__restrict__ gd,
-                                                 float *__restrict__ sd, int *__restrict__ gi, int *__restrict__ si) {
+                                                 float *__restrict__ sd, int *__restrict__ gi, int *__restrict__ si,
+                                                 const float *__restrict__ s4, const float *__restrict__ a_n2,
+                                                 const unsigned *__restrict__ b_n2max, int *__restrict__ redo /* [0] count, then r */) {
 	// one wave per row: lanes 0..3 each re-score one candidate sequentially (k ascending)
 	const int lane = threadIdx.x & 63;
 	const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -231,15 +259,65 @@ __global__ void __launch_bounds__(256) k_rescore(const float *__restrict__ A, co
 			if (sij > d1) { d2 = d1; i2 = i1; d1 = sij; i1 = js[t]; }
 			else if (sij > d2) { d2 = sij; i2 = js[t]; }
 		}
+		// guard: can a column outside the candidate list reach the second place?  (see the header)
+		const float thr4 = s4[r];
+		if (thr4 > -FLT_MAX) {
+			const float e = 9.16e-5f /* 768 * 2^-23, rounded up */ * (__fsqrt_rn(a_n2[row]) * 1.000001f) * (__fsqrt_rn(__uint_as_float(*b_n2max)) * 1.000001f);
+			if (!((double)thr4 + (double)e < d2)) redo[1 + atomicAdd(&redo[0], 1)] = r;
+		}
 		d2 = 2 - 2 * d2;
 		d1 = 2 - 2 * d1;
 		gd[row] = (float)d1; sd[row] = (float)d2; gi[row] = i1; si[row] = i2;
 	}
 }
 
+// Rows whose candidate list may be incomplete: exact scores (fp32 product, fp64 accumulate, k ascending -- Src/cMatcher.cc:57-61)
+// of ALL columns, best and second best by (score desc, column asc), both starting at FLT_MIN like the reference.
+__global__ void __launch_bounds__(256) k_exact_rows(const float *__restrict__ A, const int *__restrict__ row_ids, const float *__restrict__ B,
+                                                    int m, const int *__restrict__ redo, float *__restrict__ gd, float *__restrict__ sd,
+                                                    int *__restrict__ gi, int *__restrict__ si) {
+	__shared__ double s_d[256][2];
+	__shared__ int s_i[256][2];
+	__shared__ float s_a[KD];
+	const int n = redo[0], tid = threadIdx.x;
+	for (int it = blockIdx.x; it < n; it += gridDim.x) {
+		const int r = redo[1 + it];
+		const int row = row_ids ? row_ids[r] : r;
+		__syncthreads();
+		for (int k = tid; k < KD; k += 256) s_a[k] = A[(size_t)row * KD + k];
+		__syncthreads();
+		double d1 = FLT_MIN, d2 = FLT_MIN;
+		int i1 = -1, i2 = -1;
+		for (int j = tid; j < m; j += 256) {  // ascending j per thread
+			const float *b = B + (size_t)j * KD;
+			double sc = 0.0;
+			for (int k = 0; k < KD; k++) sc += (double)(s_a[k] * b[k]);
+			if (sc > d1) { d2 = d1; i2 = i1; d1 = sc; i1 = j; }
+			else if (sc > d2) { d2 = sc; i2 = j; }
+		}
+		s_d[tid][0] = d1; s_d[tid][1] = d2; s_i[tid][0] = i1; s_i[tid][1] = i2;
+		__syncthreads();
+		if (tid == 0) {
+			// merge the 512 partial entries by (score desc, column asc); entries with index -1 are the FLT_MIN start values
+			double b1 = FLT_MIN, b2 = FLT_MIN;
+			int j1 = -1, j2 = -1;
+			auto better = [](double s, int j, double bs, int bj) { return bj < 0 ? true : (s > bs || (s == bs && j < bj)); };
+			for (int t = 0; t < 256; t++)
+				for (int q = 0; q < 2; q++) {
+					const double sc = s_d[t][q];
+					const int j = s_i[t][q];
+					if (j < 0) continue;
+					if (better(sc, j, b1, j1)) { b2 = b1; j2 = j1; b1 = sc; j1 = j; }
+					else if (better(sc, j, b2, j2)) { b2 = sc; j2 = j; }
+				}
+			gd[row] = (float)(2 - 2 * b1); sd[row] = (float)(2 - 2 * b2); gi[row] = j1; si[row] = j2;
+		}
+	}
+}
+
 // rows: optional list of row indices into A (reverse pass over the masked targets only)
 int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const float *d_b, int m, int *d_cand, void *d_part,
-                      float *d_gd, float *d_sd, int *d_gi, int *d_si, hipStream_t st) {
+                      float *d_gd, float *d_sd, int *d_gi, int *d_si, const MatchGuard &g, hipStream_t st) {
 	if (nrows <= 0) return SIFT3D_OK;
 	// column splits: as many workgroups as fit ONE residency round (two per CU), never more than the tiles there are
 	const int rb = (nrows + BM - 1) / BM, ntiles = (m + BN - 1) / BN;
@@ -247,8 +325,11 @@ int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const f
 	const int tps = (ntiles + splits - 1) / splits;
 	splits = (ntiles + tps - 1) / tps;
 	hipLaunchKernelGGL(k_scores_top4, dim3(rb, splits), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, tps, (Cand *)d_part);
-	hipLaunchKernelGGL(k_merge_top4, dim3((nrows + 255) / 256), dim3(256), 0, st, (const Cand *)d_part, nrows, splits, d_cand);
-	hipLaunchKernelGGL(k_rescore, dim3((nrows + 3) / 4), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, d_cand, d_gd, d_sd, d_gi, d_si);
+	hipLaunchKernelGGL(k_merge_top4, dim3((nrows + 255) / 256), dim3(256), 0, st, (const Cand *)d_part, nrows, splits, d_cand, g.s4);
+	(void)hipMemsetAsync(g.redo, 0, sizeof(int), st);
+	hipLaunchKernelGGL(k_rescore, dim3((nrows + 3) / 4), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, d_cand, d_gd, d_sd, d_gi, d_si,
+	                   g.s4, g.a_n2, g.b_n2max, g.redo);
+	hipLaunchKernelGGL(k_exact_rows, dim3(std::min(nrows, 1024)), dim3(256), 0, st, d_a, d_row_ids, d_b, m, g.redo, d_gd, d_sd, d_gi, d_si);
 	return SIFT3D_OK;
 }
 
@@ -311,18 +392,26 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 			if (n) MCHK(hipMemcpy(d_a, ref_desc, sizeof(float) * kDesc * n, hipMemcpyHostToDevice));
 			if (m) MCHK(hipMemcpy(d_b, tar_desc, sizeof(float) * kDesc * m, hipMemcpyHostToDevice));
 		}
-		MCHK(hipMalloc(&d_f, sizeof(float) * 2 * big));
-		MCHK(hipMalloc(&d_i, sizeof(int) * (2 + TOPK + 1) * big));
+		MCHK(hipMalloc(&d_f, sizeof(float) * (3 * big + nn + mm + 2)));
+		MCHK(hipMalloc(&d_i, sizeof(int) * ((2 + TOPK + 2) * big + 1)));
 		MCHK(hipMalloc(&d_part, sizeof(Cand) * TOPK * kMaxSplits * big));
 		float *d_gd = d_f, *d_sd = d_f + big;
 		int *d_gi = d_i, *d_si = d_i + big, *d_cand = d_i + 2 * big, *d_rows = d_i + (2 + TOPK) * big;
+		// near-tie guard scratch: 4th fp32 score per row, squared row norms of both sets and their maxima, redo list
+		float *d_s4 = d_f + 2 * big, *d_an2 = d_f + 3 * big, *d_bn2 = d_an2 + nn;
+		unsigned *d_nmax = reinterpret_cast<unsigned *>(d_bn2 + mm);
+		int *d_redo = d_i + (2 + TOPK + 1) * big;
+		MCHK(hipMemsetAsync(d_nmax, 0, 2 * sizeof(unsigned), nullptr));
+		if (n) hipLaunchKernelGGL(k_row_norm2, dim3((n + 3) / 4), dim3(256), 0, nullptr, d_a, n, d_an2, d_nmax);
+		if (m) hipLaunchKernelGGL(k_row_norm2, dim3((m + 3) / 4), dim3(256), 0, nullptr, d_b, m, d_bn2, d_nmax + 1);
+		const MatchGuard g_fwd{d_s4, d_an2, d_nmax + 1, d_redo}, g_rev{d_s4, d_bn2, d_nmax, d_redo};
 		MCHK(hipEventCreate(&e0));
 		MCHK(hipEventCreate(&e1));
 		MCHK(hipEventRecord(e0, nullptr));
 
 		// ---- ref -> tar ----
 		if (n > 0 && m > 0) {
-			match_rows_device(d_a, nullptr, n, d_b, m, d_cand, d_part, d_gd, d_sd, d_gi, d_si, nullptr);
+			match_rows_device(d_a, nullptr, n, d_b, m, d_cand, d_part, d_gd, d_sd, d_gi, d_si, g_fwd, nullptr);
 			MCHK(hipMemcpy(gd.data(), d_gd, sizeof(float) * n, hipMemcpyDeviceToHost));
 			MCHK(hipMemcpy(sd.data(), d_sd, sizeof(float) * n, hipMemcpyDeviceToHost));
 			MCHK(hipMemcpy(gi.data(), d_gi, sizeof(int) * n, hipMemcpyDeviceToHost));
@@ -342,7 +431,7 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 			// ---- tar -> ref over the masked targets only (masked-out rows keep gIdx2 = -1) ----
 			if (!rows.empty() && n > 0) {
 				MCHK(hipMemcpy(d_rows, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
-				match_rows_device(d_b, d_rows, (int)rows.size(), d_a, n, d_cand, d_part, d_gd, d_sd, d_gi, d_si, nullptr);
+				match_rows_device(d_b, d_rows, (int)rows.size(), d_a, n, d_cand, d_part, d_gd, d_sd, d_gi, d_si, g_rev, nullptr);
 				std::vector<float> tg(m), ts(m);
 				std::vector<int> ti(m), tsi(m);
 				MCHK(hipMemcpy(tg.data(), d_gd, sizeof(float) * m, hipMemcpyDeviceToHost));

@@ -48,13 +48,21 @@ __device__ __forceinline__ void block_max_to_global(float m, unsigned *dst) {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_absmax(const float *__restrict__ src, size_t n, unsigned *dst) {
 	float m = 0.0f;
-	const size_t n4 = n / 4;
-	const float4 *s4 = reinterpret_cast<const float4 *>(src);
+	// scalar head up to the first 16-byte boundary (a z-slab's owned planes start at plane * nx * ny floats: any dword alignment),
+	// float4 body, scalar tail
+	const size_t mis = ((size_t)src >> 2) & 3;
+	const size_t head = mis ? (4 - mis < n ? 4 - mis : n) : 0;
+	const size_t n4 = (n - head) / 4;
+	const float4 *s4 = reinterpret_cast<const float4 *>(src + head);
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
 		float4 v = s4[i];
 		m = absmax_step(m, v.x); m = absmax_step(m, v.y); m = absmax_step(m, v.z); m = absmax_step(m, v.w);
 	}
-	if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = absmax_step(m, src[n4 * 4 + threadIdx.x]);
+	if (blockIdx.x == 0) {
+		if (threadIdx.x < head) m = absmax_step(m, src[threadIdx.x]);
+		const size_t tail0 = head + n4 * 4;
+		if (threadIdx.x < n - tail0) m = absmax_step(m, src[tail0 + threadIdx.x]);
+	}
 	block_max_to_global(m, dst);
 }
 

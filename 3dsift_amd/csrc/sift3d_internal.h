@@ -176,7 +176,7 @@ void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigne
                   hipStream_t st);
 
 // ---- kernels_desc.hip ----------------------------------------------------------------------
-void upload_faces(const FaceConst *faces, const FacePredict *pred);  // into __constant__ memory
+hipError_t upload_faces(const FaceConst *faces, const FacePredict *pred);  // into the current device's __constant__ memory
 // part_rank / part_world: only keypoints with slot % part_world == part_rank are described (multi-GPU split of
 // replicated octaves); 0 / 1 = all
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels,
@@ -190,8 +190,11 @@ void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, in
 // best / second-best dot of every listed row of A against all m rows of B (calMatches);
 // d_row_ids == nullptr means rows 0..nrows-1; outputs are indexed by the ORIGINAL row id.
 // d_part: scratch for the per-column-split partial top-4 lists, 8 B * 4 * 16 * nrows
+// near-tie guard scratch (see kernels_match.hip): s4[nrows], squared norms of the A rows (indexed by ORIGINAL row id), the maximal
+// squared norm of the B rows (bits), redo list [1 + nrows]
+struct MatchGuard { float *s4; const float *a_n2; const unsigned *b_n2max; int *redo; };
 int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const float *d_b, int m, int *d_cand /*nrows*4*/,
-                      void *d_part, float *d_gd, float *d_sd, int *d_gi, int *d_si, hipStream_t st);
+                      void *d_part, float *d_gd, float *d_sd, int *d_gi, int *d_si, const MatchGuard &g, hipStream_t st);
 
 // error plumbing
 void set_last_error(const std::string &s);

@@ -24,6 +24,8 @@ public:
 	// the reference's public timing fields; only matchTime / totalTime are meaningful here (device seconds)
 	float matchTime = 0.0, filterTime = 0.0, countMatchedTime = 0.0, revMatchTime = 0.0, revFilterTime = 0.0,
 	      bijectFilterTime = 0.0, converseTime = 0.0, totalTime = 0.0;
+	// extension: true when the last call matched straight from two live extractors' device-resident results
+	bool usedDeviceResults = false;
 
 	SIFT_LIBRARY_API muBruteMatcher();
 	SIFT_LIBRARY_API float getCalculationTime();

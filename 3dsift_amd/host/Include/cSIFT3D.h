@@ -96,6 +96,9 @@ public:
 
 	// extension: device-resident descriptors / coordinates for a matcher that never leaves the GPU
 	SIFT_LIBRARY_API bool GetDeviceResults(const float **d_desc, const float **d_xyz, int *n, int *device);
+	// extension: the live extractor whose GetKeypoints() produced `kp` unchanged (same count, descriptor
+	// pointers and coordinates), or nullptr.  muBruteMatcher uses it to match straight from the device-resident results.
+	SIFT_LIBRARY_API static CSIFT3D *OwnerOf(const std::vector<Keypoint> &kp);
 };
 
 class SIFT_LIBRARY_API CSIFT3DFactory {

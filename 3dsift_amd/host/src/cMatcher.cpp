@@ -19,23 +19,36 @@ std::vector<int> muBruteMatcher::getSilverIdx() { return silverIdx; }
 void muBruteMatcher::run(std::vector<Cvec> &refMatch, std::vector<Cvec> &tarMatch, const std::vector<Keypoint> &ref_kp,
                          const std::vector<Keypoint> &tar_kp, double thresHold, int mode) {
 	const int n = (int)ref_kp.size(), m = (int)tar_kp.size();
-	// gather the (possibly scattered) descriptor rows; Keypoint::desc points into extractor-owned memory
-	std::vector<float> a((size_t)n * DESC_LENGTH), b((size_t)m * DESC_LENGTH), ax((size_t)n * 3), bx((size_t)m * 3);
-	for (int i = 0; i < n; i++) {
-		if (ref_kp[i].desc) memcpy(&a[(size_t)i * DESC_LENGTH], ref_kp[i].desc, sizeof(float) * DESC_LENGTH);
-		ax[3 * i] = ref_kp[i].rx; ax[3 * i + 1] = ref_kp[i].ry; ax[3 * i + 2] = ref_kp[i].rz;
-	}
-	for (int j = 0; j < m; j++) {
-		if (tar_kp[j].desc) memcpy(&b[(size_t)j * DESC_LENGTH], tar_kp[j].desc, sizeof(float) * DESC_LENGTH);
-		bx[3 * j] = tar_kp[j].rx; bx[3 * j + 1] = tar_kp[j].ry; bx[3 * j + 2] = tar_kp[j].rz;
-	}
 	glodenIdx.assign((size_t)n, -1); silverIdx.assign((size_t)n, -1);
 	glodenDistSquare.assign((size_t)n, 0.f); silverDistSquare.assign((size_t)n, 0.f);
 	std::vector<float> pairs((size_t)(n > 0 ? n : 1) * 6);
-	int np = 0;
+	int np = 0, rc;
 	double sec = 0;
-	int rc = sift3d_match(a.data(), ax.data(), n, b.data(), bx.data(), m, thresHold, mode, 0, GetDevice(), glodenIdx.data(),
-	                      silverIdx.data(), glodenDistSquare.data(), silverDistSquare.data(), pairs.data(), &np, &sec);
+	usedDeviceResults = false;
+	// Keypoint vectors that still alias their extractors (the Example flow: GetKeypoints() straight into the matcher) are matched
+	// from the descriptors and coordinates already resident on the device: no gather, no host round trip of N x 768 floats
+	CSIFT3D *oa = CSIFT3D::OwnerOf(ref_kp), *ob = CSIFT3D::OwnerOf(tar_kp);
+	const float *da = nullptr, *xa = nullptr, *db = nullptr, *xb = nullptr;
+	int na = 0, nb = 0, deva = -1, devb = -2;
+	if (oa && ob && oa->GetDeviceResults(&da, &xa, &na, &deva) && ob->GetDeviceResults(&db, &xb, &nb, &devb) && deva == devb && na == n &&
+	    nb == m) {
+		usedDeviceResults = true;
+		rc = sift3d_match(da, xa, n, db, xb, m, thresHold, mode, 1, deva, glodenIdx.data(), silverIdx.data(), glodenDistSquare.data(),
+		                  silverDistSquare.data(), pairs.data(), &np, &sec);
+	} else {
+		// gather the (possibly scattered) descriptor rows; Keypoint::desc points into extractor-owned memory
+		std::vector<float> a((size_t)n * DESC_LENGTH), b((size_t)m * DESC_LENGTH), ax((size_t)n * 3), bx((size_t)m * 3);
+		for (int i = 0; i < n; i++) {
+			if (ref_kp[i].desc) memcpy(&a[(size_t)i * DESC_LENGTH], ref_kp[i].desc, sizeof(float) * DESC_LENGTH);
+			ax[3 * i] = ref_kp[i].rx; ax[3 * i + 1] = ref_kp[i].ry; ax[3 * i + 2] = ref_kp[i].rz;
+		}
+		for (int j = 0; j < m; j++) {
+			if (tar_kp[j].desc) memcpy(&b[(size_t)j * DESC_LENGTH], tar_kp[j].desc, sizeof(float) * DESC_LENGTH);
+			bx[3 * j] = tar_kp[j].rx; bx[3 * j + 1] = tar_kp[j].ry; bx[3 * j + 2] = tar_kp[j].rz;
+		}
+		rc = sift3d_match(a.data(), ax.data(), n, b.data(), bx.data(), m, thresHold, mode, 0, GetDevice(), glodenIdx.data(),
+		                  silverIdx.data(), glodenDistSquare.data(), silverDistSquare.data(), pairs.data(), &np, &sec);
+	}
 	if (rc != SIFT3D_OK) {
 		fprintf(stderr, "[3dsift_amd] muBruteMatcher: %s (%s)\n", sift3d_error_string(rc), sift3d_last_error());
 		return;

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "../../../include/sift3d_hip.h"
 #include "../Include/Util/matrixIO3D.h"
@@ -25,6 +27,11 @@ int GetDevice() {
 	}
 	return g_device;
 }
+
+// live extractors by the host address of their descriptor block (Keypoint::desc of row 0): lets the matcher recognise keypoint
+// vectors that still alias an extractor and read that extractor's device-resident results instead
+static std::mutex g_reg_mu;
+static std::map<const float *, CSIFT3D *> g_reg;
 
 struct CSIFT3D::Impl {
 	sift3d_handle h = nullptr;
@@ -72,12 +79,35 @@ CSIFT3D::~CSIFT3D() {
 		if (impl->h) sift3d_destroy(impl->h);
 		delete impl;
 	}
-	if (global_descriptor) free(global_descriptor);
+	if (global_descriptor) {
+		{ std::lock_guard<std::mutex> lk(g_reg_mu); g_reg.erase(global_descriptor); }
+		free(global_descriptor);
+	}
+}
+
+CSIFT3D *CSIFT3D::OwnerOf(const std::vector<Keypoint> &kp) {
+	if (kp.empty() || !kp[0].desc) return nullptr;
+	CSIFT3D *o = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(g_reg_mu);
+		auto it = g_reg.find(kp[0].desc);
+		if (it != g_reg.end()) o = it->second;
+	}
+	if (!o || o->filter.size() != kp.size() || !o->impl || o->impl->stage < 5) return nullptr;
+	for (size_t i = 0; i < kp.size(); i++) {
+		const Keypoint &a = kp[i], &b = o->filter[i];
+		if (a.desc != b.desc || a.rx != b.rx || a.ry != b.ry || a.rz != b.rz) return nullptr;
+	}
+	return o;
 }
 
 void CSIFT3D::fetch_results() {
 	filter.clear();
-	if (global_descriptor) { free(global_descriptor); global_descriptor = nullptr; }
+	if (global_descriptor) {
+		{ std::lock_guard<std::mutex> lk(g_reg_mu); g_reg.erase(global_descriptor); }
+		free(global_descriptor);
+		global_descriptor = nullptr;
+	}
 	impl->fetched = true;
 	if (!impl->h || impl->stage < 4) return;
 	int n = 0;
@@ -102,6 +132,7 @@ void CSIFT3D::fetch_results() {
 		memcpy(k.str_tensor, s.str_tensor, sizeof(k.str_tensor));
 		k.desc = global_descriptor + (size_t)i * DESC_NUMEL;
 	}
+	if (with_desc) { std::lock_guard<std::mutex> lk(g_reg_mu); g_reg[global_descriptor] = this; }
 }
 
 static void run_to(CSIFT3D *self, sift3d_handle h, int upto, int &stage, bool &fetched, SIFT_TimerPara &tm) {

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../Include/Util/common.h"
@@ -60,12 +61,32 @@ float *readNiiFile(const char *filename, int &nx, int &ny, int &nz) {
 		datatype = bswap(datatype); bitpix = bswap(bitpix); vox_offset = bswap(vox_offset);
 	}
 	if (memcmp(hdr + 344, "n+1", 3) != 0) { gzclose(f); fprintf(stderr, "readNiiFile: only single-file NIfTI-1 (n+1) is supported\n"); return nullptr; }
-	nx = dim[1]; ny = dim[0] >= 2 ? dim[2] : 1; nz = dim[0] >= 3 ? dim[3] : 1;
-	const size_t n = (size_t)nx * ny * nz, bytes = n * (size_t)(bitpix / 8);
+	// the header is untrusted input: dimensions must be positive, the element size must agree with the datatype code, and the
+	// payload of a single-file image cannot start inside the header (348 bytes + 4 extension bytes)
+	size_t esize = 0;
+	switch (datatype) {
+	case 2: case 256: esize = 1; break;
+	case 4: case 512: esize = 2; break;
+	case 8: case 16: case 768: esize = 4; break;
+	case 64: esize = 8; break;
+	default: break;
+	}
+	const int ndim = dim[0];
+	if (ndim < 1 || ndim > 7 || dim[1] <= 0 || (ndim >= 2 && dim[2] <= 0) || (ndim >= 3 && dim[3] <= 0) || esize == 0 ||
+	    bitpix != (int16_t)(8 * esize) || !(vox_offset >= 352.0f) || vox_offset > 1.0e9f) {
+		gzclose(f);
+		fprintf(stderr, "readNiiFile: bad or unsupported header (dim %d: %d %d %d, datatype %d, bitpix %d, vox_offset %g)\n", ndim,
+		        (int)dim[1], (int)dim[2], (int)dim[3], (int)datatype, (int)bitpix, (double)vox_offset);
+		nx = ny = nz = 0;
+		return nullptr;
+	}
+	nx = dim[1]; ny = ndim >= 2 ? dim[2] : 1; nz = ndim >= 3 ? dim[3] : 1;
+	const size_t n = (size_t)nx * ny * nz, bytes = n * esize;
 	long skip = (long)vox_offset - 348;
 	std::vector<unsigned char> junk((size_t)(skip > 0 ? skip : 0));
 	if (skip > 0 && gzread(f, junk.data(), (unsigned)skip) != skip) { gzclose(f); return nullptr; }
-	std::vector<unsigned char> raw(bytes);
+	std::vector<unsigned char> raw;
+	try { raw.resize(bytes); } catch (...) { gzclose(f); fprintf(stderr, "readNiiFile: out of memory\n"); nx = ny = nz = 0; return nullptr; }
 	size_t got = 0;
 	while (got < bytes) {
 		int r = gzread(f, raw.data() + got, (unsigned)std::min<size_t>(bytes - got, 1u << 30));
@@ -74,7 +95,8 @@ float *readNiiFile(const char *filename, int &nx, int &ny, int &nz) {
 	}
 	gzclose(f);
 	if (got != bytes) { fprintf(stderr, "readNiiFile: truncated payload\n"); return nullptr; }
-	float *out = new float[n];
+	float *out = new (std::nothrow) float[n];
+	if (!out) { fprintf(stderr, "readNiiFile: out of memory\n"); nx = ny = nz = 0; return nullptr; }
 	switch (datatype) {  // NIfTI datatype codes; slope/intercept deliberately ignored (see readNii.h)
 	case 2: convert<uint8_t>(raw.data(), n, false, out); break;
 	case 4: convert<int16_t>(raw.data(), n, swap, out); break;

@@ -22,6 +22,12 @@ Fixture inventory (the reference has no golden vec
                     vertices / edge midpoints, where the eps-tolerant first-hit rule matters)
   g8_match.npz      muBruteMatcher inject/biject/enhanced on two 64^3 keypoint sets (target = blobs
                     shifted +1 voxel in x), plus a permuted copy that puts a best match on index 0
+  g1_taps.npz       impulse responses of GaussianSmooth_3D (centre line along x) for the six sigmas of the default schedule and a
+                    few others: they pin the 1-D tap vectors of Src/cSIFT3D.cc:546-572, which have no accessor (G1)
+  g9_nifti.npz      small NIfTI-1 files (bytes) of several datatypes / byte orders / gzip, with non-unit scl_slope, and the
+                    float arrays the reference's readNiiFile (oracle/_ref/librefnii.so) returns for them
+
+    python tests/golden/make_golden.py g1 g9     # only these
 """
 import hashlib
 import importlib
@@ -55,9 +61,87 @@ def interior_mask_hash(level, shell):
     return sha(level[1:-1, 1:-1, 1:-1]) if shell else sha(level)
 
 
+def nifti1_bytes(vol, dtype, code, big_endian=False, slope=2.0, inter=5.0):
+    """a single-file NIfTI-1 image (348-byte header + 4 extension bytes + payload), written by hand"""
+    import struct
+    nz, ny, nx = vol.shape
+    e = ">" if big_endian else "<"
+    h = bytearray(352)
+    struct.pack_into(e + "i", h, 0, 348)
+    struct.pack_into(e + "8h", h, 40, 3, nx, ny, nz, 1, 1, 1, 1)
+    struct.pack_into(e + "h", h, 70, code)
+    struct.pack_into(e + "h", h, 72, np.dtype(dtype).itemsize * 8)
+    struct.pack_into(e + "8f", h, 76, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0)  # pixdim
+    struct.pack_into(e + "f", h, 108, 352.0)
+    struct.pack_into(e + "f", h, 112, slope)
+    struct.pack_into(e + "f", h, 116, inter)
+    h[344:348] = b"n+1\0"
+    return bytes(h) + vol.astype(np.dtype(dtype).newbyteorder(e)).tobytes()
+
+
+def make_g1(ref):
+    """The reference builds its taps inline (no accessor), so G1 pins them through the impulse response of GaussianSmooth_3D: for a unit
+    impulse the x pass leaves tap[d] exactly, the y and z passes multiply by the centre tap: line[d] = rn(tc * rn(tc * tap[d]))."""
+    g1 = {}
+    # default schedule (sigma_default 1.6, sigma_n 1.15, 3 keypoint levels) + odd ones
+    sig = [1.112430, 1.226273, 1.545008, 1.946588, 2.452547, 3.090016, 0.538701, 0.8, 4.0, 5.5]
+    for i, s_ in enumerate(sig):
+        n = 2 * 24 + 5
+        v = np.zeros((n, n, n), np.float32)
+        c = n // 2
+        v[c, c, c] = 1.0
+        out = ref.gaussian_smooth(v, np.float32(s_))
+        g1[f"sigma_{i}"] = np.float32(s_)
+        g1[f"line_{i}"] = out[c, c, :].copy()
+    np.savez_compressed(os.path.join(HERE, "g1_taps.npz"), **g1)
+
+
+def make_g9():
+    import ctypes as C
+    import gzip
+    import tempfile
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "librefnii.so"))
+    fn = lib._Z11readNiiFilePKcRiS1_S1_
+    fn.restype = C.POINTER(C.c_float)
+    fn.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rng = np.random.Generator(np.random.PCG64(9))
+    base = (rng.random((5, 6, 7)) * 200 - 60)
+    cases = [("f4_le", "f4", 16, False, False), ("f4_be", "f4", 16, True, False), ("f4_gz", "f4", 16, False, True),
+             ("i2_le", "i2", 4, False, False), ("i2_be", "i2", 4, True, False), ("u1_le", "u1", 2, False, False),
+             ("f8_le", "f8", 64, False, False), ("f8_be", "f8", 64, True, False), ("u2_le", "u2", 512, False, False),
+             ("i4_le", "i4", 8, False, False), ("i1_le", "i1", 256, False, False), ("u4_gz", "u4", 768, False, True)]
+    g9 = {"names": np.array([c[0] for c in cases])}
+    with tempfile.TemporaryDirectory() as t:
+        for name, dt, code, be, gz in cases:
+            info = np.iinfo(dt) if np.dtype(dt).kind in "iu" else None
+            vol = np.clip(base, info.min, info.max).astype(dt) if info else base.astype(dt)
+            blob = nifti1_bytes(vol, dt, code, big_endian=be)
+            if gz:
+                blob = gzip.compress(blob, mtime=0)
+            p = os.path.join(t, name + (".nii.gz" if gz else ".nii"))
+            open(p, "wb").write(blob)
+            nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
+            ptr = fn(p.encode(), C.byref(nx), C.byref(ny), C.byref(nz))
+            assert ptr and (nx.value, ny.value, nz.value) == (7, 6, 5), name
+            g9[name + "_file"] = np.frombuffer(blob, np.uint8)
+            g9[name + "_gz"] = np.bool_(gz)
+            g9[name + "_data"] = np.ctypeslib.as_array(ptr, shape=(5, 6, 7)).copy()
+            g9[name + "_plain"] = vol.astype(np.float32)  # the stored values cast to fp32 (no scl_slope / scl_inter)
+    np.savez_compressed(os.path.join(HERE, "g9_nifti.npz"), **g9)
+    for name in g9["names"]:
+        print(name, "reference == plain cast:", bool(np.array_equal(g9[name + "_data"], g9[name + "_plain"])))
+
+
 def main():
+    only = set(sys.argv[1:])
     ref = ol.load("ref")
     ref.set_threads(8)
+    if not only or "g1" in only:
+        make_g1(ref)
+    if not only or "g9" in only:
+        make_g9()
+    if only and not (only - {"g1", "g9"}):
+        return
     out = {}
 
     # ---- G2 ---------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
-"""Full-size (512^3, BASELINE.json configs[1]/[2] scale) checks of the HIP path through size-independent properties: the
-CPU oracle needs ~5 s per 512^3 volume and is exercised at this size by bench.py's parity block; here the properties
-need no reference run."""
+"""Full-size (512^3, BASELINE.json configs[1]/[2] scale) checks of the HIP path: size-independent properties that need no
+reference run, one full comparison with the CPU oracle (~5-10 s per 512^3 volume on the GPU box's host cores) and the matcher
+on the two 512^3 keypoint sets (configs[2]) against the oracle's matcher."""
 import importlib
 
 import numpy as np
@@ -99,6 +99,35 @@ def test_two_simulated_slabs_equal_the_whole(run512):
     kps, dss = exs.GetKeypoints()
     exs.close()
     assert np.array_equal(kps, kp) and np.array_equal(dss, ds)
+
+
+def test_512_cubed_vs_oracle_and_matcher(run512, orc):
+    """Full-size parity inside the suite (not only in bench.py): same keypoints as the CPU oracle on the 512^3 benchmark volume,
+    descriptors within the 1e-4 RMS bar, and -- configs[2] -- enhancedMatch of this set against the keypoints of the volume shifted by
+    one voxel, device-resident inputs, equal to the oracle's matcher on the same descriptors (pairs, indices, distances)."""
+    import os
+    import torch
+    from hipcheck import compare_keypoints
+    vol, ex, kp, ds = run512
+    orc.set_threads(max(1, min(64, (os.cpu_count() or 2) // 2)))
+    o = orc.extractor(vol.cpu().numpy()).run(5)
+    okp, odesc = o.keypoints()
+    rms = compare_keypoints(kp, ds, okp, odesc)
+    assert rms < 2e-5, rms
+    vol2 = synth.blobs_torch((N, N, N), "cuda", seed=1234, shift=(1.0, 0.0, 0.0))
+    torch.cuda.synchronize()
+    ex2 = capi.CSIFT3D(None, device_ptr=vol2.data_ptr(), shape=(N, N, N))
+    del vol2
+    ex2.KpSiftAlgorithm()
+    kp2, ds2 = ex2.GetKeypoints()
+    (da, xa, na), (db, xb, nb) = ex.device_results(), ex2.device_results()
+    got = capi.muBruteMatcher().enhancedMatch(da, xa, db, xb, 0.85, on_device=True, n=na, m=nb)
+    xh = np.stack([kp["rx"], kp["ry"], kp["rz"]], 1); xh2 = np.stack([kp2["rx"], kp2["ry"], kp2["rz"]], 1)
+    want = orc.match(ds, xh, ds2, xh2, 0.85, 3)   # the oracle's matcher on the GPU's descriptors: the matcher alone is under test
+    ex2.close()
+    assert len(want["pairs"]) > 1000
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
 
 
 def test_matcher_identity_and_shift(run512):

@@ -178,6 +178,62 @@ def test_matcher_vs_oracle_random(capi, orc):
         assert np.array_equal(got[k], want[k]), k
 
 
+def _dev(arr):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+
+
+def test_matcher_device_resident_inputs(capi, orc):
+    """on_device=True (device pointers for descriptors and coordinates) against the golden g8 vectors and the oracle."""
+    g = golden("g8_match.npz")
+    mt = capi.muBruteMatcher()
+    a, ax, b, bx = (_dev(g[k]) for k in ("da", "xa", "db", "xb"))
+    for mode in (1, 2, 3):
+        for thr in (0.85, 0.95):
+            r = mt._match(a.data_ptr(), ax.data_ptr(), b.data_ptr(), bx.data_ptr(), thr, mode, on_device=True, n=a.shape[0], m=b.shape[0])
+            for k, v in r.items():
+                assert np.array_equal(v, g[f"p_m{mode}_t{int(thr * 100)}_{k}"]), (mode, thr, k)
+    rng = np.random.Generator(np.random.PCG64(23))
+    d = np.clip(rng.normal(0.02, 0.03, size=(500, 768)), 0, None).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a_h, b_h = d[:230].copy(), d[230:].copy()
+    b_h[:60] = a_h[40:100] + rng.normal(0, 0.003, size=(60, 768)).astype(np.float32)
+    ax_h = rng.uniform(0, 100, (230, 3)).astype(np.float32); bx_h = rng.uniform(0, 100, (270, 3)).astype(np.float32)
+    a, ax, b, bx = _dev(a_h), _dev(ax_h), _dev(b_h), _dev(bx_h)
+    for mode in (1, 2, 3):
+        got = mt._match(a.data_ptr(), ax.data_ptr(), b.data_ptr(), bx.data_ptr(), 0.85, mode, on_device=True, n=230, m=270)
+        want = orc.match(a_h, ax_h, b_h, bx_h, 0.85, mode)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (mode, k)
+
+
+def test_matcher_near_ties(capi, orc):
+    """Many target rows whose scores against a reference row differ only in the last bits: the fp32 MFMA selection cannot order
+    them, the exact fp64 re-score must (Src/cMatcher.cc:52-77).  Needs the near-tie guard of kernels_match.hip."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    base = np.clip(rng.normal(0.02, 0.03, size=(40, 768)), 0, None).astype(np.float32)
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    a = base.astype(np.float32)
+    rows = []
+    for i in range(40):
+        for _ in range(7):   # seven near-copies of every reference row: perturbations of a few ulp in a handful of components
+            r = a[i].copy()
+            idx = rng.integers(0, 768, 6)
+            r[idx] = np.nextafter(r[idx], np.float32(1.0) if rng.random() < 0.5 else np.float32(-1.0)).astype(np.float32)
+            rows.append(r)
+    filler = np.clip(rng.normal(0.02, 0.03, size=(200, 768)), 0, None).astype(np.float32)
+    filler /= np.linalg.norm(filler, axis=1, keepdims=True)
+    b = np.concatenate([np.array(rows, np.float32), filler.astype(np.float32)])
+    b = b[rng.permutation(len(b))]
+    ax = rng.uniform(0, 100, (len(a), 3)).astype(np.float32); bx = rng.uniform(0, 100, (len(b), 3)).astype(np.float32)
+    mt = capi.muBruteMatcher()
+    for mode in (1, 2, 3):
+        got = mt._match(a, ax, b, bx, 0.85, mode)
+        want = orc.match(a, ax, b, bx, 0.85, mode)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (mode, k, int((got[k] != want[k]).sum()))
+
+
 @pytest.mark.parametrize("levels", [1, 2, 4])
 def test_nondefault_num_kp_levels(capi, orc, synth, levels):
     """CreateCSIFT3D(..., num_kp_levels) != 3 (Include/cSIFT3D.h:184): other sigma schedule / half widths (levels without a fused

@@ -70,6 +70,45 @@ def test_read_nii(shell, dtype, code):
         assert not fn(os.path.join(t, "missing.nii").encode(), C.byref(nx), C.byref(ny), C.byref(nz))
 
 
+def test_read_nii_matches_reference_reader(shell):
+    """g9: files + the arrays the REFERENCE's readNiiFile (layNii, compiled by `make -C oracle ref`) returned for them."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g9_nifti.npz"))
+    fn = shell._Z11readNiiFilePKcRiS1_S1_
+    fn.restype = C.POINTER(C.c_float)
+    fn.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    with tempfile.TemporaryDirectory() as t:
+        for name in g["names"]:
+            name = str(name)
+            p = os.path.join(t, name + (".nii.gz" if bool(g[name + "_gz"]) else ".nii"))
+            open(p, "wb").write(g[name + "_file"].tobytes())
+            nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
+            ptr = fn(p.encode(), C.byref(nx), C.byref(ny), C.byref(nz))
+            want = g[name + "_data"]
+            assert ptr and (nz.value, ny.value, nx.value) == want.shape, name
+            got = np.ctypeslib.as_array(ptr, shape=want.shape).copy()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+
+
+def test_read_nii_rejects_malformed_headers(shell):
+    fn = shell._Z11readNiiFilePKcRiS1_S1_
+    fn.restype = C.POINTER(C.c_float)
+    fn.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    vol = np.arange(5 * 6 * 7, dtype=np.int16).reshape(5, 6, 7)
+    good = bytearray(nifti1(vol, "i2", 4))
+    bad = {}
+    b = bytearray(good); struct.pack_into("<h", b, 42, -7); bad["negative dim"] = b
+    b = bytearray(good); struct.pack_into("<h", b, 72, 32); bad["bitpix != datatype size"] = b
+    b = bytearray(good); struct.pack_into("<f", b, 108, 100.0); bad["vox_offset inside the header"] = b
+    b = bytearray(good); struct.pack_into("<h", b, 70, 1536); bad["unsupported datatype"] = b
+    bad["truncated payload"] = good[:-10]
+    with tempfile.TemporaryDirectory() as t:
+        for why, blob in bad.items():
+            p = os.path.join(t, "x.nii")
+            open(p, "wb").write(bytes(blob))
+            nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
+            assert not fn(p.encode(), C.byref(nx), C.byref(ny), C.byref(nz)), why
+
+
 def test_matrix_io_roundtrip(shell):
     vol = np.random.default_rng(1).random((4, 5, 6)).astype(np.float32)
     with tempfile.TemporaryDirectory() as t:
@@ -102,6 +141,75 @@ def test_example_program_end_to_end(shell, orc, synth):
     lines = out.strip().splitlines()[-len(want):] if len(want) else []
     got = np.array([[float(v) for v in ln.replace(";", ",").split(",")] for ln in lines], np.float32).reshape(-1, 6)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_cpp_matcher_uses_device_resident_results(shell, synth):
+    """SURVEY 8f-2 in the C++ shell: keypoint vectors that alias live extractors are matched from the device-resident descriptors
+    (muBruteMatcher::usedDeviceResults); deep copies take the host path; both give the same pairs and indices."""
+    src = r"""
+    #include "Include/cSIFT3D.h"
+    #include "Include/cMatcher.h"
+    #include "Include/Util/matrixIO3D.h"
+    #include <cstdio>
+    #include <cstring>
+    using namespace CPUSIFT;
+    int main(int, char** a) {
+        CSIFT3D *A = CSIFT3DFactory::CreateCSIFT3D(std::string(a[1])), *B = CSIFT3DFactory::CreateCSIFT3D(std::string(a[2]));
+        A->KpSiftAlgorithm(); B->KpSiftAlgorithm();
+        std::vector<Keypoint> ka = A->GetKeypoints(), kb = B->GetKeypoints();
+        muBruteMatcher m1, m2;
+        std::vector<Cvec> r1, t1, r2, t2;
+        m1.enhancedMatch(r1, t1, ka, kb, 0.85);
+        // deep copies: descriptor pointers no longer alias the extractors
+        std::vector<float> da(ka.size() * 768), db(kb.size() * 768);
+        std::vector<Keypoint> ca = ka, cb = kb;
+        for (size_t i = 0; i < ca.size(); i++) { memcpy(&da[i * 768], ka[i].desc, 768 * 4); ca[i].desc = &da[i * 768]; }
+        for (size_t i = 0; i < cb.size(); i++) { memcpy(&db[i * 768], kb[i].desc, 768 * 4); cb[i].desc = &db[i * 768]; }
+        m2.enhancedMatch(r2, t2, ca, cb, 0.85);
+        bool same = r1.size() == r2.size() && m1.getGlodenIdx() == m2.getGlodenIdx() && m1.getSilverIdx() == m2.getSilverIdx() &&
+                    m1.getGlodenDistSquare() == m2.getGlodenDistSquare();
+        for (size_t i = 0; same && i < r1.size(); i++)
+            same = r1[i].x == r2[i].x && r1[i].y == r2[i].y && r1[i].z == r2[i].z && t1[i].x == t2[i].x && t1[i].y == t2[i].y && t1[i].z == t2[i].z;
+        printf("kp %zu %zu pairs %zu device %d host %d same %d\n", ka.size(), kb.size(), r1.size(), (int)m1.usedDeviceResults, (int)m2.usedDeviceResults, (int)same);
+        delete A; delete B;
+        return 0;
+    }"""
+    va = synth.blobs((64, 64, 64), seed=1234)
+    vb = synth.blobs((64, 64, 64), seed=1234, shift=(1.0, 0.0, 0.0))
+    with tempfile.TemporaryDirectory() as t:
+        for name, v in (("a.bin", va), ("b.bin", vb)):
+            with open(os.path.join(t, name), "wb") as f:
+                f.write(struct.pack("<3i", 64, 64, 64) + v.tobytes())
+        open(os.path.join(t, "m.cpp"), "w").write(src)
+        subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(PKG, "host"), "-o", os.path.join(t, "m"), os.path.join(t, "m.cpp"),
+                               "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-Wl,-rpath," + PKG])
+        out = subprocess.check_output([os.path.join(t, "m"), os.path.join(t, "a.bin"), os.path.join(t, "b.bin")], stderr=subprocess.STDOUT).decode()
+    last = out.strip().splitlines()[-1].split()
+    assert int(last[1]) > 20 and int(last[4]) > 5, out
+    assert last[5:] == ["device", "1", "host", "0", "same", "1"], out
+
+
+@pytest.mark.gpu
+def test_config1_256_cubed_through_nifti(shell, orc, synth):
+    """BASELINE configs[1]: two 256^3 volumes stored as NIfTI-1 files (int16 and gzip-compressed float32), read by readNiiFile, full
+    KpSiftAlgorithm + enhancedMatch through the C++ shell; keypoint counts and matched pairs equal the oracle's on the same arrays."""
+    import gzip
+    va = synth.blobs((256, 256, 256), seed=1234)
+    vb = synth.blobs((256, 256, 256), seed=1234, shift=(1.0, 0.0, 0.0))
+    qa = np.round(va * 20000).astype(np.int16)            # what an int16 scanner volume looks like; the extractor normalises by max|v|
+    fa, fb = qa.astype(np.float32), vb.astype(np.float32)
+    with tempfile.TemporaryDirectory() as t:
+        open(os.path.join(t, "a.nii"), "wb").write(nifti1(qa, "i2", 4))
+        open(os.path.join(t, "b.nii.gz"), "wb").write(gzip.compress(nifti1(vb, "f4", 16), compresslevel=1))
+        out = subprocess.check_output([os.path.join(PKG, "example_sift3d"), os.path.join(t, "a.nii"), os.path.join(t, "b.nii.gz")],
+                                      stderr=subprocess.STDOUT).decode()
+    ka, da = orc.extractor(fa).run(5).keypoints()
+    kb, db = orc.extractor(fb).run(5).keypoints()
+    xa = np.stack([ka["rx"], ka["ry"], ka["rz"]], 1); xb = np.stack([kb["rx"], kb["ry"], kb["rz"]], 1)
+    want = orc.match(da, xa, db, xb, 0.85, 3)["pairs"]
+    assert "Dimensions of reference image:256 256 256" in out
+    assert f"keypoints: {len(ka)} / {len(kb)}, matched pairs: {len(want)}" in out, out[-400:]
 
 
 def test_sift_kp_csv_roundtrip(shell):

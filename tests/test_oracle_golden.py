@@ -16,6 +16,23 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+def test_g1_taps(orc):
+    """G1: the 1-D tap vectors of GaussianSmooth_3D (Src/cSIFT3D.cc:546-572), pinned through the reference's impulse response: a unit
+    impulse leaves tap[d] after the x pass, and the y and z passes multiply by the centre tap: line[c+d] = rn(tc * rn(tc * tap[d]))."""
+    g = golden("g1_taps.npz")
+    i = 0
+    while f"sigma_{i}" in g:
+        t = orc.gaussian_taps(g[f"sigma_{i}"])
+        line = g[f"line_{i}"]
+        hw, c = (len(t) - 1) // 2, len(line) // 2
+        tc = t[hw]
+        want = np.zeros_like(line)
+        want[c - hw:c + hw + 1] = (tc * (tc * t).astype(np.float32)).astype(np.float32)  # tap index d+hw multiplies src[p-d]: symmetric
+        assert np.array_equal(bits(want), bits(line)), (i, float(g[f"sigma_{i}"]))
+        i += 1
+    assert i >= 6
+
+
 def test_g2_smooth(orc):
     g = golden("g2_smooth.npz")
     for name, src in (("v1_s0", "v1"), ("v1_s5", "v1"), ("v2_s2", "v2")):
