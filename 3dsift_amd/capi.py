@@ -142,6 +142,21 @@ def _f(a):
     return a.ctypes.data_as(_fp)
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources (3dsift_amd/csrc/*.hip, *.h, include/*.h): stamps measurements that are taken offline
+    (profiles/pyramid_traffic_*.json) with the build they belong to"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "3dsift_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "3dsift_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(root, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def device_count():
     n = C.c_int(0)
     lib().sift3d_device_count(C.byref(n))

@@ -19,8 +19,9 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 n = sys.argv[1] if len(sys.argv) > 1 else "512"
-KERNELS = ("k_fused_level", "k_downsample", "k_conv_axis")
+KERNELS = ("k_march_level", "k_fused_level", "k_downsample", "k_conv_axis")
 
 
 def one_pass(counter):
@@ -48,6 +49,8 @@ for k in sorted(set(fetch) | set(write)):
                "read_bytes_corrected": 2.0 * fetch.get(k, 0.0) * 1024.0, "write_bytes": write.get(k, 0.0) * 1024.0}
 tot_r = sum(v["read_bytes_corrected"] for v in rows.values())
 tot_w = sum(v["write_bytes"] for v in rows.values())
-print(json.dumps({"workload": f"{n}^3 fp32, pyramid build (stage 1) of one KpSiftAlgorithm", "kernels": rows,
+import importlib
+source_sha = importlib.import_module("3dsift_amd.capi").kernel_source_sha()  # ties the numbers to the kernel sources they were measured on
+print(json.dumps({"workload": f"{n}^3 fp32, pyramid build (stage 1) of one KpSiftAlgorithm", "kernel_source_sha": source_sha, "kernels": rows,
                   "total_read_bytes": tot_r, "total_write_bytes": tot_w, "total_bytes": tot_r + tot_w,
                   "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), KiB->bytes; WRITE_SIZE exact"}, indent=1))
