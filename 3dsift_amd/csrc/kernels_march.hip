@@ -123,6 +123,9 @@ __global__ void __launch_bounds__(256, (march_occ<HW, CR>())) k_march_level(cons
 	__shared__ __attribute__((aligned(1024))) float tile[2 * C::TILE_F];
 	__shared__ __attribute__((aligned(16))) float xb[2 * C::XB_F];
 	__shared__ __attribute__((aligned(16))) mf4 cring[CR ? C::CRN * C::NT : 1];
+	// DOG without the centre ring (hw >= 6): the centre piece of the plane the NEXT step completes travels by LDS-DMA as well (a
+	// compiler-tracked global load would be waited for with vmcnt(0), i.e. together with the tile DMA issued right after it)
+	__shared__ __attribute__((aligned(1024))) mf4 cenb[(DOG && !CR) ? 2 * C::NT : 1];
 	__shared__ float s_ef[3 * (kMarchMaxHW + 1)];
 	__shared__ float s_red[4];
 
@@ -156,6 +159,7 @@ __global__ void __launch_bounds__(256, (march_occ<HW, CR>())) k_march_level(cons
 		goffb[i] = (unsigned)(ok ? gy * sy + gx : y0 * sy + x0) * 4u;
 	}
 	const unsigned lds_tile = (unsigned)(unsigned long long)tile + (unsigned)wid * 1024u;
+	const unsigned lds_cen = (unsigned)(unsigned long long)cenb + (unsigned)wid * 1024u;
 
 	// ---- x-blur item of this lane: 8 outputs of one tile row; rows dealt so that every ds_read_b128 lane group is conflict-free ----
 	// The x-blur holds 3 waves' worth of items (ROWS <= 48 rows x 4 segments); the wave without items is the one with role 3, and the
@@ -238,7 +242,11 @@ __global__ void __launch_bounds__(256, (march_occ<HW, CR>())) k_march_level(cons
 		const int p_loc = e_out + HW - zoff;            // output plane it completes (local)
 		const bool emit = j >= 1 && p_loc >= zc0 && p_loc < zc1;
 		mf4 cen = {0.f, 0.f, 0.f, 0.f};
-		if (DOG && !CR) cen = *reinterpret_cast<const mf4 *>(reinterpret_cast<const char *>(src + (size_t)sz * (size_t)min(max(p_loc, 0), nz - 1)) + out_voff);
+		if (DOG && !CR) {
+			if (j >= 1) cen = cenb[(j & 1) * C::NT + tid];  // landed before the previous step's barrier (own wave's DMA, own lanes)
+			const int pn = min(max(p_loc - 1, 0), nz - 1);  // the output plane of step j + 1
+			if (!(S3D_MDIAG & 1)) m_dma16(src + (size_t)sz * (size_t)pn, out_voff, lds_cen + (unsigned)(((j + 1) & 1) * C::NT * 16));
+		}
 		if (j + 1 < nsteps) issue_dma(j + 1);
 
 		// ---------------- x-blur of feed j: tile[buf] -> xb[buf] ----------------
