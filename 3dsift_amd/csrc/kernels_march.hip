@@ -94,8 +94,11 @@ __device__ __forceinline__ float m_absmax(float m, float v) {
 #ifndef S3D_MARCH_ROT
 #define S3D_MARCH_ROT 1
 #endif
+#ifndef S3D_MARCH_VGPR_OCC
+#define S3D_MARCH_VGPR_OCC 4  /* > 0 (kernels without the centre ring): register budget for that many workgroups per CU although the grids are planned for march_occ (room for the small octaves' workgroups beside a big launch) */
+#endif
 #ifndef S3D_MARCH_YG
-#define S3D_MARCH_YG 6  /* y-blur rows requested per group */
+#define S3D_MARCH_YG 4  /* y-blur rows requested per group (6 spills at hw 8 under the 128-register budget) */
 #endif
 #ifndef S3D_MARCH_CR_MAXHW
 #define S3D_MARCH_CR_MAXHW 5  /* DoG centre ring in LDS up to this half width (three workgroups per CU still fit); wider levels re-read the centre plane */
@@ -116,7 +119,7 @@ template <int HW, bool CR>
 constexpr int march_occ() { return CR ? 3 : (HW <= 4 ? S3D_MOCC_LO : (HW == 5 ? S3D_MOCC_5 : (HW == 6 ? S3D_MOCC_6 : S3D_MOCC_8))); }
 
 template <int HW, bool DOG, bool CR>
-__global__ void __launch_bounds__(256, (march_occ<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
+__global__ void __launch_bounds__(256, ((S3D_MARCH_VGPR_OCC > 0 && !CR) ? S3D_MARCH_VGPR_OCC : march_occ<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                         unsigned *__restrict__ dogmax, int nx, int ny, ZRange zr, MTaps t, MEdge ef, int ntx,
                                                         int nty, int cz) {
 	using C = MCfg<HW>;
