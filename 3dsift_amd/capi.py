@@ -42,6 +42,7 @@ SYMBOLS = [
     "sift3d_slab_decimate", "sift3d_create_seeded", "sift3d_seed_upload", "sift3d_set_describe_partition",
     "sift3d_export_device", "sift3d_import_descriptors_device", "sift3d_run_partial_orientation",
     "sift3d_export_orientation_device", "sift3d_import_orientation_device", "sift3d_run_describe",
+    "sift3d_set_stream", "sift3d_slab_export_dogmax_device", "sift3d_slab_import_dogmax_device", "sift3d_slab_decimate_async",
 ]
 ORIENT_WORDS = 34
 
@@ -116,6 +117,10 @@ def lib():
         L.sift3d_slab_detect.argtypes = [C.c_void_p]
         L.sift3d_slab_describe.argtypes = [C.c_void_p]
         L.sift3d_slab_decimate.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_slab_decimate_async.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_slab_export_dogmax_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_slab_import_dogmax_device.argtypes = [C.c_void_p, C.c_void_p]
         L.sift3d_create_seeded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Params), C.c_int]
         L.sift3d_seed_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.sift3d_set_describe_partition.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -182,6 +187,10 @@ class CSIFT3D:
             nz, ny, nx = vol.shape
             self.shape = vol.shape
             _check(L.sift3d_create(C.byref(self._h), vol.ctypes.data_as(C.c_void_p), nx, ny, nz, C.byref(p), device, 0))
+
+    def set_stream(self, stream_handle):
+        """every later call enqueues on this hipStream_t (e.g. torch.cuda.Stream().cuda_stream); 0 / None = own stream"""
+        _check(lib().sift3d_set_stream(self._h, C.c_void_p(int(stream_handle or 0))))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -407,8 +416,15 @@ class SlabCSIFT3D(CSIFT3D):
     def describe(self):
         _check(lib().sift3d_slab_describe(self._h))
 
-    def decimate(self, dst_ptr):
-        _check(lib().sift3d_slab_decimate(self._h, C.c_void_p(int(dst_ptr))))
+    def decimate(self, dst_ptr, wait=True):
+        fn = lib().sift3d_slab_decimate if wait else lib().sift3d_slab_decimate_async
+        _check(fn(self._h, C.c_void_p(int(dst_ptr))))
+
+    def export_dogmax(self, dst_ptr):
+        _check(lib().sift3d_slab_export_dogmax_device(self._h, C.c_void_p(int(dst_ptr))))
+
+    def import_dogmax(self, src_ptr):
+        _check(lib().sift3d_slab_import_dogmax_device(self._h, C.c_void_p(int(src_ptr))))
 
 
 def CreateCSIFT3D(volume, **kw):

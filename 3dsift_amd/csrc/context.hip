@@ -136,6 +136,7 @@ using namespace s3d;
 struct sift3d_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t own_stream = nullptr;  // the stream this context created (stream may be replaced by sift3d_set_stream)
 	sift3d_params p{};
 	int nx = 0, ny = 0, nz = 0;     // dims of the first octave this context holds (global)
 	int noct = 0, ng = 0, nd = 0;
@@ -256,6 +257,7 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	if (!c) return SIFT3D_OK;
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
+	if (c->own_stream && c->own_stream != c->stream) hipStreamSynchronize(c->own_stream);
 	free_lists(c);
 	if (!c->ext_arena) hipFree(c->arena);
 	hipFree(c->d_words);
@@ -265,8 +267,8 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	for (auto &e : c->ev_seed) if (e) hipEventDestroy(e);
 	for (auto &e : c->ev_done) if (e) hipEventDestroy(e);
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
-	for (size_t o = 1; o < c->ostream.size(); o++) if (c->ostream[o] && c->ostream[o] != c->stream) hipStreamDestroy(c->ostream[o]);
-	if (c->stream) hipStreamDestroy(c->stream);
+	for (size_t o = 1; o < c->ostream.size(); o++) if (c->ostream[o] && c->ostream[o] != c->stream && c->ostream[o] != c->own_stream) hipStreamDestroy(c->ostream[o]);
+	if (c->own_stream) hipStreamDestroy(c->own_stream);
 	delete c;
 	return SIFT3D_OK;
 }
@@ -422,6 +424,7 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	c->ostream.assign((size_t)std::max(1, c->noct), nullptr);
 	c->ev_seed.assign(c->ostream.size(), nullptr);
 	c->ev_done.assign(c->ostream.size(), nullptr);
+	c->own_stream = c->stream;
 	c->ostream[0] = c->stream;
 	// S3D_ONE_STREAM=1 (profiling): every octave on the main stream, so a kernel trace shows isolated launch durations
 	const bool one_stream = [] { const char *e = getenv("S3D_ONE_STREAM"); return e && e[0] == '1'; }();
@@ -1073,6 +1076,37 @@ extern "C" int sift3d_slab_level_hw(sift3d_handle c, int i, int *hw) {
 	return SIFT3D_OK;
 }
 
+// The caller's stream (a hipStream_t of the context's device, e.g. torch.cuda.Stream().cuda_stream) becomes the stream every later
+// call of this handle enqueues on: a communication layer that orders its transfers behind / in front of that stream (RCCL through
+// torch.distributed does) then needs no host synchronisation between the levels.  nullptr restores the context's own stream.
+extern "C" int sift3d_set_stream(sift3d_handle c, void *stream) {
+	if (!c) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	S3D_HIP(hipStreamSynchronize(c->stream));
+	hipStream_t st = stream ? (hipStream_t)stream : c->own_stream;
+	for (auto &o : c->ostream) if (o == c->stream) o = st;
+	c->stream = st;
+	return SIFT3D_OK;
+}
+
+// local max|DoG| of the octave's levels as nd floats in device memory, and back after the caller's MAX all-reduce: D2D copies on
+// the handle's stream, no host round trip (the host forms sift3d_slab_get/set_dogmax stay for tests)
+extern "C" int sift3d_slab_export_dogmax_device(sift3d_handle c, float *d_dst) {
+	if (!c || !c->slab || !d_dst) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	S3D_HIP(hipMemcpyAsync(d_dst, c->d_dogmax, sizeof(unsigned) * (size_t)c->nd, hipMemcpyDeviceToDevice, c->stream));
+	return SIFT3D_OK;
+}
+extern "C" int sift3d_slab_import_dogmax_device(sift3d_handle c, const float *d_src) {
+	if (!c || !c->slab || !d_src) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	S3D_HIP(hipMemcpyAsync(c->d_dogmax, d_src, sizeof(unsigned) * (size_t)c->nd, hipMemcpyDeviceToDevice, c->stream));
+	return SIFT3D_OK;
+}
+
 extern "C" int sift3d_slab_level(sift3d_handle c, int i) {
 	if (!c || !c->slab || i < 0 || i >= c->ng) return SIFT3D_ERR_ARG;
 	int rc = set_device(c->device);
@@ -1085,7 +1119,13 @@ extern "C" int sift3d_slab_level(sift3d_handle c, int i) {
 		// octave > 0: level 0 is the decimated G[octave-1][num_kp_levels], written by the caller
 		ok = c->seeded ? true : launch_fused_level(c->in.d, L.d, nullptr, nullptr, L.nx, L.ny, zr, c->base_taps, c->stream);
 	} else {
-		ok = launch_fused_level(c->gss[i - 1].d, L.d, c->dog[i - 1].d, c->d_dogmax + (i - 1), L.nx, L.ny, zr, c->taps[i], c->stream);
+		// like the single-volume path, the first and last DoG level of the octave are not materialised (read only as the centre-voxel
+		// neighbour of extremum candidates: no halo, no abs-max)
+		static const bool dog_eager = [] { const char *e = getenv("S3D_DOG_EAGER"); return e && e[0] == '1'; }();
+		c->dog_elide = !dog_eager && c->nd >= 3;
+		const bool elided = c->dog_elide && (i - 1 == 0 || i - 1 == c->nd - 1);
+		ok = launch_fused_level(c->gss[i - 1].d, L.d, elided ? nullptr : c->dog[i - 1].d, elided ? nullptr : c->d_dogmax + (i - 1), L.nx, L.ny,
+		                        zr, c->taps[i], c->stream);
 	}
 	if (!ok) { set_last_error("no fused kernel for this level"); return SIFT3D_ERR_STATE; }
 	c->stage = std::max(c->stage, 1);
@@ -1155,6 +1195,11 @@ extern "C" int sift3d_slab_detect(sift3d_handle c) {
 			DL.level_id[i - 1] = i;
 			DL.scale[i - 1] = c->dog[i].scale;
 		}
+		if (c->dog_elide) {
+			DL.prev0_hi = c->gss[1].d; DL.prev0_lo = c->gss[0].d;
+			DL.nextl_hi = c->gss[c->nd].d; DL.nextl_lo = c->gss[c->nd - 1].d;
+			DL.nextl_slot = nl - 1;
+		}
 		const Level &C = c->dog[1];
 		launch_detect_octave(DL, nl, C.nx, C.ny, C.zr(c->own0 - C.zoff, c->own1 - C.zoff), c->p.peak_thresh, c->octave_base, c->det,
 		                     c->d_ext, c->ext_cap, c->stream);
@@ -1185,7 +1230,10 @@ extern "C" int sift3d_slab_describe(sift3d_handle c) {
 	return SIFT3D_OK;
 }
 
-extern "C" int sift3d_slab_decimate(sift3d_handle c, float *d_dst) {
+static int slab_decimate_impl(sift3d_handle c, float *d_dst, bool sync);
+extern "C" int sift3d_slab_decimate(sift3d_handle c, float *d_dst) { return slab_decimate_impl(c, d_dst, true); }
+extern "C" int sift3d_slab_decimate_async(sift3d_handle c, float *d_dst) { return slab_decimate_impl(c, d_dst, false); }
+static int slab_decimate_impl(sift3d_handle c, float *d_dst, bool sync) {
 	if (!c || !c->slab || !d_dst) return SIFT3D_ERR_ARG;
 	int rc = set_device(c->device);
 	if (rc) return rc;
@@ -1195,6 +1243,6 @@ extern "C" int sift3d_slab_decimate(sift3d_handle c, float *d_dst) {
 	const int nz2 = std::min(c->own1 / 2, c->nz / 2) - c->own0 / 2;
 	if (nz2 > 0)
 		launch_downsample(P.d + pl * (size_t)(c->own0 - P.zoff), P.nx, P.ny, d_dst, P.nx / 2, P.ny / 2, nz2, c->stream);
-	S3D_HIP(hipStreamSynchronize(c->stream));
+	if (sync) S3D_HIP(hipStreamSynchronize(c->stream));
 	return SIFT3D_OK;
 }

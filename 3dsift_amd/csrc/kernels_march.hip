@@ -431,28 +431,44 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	const int nzo = zr.zo1 - zr.zo0;
 	if (nzo <= 0) return;
 	const int ntx = nx / C::TX, nty = ny / C::TY, ntiles = ntx * nty;
-	// z chunking: the chunk count that minimises (residency rounds) x (planes marched per workgroup); a chunk pays a ramp of 2*HW (+1) planes
-	const int full_slots = 256 * (dog ? march_occ<HW, (HW <= S3D_MARCH_CR_MAXHW)>() : march_occ<HW, false>());
-	const int slots = plan_slots > 0 ? std::min(plan_slots, full_slots) : full_slots;
+	// z chunking.  A CU retires workgroup-planes at about the same rate with three or four resident workgroups (measured: the fourth
+	// buys nothing at 512^3), so a residency round of R workgroups costs (planes marched) x max(1, R / 768); what the fourth slot does
+	// buy is ONE round instead of two when a level has more tiles than 768 (1024^2 levels: 1024 tiles -- the z-slabs of configs[3]).
+	// Kernels with the DoG centre ring in LDS fit three per CU; where a fourth slot saves a round the ring-less instantiation runs.
+	constexpr bool kHasCR = HW <= S3D_MARCH_CR_MAXHW;
 	const int ramp = 2 * HW + 1;
-	int best_cz = nzo;
-	double best_cost = 1e300;
-	for (int n = 1; n <= nzo && n <= 64; n++) {
-		const int czn = (nzo + n - 1) / n, nch = (nzo + czn - 1) / czn;
-		const long wgs = (long)ntiles * nch, rounds = (wgs + slots - 1) / slots;
-		const double cost = (double)rounds * (czn + ramp);
-		if (cost < best_cost - 1e-9) { best_cost = cost; best_cz = czn; }
-	}
-	const int cz = best_cz, nchunks = (nzo + cz - 1) / cz;
+	auto plan = [&](int cap, int &cz_out) {
+		if (plan_slots > 0) cap = std::min(cap, plan_slots);
+		double best = 1e300;
+		cz_out = nzo;
+		for (int n = 1; n <= nzo && n <= 64; n++) {
+			const int czn = (nzo + n - 1) / n, nch = (nzo + czn - 1) / czn;
+			long left = (long)ntiles * nch;
+			double cost = 0.0;
+			while (left > 0) {
+				const long r = std::min<long>(left, cap);
+				cost += (double)(czn + ramp) * std::max(1.0, (double)r / 768.0);
+				left -= r;
+			}
+			if (cost < best - 1e-9) { best = cost; cz_out = czn; }
+		}
+		return best;
+	};
+	int cz3 = nzo, cz4 = nzo;
+	const double cost3 = plan(768, cz3), cost4 = plan(1024, cz4);
+	// dog + ring: three per CU unless four without the ring are clearly ahead; everything else may use the fourth slot
+	const bool use_cr = dog && kHasCR && !(cost4 * 1.12 < cost3);
+	const int cz = (dog && kHasCR) ? (use_cr ? cz3 : cz4) : (cost4 < cost3 ? cz4 : cz3);
+	const int nchunks = (nzo + cz - 1) / cz;
 	MEdge ef;
 	memset(&ef, 0, sizeof(ef));
 	march_edge_fractions(nx, HW, ef.f[0]);
 	march_edge_fractions(ny, HW, ef.f[1]);
 	march_edge_fractions(zr.nzg, HW, ef.f[2]);
 	const dim3 grid((unsigned)(ntiles * nchunks)), block(C::NT);
-	// DoG centre ring in LDS where three workgroups per CU still fit (hw <= 5); wider levels re-read the centre plane (L2)
-	constexpr bool CR = HW <= S3D_MARCH_CR_MAXHW;
-	if (dog) hipLaunchKernelGGL((k_march_level<HW, true, CR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
+	// DoG centre ring in LDS where three workgroups per CU still fit (hw <= 5); otherwise the centre piece travels by LDS-DMA
+	if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
+	else if (dog) hipLaunchKernelGGL((k_march_level<HW, true, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
 	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
 }
 

@@ -17,7 +17,13 @@ pipeline, with results equal to the single-GPU run (pyramid / extrema bit for bi
              replicated in a SEEDED context; their orientation work is dealt by extremum index (integer all-reduce(SUM)
              of zero-padded rows restores it exactly), their descriptor work by keypoint and stays distributed.
 
-The same lock-step driver runs over a communicator:
+Ordering (r02): all device work of a rank's sharded octaves is enqueued on ONE torch stream, which the slab contexts adopt
+(sift3d_set_stream); the exchanges are posted in that stream's order (RCCL work is ordered behind the current stream and
+`Work.wait()` makes the stream -- not the host -- wait), the DoG maxima are all-reduced as a device tensor, and the host only
+synchronises before the extrema counts are read back.  The replicated tail (octaves >= S: small, launch-latency bound, with its
+own collectives) runs on a second host thread on the tail context's own stream, beside the sharded detection / descriptors.
+
+The same driver runs over a communicator:
   DistComm  one worker per process, torch.distributed (backend "nccl" == RCCL); works with gloo on CPU tensors for tests
   SimComm   all workers in ONE process on one GPU (device copies instead of sends) -- the bit-exact equality test against
             the single-volume result runs this way on a 1-GPU box (tests/test_gpu_slab.py)
@@ -114,7 +120,10 @@ def merge_keypoints(parts_oct0, tail):
 # communicators
 # --------------------------------------------------------------------------------------------------------------------
 class SimComm:
-    """All ranks live in this process (one GPU): sends become device copies, reductions are computed directly."""
+    """All ranks live in this process (one GPU): sends become device copies on the caller's current stream, reductions are
+    computed directly."""
+
+    stream_ordered = True
 
     def __init__(self, world):
         self.world = world
@@ -123,12 +132,14 @@ class SimComm:
         return list(range(self.world))
 
     def exchange(self, workers, transfers):
-        import torch
         for t in transfers:
             workers[t.dst].view(t.kind, t.idx, t.zg0, t.zg1, t.stage).copy_(workers[t.src].view(t.kind, t.idx, t.zg0, t.zg1, t.stage))
         return None
 
     def wait(self, handle):
+        pass  # the copies are ordered on the stream they were issued on
+
+    def sync(self):
         import torch
         if torch.cuda.is_available():
             torch.cuda.synchronize()
@@ -137,6 +148,15 @@ class SimComm:
         m = np.maximum.reduce([np.asarray(a, np.float32) for a in per_worker])
         return [m.copy() for _ in per_worker]
 
+    def allreduce_max_(self, per_worker_tensor):
+        """in-place MAX over the workers' device tensors (stream ordered)"""
+        import torch
+        m = per_worker_tensor[0].clone()
+        for t in per_worker_tensor[1:]:
+            torch.maximum(m, t, out=m)
+        for t in per_worker_tensor:
+            t.copy_(m)
+
     def allgather_planes(self, per_worker_tensor, outs, counts):
         """outs[w][off_r : off_r + counts[r]] = tensor of rank r, for every worker w"""
         off = 0
@@ -144,7 +164,6 @@ class SimComm:
             for o in outs:
                 o[off:off + counts[r]].copy_(t[:counts[r]])
             off += counts[r]
-        self.wait(None)
 
     def allreduce_sum_(self, per_worker_tensor):
         if not per_worker_tensor:
@@ -154,28 +173,30 @@ class SimComm:
             total += t
         for t in per_worker_tensor:
             t.copy_(total)
-        self.wait(None)
 
     def gather_objects(self, per_worker):
         return list(per_worker)
 
 
 class DistComm:
-    """One worker per process over torch.distributed (nccl == RCCL on ROCm; gloo with CPU tensors in the tests)."""
+    """One worker per process over torch.distributed (nccl == RCCL on ROCm; gloo with CPU tensors in the tests).  With RCCL the
+    collectives and point-to-point operations are ordered behind the CURRENT torch stream and `Work.wait()` blocks that stream,
+    not the host: the driver issues them under the worker's stream and never synchronises the host between the levels."""
 
     def __init__(self):
         import torch.distributed as dist
         self.dist = dist
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        self.stream_ordered = dist.get_backend() == "nccl"
 
     def local_ranks(self):
         return [self.rank]
 
-    def _sync(self, tensor=None):
+    def sync(self):
         import torch
-        if torch.cuda.is_available() and (tensor is None or tensor.is_cuda):
-            torch.cuda.current_stream().synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
     def exchange(self, workers, transfers):
         """workers: [the local worker].  Posts every send / receive this rank takes part in as ONE batched group."""
@@ -193,8 +214,7 @@ class DistComm:
 
     def wait(self, handle):
         for r in handle or []:
-            r.wait()
-        self._sync()
+            r.wait()  # RCCL: the current stream waits; gloo: the host waits
 
     def allreduce_max(self, per_worker):
         import torch
@@ -204,6 +224,9 @@ class DistComm:
         t = t.to(dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return [t.cpu().numpy()]
+
+    def allreduce_max_(self, per_worker_tensor):
+        self.dist.all_reduce(per_worker_tensor[0], op=self.dist.ReduceOp.MAX)
 
     def allgather_planes(self, per_worker_tensor, outs, counts):
         import torch
@@ -220,13 +243,11 @@ class DistComm:
             for r in range(self.world):
                 out[off:off + counts[r]].copy_(bufs[r][: counts[r]])
                 off += counts[r]
-        self._sync(out)
 
     def allreduce_sum_(self, per_worker_tensor):
         t = per_worker_tensor[0]
         if t.numel():
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        self._sync(t)
 
     def gather_objects(self, per_worker):
         out = [None] * self.world
@@ -268,7 +289,7 @@ class SlabStage:
 class SlabWorker:
     """The sharded octaves (SlabStage each) + the seeded, replicated tail context of one rank."""
 
-    def __init__(self, rank, world, dims, device=0, halo=None, sharded_octaves=1, **params):
+    def __init__(self, rank, world, dims, device=0, halo=None, sharded_octaves=1, stream=None, **params):
         import torch
         from . import capi
         nx, ny, nz = dims
@@ -294,6 +315,11 @@ class SlabWorker:
         self.ctx = self.stages[0].ctx
         self.arena = self.stages[0].arena
         dev = torch.device("cuda", device)
+        # one stream for everything the sharded octaves enqueue (kernels, exchanges, reductions); see the module docstring
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        for st in self.stages:
+            st.ctx.set_stream(self.stream.cuda_stream)
+        self.dogmax = [torch.zeros(8, dtype=torch.float32, device=dev) for _ in self.stages]
         # replicated tail (octaves >= S): seeded with the all-gathered level 0 of octave S
         self.tail = None
         self.seed = self.seed_mine = None
@@ -312,6 +338,7 @@ class SlabWorker:
         if self.tail is not None:
             self.tail.close()
         for st in self.stages:
+            st.ctx.set_stream(0)  # the torch stream may die before the context
             st.ctx.close()
 
 
@@ -324,8 +351,11 @@ class SlabExtractor:
     def __init__(self, dims, comm, device=0, halo=None, sharded_octaves=2, **params):
         self.dims, self.comm = dims, comm
         self.world = comm.world
+        import torch
         devs = device if isinstance(device, (list, tuple)) else [device] * len(comm.local_ranks())
-        self.workers = {r: SlabWorker(r, self.world, dims, device=d, halo=halo, sharded_octaves=sharded_octaves, **params)
+        # simulated ranks share ONE stream (their "sends" are copies between the workers' buffers, ordered on that stream)
+        shared = torch.cuda.Stream(device=torch.device("cuda", devs[0])) if isinstance(comm, SimComm) else None
+        self.workers = {r: SlabWorker(r, self.world, dims, device=d, halo=halo, sharded_octaves=sharded_octaves, stream=shared, **params)
                         for r, d in zip(comm.local_ranks(), devs)}
         w0 = next(iter(self.workers.values()))
         self.bounds, self.halo, self.levels, self.noct, self.S = w0.bounds, w0.halo, w0.levels, w0.noct, w0.S
@@ -357,52 +387,97 @@ class SlabExtractor:
             w.ctx.input_scale(float(m[0]))
         nz = self.dims[2]
         hw0 = self.hws[0] + 1
-        self.comm.wait(self.comm.exchange(ws, halo_transfers(self.bounds, nz, KIND_INPUT, 0, 0, hw0)))
+        import torch
+        with torch.cuda.stream(ws[0].stream):
+            self.comm.wait(self.comm.exchange(ws, halo_transfers(self.bounds, nz, KIND_INPUT, 0, 0, hw0)))
+        self.comm.sync()
 
     def KpSiftAlgorithm(self):
         """CSIFT3D::KpSiftAlgorithm (Src/cSIFT3D.cc:165-235) over the slabs."""
+        import threading
         import time
         import torch
         comm, ws = self.comm, self._wl()
+        cur = ws[0].stream   # DistComm: the local worker's stream; SimComm: the stream all simulated ranks share
         deferred = []
+        comm.sync()
         t0 = time.perf_counter()
-        for s in range(self.S):
-            sts = [w.stages[s] for w in ws]
-            bounds, nzs = sts[0].bounds, sts[0].dims[2]
-            for i in range(self.ng):
-                for st in sts:
-                    st.ctx.level_async(i)          # level 0 of an octave > 0 was written by the decimation below
-                for st in sts:
-                    st.ctx.sync()
-                urgent_h = self.hws[i + 1] + 1 if i + 1 < self.ng else 0   # planes p-hw-1 .. p+hw of the next level's z-march
-                # the planes level i+1 needs first, then the wider keypoint-window halo and the DoG plane behind it
-                h_urgent = comm.exchange(ws, halo_transfers(bounds, nzs, KIND_GSS, i, 0, urgent_h, s))
-                late = halo_transfers(bounds, nzs, KIND_GSS, i, urgent_h, self.need[i], s)
-                if 1 <= i - 1 <= self.levels:
-                    late += halo_transfers(bounds, nzs, KIND_DOG, i - 1, 0, 1, s)
-                deferred.append(comm.exchange(ws, late))
-                if i == self.levels and s + 1 < self.noct:
-                    # G[s+1][0] = DownSample_3D(G[s][levels]) (Src/cSIFT3D.cc:293-296, 321-344), owned planes only:
-                    # straight into the next sharded octave's level-0 buffer, or into the all-gather piece of the tail
-                    for w in ws:
-                        if s + 1 < self.S:
-                            nst = w.stages[s + 1]
-                            if nst.z1 > nst.z0:
-                                w.stages[s].ctx.decimate(nst.view(KIND_GSS, 0, nst.z0, nst.z1).data_ptr())
-                        else:
-                            w.stages[s].ctx.decimate(w.seed_mine.data_ptr())
-                comm.wait(h_urgent)
-            # DoG maxima -> global (threshold of Detect_KeyPoints, Src/cSIFT3D.cc:379-384)
-            mx = comm.allreduce_max([st.ctx.get_dogmax() for st in sts])
-            for st, m in zip(sts, mx):
-                st.ctx.set_dogmax(m)
-        for h in deferred:
-            comm.wait(h)
-        self.times["pyramid"] = time.perf_counter() - t0
+        with torch.cuda.stream(cur):
+            for s in range(self.S):
+                sts = [w.stages[s] for w in ws]
+                bounds, nzs = sts[0].bounds, sts[0].dims[2]
+                for i in range(self.ng):
+                    for st in sts:
+                        st.ctx.level_async(i)          # level 0 of an octave > 0 was written by the decimation below
+                    urgent_h = self.hws[i + 1] + 1 if i + 1 < self.ng else 0   # planes p-hw-1 .. p+hw of the next level's z-march
+                    # the planes level i+1 needs first, then the wider keypoint-window halo and the DoG plane behind it; both are
+                    # ordered behind the level kernel on the stream, only the first is awaited (by the stream) before level i+1
+                    h_urgent = comm.exchange(ws, halo_transfers(bounds, nzs, KIND_GSS, i, 0, urgent_h, s))
+                    late = halo_transfers(bounds, nzs, KIND_GSS, i, urgent_h, self.need[i], s)
+                    if 1 <= i - 1 <= self.levels:
+                        late += halo_transfers(bounds, nzs, KIND_DOG, i - 1, 0, 1, s)
+                    deferred.append(comm.exchange(ws, late))
+                    if i == self.levels and s + 1 < self.noct:
+                        # G[s+1][0] = DownSample_3D(G[s][levels]) (Src/cSIFT3D.cc:293-296, 321-344), owned planes only:
+                        # straight into the next sharded octave's level-0 buffer, or into the all-gather piece of the tail
+                        for w in ws:
+                            if s + 1 < self.S:
+                                nst = w.stages[s + 1]
+                                if nst.z1 > nst.z0:
+                                    w.stages[s].ctx.decimate(nst.view(KIND_GSS, 0, nst.z0, nst.z1).data_ptr(), wait=False)
+                            else:
+                                w.stages[s].ctx.decimate(w.seed_mine.data_ptr(), wait=False)
+                    comm.wait(h_urgent)
+                # DoG maxima -> global (threshold of Detect_KeyPoints, Src/cSIFT3D.cc:379-384): MAX all-reduce of a device tensor
+                for w, st in zip(ws, sts):
+                    st.ctx.export_dogmax(w.dogmax[s].data_ptr())
+                comm.allreduce_max_([w.dogmax[s] for w in ws])
+                for w, st in zip(ws, sts):
+                    st.ctx.import_dogmax(w.dogmax[s].data_ptr())
+            for h in deferred:
+                comm.wait(h)
+            if self.noct > self.S:
+                comm.allgather_planes([w.seed_mine for w in ws], [w.seed for w in ws], ws[0].counts2)
+            ev_seed = torch.cuda.Event()
+            ev_seed.record(cur)
+        self.times["pyramid_enqueue"] = time.perf_counter() - t0
+
+        # ---- replicated tail on its own thread / stream, beside the sharded detection and descriptors -------------------------
+        err = []
+
+        def tail_body():
+            try:
+                torch.cuda.set_device(ws[0].device)   # the current device is per thread
+                ev_seed.synchronize()   # the all-gathered level 0 of octave S exists
+                for w in ws:
+                    w.tail.seed(w.seed.data_ptr())
+                # replicated pyramid + extrema of the remaining octaves; orientation dealt by extremum index, results restored
+                # on every rank by an integer all-reduce(SUM) of zero-padded rows (exact); descriptors dealt by keypoint and
+                # LEFT distributed, like the sharded keypoints (GetKeypoints / the matcher's all-gather collect them)
+                for w in ws:
+                    w.tail.run_partial_orientation()
+                bufs = []
+                for w in ws:
+                    b = torch.empty(w.tail.num_extrema() * capi_words(), dtype=torch.int32, device=w.arena.device)
+                    if b.numel():
+                        w.tail.export_orientation(b.data_ptr())
+                    bufs.append(b)
+                comm.allreduce_sum_(bufs)
+                torch.cuda.current_stream().synchronize()
+                for w, b in zip(ws, bufs):
+                    if b.numel():
+                        w.tail.import_orientation(b.data_ptr())
+                    w.tail.run_describe()
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
+                err.append(e)
+
+        th = None
+        t2 = time.perf_counter()
         if self.noct > self.S:
-            comm.allgather_planes([w.seed_mine for w in ws], [w.seed for w in ws], ws[0].counts2)
-            for w in ws:
-                w.tail.seed(w.seed.data_ptr())
+            th = threading.Thread(target=tail_body, daemon=True)
+            th.start()
+        cur.synchronize()
+        self.times["pyramid"] = time.perf_counter() - t0
         t1 = time.perf_counter()
         for s in range(self.S):
             for w in ws:
@@ -410,24 +485,10 @@ class SlabExtractor:
             for w in ws:
                 w.stages[s].ctx.describe()
         self.times["keypoints_sharded"] = time.perf_counter() - t1
-        t2 = time.perf_counter()
-        if self.noct > self.S:
-            # replicated pyramid + extrema of the remaining octaves; orientation dealt by extremum index, results restored
-            # on every rank by an integer all-reduce(SUM) of zero-padded rows (exact); descriptors dealt by keypoint and
-            # LEFT distributed, like the sharded keypoints (GetKeypoints / the matcher's all-gather collect them)
-            for w in ws:
-                w.tail.run_partial_orientation()
-            bufs = []
-            for w in ws:
-                b = torch.empty(w.tail.num_extrema() * capi_words(), dtype=torch.int32, device=w.arena.device)
-                if b.numel():
-                    w.tail.export_orientation(b.data_ptr())
-                bufs.append(b)
-            comm.allreduce_sum_(bufs)
-            for w, b in zip(ws, bufs):
-                if b.numel():
-                    w.tail.import_orientation(b.data_ptr())
-                w.tail.run_describe()
+        if th is not None:
+            th.join()
+            if err:
+                raise err[0]
         self.times["tail"] = time.perf_counter() - t2
         self.times["total"] = time.perf_counter() - t0
         return self

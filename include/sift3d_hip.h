@@ -160,6 +160,13 @@ int sift3d_slab_level(sift3d_handle h, int i);
 int sift3d_slab_level_hw(sift3d_handle h, int i, int *hw);   /* half width of the Gaussian that produces GSS level i */
 int sift3d_slab_halo_planes(sift3d_handle h, int gss_level, int *planes); /* planes of GSS level i its consumers need per side */
 int sift3d_slab_sync(sift3d_handle h);
+/* Stream-ordered driving (no host synchronisation between the levels): every later call of the handle enqueues on the caller's
+ * stream (a hipStream_t of the handle's device; NULL = the handle's own stream again); the DoG maxima travel as nd floats in
+ * device memory around the caller's MAX all-reduce; the decimation does not wait for completion. */
+int sift3d_set_stream(sift3d_handle h, void *hip_stream);
+int sift3d_slab_export_dogmax_device(sift3d_handle h, float *d_dst);
+int sift3d_slab_import_dogmax_device(sift3d_handle h, const float *d_src);
+int sift3d_slab_decimate_async(sift3d_handle h, float *d_dst);
 int sift3d_slab_get_dogmax(sift3d_handle h, float *max5);          /* local maxima of the DoG levels (host) */
 int sift3d_slab_set_dogmax(sift3d_handle h, const float *max5);    /* global maxima after the all-reduce */
 int sift3d_slab_detect(sift3d_handle h);                            /* extrema of the owned planes (DoG halos of 1 plane exchanged) */

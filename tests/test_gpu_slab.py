@@ -69,6 +69,37 @@ def test_slab_equals_single_volume(shape, world, sharded):
     ref.close()
 
 
+def test_config3_1024x1024x512_eight_slabs_equal_the_single_volume():
+    """BASELINE configs[3] at full size: 1024 x 1024 x 512 over 8 (simulated) ranks, two sharded octaves (64- and 32-plane slabs, both
+    thinner than the 38-plane halo) + replicated tail, against the single-volume extractor: same keypoints, same descriptors, bit
+    for bit; the DoG maxima (reduced on the device) and the owned planes of the seed level of octave 1 as a pyramid probe."""
+    import torch
+    nx, ny, nz = 1024, 1024, 512
+    vol = synth.blobs_torch((nz, ny, nx), "cuda", seed=4321)
+    torch.cuda.synchronize()
+    ref = capi.CSIFT3D(None, device_ptr=vol.data_ptr(), shape=(nz, ny, nx))
+    ref.KpSiftAlgorithm()
+    kp_ref, ds_ref = ref.GetKeypoints()
+    g10 = ref.gss(1, 0)
+    ref.close()
+    assert len(kp_ref) > 20000
+    ex = slab.SlabExtractor((nx, ny, nz), slab.SimComm(8), sharded_octaves=2)
+    assert ex.S == 2
+    ex.load(device_slabs={r: vol[z0:z1] for r, (z0, z1) in enumerate(ex.bounds)})
+    del vol
+    ex.KpSiftAlgorithm()
+    for w in ex._wl():
+        st = w.stages[1]
+        got = st.ctx.held_level(0, 0)[w.halo:w.halo + (st.z1 - st.z0)]
+        assert np.array_equal(got, g10[st.z0:st.z1]), w.rank
+    kp, ds = ex.GetKeypoints()
+    ex.close()
+    assert len(kp) == len(kp_ref)
+    for f in kp_ref.dtype.names:
+        assert np.array_equal(kp[f], kp_ref[f]), f
+    assert np.array_equal(ds, ds_ref)
+
+
 def test_slab_halo_too_small_is_refused():
     import torch
     nx = ny = nz = 64
