@@ -57,3 +57,14 @@ def ordered_pairs(world):
 def my_pairs(rank, world):
     """Round-robin deal of the ordered pairs: 7 per rank for 8 volumes."""
     return [p for k, p in enumerate(ordered_pairs(world)) if k % world == rank]
+
+
+def allpairs_match(desc, xyz, match_fn):
+    """BASELINE configs[4] matching step: all-gather every rank's (ragged) descriptors and coordinates, then run
+    `match_fn(desc_i, xyz_i, desc_j, xyz_j)` (enhancedMatch) on this rank's share of the ordered volume pairs.
+    Returns {(i, j): result of match_fn} for the pairs dealt to this rank (all pairs without a process group)."""
+    descs = allgather_ragged(desc)
+    xyzs = allgather_ragged(xyz)
+    world = len(descs)
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    return {(i, j): match_fn(descs[i], xyzs[i], descs[j], xyzs[j]) for (i, j) in my_pairs(rank, world)}

@@ -36,6 +36,64 @@ WORKER = textwrap.dedent("""
 """) % ROOT
 
 
+WORKER_ALLPAIRS = textwrap.dedent("""
+    import importlib, os, sys, pickle, numpy as np, torch
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    d = importlib.import_module("3dsift_amd.dist")
+    import oracle_lib as ol
+    orc = ol.load("orc"); orc.set_threads(2)
+    rank, world = d.init_from_env(backend="gloo")
+    sets = pickle.load(open(os.environ["S3D_SETS"], "rb"))          # [(desc, xyz)] per volume; this rank owns volume `rank`
+    desc, xyz = sets[rank]
+    fn = lambda a, ax, b, bx: orc.match(a.numpy(), ax.numpy(), b.numpy(), bx.numpy(), 0.85, 3)
+    mine = d.allpairs_match(torch.from_numpy(desc), torch.from_numpy(xyz), fn)
+    pickle.dump(mine, open(os.environ["S3D_OUT"] + str(rank), "wb"))
+    import torch.distributed as dist
+    dist.barrier()
+    print("rank", rank, "ok", sorted(mine))
+""") % (ROOT, ROOT)
+
+
+def test_gloo_world2_allpairs_equals_single_process(tmp_path):
+    """BASELINE configs[4] on the CPU: every rank contributes the descriptors of its own volume (ragged), the ordered pairs are dealt
+    to the ranks, and the union of the per-rank enhancedMatch results equals the single-process results (the oracle's matcher is the
+    match function here; the GPU bench passes sift3d_match with device-resident inputs to the same code)."""
+    import pickle
+    import sys as _sys
+    import numpy as np
+    _sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    orc = ol.load("orc")
+    rng = np.random.Generator(np.random.PCG64(3))
+    base = np.clip(rng.normal(0.02, 0.03, size=(60, 768)), 0, None).astype(np.float32)
+    sets = []
+    for n in (40, 53):   # ragged: volume 1 holds more keypoints; both are noisy views of the same 60 features
+        idx = rng.permutation(60)[:n] if n <= 60 else np.arange(60)
+        dsc = base[idx % 60][:n] + rng.normal(0, 0.004, size=(n, 768)).astype(np.float32)
+        dsc = np.concatenate([dsc, np.clip(rng.normal(0.02, 0.03, size=(max(0, n - len(dsc)), 768)), 0, None).astype(np.float32)])[:n]
+        dsc = (dsc / np.linalg.norm(dsc, axis=1, keepdims=True)).astype(np.float32)
+        sets.append((dsc, rng.uniform(0, 100, (n, 3)).astype(np.float32)))
+    pickle.dump(sets, open(tmp_path / "sets.pkl", "wb"))
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   S3D_SETS=str(tmp_path / "sets.pkl"), S3D_OUT=str(tmp_path / "out"))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER_ALLPAIRS], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+    got = {}
+    for r in range(2):
+        got.update(pickle.load(open(str(tmp_path / "out") + str(r), "rb")))
+    assert sorted(got) == [(0, 1), (1, 0)]
+    for (i, j), res in got.items():
+        want = orc.match(sets[i][0], sets[i][1], sets[j][0], sets[j][1], 0.85, 3)
+        assert len(want["pairs"]) > 5
+        for k in want:
+            assert np.array_equal(res[k], want[k]), (i, j, k)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
