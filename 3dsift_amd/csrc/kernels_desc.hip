@@ -75,6 +75,9 @@ constexpr int kFaceStride = 16;  // floats per face in the LDS table
 #ifndef S3D_DESC_CLIPM
 #define S3D_DESC_CLIPM 2.0f  /* widening of the cube clip of a column's z range, voxels */
 #endif
+#ifndef S3D_DESC_ATTR
+#define S3D_DESC_ATTR
+#endif
 #ifndef S3D_DESC_SPREAD
 #define S3D_DESC_SPREAD 1
 #endif
@@ -278,7 +281,7 @@ constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <=
 // LUT_LDS: the window's weight table is staged in LDS (default parameters: 1293 entries).  Larger windows (sigma_default well
 // above 1.6) read the table from global memory instead (L2-resident, a few KB): slower, but no size limit.
 template <bool LUT_LDS>
-__global__ void __launch_bounds__(256) k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
+__global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
                                                   const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap,
                                                   int part_rank, int part_world, const int *__restrict__ order,

@@ -17,9 +17,11 @@ python3 $REPO/scripts/measure_traffic.py 512 > $OUT/${TAG}_pyramid_traffic_512.j
 head -12 $OUT/${TAG}_rocprofv3_kernel_stats.csv
 # SQ counters of the two dominant kernels (separate --pmc passes, no trace options)
 python3 $REPO/scripts/pmc_kernel.py k_describe 512 5 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES > $OUT/${TAG}_pmc_k_describe.json
-python3 $REPO/scripts/pmc_kernel.py k_fused_level 512 1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES > $OUT/${TAG}_pmc_k_fused_level.json
+S3D_ONE_STREAM=1 python3 $REPO/scripts/pmc_kernel.py k_march_level 512 1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES > $OUT/${TAG}_pmc_k_march_level.json
 # z-slab workload on one GPU: the plain single-GPU run and the simulated 2- and 8-rank runs
 cd $REPO
 ( python3 bench.py --workload slab --steps 3 --warmup 1 2>/dev/null; python3 bench.py --workload slab --sim-ranks 2 --steps 3 --warmup 1 2>/dev/null; python3 bench.py --workload slab --sim-ranks 8 --steps 3 --warmup 1 2>/dev/null ) > $OUT/${TAG}_slab_sim.json
 bash $REPO/scripts/kernel_times.sh > $OUT/${TAG}_kernel_times.txt 2>&1
+bash $REPO/scripts/level_times.sh 512 > $OUT/${TAG}_levels_isolated.txt 2>&1
+bash $REPO/scripts/timeline.sh 512 > $OUT/${TAG}_timeline.txt 2>&1
 cat $OUT/${TAG}_bench.json
