@@ -545,11 +545,16 @@ static void smooth_level(sift3d_ctx *c, int o, const float *src, const Level &ds
 	// are planned for that third; otherwise those chains starve and run as a tail after octave 0 has finished.
 	static const int tail_slots = [] { const char *e = getenv("S3D_O0_TAIL_SLOTS"); return e ? atoi(e) : S3D_O0_TAIL_SLOTS_DEFAULT; }();
 	static const int bg_slots = [] { const char *e = getenv("S3D_BG_SLOTS"); return e ? atoi(e) : S3D_BG_SLOTS_DEFAULT; }();
+	// wave priority: the launches of octaves >= 2 (1/64 of the work, but each octave waits for level 3 of the one above, and beside the
+	// big launches their workgroups crawl) run at the highest wave priority: 2.82 -> 2.71 ms per 512^3 pyramid.  Raising octave 1 too
+	// (S3D_PRIO=1) costs octave 0 as much as it gains.
+	static const int prio_mode = [] { const char *e = getenv("S3D_PRIO"); return e ? atoi(e) : 2; }();
+	const int prio = (prio_mode && c->noct > 1) ? (o >= 2 ? 2 : (o == 1 && prio_mode == 1 ? 1 : 0)) : 0;
 	const int plan_slots = c->noct > 1 ? (o == 0 ? (level > c->p.num_kp_levels ? tail_slots : 0) : bg_slots) : 0;
 	// hot path: one fused pass (x, y, z blur + DoG + abs-max); prev == src for every DoG-producing level
 	static const int fused_min = [] { const char *e = getenv("S3D_FUSED_MIN"); return e ? atoi(e) : S3D_FUSED_MIN_DEFAULT; }();
 	if (c->use_fused && (prev == nullptr || prev == src) && std::min(dst.nx, std::min(dst.ny, dst.nz)) >= fused_min &&
-	    launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.zr_all(), t, st, plan_slots))
+	    launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.zr_all(), t, st, plan_slots, prio))
 		return;
 	launch_conv_axis(0, src, c->tmpA[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
 	launch_conv_axis(1, c->tmpA[o], c->tmpB[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);

@@ -787,10 +787,10 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 // returns false when no fused instantiation exists for this half width (caller uses the generic
 // separable kernels of kernels_pyramid.hip instead -- still the HIP path)
 bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr,
-                        const Taps &t, hipStream_t st, int plan_slots) {
+                        const Taps &t, hipStream_t st, int plan_slots, int prio) {
 	// the halo-extension form of the boundary rule needs n >= 2*hw+2 along x and y (see header)
 	if (nx < 2 * t.hw + 2 || ny < 2 * t.hw + 2) return false;
-	if (launch_march_level(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots)) return true;  // tile-aligned shapes (kernels_march.hip)
+	if (launch_march_level(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio)) return true;  // tile-aligned shapes (kernels_march.hip)
 	switch (t.hw) {
 	case 2: launch_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
 	case 3: launch_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;

@@ -121,7 +121,7 @@ constexpr int march_occ() { return CR ? 3 : (HW <= 4 ? S3D_MOCC_LO : (HW == 5 ? 
 template <int HW, bool DOG, bool CR>
 __global__ void __launch_bounds__(256, ((S3D_MARCH_VGPR_OCC > 0 && !CR) ? S3D_MARCH_VGPR_OCC : march_occ<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                         unsigned *__restrict__ dogmax, int nx, int ny, ZRange zr, MTaps t, MEdge ef, int ntx,
-                                                        int nty, int cz) {
+                                                        int nty, int cz, int prio) {
 	using C = MCfg<HW>;
 	__shared__ __attribute__((aligned(1024))) float tile[2 * C::TILE_F];
 	__shared__ __attribute__((aligned(16))) float xb[2 * C::XB_F];
@@ -132,6 +132,10 @@ __global__ void __launch_bounds__(256, ((S3D_MARCH_VGPR_OCC > 0 && !CR) ? S3D_MA
 	__shared__ float s_ef[3 * (kMarchMaxHW + 1)];
 	__shared__ float s_red[4];
 
+	// wave priority of the launch (issue arbitration between resident waves): the small octaves' launches sit on the critical chain
+	// octave -> octave while the big launches of octave 0 fill the machine; they run at a raised priority
+	if (prio >= 2) __builtin_amdgcn_s_setprio(3);
+	else if (prio == 1) __builtin_amdgcn_s_setprio(1);
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 	if (tid < 3 * (kMarchMaxHW + 1)) s_ef[tid] = ef.f[tid / (kMarchMaxHW + 1)][tid % (kMarchMaxHW + 1)];
@@ -424,7 +428,7 @@ static void march_edge_fractions(int n, int hw, float *f) {  // Src/cSIFT3D.cc:7
 
 template <int HW>
 static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &tg,
-                            hipStream_t st, int plan_slots) {
+                            hipStream_t st, int plan_slots, int prio) {
 	using C = MCfg<HW>;
 	MTaps t;
 	for (int i = 0; i < 2 * kMarchMaxHW + 1; i++) t.w[i] = i < 2 * HW + 1 ? tg.w[i] : 0.0f;
@@ -467,25 +471,25 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	march_edge_fractions(zr.nzg, HW, ef.f[2]);
 	const dim3 grid((unsigned)(ntiles * nchunks)), block(C::NT);
 	// DoG centre ring in LDS where three workgroups per CU still fit (hw <= 5); otherwise the centre piece travels by LDS-DMA
-	if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
-	else if (dog) hipLaunchKernelGGL((k_march_level<HW, true, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
-	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz);
+	if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio);
+	else if (dog) hipLaunchKernelGGL((k_march_level<HW, true, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio);
+	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio);
 }
 
 // false => not applicable (shape not tile aligned, level too small for the extended-line boundary form, half width without an
 // instantiation): the caller falls through to kernels_fused.hip / kernels_pyramid.hip
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
-                        hipStream_t st, int plan_slots) {
+                        hipStream_t st, int plan_slots, int prio) {
 	static const bool off = [] { const char *e = getenv("S3D_MARCH"); return e && e[0] == '0'; }();
 	if (off) return false;
 	if ((nx % 32) || (ny % 32) || nx < 2 * t.hw + 2 || ny < 2 * t.hw + 2 || zr.nzg < 2 * t.hw + 2) return false;
 	switch (t.hw) {
-	case 2: launch_march_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
-	case 3: launch_march_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
-	case 4: launch_march_hw<4>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
-	case 5: launch_march_hw<5>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
-	case 6: launch_march_hw<6>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
-	case 8: launch_march_hw<8>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots); return true;
+	case 2: launch_march_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
+	case 3: launch_march_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
+	case 4: launch_march_hw<4>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
+	case 5: launch_march_hw<5>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
+	case 6: launch_march_hw<6>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
+	case 8: launch_march_hw<8>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
 	default: return false;
 	}
 }

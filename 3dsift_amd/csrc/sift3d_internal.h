@@ -119,10 +119,10 @@ void launch_conv_axis(int axis, const float *src, float *dst, int nx, int ny, in
                       const float *prev, float *dog, unsigned *d_dogmax, hipStream_t st);
 // fused single-pass level kernel (kernels_fused.hip); false => no instantiation for this half width
 bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr,
-                        const Taps &t, hipStream_t st, int plan_slots = 0);
+                        const Taps &t, hipStream_t st, int plan_slots = 0, int prio = 0);
 // tile-aligned levels (kernels_march.hip): descending z-march with scatter accumulators; false => not applicable, use the above
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
-                        hipStream_t st, int plan_slots = 0);
+                        hipStream_t st, int plan_slots = 0, int prio = 0 /* wave priority class: 0 normal, 1, 2 */);
 void launch_downsample(const float *src, int snx, int sny, float *dst, int nx, int ny, int nz, hipStream_t st);
 
 // ---- kernels_detect.hip --------------------------------------------------------------------
