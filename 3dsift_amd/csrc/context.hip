@@ -148,6 +148,9 @@ struct sift3d_ctx {
 	int own0 = 0, own1 = 0, halo = 0;
 	// single-volume path: DoG[o][0] and DoG[o][nd-1] are not written by the pyramid (see DetectLevels); copy_level forms them
 	bool dog_elide = false;
+	bool g_last_elide = false;      // the last Gaussian level of every octave is not built (DetectLevels::lazy_src); implies dog_elide
+	std::vector<char> g_last_built; // per octave: built on request (sift3d_copy_level)
+	unsigned *d_prov = nullptr;     // parked candidates of the lazy level + [prov_cap] = their count
 	bool desc_lut_lds = true;       // every descriptor window weight table fits the LDS copy (kMaxDescLut)
 	bool ext_arena = false;         // level buffers live in memory owned by the caller
 	int part_rank = 0, part_world = 1;  // descriptor work split of replicated octaves
@@ -207,6 +210,7 @@ static void free_lists(sift3d_ctx *c) {
 	hipFree(c->d_kpout); c->d_kpout = nullptr;
 	hipFree(c->d_desc); c->d_desc = nullptr;
 	hipFree(c->d_xyz); c->d_xyz = nullptr;
+	hipFree(c->d_prov); c->d_prov = nullptr;
 }
 
 static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
@@ -219,6 +223,8 @@ static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
 	S3D_HIP(hipMalloc(&c->d_kpout, sizeof(sift3d_keypoint) * (size_t)c->kp_cap));
 	S3D_HIP(hipMalloc(&c->d_desc, sizeof(float) * kDesc * (size_t)c->kp_cap));
 	S3D_HIP(hipMalloc(&c->d_xyz, sizeof(float) * 3 * (size_t)c->kp_cap));
+	S3D_HIP(hipMalloc(&c->d_prov, sizeof(unsigned) * ((size_t)c->ext_cap + 1)));
+	c->det.prov = c->d_prov; c->det.prov_count = c->d_prov + c->ext_cap; c->det.prov_cap = c->ext_cap;
 	return SIFT3D_OK;
 }
 
@@ -571,6 +577,11 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 	// S3D_DOG_EAGER=1: write every DoG level (A/B; the z-slab path always does)
 	static const bool dog_eager = [] { const char *e = getenv("S3D_DOG_EAGER"); return e && e[0] == '1'; }();
 	c->dog_elide = !dog_eager && c->nd >= 3;
+	// the last Gaussian level is only ever read at the voxels that pass seven of the eight extremum tests of the last keypoint level:
+	// it is not built at all; those voxels get the value from k_lazy_next (DetectLevels::lazy_src).  S3D_GLAST_EAGER=1 builds it.
+	static const bool glast_eager = [] { const char *e = getenv("S3D_GLAST_EAGER"); return e && e[0] == '1'; }();
+	c->g_last_elide = c->dog_elide && !glast_eager && c->use_fused && 2 * (2 * c->taps[c->ng - 1].hw + 1) <= kLazySlots;
+	c->g_last_built.assign((size_t)std::max(1, c->noct), 0);
 	for (int attempt = 0; attempt < 4; attempt++) {
 		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(std::max(1, c->noct * c->nd) + 4), st));
 		S3D_HIP(hipEventRecord(c->ev[0], st));
@@ -595,6 +606,7 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 				} else {
 					const Level &P = c->gss[(size_t)o * c->ng + i - 1];
 					const Level &D = c->dog[(size_t)o * c->nd + i - 1];
+					if (c->g_last_elide && i == c->ng - 1) continue;  // never built (k_lazy_next / sift3d_copy_level form what is asked for)
 					if (c->dog_elide && (i - 1 == 0 || i - 1 == c->nd - 1)) smooth_level(c, o, P.d, L, c->taps[i], nullptr, nullptr, nullptr, i);
 					else smooth_level(c, o, P.d, L, c->taps[i], P.d, D.d, c->d_dogmax + (size_t)o * c->nd + i - 1, i);
 				}
@@ -623,9 +635,11 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 					DL.prev0_hi = c->gss[(size_t)o * c->ng + 1].d; DL.prev0_lo = c->gss[(size_t)o * c->ng].d;
 					DL.nextl_hi = c->gss[(size_t)o * c->ng + c->nd].d; DL.nextl_lo = c->gss[(size_t)o * c->ng + c->nd - 1].d;
 					DL.nextl_slot = nl - 1;
+					if (c->g_last_elide) { DL.nextl_hi = nullptr; DL.lazy_src = DL.nextl_lo; }
 				}
 				const Level &C = c->dog[(size_t)o * c->nd + 1];
-				launch_detect_octave(DL, nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, c->det, c->d_ext, c->ext_cap, st);
+				launch_detect_octave(DL, nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, c->det, c->d_ext, c->ext_cap, st,
+				                     c->g_last_elide ? &c->taps[c->ng - 1] : nullptr);
 			}
 		S3D_HIP(hipEventRecord(c->ev[3], st));
 		// ---- Assign_Orientation (Src/cSIFT3D.cc:427-482) ----
@@ -740,6 +754,16 @@ extern "C" int sift3d_copy_level(sift3d_handle c, int is_dog, int idx, float *ou
 	if (!L) return SIFT3D_ERR_ARG;
 	int rc = set_device(c->device);
 	if (rc) return rc;
+	if (c->g_last_elide && !c->slab) {
+		// the last Gaussian level of the octave (and the DoG level behind it) was never built: build it now, once
+		const int o = is_dog ? idx / c->nd : idx / c->ng, i = is_dog ? idx % c->nd : idx % c->ng;
+		if (((is_dog && i == c->nd - 1) || (!is_dog && i == c->ng - 1)) && !c->g_last_built[(size_t)o]) {
+			const Level &G = c->gss[(size_t)o * c->ng + c->ng - 1], &P = c->gss[(size_t)o * c->ng + c->ng - 2];
+			smooth_level(c, o, P.d, G, c->taps[c->ng - 1], nullptr, nullptr, nullptr, c->ng - 1);
+			S3D_HIP(hipStreamSynchronize(c->ostream[o]));
+			c->g_last_built[(size_t)o] = 1;
+		}
+	}
 	if (is_dog && c->dog_elide && (idx % c->nd == 0 || idx % c->nd == c->nd - 1)) {
 		// an elided DoG level (never written by the pipeline): form it now, exactly like Sub, into its arena slot
 		const int o = idx / c->nd, i = idx % c->nd;

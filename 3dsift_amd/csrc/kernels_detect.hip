@@ -13,6 +13,9 @@
 //   k_scan : one workgroup turns the block counts into exclusive offsets on top of the running total
 //   k_emit : one thread per ballot word; words with hits (rare) write their extrema at offset + rank
 // No host synchronisation anywhere; the running total stays on the device.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "sift3d_internal.h"
 
 namespace s3d {
@@ -32,7 +35,9 @@ constexpr int kThreads = 256;
 // candidate) and the compiler drains them at each join: one memory round trip per word.
 constexpr int kQueue = 640;  // >= 63 left over + 8 words x 64 lanes pushed before the next drain
 __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int ny, ZRange zr, int nyb, float peak_thresh,
-                                                   unsigned long long *__restrict__ masks, unsigned *__restrict__ block_counts) {
+                                                   unsigned long long *__restrict__ masks, unsigned *__restrict__ block_counts,
+                                                   unsigned *__restrict__ prov, unsigned *__restrict__ prov_count, unsigned prov_cap,
+                                                   unsigned *__restrict__ total) {
 	__shared__ unsigned s_cnt[kThreads / 64];
 	__shared__ float s_qv[kThreads / 64][kQueue];
 	__shared__ unsigned short s_qi[kThreads / 64][kQueue];
@@ -46,6 +51,7 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	const float *__restrict__ prev = L.prev[lvl];
 	const float *__restrict__ next = L.next[lvl];
 	const bool lazy_prev = lvl == 0 && L.prev0_hi != nullptr, lazy_next = lvl == L.nextl_slot && L.nextl_hi != nullptr;
+	const bool lazy_g = lvl == L.nextl_slot && L.lazy_src != nullptr;  // the level behind `next` does not exist: park the candidates
 	const float thr = peak_thresh * __uint_as_float(*L.absmax_bits[lvl]);
 	const int wpr = (nx + 63) >> 6;
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -76,8 +82,26 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 		const size_t ic = act ? i : sz * (size_t)z + sy + 1;
 		// elided first / last DoG level: formed from the two Gaussian levels like Sub does (block-uniform choice)
 		const float n0 = lazy_prev ? (L.prev0_hi[ic] - L.prev0_lo[ic]) * (-1.0f) : prev[ic];
-		const float n7 = lazy_next ? (L.nextl_hi[ic] - L.nextl_lo[ic]) * (-1.0f) : next[ic];
 		const float n1 = cur[ic - 1], n2 = cur[ic + 1], n3 = cur[ic + sy], n4 = cur[ic - sy], n5 = cur[ic + sz], n6 = cur[ic - sz];
+		if (lazy_g) {  // block-uniform
+			const bool mn7 = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6;
+			const bool mx7 = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6;
+			// one counter increment per wave (a single word takes ~90 atomics per microsecond: one per candidate cost 0.45 ms)
+			const bool park = act && (mn7 || mx7);
+			const unsigned long long pm = __ballot(park);
+			if (pm) {
+				unsigned base = 0;
+				if (lane == 0) base = atomicAdd(prov_count, (unsigned)__popcll(pm));
+				base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+				if (park) {
+					const unsigned slot = base + (unsigned)__popcll(pm & lt);
+					if (slot < prov_cap) prov[slot] = (unsigned)i | (mx7 ? 0x80000000u : 0u);
+					else total[1] = 1u;  // overflow: the host regrows the lists and reruns
+				}
+			}
+			return;
+		}
+		const float n7 = lazy_next ? (L.nextl_hi[ic] - L.nextl_lo[ic]) * (-1.0f) : next[ic];
 		const bool mn = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 && v < n7;
 		const bool mx = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 && v > n7;
 		if (act && (mn || mx)) atomicOr(&mloc[rr * 64 + xw], 1ull << bit);
@@ -136,6 +160,199 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	if (lane == 0) s_cnt[wid] = cnt;
 	__syncthreads();
 	if (threadIdx.x == 0) block_counts[b] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// Parked candidates of the last keypoint level (DetectLevels::lazy_src): one workgroup evaluates the missing Gaussian level at one
+// voxel -- x-blur of every (row, plane) the y and z taps reach, y-blur per plane, z-blur -- with the code of k_conv_axis (interior
+// chain where the output is interior along the axis, boundary_term for every tap otherwise), forms the DoG value like Sub and
+// finishes the extremum test; hits are ORed into the ballot words and counted into their block, before k_scan runs.
+__device__ __forceinline__ void lazy_tap_src(int p, int d, int n, int &lo, int &hi, float &frac, bool interior) {
+	if (interior) { lo = hi = p - d; frac = 0.0f; return; }
+	const int dim_end = n - 1;
+	float c = (float)p - (float)d * 1.0f;
+	if (c < 0.0f) c = -1.0f * c;
+	else if (c >= (float)dim_end) c = (float)(2 * dim_end) - c - 0.1f;
+	lo = (int)c;
+	frac = c - (float)lo;
+	hi = lo + 1;
+	lo = min(max(lo, 0), dim_end);  // same clamp as boundary_term (kernels_pyramid.hip)
+	hi = min(max(hi, 0), dim_end);
+}
+constexpr int kLT = kLazySlots / 2 - 1;   // taps at most (17)
+constexpr int kLR = kLT + 1;              // real samples an axis reads: one contiguous range of at most 2 hw + 2 indices
+constexpr int kLP = kLR + 1;              // x pitch of the staged block (odd: lanes = rows read conflict-free)
+__global__ void __launch_bounds__(256) k_lazy_next(DetectLevels L, Taps t, int nx, int ny, ZRange zr, int nyb,
+                                                   const unsigned *__restrict__ prov, const unsigned *__restrict__ prov_count,
+                                                   unsigned prov_cap, unsigned long long *__restrict__ masks,
+                                                   unsigned *__restrict__ block_counts) {
+	// one WORKGROUP per parked candidate: the block of real samples the three passes reach (at most 18^3 voxels, rows contiguous in
+	// memory) is staged in LDS with coalesced loads -- one wave per candidate with a window per lane touched 64 cache lines per load
+	// instruction and was bound by the texture addresser (0.45 ms per 512^3 run) -- then x-blur per (row, plane), y-blur per plane, z-blur
+	__shared__ float s_blk[kLR * kLR * kLP];
+	__shared__ float s_x[kLR * kLR];
+	__shared__ float s_y[kLR];
+	__shared__ float s_w[kMaxTaps];
+	__shared__ int s_lo[3][kLT], s_hi[3][kLT];
+	__shared__ float s_fr[3][kLT];
+	__shared__ int s_rng[6];  // xmin, cx, ymin, cy, zmin, cz
+	const int hw = t.hw, nt = 2 * hw + 1, tid = threadIdx.x;
+	for (int i = tid; i < nt; i += 256) s_w[i] = t.w[i];
+	const unsigned count = min(*prov_count, prov_cap);
+	const int lvl = L.nextl_slot;
+	const float *__restrict__ src = L.lazy_src;
+	const float *__restrict__ cur = L.cur[lvl];
+	const int wpr = (nx + 63) >> 6, nzs = zr.zo1 - zr.zo0, nzg = zr.nzg;
+	const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+	for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
+		const unsigned ent = prov[e];
+		const size_t ic = (size_t)(ent & 0x7FFFFFFFu);
+		const bool as_max = (ent >> 31) != 0;
+		const int zl = (int)(ic / sz), rem = (int)(ic - (size_t)zl * sz), y = rem / nx, x = rem - y * nx;
+		const int zg = zl + zr.zoff;  // global plane
+		const bool ix = x >= hw && x <= nx - 2 - hw, iy = y >= hw && y <= ny - 2 - hw, iz = zg >= hw && zg <= nzg - 2 - hw;
+		__syncthreads();  // the previous candidate is finished with the LDS arrays
+		if (hw == 8 && ix && iy && iz) {
+			// interior voxel, default half width (block-uniform): the block is exactly 17^3, every index is a compile-time constant --
+			// no tap tables, the LDS reads of a chain are independent of each other
+			constexpr int H = 8, N = 17;
+			const float *base = src + ic - (size_t)H * sz - (size_t)H * sy - (size_t)H;
+			{
+				// all loads of a thread first, then the LDS writes: a load -> store loop serialises on the memory latency (20 round trips)
+				constexpr int NS = (N * N * N + 255) / 256;
+				float v[NS];
+#pragma unroll
+				for (int q = 0; q < NS; q++) {
+					const int i = min(tid + 256 * q, N * N * N - 1);
+					const int xi = i % N, r = i / N, yi = r % N, zi2 = r / N;
+					v[q] = base[sz * (size_t)zi2 + sy * (size_t)yi + (size_t)xi];
+				}
+#pragma unroll
+				for (int q = 0; q < NS; q++) {
+					const int i = tid + 256 * q;
+					if (i < N * N * N) {
+						const int xi = i % N, r = i / N, yi = r % N, zi2 = r / N;
+						s_blk[(zi2 * kLR + yi) * kLP + xi] = v[q];
+					}
+				}
+			}
+			__syncthreads();
+			for (int s = tid; s < N * N; s += 256) {
+				const int zi2 = s / N, yi = s - zi2 * N;
+				const float *row = &s_blk[(zi2 * kLR + yi) * kLP];
+				float acc = 0.0f;
+#pragma unroll
+				for (int k = 0; k < N; k++) acc = acc + t.w[k] * row[2 * H - k];  // tap k reads x - (k - H)
+				s_x[zi2 * kLR + yi] = acc;
+			}
+			__syncthreads();
+			if (tid < N) {
+				const float *col = &s_x[tid * kLR];
+				float acc = 0.0f;
+#pragma unroll
+				for (int k = 0; k < N; k++) acc = acc + t.w[k] * col[2 * H - k];
+				s_y[tid] = acc;
+			}
+			__syncthreads();
+			if (tid == 0) {
+				float acc = 0.0f;
+#pragma unroll
+				for (int k = 0; k < N; k++) acc = acc + t.w[k] * s_y[2 * H - k];
+				const float n7 = (acc - src[ic]) * (-1.0f);  // Sub, Src/cSIFT3D.cc:875
+				const float v = cur[ic];
+				if (as_max ? (v > n7) : (v < n7)) {
+					const int zi = zl - zr.zo0;
+					atomicOr(&masks[((size_t)(lvl * nzs + zi) * ny + y) * wpr + (x >> 6)], 1ull << (x & 63));
+					atomicAdd(&block_counts[(lvl * nzs + zi) * nyb + y / kRows], 1u);
+				}
+			}
+			continue;
+		}
+		if (tid < 3 * nt) {  // tap tables of the three axes (boundary_term's source samples; interior: lo = hi = p - d, frac 0)
+			const int ax = tid / nt, k = tid - ax * nt;
+			int lo, hi; float fr;
+			if (ax == 0) lazy_tap_src(x, k - hw, nx, lo, hi, fr, ix);
+			else if (ax == 1) lazy_tap_src(y, k - hw, ny, lo, hi, fr, iy);
+			else lazy_tap_src(zg, k - hw, nzg, lo, hi, fr, iz);
+			s_lo[ax][k] = lo; s_hi[ax][k] = hi; s_fr[ax][k] = fr;
+		}
+		__syncthreads();
+		if (tid < 3) {  // contiguous range of real samples per axis
+			int mn = 1 << 30, mxv = -1;
+			for (int k = 0; k < nt; k++) { mn = min(mn, s_lo[tid][k]); mxv = max(mxv, s_hi[tid][k]); }
+			s_rng[2 * tid] = mn; s_rng[2 * tid + 1] = min(mxv - mn + 1, kLR);
+		}
+		__syncthreads();
+		const int xmin = s_rng[0], cx = s_rng[1], ymin = s_rng[2], cy = s_rng[3], zmin = s_rng[4], cz = s_rng[5];
+		// ---- stage the block: x fastest, so a wave's loads run along rows ----
+		for (int i0 = tid; i0 < cx * cy * cz; i0 += 256 * 8) {
+			float v[8];
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const int i = min(i0 + 256 * q, cx * cy * cz - 1);
+				const int xi = i % cx, r = i / cx, yi = r % cy, zi2 = r / cy;
+				v[q] = src[sz * (size_t)(zmin + zi2 - zr.zoff) + sy * (size_t)(ymin + yi) + (size_t)(xmin + xi)];
+			}
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				const int i = i0 + 256 * q;
+				if (i < cx * cy * cz) {
+					const int xi = i % cx, r = i / cx, yi = r % cy, zi2 = r / cy;
+					s_blk[(zi2 * kLR + yi) * kLP + xi] = v[q];
+				}
+			}
+		}
+		__syncthreads();
+		// ---- x-blur per (row, plane) ----
+		for (int s = tid; s < cy * cz; s += 256) {
+			const int zi2 = s / cy, yi = s - zi2 * cy;
+			const float *row = &s_blk[(zi2 * kLR + yi) * kLP] - xmin;
+			float acc = 0.0f;
+			if (ix) {
+				for (int k = 0; k < nt; k++) acc = acc + s_w[k] * row[s_lo[0][k]];
+			} else {
+				for (int k = 0; k < nt; k++) {
+					const float f = s_fr[0][k];
+					acc = acc + s_w[k] * ((1.0f - f) * row[s_lo[0][k]] + f * row[s_hi[0][k]]);
+				}
+			}
+			s_x[zi2 * kLR + yi] = acc;
+		}
+		__syncthreads();
+		// ---- y-blur per plane ----
+		if (tid < cz) {
+			const float *col = &s_x[tid * kLR] - ymin;
+			float acc = 0.0f;
+			if (iy) {
+				for (int k = 0; k < nt; k++) acc = acc + s_w[k] * col[s_lo[1][k]];
+			} else {
+				for (int k = 0; k < nt; k++) {
+					const float f = s_fr[1][k];
+					acc = acc + s_w[k] * ((1.0f - f) * col[s_lo[1][k]] + f * col[s_hi[1][k]]);
+				}
+			}
+			s_y[tid] = acc;
+		}
+		__syncthreads();
+		if (tid == 0) {
+			const float *pl = s_y - zmin;
+			float acc = 0.0f;
+			if (iz) {
+				for (int k = 0; k < nt; k++) acc = acc + s_w[k] * pl[s_lo[2][k]];
+			} else {
+				for (int k = 0; k < nt; k++) {
+					const float f = s_fr[2][k];
+					acc = acc + s_w[k] * ((1.0f - f) * pl[s_lo[2][k]] + f * pl[s_hi[2][k]]);
+				}
+			}
+			const float n7 = (acc - src[ic]) * (-1.0f);  // Sub, Src/cSIFT3D.cc:875
+			const float v = cur[ic];
+			if (as_max ? (v > n7) : (v < n7)) {
+				const int zi = zl - zr.zo0;
+				atomicOr(&masks[((size_t)(lvl * nzs + zi) * ny + y) * wpr + (x >> 6)], 1ull << (x & 63));
+				atomicAdd(&block_counts[(lvl * nzs + zi) * nyb + y / kRows], 1u);
+			}
+		}
+	}
 }
 
 // exclusive scan of block_counts[0..nblocks) by ONE workgroup; offsets start at the running total
@@ -233,13 +450,26 @@ __global__ void __launch_bounds__(kThreads) k_emit(const unsigned long long *__r
 }
 
 void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, float peak_thresh, int octave,
-                          const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st) {
+                          const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st, const Taps *lazy_taps) {
 	const int nyb = (ny + kRows - 1) / kRows;
 	const int nzl = zr.zo1 - zr.zo0;
 	if (nzl <= 0) return;
 	const unsigned nblocks = (unsigned)(nlevels * nzl * nyb);
 	if (nblocks == 0) return;
-	hipLaunchKernelGGL(k_mark, dim3(nblocks), dim3(kThreads), 0, st, L, nx, ny, zr, nyb, peak_thresh, b.masks, b.block_counts);
+	const bool lazy = L.lazy_src != nullptr && lazy_taps != nullptr && b.prov != nullptr;
+	if (lazy) (void)hipMemsetAsync(b.prov_count, 0, sizeof(unsigned), st);
+	hipLaunchKernelGGL(k_mark, dim3(nblocks), dim3(kThreads), 0, st, L, nx, ny, zr, nyb, peak_thresh, b.masks, b.block_counts, b.prov,
+	                   b.prov_count, b.prov_cap, b.total);
+	static const int lazy_grid = [] { const char *e = getenv("S3D_LAZY_GRID"); return e ? atoi(e) : 256 * 5; }();
+	if (lazy) hipLaunchKernelGGL(k_lazy_next, dim3(lazy_grid), dim3(256), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
+	                             b.masks, b.block_counts);
+	static const bool dbg = [] { const char *e = getenv("S3D_LAZY_DEBUG"); return e && e[0] == '1'; }();
+	if (lazy && dbg) {
+		unsigned n = 0;
+		hipStreamSynchronize(st);
+		hipMemcpy(&n, b.prov_count, sizeof(unsigned), hipMemcpyDeviceToHost);
+		fprintf(stderr, "lazy level: octave %d, %u parked candidates (%d x %d x %d)\n", octave, n, nx, ny, nzl);
+	}
 	hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b.block_counts, b.block_offsets, nblocks, b.total);
 	hipLaunchKernelGGL(k_emit, dim3(nblocks), dim3(kThreads), 0, st, b.masks, b.block_offsets, nx, ny, zr, nyb, octave, L, out, cap,
 	                   b.total);

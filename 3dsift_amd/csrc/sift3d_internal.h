@@ -131,6 +131,11 @@ struct DetectBufs {
 	unsigned *block_counts;     // per block
 	unsigned *block_offsets;    // exclusive scan (+ running base)
 	unsigned *total;            // [0] running total over all levels, [1] overflow flag
+	// lazy last Gaussian level (see DetectLevels::lazy_src): candidates that passed seven of the eight neighbour tests and wait
+	// for the value of the level that is not materialised: entry = local voxel index | (tested as maximum) << 31
+	unsigned *prov = nullptr;
+	unsigned *prov_count = nullptr;
+	unsigned prov_cap = 0;
 };
 // the keypoint levels of one octave (DoG levels 1..num_kp_levels), handled by one launch of each detect kernel
 constexpr int kMaxKpLevels = 5;
@@ -142,12 +147,19 @@ struct DetectLevels {
 	const float *prev0_hi, *prev0_lo;        // prev of level slot 0 = DoG[0] = (G[1] - G[0]) * (-1)
 	const float *nextl_hi, *nextl_lo;        // next of level slot nextl_slot = DoG[nd-1] = (G[nd] - G[nd-1]) * (-1)
 	int nextl_slot;
+	// The LAST Gaussian level of an octave, G[nd], is read by nothing but that formula -- not by a keypoint window (levels 1..nd-2),
+	// not by the next octave (seeded by G[num_kp_levels]) -- i.e. only at the few thousand voxels of level slot nextl_slot that
+	// pass the other seven tests.  lazy_src != null: the level was NOT built; those voxels are parked (DetectBufs::prov) and
+	// k_lazy_next evaluates G[nd] = gauss_z(gauss_y(gauss_x(lazy_src))) at each of them with the arithmetic of the level kernels
+	// (same tap chain, same boundary terms), then finishes the test.  lazy_src = G[nd-1], which is also nextl_lo.
+	const float *lazy_src;
 	const unsigned *absmax_bits[kMaxKpLevels];
 	int level_id[kMaxKpLevels];
 	float scale[kMaxKpLevels];
 };
+constexpr int kLazySlots = 36;  // k_lazy_next: 2 * (2 hw + 1) source slots per axis (boundary voxels) fit for hw <= 8
 void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, float peak_thresh, int octave,
-                          const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st);
+                          const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st, const Taps *lazy_taps = nullptr);
 
 // ---- kernels_orient.hip --------------------------------------------------------------------
 // Level pointers reach the keypoint kernels through a table in device memory, so the compiler cannot prove their address
