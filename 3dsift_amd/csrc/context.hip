@@ -754,6 +754,17 @@ extern "C" int sift3d_copy_level(sift3d_handle c, int is_dog, int idx, float *ou
 	if (!L) return SIFT3D_ERR_ARG;
 	int rc = set_device(c->device);
 	if (rc) return rc;
+	if (c->g_last_elide && c->slab) {
+		// z-slab context: build the owned planes of the last Gaussian level on request (G[nd-1] holds its halo)
+		const int i = is_dog ? idx % c->nd : idx % c->ng;
+		if (((is_dog && i == c->nd - 1) || (!is_dog && i == c->ng - 1)) && (c->g_last_built.empty() || !c->g_last_built[0])) {
+			const Level &G = c->gss[c->ng - 1];
+			if (!launch_fused_level(c->gss[c->ng - 2].d, G.d, nullptr, nullptr, G.nx, G.ny, G.zr(c->own0 - G.zoff, c->own1 - G.zoff), c->taps[c->ng - 1],
+			                        c->stream)) return SIFT3D_ERR_STATE;
+			S3D_HIP(hipStreamSynchronize(c->stream));
+			c->g_last_built.assign(1, 1);
+		}
+	}
 	if (c->g_last_elide && !c->slab) {
 		// the last Gaussian level of the octave (and the DoG level behind it) was never built: build it now, once
 		const int o = is_dog ? idx / c->nd : idx / c->ng, i = is_dog ? idx % c->nd : idx % c->ng;
@@ -1144,6 +1155,7 @@ extern "C" int sift3d_slab_level(sift3d_handle c, int i) {
 	const ZRange zr = L.zr(c->own0 - L.zoff, c->own1 - L.zoff);
 	bool ok;
 	if (i == 0) {
+		c->g_last_built.assign(1, 0);
 		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(c->nd + 4), c->stream));
 		// octave > 0: level 0 is the decimated G[octave-1][num_kp_levels], written by the caller
 		ok = c->seeded ? true : launch_fused_level(c->in.d, L.d, nullptr, nullptr, L.nx, L.ny, zr, c->base_taps, c->stream);
@@ -1151,7 +1163,12 @@ extern "C" int sift3d_slab_level(sift3d_handle c, int i) {
 		// like the single-volume path, the first and last DoG level of the octave are not materialised (read only as the centre-voxel
 		// neighbour of extremum candidates: no halo, no abs-max)
 		static const bool dog_eager = [] { const char *e = getenv("S3D_DOG_EAGER"); return e && e[0] == '1'; }();
+		static const bool glast_eager = [] { const char *e = getenv("S3D_GLAST_EAGER"); return e && e[0] == '1'; }();
 		c->dog_elide = !dog_eager && c->nd >= 3;
+		// ... and the last Gaussian level is not built at all (k_lazy_next evaluates it at the parked extremum candidates; its source
+		// level G[nd-1] holds the hw+1 halo planes the caller exchanged for this level)
+		c->g_last_elide = c->dog_elide && !glast_eager && 2 * (2 * c->taps[c->ng - 1].hw + 1) <= kLazySlots;
+		if (c->g_last_elide && i == c->ng - 1) { c->stage = std::max(c->stage, 1); return SIFT3D_OK; }
 		const bool elided = c->dog_elide && (i - 1 == 0 || i - 1 == c->nd - 1);
 		ok = launch_fused_level(c->gss[i - 1].d, L.d, elided ? nullptr : c->dog[i - 1].d, elided ? nullptr : c->d_dogmax + (i - 1), L.nx, L.ny,
 		                        zr, c->taps[i], c->stream);
@@ -1228,10 +1245,11 @@ extern "C" int sift3d_slab_detect(sift3d_handle c) {
 			DL.prev0_hi = c->gss[1].d; DL.prev0_lo = c->gss[0].d;
 			DL.nextl_hi = c->gss[c->nd].d; DL.nextl_lo = c->gss[c->nd - 1].d;
 			DL.nextl_slot = nl - 1;
+			if (c->g_last_elide) { DL.nextl_hi = nullptr; DL.lazy_src = DL.nextl_lo; }
 		}
 		const Level &C = c->dog[1];
 		launch_detect_octave(DL, nl, C.nx, C.ny, C.zr(c->own0 - C.zoff, c->own1 - C.zoff), c->p.peak_thresh, c->octave_base, c->det,
-		                     c->d_ext, c->ext_cap, c->stream);
+		                     c->d_ext, c->ext_cap, c->stream, c->g_last_elide ? &c->taps[c->ng - 1] : nullptr);
 		bool again;
 		rc = slab_count_and_regrow(c, again);
 		if (rc) return rc;
