@@ -73,7 +73,7 @@ constexpr int kFaceStride = 16;  // floats per face in the LDS table
 #define S3D_DESC_FASTMATH 0
 #endif
 #ifndef S3D_DESC_CLIPM
-#define S3D_DESC_CLIPM 2.0f  /* widening of the cube clip of a column's z range, voxels */
+#define S3D_DESC_CLIPM 0.25f /* widening of the cube clip of a column's z range, voxels */
 #endif
 #ifndef S3D_DESC_ATTR
 #define S3D_DESC_ATTR
@@ -265,7 +265,7 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 
 #if defined(S3D_EXP) && S3D_EXP == 21
 // in-kernel stamps (development): cycles per phase, summed per wave over the whole kernel, for the first 64 workgroups
-__device__ unsigned long long g_dstamp[64][4][8];
+__device__ unsigned long long g_dstamp[64][4][10];
 #define S3D_DSTAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; }
 #else
 #define S3D_DSTAMP(i)
@@ -273,6 +273,25 @@ __device__ unsigned long long g_dstamp[64][4][8];
 #ifndef S3D_DESC_X3
 #define S3D_DESC_X3 1
 #endif
+#ifndef S3D_DESC_C2
+#define S3D_DESC_C2 1
+#endif
+#ifndef S3D_DESC_SORT
+#define S3D_DESC_SORT 1
+#endif
+// Sorted column pairs (S3D_DESC_SORT).  A lane marches two adjacent columns (x, x+1).  The pairs of a window -- in chunks of
+// kPairCap of them, whole window rows -- are sorted by the length of their z range and dealt to the waves 64 at a time, longest
+// first: the lanes of a wave finish together.  (A fixed 16 x 8 tiling of the circular footprint leaves 35-45 % of the lane-steps
+// idle: rim tiles march their longest chord with most lanes outside the sphere.  Sorting the WHOLE window is slower again: the 64
+// columns of a wave then lie on a thin ring and share no cache lines; ~1000 pairs = 27 rows of the largest default window is the
+// measured optimum.  Sorting units of 2x1 ... 4x2 lanes instead of single pairs: no better.)
+#ifndef S3D_DESC_UCAP
+#define S3D_DESC_UCAP 1024
+#endif
+#ifndef S3D_DESC_LSHIFT
+#define S3D_DESC_LSHIFT 0
+#endif
+constexpr int kPairCap = S3D_DESC_UCAP, kLenBins = 128, kLenShift = S3D_DESC_LSHIFT;
 typedef float f3g __attribute__((ext_vector_type(3), aligned(4)));
 typedef float f4g __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2g __attribute__((ext_vector_type(2), aligned(4)));
@@ -295,6 +314,12 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	__shared__ __attribute__((aligned(16))) float s_face[kFaces * kFaceStride];
 	__shared__ int s_fidx[kFaces * 4];
 	__shared__ float red[4];
+#if S3D_DESC_C2 && S3D_DESC_SORT
+	__shared__ unsigned short s_units[kPairCap];  // the non-empty column pairs of the chunk, longest z range first
+	__shared__ unsigned s_chord[kPairCap];        // z ranges of a pair's two columns: (za0, zb0, za1, zb1) - z0, one byte each
+	__shared__ unsigned s_cnt[kLenBins];          // counting sort: pairs per length, then the running start of each length
+	__shared__ unsigned s_nnz;
+#endif
 	const unsigned count = min(d_count[0], cap);
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
@@ -319,7 +344,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	if (tid < 32) s_predf[tid] = c_pred.face[tid];
 	int cur_lut = -1;
 #if defined(S3D_EXP) && S3D_EXP == 21
-	unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
+	unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
 #endif
 	float(*q)[kQCap] = s_q[wid];
 	bin_t *hist_rep = &hist[lane % kRep];
@@ -412,38 +437,22 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		// Columns are dealt to the waves as 8x8 tiles of the window's (x, y) footprint: chord lengths (and the cube clip)
 		// vary slowly across a tile, so the lanes of a wave finish their z-march together (a 64x1 row segment spans
 		// the circle from rim to centre and leaves ~40 % of the lane-steps idle)
-#ifndef S3D_DESC_C2
-#define S3D_DESC_C2 1
-#endif
 #if S3D_DESC_C2
 		// Two adjacent columns (x, x+1) per lane, 8 lanes x 8 rows per wave = a 16 x 8 footprint.  The march is bound by the ISSUE
 		// of its vector-memory instructions, so the stencil of both columns comes from three loads per step: one 16-byte row
 		// piece (x-1 .. x+2) that also carries the centre values, requested two planes ahead, and two 8-byte pieces of the rows
 		// y-1 and y+1 -- 1.5 instructions per voxel instead of 4.  Queue order differs from the one-column form, the integer
 		// histogram sums do not.
-		constexpr int kLX = 8, kTH = 8;
-		const int tiles_x = (wx + 2 * kLX - 1) / (2 * kLX), tiles_y = (wy + kTH - 1) / kTH;
-		const int ntiles = ncol > 0 ? tiles_x * tiles_y : 0;
-		// tiles are handed to the four waves through an LDS counter: rim and centre tiles differ several-fold in work and a
-		// window only has 15-50 of them, so a static deal leaves waves idle at the barrier that closes the keypoint
-		for (;;) {
-			int tile = 0;
-			if (lane == 0) tile = (int)atomicAdd(&s_tile, 1u);
-			tile = __builtin_amdgcn_readfirstlane(tile);  // wave-uniform
-			if (tile >= ntiles) break;
-			const int ty = tile / tiles_x, tx = tile - ty * tiles_x;  // (a centre-out order, longest chords first, measured no better)
-			const int lxa = tx * 2 * kLX + 2 * (lane % kLX), ly = ty * kTH + (lane / kLX);
-			const int xa = x0 + lxa, y = y0 + ly;
-			const int dy = y - cyi;
+		// chord of the lane's two columns (xa, xa + 1) of window row ly: in-sphere range clipped to the rotated 4x4x4 cube
+		auto setup_pair = [&](int lxa, int ly, bool lane_ok, int (&rr)[2], int (&za)[2], int (&zb)[2], float (&px)[2], float (&py)[2],
+		                      float (&pz)[2], bool (&colok)[2]) {
+			const int dy = y0 + ly - cyi;
 			const float vyd = (float)dy * u;
-			int rr[2], za[2], zb[2];
-			float px[2], py[2], pz[2];
-			bool colok[2];
 #pragma unroll
 			for (int k = 0; k < 2; k++) {
-				const int dx = xa + k - cxi;
+				const int dx = x0 + lxa + k - cxi;
 				rr[k] = dx * dx + dy * dy;
-				colok[k] = tile < ntiles && lxa + k < wx && ly < wy && rr[k] <= nin;
+				colok[k] = lane_ok && lxa + k < wx && ly < wy && rr[k] <= nin;
 				const float vxd = (float)dx * u;
 				// partial rotations: (R0*vx + R1*vy) is evaluated first in the reference's left-to-right sums
 				px[k] = R0 * vxd + R1 * vyd; py[k] = R3 * vxd + R4 * vyd; pz[k] = R6 * vxd + R7 * vyd;
@@ -454,8 +463,8 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 					while ((h + 1) * (h + 1) <= nin - rr[k]) h++;
 					while (h * h > nin - rr[k]) h--;
 					za[k] = max(z0, czi - h); zb[k] = min(z1, czi + h);
-					// clip the z range to the rotated 4x4x4 cube (iteration-count optimisation only, widened by 2 voxels: the
-					// reference's exact fp32 test still runs on every visited voxel)
+					// clip the z range to the rotated 4x4x4 cube (iteration-count optimisation only, widened by S3D_DESC_CLIPM voxels:
+					// the reference's exact fp32 test still runs on every visited voxel)
 					float lo = (float)(za[k] - czi), hi = (float)(zb[k] - czi);
 					const float pr[3] = {px[k], py[k], pz[k]}, rr3[3] = {R2 * u, R5 * u, R8 * u};
 #pragma unroll
@@ -474,6 +483,104 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 				}
 				if (!(colok[k] && zb[k] >= za[k])) { colok[k] = false; za[k] = 1 << 28; zb[k] = -(1 << 28); }  // empty column
 			}
+		};
+#if S3D_DESC_SORT
+		const int nux = (wx + 1) / 2, nuy = wy;  // pairs per window row, rows
+		// (more than kPairCap pairs per row, or z ranges beyond a byte: only with windows far larger than the default parameters')
+		const bool chord_cached = z1 - z0 < 255;
+		const int rows_per_chunk = nux > 0 && nux <= kPairCap ? kPairCap / nux : 0;
+		for (int uy0 = 0; ncol > 0 && rows_per_chunk > 0 && uy0 < nuy; uy0 += rows_per_chunk) {
+		const int nch = min(nuy - uy0, rows_per_chunk) * nux;  // pairs of this chunk
+		if (uy0 > 0) __syncthreads();                        // previous chunk's march is done with s_units / s_tile
+		for (int i = tid; i < kLenBins; i += 256) s_cnt[i] = 0u;
+		if (tid == 0) s_tile = 0u;
+		__syncthreads();
+		for (int uu = tid; uu < nch; uu += 256) {
+			const int uyi = uu / nux, uxi = uu - uyi * nux;
+			int rr[2], za[2], zb[2];
+			float px[2], py[2], pz[2];
+			bool colok[2];
+			setup_pair(uxi * 2, uy0 + uyi, true, rr, za, zb, px, py, pz, colok);
+			const int len = (colok[0] || colok[1]) ? max(zb[0], zb[1]) - min(za[0], za[1]) + 1 : 0;
+			// an empty column is stored as the range (255, 0)
+			s_chord[uu] = chord_cached ? (colok[0] ? (unsigned)(za[0] - z0) | (unsigned)(zb[0] - z0) << 8 : 255u) |
+			                                 (colok[1] ? (unsigned)(za[1] - z0) | (unsigned)(zb[1] - z0) << 8 : 255u) << 16
+			                           : (unsigned)len;
+			if (len > 0) atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u);  // key 0 = empty pair
+		}
+		__syncthreads();
+		if (wid == 0) {  // running start of every key, longest first
+			const unsigned ca = s_cnt[kLenBins - 1 - 2 * lane], cb = s_cnt[kLenBins - 2 - 2 * lane];
+			unsigned incl = ca + cb;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const unsigned t = __shfl_up(incl, o, 64);
+				if (lane >= o) incl += t;
+			}
+			s_cnt[kLenBins - 1 - 2 * lane] = incl - ca - cb;
+			s_cnt[kLenBins - 2 - 2 * lane] = incl - cb;
+			if (lane == 63) s_nnz = incl - cb;  // key 0 comes last: everything before it is non-empty
+		}
+		__syncthreads();
+		for (int uu = tid; uu < nch; uu += 256) {
+			const unsigned ch = s_chord[uu];
+			int len;
+			if (chord_cached) {
+				const int a0 = ch & 255, b0 = (ch >> 8) & 255, a1 = (ch >> 16) & 255, b1 = ch >> 24;
+				len = max(b0, b1) - min(a0, a1) + 1;  // (255, 0) never wins a min / max against a real range; both empty: < 0
+			} else {
+				len = (int)ch;
+			}
+			if (len > 0) s_units[atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u)] = (unsigned short)uu;
+		}
+		__syncthreads();
+		const int nnz = (int)s_nnz, ntiles = (nnz + 63) / 64;
+#else
+		constexpr int kLX = 8, kTH = 8;
+		const int tiles_x = (wx + 2 * kLX - 1) / (2 * kLX), tiles_y = (wy + kTH - 1) / kTH;
+		const int ntiles = ncol > 0 ? tiles_x * tiles_y : 0;
+		{
+#endif
+		// groups of units (or tiles) are handed to the four waves through an LDS counter: they differ several-fold in work, so
+		// a static deal leaves waves idle at the barrier that closes the keypoint
+		for (;;) {
+			int tile = 0;
+			if (lane == 0) tile = (int)atomicAdd(&s_tile, 1u);
+			tile = __builtin_amdgcn_readfirstlane(tile);  // wave-uniform
+			if (tile >= ntiles) break;
+#if S3D_DESC_SORT
+			const int uidx = tile * 64 + lane;
+			const bool lane_ok = uidx < nnz;
+			const int uu = s_units[lane_ok ? uidx : 0];
+			const int uyi = uu / nux, uxi = uu - uyi * nux;
+			const int lxa = uxi * 2, ly = uy0 + uyi;
+#else
+			const int ty = tile / tiles_x, tx = tile - ty * tiles_x;  // (a centre-out order, longest chords first, measured no better)
+			const int lxa = tx * 2 * kLX + 2 * (lane % kLX), ly = ty * kTH + (lane / kLX);
+			const bool lane_ok = true;
+#endif
+			const int xa = x0 + lxa, y = y0 + ly;
+			int rr[2], za[2], zb[2];
+			float px[2], py[2], pz[2];
+			bool colok[2];
+#if S3D_DESC_SORT
+			if (chord_cached) {  // block-uniform
+				const unsigned ch = s_chord[uu];
+				const int dy = y - cyi;
+				const float vyd = (float)dy * u;
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					const int dx = xa + k - cxi;
+					rr[k] = dx * dx + dy * dy;
+					const float vxd = (float)dx * u;
+					px[k] = R0 * vxd + R1 * vyd; py[k] = R3 * vxd + R4 * vyd; pz[k] = R6 * vxd + R7 * vyd;
+					const int a = (ch >> (16 * k)) & 255, b = (ch >> (16 * k + 8)) & 255;
+					colok[k] = lane_ok && b >= a;
+					za[k] = colok[k] ? z0 + a : 1 << 28; zb[k] = colok[k] ? z0 + b : -(1 << 28);
+				}
+			} else
+#endif
+				setup_pair(lxa, ly, lane_ok, rr, za, zb, px, py, pz, colok);
 			const bool anycol = colok[0] || colok[1];
 			const int zA = min(za[0], za[1]), zB = max(zb[0], zb[1]);  // the lane marches the union of its two chords
 			const int zlen = anycol ? zB - zA + 1 : 0;
@@ -502,6 +609,9 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
 				const f2g ymN = *reinterpret_cast<g2p>(cn - sy), ypN = *reinterpret_cast<g2p>(cn + sy);
 				S3D_DSTAMP(2)  // back-edge + issue of the next step's loads
+#if defined(S3D_EXP) && S3D_EXP == 21
+				st_acc[8]++;
+#endif
 				const int dz = z - czi;
 				const float vzd = (float)dz * u;
 				float bxk[2], byk[2], bzk[2], rxk[2], ryk[2], rzk[2];
@@ -550,11 +660,15 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 						                 s_face, s_fidx, s_predn, s_predf, hist_rep, spread);
 						qhead = (qhead + 64) & (kQCap - 1);
 						qcount -= 64;
+#if defined(S3D_EXP) && S3D_EXP == 21
+						st_acc[9]++;
+#endif
 					}
 					S3D_DSTAMP(5)  // pop (accumulate 64 voxels)
 				}
 			}
 		}
+		}  // chunk of unit rows (S3D_DESC_SORT) / plain block
 #else
 #ifndef S3D_DESC_TW
 #define S3D_DESC_TW 8
@@ -745,7 +859,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	}
 #if defined(S3D_EXP) && S3D_EXP == 21
 	if (blockIdx.x < 64 && lane == 0)
-		for (int i = 0; i < 8; i++) g_dstamp[blockIdx.x][wid][i] = st_acc[i];
+		for (int i = 0; i < 10; i++) g_dstamp[blockIdx.x][wid][i] = st_acc[i];
 #endif
 }
 
@@ -753,8 +867,10 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
                      const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world, const int *order,
                      const unsigned *d_nkp, unsigned *d_work, hipStream_t st, bool lut_in_lds) {
 	(void)hipMemsetAsync(d_work, 0, sizeof(unsigned), st);
+	// development: S3D_DESC_DYNLDS=bytes of unused dynamic LDS per workgroup (occupancy experiments: fewer workgroups per CU)
+	static const unsigned dyn_lds = [] { const char *e = getenv("S3D_DESC_DYNLDS"); return e ? (unsigned)atoi(e) : 0u; }();
 	if (lut_in_lds)
-		hipLaunchKernelGGL(k_describe<true>, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
+		hipLaunchKernelGGL(k_describe<true>, dim3(256 * 8), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
 		                   part_rank, part_world, order, d_nkp, d_work);
 	else
 		hipLaunchKernelGGL(k_describe<false>, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
@@ -762,14 +878,17 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
 #if defined(S3D_EXP) && S3D_EXP == 21
 	{
 		hipStreamSynchronize(st);
-		static unsigned long long h[64][4][8];
+		static unsigned long long h[64][4][10];
 		hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dstamp), sizeof(h));
 		const char *nm[8] = {"kp setup", "batch setup", "backedge+loads", "step math", "push", "pop", "drain", "normalise"};
 		double tot = 0, a[8] = {0};
 		for (int i = 0; i < 8; i++) { for (int b = 0; b < 64; b++) for (int w = 0; w < 4; w++) a[i] += (double)h[b][w][i]; tot += a[i]; }
 		fprintf(stderr, "DSTAMP share of wave time:");
 		for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * a[i] / tot);
-		fprintf(stderr, " | cycles per wave %.0f\n", tot / 256.0);
+		double nst = 0, npop = 0;
+		for (int b = 0; b < 64; b++) for (int w = 0; w < 4; w++) { nst += (double)h[b][w][8]; npop += (double)h[b][w][9]; }
+		fprintf(stderr, " | cycles per wave %.0f | steps/wave %.0f pops/wave %.0f | cycles per step (2+3+4) %.0f per pop %.0f\n", tot / 256.0, nst / 256.0,
+		        npop / 256.0, (a[2] + a[3] + a[4]) / nst, a[5] / npop);
 	}
 #endif
 }
