@@ -174,6 +174,9 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
                                                  float R0, float R1, float R2, float R3, float R4, float R5, float R6, float R7, float R8,
                                                  float fix_scale, const float *s_face, const int *s_fidx, const float *s_predn,
                                                  const int *s_predf, bin_t *hist_rep, int spread /* lane constant: bits 0..2 = r */) {
+#if defined(S3D_DDIAG) && (S3D_DDIAG & 2)  // timing only: march and queue without the heavy part
+	return 0.0f;
+#endif
 	const float rx = R0 * gx + R1 * gy + R2 * gz;
 	const float ry = R3 * gx + R4 * gy + R5 * gz;
 	const float rz = R6 * gx + R7 * gy + R8 * gz;
@@ -236,9 +239,15 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 		if (badx[ddx] || bady[ddy] || badz[ddz]) continue;
 		const float wgt = pxy[ddx * 2 + ddy] * az[ddz];
 		const int off = (ddx ? stx : 0) + (ddy ? sty : 0) + (ddz ? stz : 0);
+#if defined(S3D_DDIAG) && (S3D_DDIAG & 1)  // timing only: the 24 adds are computed but not sent to the LDS
+		asm volatile("" ::"v"(h0 + off), "v"(cvt_rpi(wgt * m0)));
+		asm volatile("" ::"v"(h1 + off), "v"(cvt_rpi(wgt * m1)));
+		asm volatile("" ::"v"(h2 + off), "v"(cvt_rpi(wgt * m2)));
+#else
 		atomicAdd(h0 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m0));
 		atomicAdd(h1 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m1));
 		atomicAdd(h2 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m2));
+#endif
 	}
 #else
 	const float pxy[4] = {wx0 * wy0, wx0 * fy, fx * wy0, fx * fy};  // index ddx*2 + ddy
@@ -276,6 +285,14 @@ __device__ unsigned long long g_dstamp[64][4][10];
 #ifndef S3D_DESC_C2
 #define S3D_DESC_C2 1
 #endif
+#ifdef S3D_DDIAG  // timing-only builds (wrong results): 1 no histogram adds, 2 no heavy part, 4 / 16 no / only the 16-byte load, 8 no queue
+#define S3D_DDIAG_V S3D_DDIAG
+#if (S3D_DDIAG & 20) && (!defined(S3D_DESC_SH) || S3D_DESC_SH > 1)
+#error "S3D_DDIAG bits 4 and 16 need -DS3D_DESC_SH=1"
+#endif
+#else
+#define S3D_DDIAG_V 0
+#endif
 #ifndef S3D_DESC_SORT
 #define S3D_DESC_SORT 1
 #endif
@@ -291,7 +308,27 @@ __device__ unsigned long long g_dstamp[64][4][10];
 #ifndef S3D_DESC_LSHIFT
 #define S3D_DESC_LSHIFT 0
 #endif
-constexpr int kPairCap = S3D_DESC_UCAP, kLenBins = 128, kLenShift = S3D_DESC_LSHIFT;
+// Strips (S3D_DESC_SH > 1): the sorted unit is a vertical strip of kSH column pairs (same x, kSH consecutive rows) on kSH
+// consecutive lanes, marched over the union of their z ranges in lock step.  The y neighbours of a pair are the centre values its
+// strip neighbours hold in registers (DPP row shifts); only the first / last lane of a strip loads a row from memory.
+#ifndef S3D_DESC_SH
+#define S3D_DESC_SH 4
+#endif
+constexpr int kPairCap = S3D_DESC_UCAP, kLenBins = 128, kLenShift = S3D_DESC_LSHIFT, kSH = S3D_DESC_SH;
+static_assert(kSH >= 1 && kSH <= 16 && (kSH & (kSH - 1)) == 0, "strip height: power of two within a DPP row");
+// value of the lane below / above in the 16-lane row.  Inline asm and volatile: hipcc sinks __builtin_amdgcn_update_dpp into the
+// branch it makes of a following select, where the source lanes are masked off and the DPP read returns 0.  (s_nop: a VALU
+// write of the source needs two wait states before a DPP read, and the hazard pass does not look into inline asm.)
+__device__ __forceinline__ float dpp_from_lane_below(float v) {
+	float r;
+	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "0"(0.0f));
+	return r;
+}
+__device__ __forceinline__ float dpp_from_lane_above(float v) {
+	float r;
+	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "0"(0.0f));
+	return r;
+}
 typedef float f3g __attribute__((ext_vector_type(3), aligned(4)));
 typedef float f4g __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2g __attribute__((ext_vector_type(2), aligned(4)));
@@ -485,28 +522,32 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			}
 		};
 #if S3D_DESC_SORT
-		const int nux = (wx + 1) / 2, nuy = wy;  // pairs per window row, rows
-		// (more than kPairCap pairs per row, or z ranges beyond a byte: only with windows far larger than the default parameters')
+		const int nux = (wx + 1) / 2, nuy = (wy + kSH - 1) / kSH;  // strips per strip row (= pairs per window row), strip rows
+		// (more than kPairCap pairs per strip row, or z ranges beyond a byte: only with windows far larger than the default parameters')
 		const bool chord_cached = z1 - z0 < 255;
-		const int rows_per_chunk = nux > 0 && nux <= kPairCap ? kPairCap / nux : 0;
+		const int rows_per_chunk = nux > 0 && nux * kSH <= kPairCap ? kPairCap / (nux * kSH) : 0;
 		for (int uy0 = 0; ncol > 0 && rows_per_chunk > 0 && uy0 < nuy; uy0 += rows_per_chunk) {
-		const int nch = min(nuy - uy0, rows_per_chunk) * nux;  // pairs of this chunk
+		const int nch = min(nuy - uy0, rows_per_chunk) * nux;  // strips of this chunk
 		if (uy0 > 0) __syncthreads();                        // previous chunk's march is done with s_units / s_tile
 		for (int i = tid; i < kLenBins; i += 256) s_cnt[i] = 0u;
 		if (tid == 0) s_tile = 0u;
 		__syncthreads();
-		for (int uu = tid; uu < nch; uu += 256) {
+		for (int ps = tid; ps < nch * kSH; ps += 256) {  // pair slot = strip * kSH + row of the strip: kSH consecutive lanes per strip
+			const int uu = ps / kSH, spos = ps % kSH;
 			const int uyi = uu / nux, uxi = uu - uyi * nux;
 			int rr[2], za[2], zb[2];
 			float px[2], py[2], pz[2];
 			bool colok[2];
-			setup_pair(uxi * 2, uy0 + uyi, true, rr, za, zb, px, py, pz, colok);
-			const int len = (colok[0] || colok[1]) ? max(zb[0], zb[1]) - min(za[0], za[1]) + 1 : 0;
+			setup_pair(uxi * 2, (uy0 + uyi) * kSH + spos, true, rr, za, zb, px, py, pz, colok);
+			int lo = min(za[0], za[1]), hi = max(zb[0], zb[1]);  // empty columns: (2^28, -2^28)
+#pragma unroll
+			for (int o = kSH / 2; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+			const int len = hi >= lo ? hi - lo + 1 : 0;  // z steps of the strip
 			// an empty column is stored as the range (255, 0)
-			s_chord[uu] = chord_cached ? (colok[0] ? (unsigned)(za[0] - z0) | (unsigned)(zb[0] - z0) << 8 : 255u) |
+			s_chord[ps] = chord_cached ? (colok[0] ? (unsigned)(za[0] - z0) | (unsigned)(zb[0] - z0) << 8 : 255u) |
 			                                 (colok[1] ? (unsigned)(za[1] - z0) | (unsigned)(zb[1] - z0) << 8 : 255u) << 16
 			                           : (unsigned)len;
-			if (len > 0) atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u);  // key 0 = empty pair
+			if (spos == 0 && len > 0) atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u);  // key 0 = empty
 		}
 		__syncthreads();
 		if (wid == 0) {  // running start of every key, longest first
@@ -523,18 +564,23 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		}
 		__syncthreads();
 		for (int uu = tid; uu < nch; uu += 256) {
-			const unsigned ch = s_chord[uu];
 			int len;
 			if (chord_cached) {
-				const int a0 = ch & 255, b0 = (ch >> 8) & 255, a1 = (ch >> 16) & 255, b1 = ch >> 24;
-				len = max(b0, b1) - min(a0, a1) + 1;  // (255, 0) never wins a min / max against a real range; both empty: < 0
+				int lo = 255, hi = 0;
+#pragma unroll
+				for (int r = 0; r < kSH; r++) {
+					const unsigned ch = s_chord[uu * kSH + r];
+					// (255, 0) never wins a min / max against a real range
+					lo = min(lo, (int)min(ch & 255, (ch >> 16) & 255)); hi = max(hi, (int)max((ch >> 8) & 255, ch >> 24));
+				}
+				len = hi - lo + 1;  // all empty: < 0
 			} else {
-				len = (int)ch;
+				len = (int)s_chord[uu * kSH];
 			}
 			if (len > 0) s_units[atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u)] = (unsigned short)uu;
 		}
 		__syncthreads();
-		const int nnz = (int)s_nnz, ntiles = (nnz + 63) / 64;
+		const int nnz = (int)s_nnz, ntiles = (nnz * kSH + 63) / 64;
 #else
 		constexpr int kLX = 8, kTH = 8;
 		const int tiles_x = (wx + 2 * kLX - 1) / (2 * kLX), tiles_y = (wy + kTH - 1) / kTH;
@@ -549,11 +595,11 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			tile = __builtin_amdgcn_readfirstlane(tile);  // wave-uniform
 			if (tile >= ntiles) break;
 #if S3D_DESC_SORT
-			const int uidx = tile * 64 + lane;
+			const int uidx = tile * (64 / kSH) + lane / kSH, spos = lane % kSH;
 			const bool lane_ok = uidx < nnz;
 			const int uu = s_units[lane_ok ? uidx : 0];
 			const int uyi = uu / nux, uxi = uu - uyi * nux;
-			const int lxa = uxi * 2, ly = uy0 + uyi;
+			const int lxa = uxi * 2, ly = (uy0 + uyi) * kSH + spos;
 #else
 			const int ty = tile / tiles_x, tx = tile - ty * tiles_x;  // (a centre-out order, longest chords first, measured no better)
 			const int lxa = tx * 2 * kLX + 2 * (lane % kLX), ly = ty * kTH + (lane / kLX);
@@ -565,7 +611,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			bool colok[2];
 #if S3D_DESC_SORT
 			if (chord_cached) {  // block-uniform
-				const unsigned ch = s_chord[uu];
+				const unsigned ch = s_chord[uu * kSH + spos];
 				const int dy = y - cyi;
 				const float vyd = (float)dy * u;
 #pragma unroll
@@ -581,9 +627,21 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			} else
 #endif
 				setup_pair(lxa, ly, lane_ok, rr, za, zb, px, py, pz, colok);
+#if S3D_DESC_SORT && S3D_DESC_SH > 1
+			// every lane of a strip marches the strip's z range: it holds the y neighbours of the lanes beside it, also where its own
+			// columns are outside the sphere.  Row wy (one past the window) is such a provider; rows beyond it are nobody's neighbour.
+			int zA = min(za[0], za[1]), zB = max(zb[0], zb[1]);
+#pragma unroll
+			for (int o = kSH / 2; o > 0; o >>= 1) { zA = min(zA, __shfl_xor(zA, o, 64)); zB = max(zB, __shfl_xor(zB, o, 64)); }
+			const int zlen = (lane_ok && zB >= zA && ly <= wy) ? zB - zA + 1 : 0;
+			const bool top = spos == 0, bot = spos == kSH - 1;
+			// the strip's first lane loads row y-1, its last lane row y+1 (when its own row is inside the window: y+1 <= ny-1)
+			const ptrdiff_t e_off = top ? -(ptrdiff_t)sy : (bot && ly < wy ? (ptrdiff_t)sy : (ptrdiff_t)0);
+#else
 			const bool anycol = colok[0] || colok[1];
 			const int zA = min(za[0], za[1]), zB = max(zb[0], zb[1]);  // the lane marches the union of its two chords
 			const int zlen = anycol ? zB - zA + 1 : 0;
+#endif
 			int maxlen = zlen;
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
@@ -592,22 +650,45 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			if (maxlen == 0) continue;  // wave-uniform
 			// lanes without a column march on the keypoint's own column (always in bounds) and are masked.  Column a of a lane
 			// satisfies 1 <= x <= nx-2 whenever one of its columns is valid, so x-1 .. x+2 stays inside the level (x+2 = nx is the
-			// first element of the next row, and y <= ny-2).
+			// first element of the next row, and y <= ny-2; the provider row of a strip may be y = ny-1: its x+2 can then be the
+			// first element of the next plane -- of the next LEVEL of the arena for a window in the far corner; keypoint levels are
+			// never the last level of the arena).
 			gfloat_p c = zlen > 0 ? Ld + (size_t)xa + (size_t)sy * (size_t)y + (size_t)sz * (size_t)(zA - L.zoff) : centre;
 			typedef const f4g __attribute__((address_space(1))) *g4p;
 			typedef const f2g __attribute__((address_space(1))) *g2p;
 			f4g rowC = *reinterpret_cast<g4p>(c - 1);         // plane z:   x-1, a, b, x+2
 			f4g rowN = *reinterpret_cast<g4p>(c + sz - 1);    // plane z+1 (centres of both columns in .y .z)
 			f2g cmv = *reinterpret_cast<g2p>(c - sz);         // centres of plane z-1
+#if S3D_DESC_SORT && S3D_DESC_SH > 1
+			f2g edC = f2g{0.f, 0.f};
+			if (top || bot) edC = *reinterpret_cast<g2p>(c + e_off);  // the strip's outer row of plane z
+#else
 			f2g ymC = *reinterpret_cast<g2p>(c - sy), ypC = *reinterpret_cast<g2p>(c + sy);
+#endif
 			int z = zA;
 			for (int step = 0; step < maxlen; step++) {
 				// software pipeline: the row piece of plane z+2 and the y rows of plane z+1 are requested now; clamped addresses stay
 				// inside the planes zA-1 .. zB+1 of the window
 				const bool more = step + 1 < zlen;
 				const gfloat_p cn = more ? c + sz : c;
+#if defined(S3D_DDIAG) && (S3D_DDIAG & 4)  // timing only: no vector-memory instructions in the step
+				f4g rowNN = rowN; f2g ymN = ypC, ypN = ymC;
+				asm volatile("" : "+v"(rowNN.x), "+v"(rowNN.y), "+v"(rowNN.z), "+v"(rowNN.w), "+v"(ymN.x), "+v"(ymN.y), "+v"(ypN.x), "+v"(ypN.y) : "v"(cn));
+#elif defined(S3D_DDIAG) && (S3D_DDIAG & 16)  // timing only: only the 16-byte load
+				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
+				f2g ymN = ypC, ypN = ymC;
+				asm volatile("" : "+v"(ymN.x), "+v"(ymN.y), "+v"(ypN.x), "+v"(ypN.y) : "v"(cn));
+#elif S3D_DESC_SORT && S3D_DESC_SH > 1
+				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
+				f2g edN = edC;
+				if (top || bot) edN = *reinterpret_cast<g2p>(cn + e_off);
+				// y neighbours of plane z: the centre values of the lanes beside this one (same strip, same plane)
+				const f2g dn = f2g{dpp_from_lane_below(rowC.y), dpp_from_lane_below(rowC.z)}, up = f2g{dpp_from_lane_above(rowC.y), dpp_from_lane_above(rowC.z)};
+				const f2g ymC = top ? edC : dn, ypC = bot ? edC : up;
+#else
 				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
 				const f2g ymN = *reinterpret_cast<g2p>(cn - sy), ypN = *reinterpret_cast<g2p>(cn + sy);
+#endif
 				S3D_DSTAMP(2)  // back-edge + issue of the next step's loads
 #if defined(S3D_EXP) && S3D_EXP == 21
 				st_acc[8]++;
@@ -638,14 +719,18 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 					actk[k] = act && !(g2 < kBaryEps * 0.99f);
 					bxk[k] = bx; byk[k] = by; bzk[k] = bz; rxk[k] = gx; ryk[k] = gy; rzk[k] = gz;
 				}
+#if S3D_DESC_SORT && S3D_DESC_SH > 1 && !(S3D_DDIAG_V & 20)
+				cmv = f2g{rowC.y, rowC.z}; rowC = rowN; rowN = rowNN; edC = edN;
+#else
 				cmv = f2g{rowC.y, rowC.z}; rowC = rowN; rowN = rowNN; ymC = ymN; ypC = ypN;
+#endif
 				c = cn; z += more ? 1 : 0;
 				S3D_DSTAMP(3)  // step arithmetic
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
 					// ---- push the active lanes into the wave's queue (compaction by ballot rank) ----
 					const unsigned long long m = __ballot(actk[k]);
-					if (m) {
+					if (m && !(S3D_DDIAG_V & 8)) {
 						if (actk[k]) {
 							const int pos = (qhead + qcount + (int)__popcll(m & ((1ull << lane) - 1ull))) & (kQCap - 1);
 							q[0][pos] = bxk[k]; q[1][pos] = byk[k]; q[2][pos] = bzk[k]; q[3][pos] = rxk[k]; q[4][pos] = ryk[k]; q[5][pos] = rzk[k];
