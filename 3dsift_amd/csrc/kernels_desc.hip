@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
                                                   const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap,
                                                   int part_rank, int part_world, const int *__restrict__ order,
-                                                  const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work) {
+                                                  const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work, int dev_flags) {
 	__shared__ unsigned s_item, s_tile;
 	__shared__ bin_t hist[kBins * kRep];  // [bin][replica], two's-complement fixed point, units of 1 / lut.fix_scale
 	__shared__ float s_lut[LUT_LDS ? kMaxDescLut : 1];
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 #if S3D_DESC_SORT
 		const int nux = (wx + 1) / 2, nuy = (wy + kSH - 1) / kSH;  // strips per strip row (= pairs per window row), strip rows
 		// (more than kPairCap pairs per strip row, or z ranges beyond a byte: only with windows far larger than the default parameters')
-		const bool chord_cached = z1 - z0 < 255;
+		const bool chord_cached = z1 - z0 < 255 && !(dev_flags & 1);
 		const int rows_per_chunk = nux > 0 && nux * kSH <= kPairCap ? kPairCap / (nux * kSH) : 0;
 		for (int uy0 = 0; ncol > 0 && rows_per_chunk > 0 && uy0 < nuy; uy0 += rows_per_chunk) {
 		const int nch = min(nuy - uy0, rows_per_chunk) * nux;  // strips of this chunk
@@ -694,18 +694,19 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 				st_acc[8]++;
 #endif
 				const int dz = z - czi;
+				const int dz2 = __mul24(dz, dz);  // |dz| < 2^11 (full-rate 24-bit multiply; v_mul_lo_u32 issues at quarter rate)
 				const float vzd = (float)dz * u;
 				float bxk[2], byk[2], bzk[2], rxk[2], ryk[2], rzk[2];
 				bool actk[2];
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
-					const bool in = step < zlen && z >= za[k] && z <= zb[k];
+					const bool in = step < zlen && (unsigned)(z - za[k]) <= (unsigned)(zb[k] - za[k]);  // empty column: za = 2^28, zb = -2^28
 					float bx = px[k] + R2 * vzd, by = py[k] + R5 * vzd, bz = pz[k] + R8 * vzd;
 					bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
 					bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
 					// inside the 4x4x4 cube: the reference's !(b <= -0.5 || b >= 3.5) per axis (Src/cSIFT3D.cc:1299-1303)
 					bool act = in && fminf(fminf(bx, by), bz) > -0.5f && fmaxf(fmaxf(bx, by), bz) < 3.5f;
-					const float w = LUT_LDS ? s_lut[in ? rr[k] + dz * dz : 0] : lut_g[in ? rr[k] + dz * dz : 0];
+					const float w = LUT_LDS ? s_lut[in ? rr[k] + dz2 : 0] : lut_g[in ? rr[k] + dz2 : 0];
 					const float nxm = k ? rowC.y : rowC.x, nxp = k ? rowC.w : rowC.z;
 					const float nym = k ? ymC.y : ymC.x, nyp = k ? ypC.y : ypC.x;
 					const float cp = k ? rowN.z : rowN.y, cm = k ? cmv.y : cmv.x;
@@ -954,12 +955,14 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
 	(void)hipMemsetAsync(d_work, 0, sizeof(unsigned), st);
 	// development: S3D_DESC_DYNLDS=bytes of unused dynamic LDS per workgroup (occupancy experiments: fewer workgroups per CU)
 	static const unsigned dyn_lds = [] { const char *e = getenv("S3D_DESC_DYNLDS"); return e ? (unsigned)atoi(e) : 0u; }();
+	// development / tests: S3D_DESC_NOCACHE=1 takes the path of windows whose z ranges do not fit the byte cache (recomputed chords)
+	static const int dev_flags = [] { const char *e = getenv("S3D_DESC_NOCACHE"); return e && e[0] == '1' ? 1 : 0; }();
 	if (lut_in_lds)
 		hipLaunchKernelGGL(k_describe<true>, dim3(256 * 8), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-		                   part_rank, part_world, order, d_nkp, d_work);
+		                   part_rank, part_world, order, d_nkp, d_work, dev_flags);
 	else
 		hipLaunchKernelGGL(k_describe<false>, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-		                   part_rank, part_world, order, d_nkp, d_work);
+		                   part_rank, part_world, order, d_nkp, d_work, dev_flags);
 #if defined(S3D_EXP) && S3D_EXP == 21
 	{
 		hipStreamSynchronize(st);

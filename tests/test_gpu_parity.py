@@ -299,3 +299,25 @@ def test_dog_elision_matches_eager_build(capi, synth, tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
     assert outs[0] == outs[1] and int(outs[0].split()[2]) > 20
+
+
+def test_descriptor_chord_cache_matches_recomputed_chords(capi, synth):
+    """k_describe keeps the z range of every column of a window in a byte cache in LDS; windows whose ranges do not fit a byte
+    (far larger than any default window) recompute them instead.  S3D_DESC_NOCACHE=1 forces that path: same descriptors, bit
+    for bit (the histogram sums are integers: the order in which the columns are visited does not matter)."""
+    import subprocess, sys, os
+    code = (
+        "import importlib,hashlib,sys,numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "capi=importlib.import_module('3dsift_amd.capi'); synth=importlib.import_module('3dsift_amd.synth')\n"
+        "ex=capi.CreateCSIFT3D(synth.blobs((96,80,72),seed=5,noise=0.01)).KpSiftAlgorithm()\n"
+        "h=hashlib.sha1(); kp,d=ex.GetKeypoints(); h.update(kp.tobytes()); h.update(d.tobytes())\n"
+        "print('HASH',h.hexdigest(),len(kp))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    )
+    outs = []
+    for nocache in ("0", "1"):
+        env = dict(os.environ, S3D_DESC_NOCACHE=nocache)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
+    assert outs[0] == outs[1] and int(outs[0].split()[2]) > 20
