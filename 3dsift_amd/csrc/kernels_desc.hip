@@ -228,7 +228,8 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 	const float ax[2] = {qx ? fx : wx0, qx ? wx0 : fx}, ay[2] = {qy ? fy : wy0, qy ? wy0 : fy}, az[2] = {qz ? fz : wz0, qz ? wz0 : fz};
 	const bool badx[2] = {qx && !okx, !qx && !okx}, bady[2] = {qy && !oky, !qy && !oky}, badz[2] = {qz && !okz, !qz && !okz};
 	const int stx = qx ? -kSX * kRep : kSX * kRep, sty = qy ? -kSY * kRep : kSY * kRep, stz = qz ? -kSZ * kRep : kSZ * kRep;
-	const int base = ((ix + (qx ? 1 : 0)) * kSX + (iy + (qy ? 1 : 0)) * kSY + (iz + (qz ? 1 : 0)) * kSZ) * kRep;
+	// (24-bit multiplies: full rate; v_mul_lo_u32 issues at a quarter of it)
+	const int base = __mul24(ix + (qx ? 1 : 0), kSX * kRep) + __mul24(iy + (qy ? 1 : 0), kSY * kRep) + __mul24(iz + (qz ? 1 : 0), kSZ * kRep);
 	const float pxy[4] = {ax[0] * ay[0], ax[0] * ay[1], ax[1] * ay[0], ax[1] * ay[1]};  // index ddx*2 + ddy
 	bin_t *h0 = hist_rep + base + s_fidx[f * 4] * kRep;
 	bin_t *h1 = hist_rep + base + s_fidx[f * 4 + 1] * kRep;
@@ -238,15 +239,15 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 		const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;
 		if (badx[ddx] || bady[ddy] || badz[ddz]) continue;
 		const float wgt = pxy[ddx * 2 + ddy] * az[ddz];
-		const int off = (ddx ? stx : 0) + (ddy ? sty : 0) + (ddz ? stz : 0);
+		const int off = ((ddx ? stx : 0) + (ddy ? sty : 0) + (ddz ? stz : 0)) * (int)sizeof(bin_t);  // bytes: a lane constant, hoisted
 #if defined(S3D_DDIAG) && (S3D_DDIAG & 1)  // timing only: the 24 adds are computed but not sent to the LDS
-		asm volatile("" ::"v"(h0 + off), "v"(cvt_rpi(wgt * m0)));
-		asm volatile("" ::"v"(h1 + off), "v"(cvt_rpi(wgt * m1)));
-		asm volatile("" ::"v"(h2 + off), "v"(cvt_rpi(wgt * m2)));
+		asm volatile("" ::"v"(reinterpret_cast<char *>(h0) + off), "v"(cvt_rpi(wgt * m0)));
+		asm volatile("" ::"v"(reinterpret_cast<char *>(h1) + off), "v"(cvt_rpi(wgt * m1)));
+		asm volatile("" ::"v"(reinterpret_cast<char *>(h2) + off), "v"(cvt_rpi(wgt * m2)));
 #else
-		atomicAdd(h0 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m0));
-		atomicAdd(h1 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m1));
-		atomicAdd(h2 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m2));
+		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h0) + off), (bin_t)(sbin_t)cvt_rpi(wgt * m0));
+		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h1) + off), (bin_t)(sbin_t)cvt_rpi(wgt * m1));
+		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h2) + off), (bin_t)(sbin_t)cvt_rpi(wgt * m2));
 #endif
 	}
 #else
