@@ -297,37 +297,44 @@ __device__ unsigned long long g_dstamp[64][4][10];
 #ifndef S3D_DESC_SORT
 #define S3D_DESC_SORT 1
 #endif
-// Sorted column pairs (S3D_DESC_SORT).  A lane marches two adjacent columns (x, x+1).  The pairs of a window -- in chunks of
-// kPairCap of them, whole window rows -- are sorted by the length of their z range and dealt to the waves 64 at a time, longest
-// first: the lanes of a wave finish together.  (A fixed 16 x 8 tiling of the circular footprint leaves 35-45 % of the lane-steps
-// idle: rim tiles march their longest chord with most lanes outside the sphere.  Sorting the WHOLE window is slower again: the 64
-// columns of a wave then lie on a thin ring and share no cache lines; ~1000 pairs = 27 rows of the largest default window is the
-// measured optimum.  Sorting units of 2x1 ... 4x2 lanes instead of single pairs: no better.)
+// Sorted units (S3D_DESC_SORT).  A lane marches two adjacent columns (x, x+1).  A unit is a block of kPX such pairs by kSH rows on
+// kPX * kSH consecutive lanes.  The units of a window -- in chunks of kPairCap pairs, whole unit rows -- are sorted by the length of
+// their z range and dealt to the waves 64 lanes at a time, longest first: the lanes of a wave finish together.  (A fixed 16 x 8
+// tiling of the circular footprint leaves 35-45 % of the lane-steps idle: rim tiles march their longest chord with most lanes
+// outside the sphere.  Measured at 512^3, k_describe: tiles 4.92 ms, sorted single pairs 4.71, 1x4 units 4.39, 2x4 units 4.26,
+// 2x2 / 4x2 4.32, 4x4 4.46, 1x8 4.50.)
 #ifndef S3D_DESC_UCAP
 #define S3D_DESC_UCAP 1024
 #endif
 #ifndef S3D_DESC_LSHIFT
 #define S3D_DESC_LSHIFT 0
 #endif
-// Strips (S3D_DESC_SH > 1): the sorted unit is a vertical strip of kSH column pairs (same x, kSH consecutive rows) on kSH
-// consecutive lanes, marched over the union of their z ranges in lock step.  The y neighbours of a pair are the centre values its
-// strip neighbours hold in registers (DPP row shifts); only the first / last lane of a strip loads a row from memory.
+// Units higher than one row (S3D_DESC_SH > 1) march the union of their z ranges in lock step, so the y neighbours of a pair are
+// the centre values the lanes kPX below / above hold in registers (DPP row shifts); only the first / last row of a unit loads its
+// outer row from memory: two vector-memory instructions per step, the second with a quarter of the lanes, instead of three.  The
+// march is bound by the cache lines its loads touch (timing-only builds, S3D_DDIAG): wider units share the lines of a row.
 #ifndef S3D_DESC_SH
 #define S3D_DESC_SH 4
 #endif
-constexpr int kPairCap = S3D_DESC_UCAP, kLenBins = 128, kLenShift = S3D_DESC_LSHIFT, kSH = S3D_DESC_SH;
-static_assert(kSH >= 1 && kSH <= 16 && (kSH & (kSH - 1)) == 0, "strip height: power of two within a DPP row");
+#ifndef S3D_DESC_PX
+#define S3D_DESC_PX 2
+#endif
+constexpr int kPairCap = S3D_DESC_UCAP, kLenBins = 128, kLenShift = S3D_DESC_LSHIFT, kSH = S3D_DESC_SH, kPX = S3D_DESC_PX;
+constexpr int kUL = kPX * kSH;  // lanes of a unit: kPX pairs wide, kSH rows high, row-major on consecutive lanes
+static_assert(kSH >= 1 && kPX >= 1 && kUL <= 16 && (kSH & (kSH - 1)) == 0 && (kPX & (kPX - 1)) == 0, "a unit is a power of two of lanes within a DPP row");
 // value of the lane below / above in the 16-lane row.  Inline asm and volatile: hipcc sinks __builtin_amdgcn_update_dpp into the
 // branch it makes of a following select, where the source lanes are masked off and the DPP read returns 0.  (s_nop: a VALU
 // write of the source needs two wait states before a DPP read, and the hazard pass does not look into inline asm.)
-__device__ __forceinline__ float dpp_from_lane_below(float v) {
+template <int N>
+__device__ __forceinline__ float dpp_from_lane_below(float v) {  // lane - N of the row
 	float r;
-	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "0"(0.0f));
+	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N), "0"(0.0f));
 	return r;
 }
-__device__ __forceinline__ float dpp_from_lane_above(float v) {
+template <int N>
+__device__ __forceinline__ float dpp_from_lane_above(float v) {  // lane + N of the row
 	float r;
-	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "0"(0.0f));
+	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N), "0"(0.0f));
 	return r;
 }
 typedef float f3g __attribute__((ext_vector_type(3), aligned(4)));
@@ -523,26 +530,26 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			}
 		};
 #if S3D_DESC_SORT
-		const int nux = (wx + 1) / 2, nuy = (wy + kSH - 1) / kSH;  // strips per strip row (= pairs per window row), strip rows
+		const int nux = ((wx + 1) / 2 + kPX - 1) / kPX, nuy = (wy + kSH - 1) / kSH;  // units per unit row, unit rows
 		// (more than kPairCap pairs per strip row, or z ranges beyond a byte: only with windows far larger than the default parameters')
 		const bool chord_cached = z1 - z0 < 255 && !(dev_flags & 1);
-		const int rows_per_chunk = nux > 0 && nux * kSH <= kPairCap ? kPairCap / (nux * kSH) : 0;
+		const int rows_per_chunk = nux > 0 && nux * kUL <= kPairCap ? kPairCap / (nux * kUL) : 0;
 		for (int uy0 = 0; ncol > 0 && rows_per_chunk > 0 && uy0 < nuy; uy0 += rows_per_chunk) {
 		const int nch = min(nuy - uy0, rows_per_chunk) * nux;  // strips of this chunk
 		if (uy0 > 0) __syncthreads();                        // previous chunk's march is done with s_units / s_tile
 		for (int i = tid; i < kLenBins; i += 256) s_cnt[i] = 0u;
 		if (tid == 0) s_tile = 0u;
 		__syncthreads();
-		for (int ps = tid; ps < nch * kSH; ps += 256) {  // pair slot = strip * kSH + row of the strip: kSH consecutive lanes per strip
-			const int uu = ps / kSH, spos = ps % kSH;
+		for (int ps = tid; ps < nch * kUL; ps += 256) {  // pair slot = unit * kUL + position in the unit: kUL consecutive lanes per unit
+			const int uu = ps / kUL, spos = ps % kUL;
 			const int uyi = uu / nux, uxi = uu - uyi * nux;
 			int rr[2], za[2], zb[2];
 			float px[2], py[2], pz[2];
 			bool colok[2];
-			setup_pair(uxi * 2, (uy0 + uyi) * kSH + spos, true, rr, za, zb, px, py, pz, colok);
+			setup_pair((uxi * kPX + spos % kPX) * 2, (uy0 + uyi) * kSH + spos / kPX, true, rr, za, zb, px, py, pz, colok);
 			int lo = min(za[0], za[1]), hi = max(zb[0], zb[1]);  // empty columns: (2^28, -2^28)
 #pragma unroll
-			for (int o = kSH / 2; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+			for (int o = kUL / 2; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
 			const int len = hi >= lo ? hi - lo + 1 : 0;  // z steps of the strip
 			// an empty column is stored as the range (255, 0)
 			s_chord[ps] = chord_cached ? (colok[0] ? (unsigned)(za[0] - z0) | (unsigned)(zb[0] - z0) << 8 : 255u) |
@@ -569,19 +576,19 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			if (chord_cached) {
 				int lo = 255, hi = 0;
 #pragma unroll
-				for (int r = 0; r < kSH; r++) {
-					const unsigned ch = s_chord[uu * kSH + r];
+				for (int r = 0; r < kUL; r++) {
+					const unsigned ch = s_chord[uu * kUL + r];
 					// (255, 0) never wins a min / max against a real range
 					lo = min(lo, (int)min(ch & 255, (ch >> 16) & 255)); hi = max(hi, (int)max((ch >> 8) & 255, ch >> 24));
 				}
 				len = hi - lo + 1;  // all empty: < 0
 			} else {
-				len = (int)s_chord[uu * kSH];
+				len = (int)s_chord[uu * kUL];
 			}
 			if (len > 0) s_units[atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u)] = (unsigned short)uu;
 		}
 		__syncthreads();
-		const int nnz = (int)s_nnz, ntiles = (nnz * kSH + 63) / 64;
+		const int nnz = (int)s_nnz, ntiles = (nnz * kUL + 63) / 64;
 #else
 		constexpr int kLX = 8, kTH = 8;
 		const int tiles_x = (wx + 2 * kLX - 1) / (2 * kLX), tiles_y = (wy + kTH - 1) / kTH;
@@ -596,11 +603,11 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			tile = __builtin_amdgcn_readfirstlane(tile);  // wave-uniform
 			if (tile >= ntiles) break;
 #if S3D_DESC_SORT
-			const int uidx = tile * (64 / kSH) + lane / kSH, spos = lane % kSH;
+			const int uidx = tile * (64 / kUL) + lane / kUL, spos = lane % kUL;
 			const bool lane_ok = uidx < nnz;
 			const int uu = s_units[lane_ok ? uidx : 0];
 			const int uyi = uu / nux, uxi = uu - uyi * nux;
-			const int lxa = uxi * 2, ly = (uy0 + uyi) * kSH + spos;
+			const int lxa = (uxi * kPX + spos % kPX) * 2, ly = (uy0 + uyi) * kSH + spos / kPX;
 #else
 			const int ty = tile / tiles_x, tx = tile - ty * tiles_x;  // (a centre-out order, longest chords first, measured no better)
 			const int lxa = tx * 2 * kLX + 2 * (lane % kLX), ly = ty * kTH + (lane / kLX);
@@ -612,7 +619,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			bool colok[2];
 #if S3D_DESC_SORT
 			if (chord_cached) {  // block-uniform
-				const unsigned ch = s_chord[uu * kSH + spos];
+				const unsigned ch = s_chord[uu * kUL + spos];
 				const int dy = y - cyi;
 				const float vyd = (float)dy * u;
 #pragma unroll
@@ -633,9 +640,9 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			// columns are outside the sphere.  Row wy (one past the window) is such a provider; rows beyond it are nobody's neighbour.
 			int zA = min(za[0], za[1]), zB = max(zb[0], zb[1]);
 #pragma unroll
-			for (int o = kSH / 2; o > 0; o >>= 1) { zA = min(zA, __shfl_xor(zA, o, 64)); zB = max(zB, __shfl_xor(zB, o, 64)); }
-			const int zlen = (lane_ok && zB >= zA && ly <= wy) ? zB - zA + 1 : 0;
-			const bool top = spos == 0, bot = spos == kSH - 1;
+			for (int o = kUL / 2; o > 0; o >>= 1) { zA = min(zA, __shfl_xor(zA, o, 64)); zB = max(zB, __shfl_xor(zB, o, 64)); }
+			const int zlen = (lane_ok && zB >= zA && ly <= wy && lxa < wx) ? zB - zA + 1 : 0;
+			const bool top = spos / kPX == 0, bot = spos / kPX == kSH - 1;
 			// the strip's first lane loads row y-1, its last lane row y+1 (when its own row is inside the window: y+1 <= ny-1)
 			const ptrdiff_t e_off = top ? -(ptrdiff_t)sy : (bot && ly < wy ? (ptrdiff_t)sy : (ptrdiff_t)0);
 #else
@@ -680,11 +687,17 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 				f2g ymN = ypC, ypN = ymC;
 				asm volatile("" : "+v"(ymN.x), "+v"(ymN.y), "+v"(ypN.x), "+v"(ypN.y) : "v"(cn));
 #elif S3D_DESC_SORT && S3D_DESC_SH > 1
+#if S3D_DDIAG_V & 32  // timing only: the four lanes of a strip request ONE address (16 cache lines per instruction instead of 64)
+				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1 - (ptrdiff_t)sy * (spos / kPX));
+#else
 				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
+#endif
 				f2g edN = edC;
+#if !(S3D_DDIAG_V & 64)  // timing only: no outer-row load
 				if (top || bot) edN = *reinterpret_cast<g2p>(cn + e_off);
+#endif
 				// y neighbours of plane z: the centre values of the lanes beside this one (same strip, same plane)
-				const f2g dn = f2g{dpp_from_lane_below(rowC.y), dpp_from_lane_below(rowC.z)}, up = f2g{dpp_from_lane_above(rowC.y), dpp_from_lane_above(rowC.z)};
+				const f2g dn = f2g{dpp_from_lane_below<kPX>(rowC.y), dpp_from_lane_below<kPX>(rowC.z)}, up = f2g{dpp_from_lane_above<kPX>(rowC.y), dpp_from_lane_above<kPX>(rowC.z)};
 				const f2g ymC = top ? edC : dn, ypC = bot ? edC : up;
 #else
 				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
