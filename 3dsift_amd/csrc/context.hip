@@ -317,7 +317,7 @@ static void plan_pyramid(sift3d_ctx *c, int noct_total) {
 static int build_luts(sift3d_ctx *c) {
 	std::vector<WinLut> luts((size_t)std::max(1, c->noct + c->octave_base) * 8 * 2);
 	std::vector<float> pool;
-	for (auto &l : luts) { l.off = 0; l.len = 0; l.nin = -1; l.radius = 0; l.sigma = 0; l.fix_scale = 1.0f; l.wsum = 1.0f; }
+	for (auto &l : luts) { l.off = 0; l.len = 0; l.nin = -1; l.radius = 0; l.sigma = 0; l.fix_scale = 1.0f; l.wsum = 1.0f; l.list_off = -1; l.list_R = 0; }
 	for (int o = 0; o < c->noct; o++)
 		for (int lv = 1; lv <= c->p.num_kp_levels && lv < 8; lv++) {
 			const Level &D = c->dog[(size_t)o * c->nd + lv];  // keypoint scale = DoG level scale (Src/cSIFT3D.cc:407)
@@ -360,6 +360,21 @@ static int build_luts(sift3d_ctx *c) {
 								if (n <= L.nin) ws += (double)pool[(size_t)L.off + n] * (which == 1 ? (double)u / 0.5 : 1.0);
 							}
 					L.wsum = (float)std::max(ws, 1.0);
+					if (which == 0 && R <= 127 && L.nin < 65536) {  // lattice points of the orientation sphere (WinLut::list_off)
+						std::vector<unsigned> words((size_t)2 * R + 2);
+						for (int dz = -R; dz <= R; dz++) {
+							words[(size_t)(dz + R)] = (unsigned)(words.size() - ((size_t)2 * R + 2));
+							for (int dy = -R; dy <= R; dy++)
+								for (int dx = -R; dx <= R; dx++) {
+									const int n = dx * dx + dy * dy + dz * dz;
+									if (n <= L.nin) words.push_back((unsigned)(dx + 128) | (unsigned)(dy + 128) << 8 | (unsigned)n << 16);
+								}
+						}
+						words[(size_t)2 * R + 1] = (unsigned)(words.size() - ((size_t)2 * R + 2));
+						L.list_off = (int)pool.size(); L.list_R = R;
+						pool.resize(pool.size() + words.size());
+						memcpy(pool.data() + L.list_off, words.data(), words.size() * sizeof(unsigned));
+					}
 				}
 			}
 		}

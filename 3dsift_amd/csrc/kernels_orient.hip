@@ -224,6 +224,27 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 			request(z0);     deposit(1);
 			request(z0 + 1);
 			int sm = 0, sc = 1, sp = 2;  // slots of planes z-1, z, z+1
+			// lattice list of the window sphere (see the plane loop): up to kEL entries per lane and plane, held in registers
+			constexpr int kEL = 8;
+			const unsigned *__restrict__ lst = reinterpret_cast<const unsigned *>(lutpool) + (lut.list_off >= 0 ? lut.list_off : 0);
+			const int LR = lut.list_R;
+			const unsigned *__restrict__ ent = lst + 2 * LR + 2;
+			const bool use_list = lut.list_off >= 0 && (int)lst[LR + 1] - (int)lst[LR] <= 64 * kEL;  // the central plane is the largest
+			const int ox = cxi - x0 - 128, oy = cyi - y0 - 128;  // entry -> window coordinates
+			unsigned En[kEL];
+			int cntn = 0;
+			auto fetch_entries = [&](int dzp) {
+				const int pi = dzp + LR;
+				const bool has = use_list && pi >= 0 && pi <= 2 * LR;
+				const int e0 = has ? (int)lst[pi] : 0, e1 = has ? (int)lst[pi + 1] : 0;
+				cntn = e1 - e0;
+#pragma unroll
+				for (int i = 0; i < kEL; i++) {
+					const int idx = e0 + i * 64 + lane;
+					En[i] = ent[idx < e1 ? idx : e0];
+				}
+			};
+			fetch_entries(z0 - czi);
 			for (int z = z0; z <= z1; z++) {
 				deposit(sp);                       // plane z+1 (requested one iteration ago)
 				request(min(z + 2, z1 + 1));       // in flight while plane z is processed
@@ -235,6 +256,48 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 				// kUn voxels per pass, all LDS reads (weights included) issued before the first use; inactive voxels read
 				// valid addresses and are masked, so the loop body is branch-free and pipelines
 				constexpr int kUn = 2;
+				if (use_list) {
+					// the lattice points of the window sphere in this plane come from a list (WinLut::list_off): 52 % of the box is
+					// outside the sphere, and the list also carries n = dx^2 + dy^2 + dz^2.  Windows clipped by the level border skip
+					// the entries outside their box.  This plane's entries were requested one plane ago (a load inside the pass loop
+					// would put a memory round trip in front of every pass).
+					unsigned E[kEL];
+#pragma unroll
+					for (int i = 0; i < kEL; i++) E[i] = En[i];
+					const int cnt = cntn;
+					fetch_entries(dz + 1);
+#pragma unroll
+					for (int p0 = 0; p0 < kEL; p0 += kUn) {
+						if (p0 * 64 >= cnt) break;  // wave-uniform
+						float nb[kUn][6], w[kUn];
+#pragma unroll
+						for (int q = 0; q < kUn; q++) {
+							const unsigned e = E[p0 + q];
+							const int lx = (int)(e & 255u) + ox, ly = (int)((e >> 8) & 255u) + oy;
+							const bool ok = (p0 + q) * 64 + lane < cnt && (unsigned)lx < (unsigned)wx && (unsigned)ly < (unsigned)wy;
+							w[q] = ok ? wl[e >> 16] : -1.0f;
+							const int o = ok ? (ly + 1) * kTileW + lx + 1 : kTileW + 1;
+							nb[q][0] = pc[o + 1]; nb[q][1] = pc[o - 1]; nb[q][2] = pc[o + kTileW]; nb[q][3] = pc[o - kTileW];
+							nb[q][4] = pp[o]; nb[q][5] = pm[o];
+						}
+#pragma unroll
+						for (int q = 0; q < kUn; q++) {
+							if (w[q] < 0.0f) continue;  // outside the clipped box / past the end of the plane's list
+							float vx = 0.5f * (nb[q][0] - nb[q][1]);
+							float vy = 0.5f * (nb[q][2] - nb[q][3]);
+							float vz = 0.5f * (nb[q][4] - nb[q][5]);
+							vx = vx * inv_u; vy = vy * inv_u; vz = vz * inv_u;
+							const float ww = w[q];
+							t00 = t00 + vx * vx * ww;
+							t01 = t01 + vx * vy * ww;
+							t02 = t02 + vx * vz * ww;
+							t11 = t11 + vy * vy * ww;
+							t12 = t12 + vy * vz * ww;
+							t22 = t22 + vz * vz * ww;
+							g0 = g0 + vx * ww; g1 = g1 + vy * ww; g2 = g2 + vz * ww;
+						}
+					}
+				} else
 				for (int v0 = lane; v0 < plane; v0 += 64 * kUn) {
 					float nb[kUn][6], w[kUn];
 #pragma unroll

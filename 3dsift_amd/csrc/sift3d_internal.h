@@ -98,6 +98,10 @@ struct WinLut {
 	// 1/fix_scale (a power of two chosen so that no bin can overflow an int32 for this window size, see build_luts)
 	float fix_scale;
 	float wsum;  // sum of the (unscaled) Gaussian weights over the lattice points of the window sphere (gradient-mass estimate)
+	// orientation tables only: the lattice points of the window sphere, plane by plane, as 32-bit words in the same pool
+	// (-1: none).  At list_off: 2 list_R + 2 running starts (plane dz = -list_R .. list_R, then the end), then the entries
+	// (dx + 128) | (dy + 128) << 8 | n << 16 in (dz, dy, dx) order.  k_orient walks this list instead of the window's box.
+	int list_off, list_R;
 };
 constexpr int kMaxDescLut = 1536;  // descriptor window table entries staged in LDS (default params: 1293)
 
