@@ -170,6 +170,12 @@ struct sift3d_ctx {
 	unsigned *d_inmax = nullptr, *d_dogmax = nullptr, *d_total = nullptr, *d_nkp = nullptr;
 	DetectBufs det{};
 	size_t det_blocks = 0;
+	// octaves >= 1 own a slice of a second detection scratch: their masks are formed on a second stream beside octave 0's, only
+	// the ordered compaction into the extrema list stays serial (S3D_DET_SERIAL=1: everything on one stream, one scratch)
+	std::vector<DetectBufs> det_o;
+	unsigned long long *d_masks2 = nullptr;
+	unsigned *d_counts2 = nullptr, *d_offsets2 = nullptr, *d_prov2 = nullptr;
+	hipEvent_t ev_det_fork = nullptr, ev_det_join = nullptr;
 	DevKp *d_ext = nullptr;
 	int *d_codes = nullptr, *d_order = nullptr;  // d_order: slot -> extremum index
 	unsigned ext_cap = 0, kp_cap = 0;
@@ -211,6 +217,7 @@ static void free_lists(sift3d_ctx *c) {
 	hipFree(c->d_desc); c->d_desc = nullptr;
 	hipFree(c->d_xyz); c->d_xyz = nullptr;
 	hipFree(c->d_prov); c->d_prov = nullptr;
+	hipFree(c->d_prov2); c->d_prov2 = nullptr;
 }
 
 static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
@@ -225,6 +232,16 @@ static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
 	S3D_HIP(hipMalloc(&c->d_xyz, sizeof(float) * 3 * (size_t)c->kp_cap));
 	S3D_HIP(hipMalloc(&c->d_prov, sizeof(unsigned) * ((size_t)c->ext_cap + 1)));
 	c->det.prov = c->d_prov; c->det.prov_count = c->d_prov + c->ext_cap; c->det.prov_cap = c->ext_cap;
+	if (c->det_o.size() > 1) {  // octaves >= 1: equal slices of a second parking list, each followed by its counter
+		const size_t n2 = c->det_o.size() - 1;
+		const unsigned slice = std::max(64u, (unsigned)(c->ext_cap / n2));
+		S3D_HIP(hipMalloc(&c->d_prov2, sizeof(unsigned) * ((size_t)slice + 1) * n2));
+		for (size_t o = 1; o < c->det_o.size(); o++) {
+			c->det_o[o].prov = c->d_prov2 + (o - 1) * ((size_t)slice + 1);
+			c->det_o[o].prov_count = c->det_o[o].prov + slice;
+			c->det_o[o].prov_cap = slice;
+		}
+	}
 	return SIFT3D_OK;
 }
 
@@ -268,6 +285,9 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	if (!c->ext_arena) hipFree(c->arena);
 	hipFree(c->d_words);
 	hipFree(c->det.masks); hipFree(c->det.block_counts); hipFree(c->det.block_offsets);
+	hipFree(c->d_masks2); hipFree(c->d_counts2); hipFree(c->d_offsets2);
+	if (c->ev_det_fork) hipEventDestroy(c->ev_det_fork);
+	if (c->ev_det_join) hipEventDestroy(c->ev_det_join);
 	hipFree(c->d_levels); hipFree(c->d_luts); hipFree(c->d_lutpool);
 	for (auto &e : c->ev) if (e) hipEventDestroy(e);
 	for (auto &e : c->ev_seed) if (e) hipEventDestroy(e);
@@ -497,6 +517,31 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 		CHECKED(hipMalloc(&c->det.block_offsets, sizeof(unsigned) * std::max<size_t>(c->det_blocks, 1)));
 	}
 	c->det.total = c->d_total;
+	{
+		static const bool det_serial = [] { const char *e = getenv("S3D_DET_SERIAL"); return e && e[0] == '1'; }();
+		if (!c->slab && c->noct > 1 && !det_serial && c->ostream.size() > 1 && c->ostream[1] != c->stream) {
+			const size_t kl = (size_t)c->p.num_kp_levels;
+			c->det_o.assign((size_t)c->noct, DetectBufs{});
+			size_t words = 0, blocks = 0;
+			std::vector<size_t> woff((size_t)c->noct, 0), boff((size_t)c->noct, 0);
+			for (int o = 1; o < c->noct; o++) {
+				const Level &D = c->dog[(size_t)o * c->nd + 1];
+				woff[(size_t)o] = words; boff[(size_t)o] = blocks;
+				words += kl * (size_t)D.nz * D.ny * ((D.nx + 63) / 64);
+				blocks += kl * (size_t)D.nz * ((D.ny + 15) / 16);
+			}
+			CHECKED(hipMalloc(&c->d_masks2, sizeof(unsigned long long) * std::max<size_t>(words, 1)));
+			CHECKED(hipMalloc(&c->d_counts2, sizeof(unsigned) * std::max<size_t>(blocks, 1)));
+			CHECKED(hipMalloc(&c->d_offsets2, sizeof(unsigned) * std::max<size_t>(blocks, 1)));
+			for (int o = 1; o < c->noct; o++) {
+				DetectBufs &b = c->det_o[(size_t)o];
+				b.masks = c->d_masks2 + woff[(size_t)o]; b.block_counts = c->d_counts2 + boff[(size_t)o];
+				b.block_offsets = c->d_offsets2 + boff[(size_t)o]; b.total = c->d_total;
+			}
+			CHECKED(hipEventCreateWithFlags(&c->ev_det_fork, hipEventDisableTiming));
+			CHECKED(hipEventCreateWithFlags(&c->ev_det_join, hipEventDisableTiming));
+		}
+	}
 
 	// level table for the keypoint kernels, indexed by ABSOLUTE octave
 	std::vector<LevelRef> lr((size_t)std::max(1, c->noct + c->octave_base) * 8, LevelRef{nullptr, 0, 0, 0, 1.f, 0});
@@ -633,9 +678,13 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		S3D_HIP(hipEventRecord(c->ev[1], st));
 		S3D_HIP(hipEventRecord(c->ev[2], st));  // DoG is fused: zero-length stage
 		// ---- Detect_KeyPoints (Src/cSIFT3D.cc:362-425) ----
-		if (upto >= 3)
+		if (upto >= 3) {
+			const bool two = c->det_o.size() > 1;  // masks of octaves >= 1 on a second stream beside octave 0's
+			hipStream_t sb = two ? c->ostream[1] : st;
+			if (two) { S3D_HIP(hipEventRecord(c->ev_det_fork, st)); S3D_HIP(hipStreamWaitEvent(sb, c->ev_det_fork, 0)); }
+			std::vector<DetectLevels> DLs((size_t)c->noct);
 			for (int o = 0; o < c->noct; o++) {
-				DetectLevels DL;
+				DetectLevels &DL = DLs[(size_t)o];
 				memset(&DL, 0, sizeof(DL));
 				const int nl = c->nd - 2;  // DoG levels 1 .. nd-2 (Src/cSIFT3D.cc:376)
 				for (int i = 1; i <= nl; i++) {
@@ -652,10 +701,24 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 					DL.nextl_slot = nl - 1;
 					if (c->g_last_elide) { DL.nextl_hi = nullptr; DL.lazy_src = DL.nextl_lo; }
 				}
-				const Level &C = c->dog[(size_t)o * c->nd + 1];
-				launch_detect_octave(DL, nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, c->det, c->d_ext, c->ext_cap, st,
-				                     c->g_last_elide ? &c->taps[c->ng - 1] : nullptr);
 			}
+			const int nl = c->nd - 2;
+			const Taps *lt = c->g_last_elide ? &c->taps[c->ng - 1] : nullptr;
+			if (two) {
+				for (int o = 1; o < c->noct; o++) {
+					const Level &C = c->dog[(size_t)o * c->nd + 1];
+					launch_detect_mark(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, c->det_o[(size_t)o], sb, lt);
+				}
+				S3D_HIP(hipEventRecord(c->ev_det_join, sb));
+			}
+			for (int o = 0; o < c->noct; o++) {
+				const Level &C = c->dog[(size_t)o * c->nd + 1];
+				const DetectBufs &b = (two && o > 0) ? c->det_o[(size_t)o] : c->det;
+				if (!(two && o > 0)) launch_detect_mark(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, b, st, lt);
+				if (two && o == 1) S3D_HIP(hipStreamWaitEvent(st, c->ev_det_join, 0));
+				launch_detect_emit(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), o + c->octave_base, b, c->d_ext, c->ext_cap, st);
+			}
+		}
 		S3D_HIP(hipEventRecord(c->ev[3], st));
 		// ---- Assign_Orientation (Src/cSIFT3D.cc:427-482) ----
 		if (upto >= 4) {

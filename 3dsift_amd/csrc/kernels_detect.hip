@@ -449,8 +449,10 @@ __global__ void __launch_bounds__(kThreads) k_emit(const unsigned long long *__r
 	}
 }
 
-void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, float peak_thresh, int octave,
-                          const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st, const Taps *lazy_taps) {
+// first half of an octave's detection: the ballot masks of the strict extrema (k_mark) and the parked candidates of the lazy level
+// (k_lazy_next).  Octaves with their own scratch (DetectBufs) can run this half concurrently.
+void launch_detect_mark(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, float peak_thresh, int octave,
+                        const DetectBufs &b, hipStream_t st, const Taps *lazy_taps) {
 	const int nyb = (ny + kRows - 1) / kRows;
 	const int nzl = zr.zo1 - zr.zo0;
 	if (nzl <= 0) return;
@@ -470,9 +472,25 @@ void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, co
 		hipMemcpy(&n, b.prov_count, sizeof(unsigned), hipMemcpyDeviceToHost);
 		fprintf(stderr, "lazy level: octave %d, %u parked candidates (%d x %d x %d)\n", octave, n, nx, ny, nzl);
 	}
+}
+
+// second half: ordered compaction into the extrema list (appends after everything emitted before: octaves in order, one stream)
+void launch_detect_emit(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, int octave, const DetectBufs &b, DevKp *out,
+                        unsigned cap, hipStream_t st) {
+	const int nyb = (ny + kRows - 1) / kRows;
+	const int nzl = zr.zo1 - zr.zo0;
+	if (nzl <= 0) return;
+	const unsigned nblocks = (unsigned)(nlevels * nzl * nyb);
+	if (nblocks == 0) return;
 	hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b.block_counts, b.block_offsets, nblocks, b.total);
 	hipLaunchKernelGGL(k_emit, dim3(nblocks), dim3(kThreads), 0, st, b.masks, b.block_offsets, nx, ny, zr, nyb, octave, L, out, cap,
 	                   b.total);
+}
+
+void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, float peak_thresh, int octave,
+                          const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st, const Taps *lazy_taps) {
+	launch_detect_mark(L, nlevels, nx, ny, zr, peak_thresh, octave, b, st, lazy_taps);
+	launch_detect_emit(L, nlevels, nx, ny, zr, octave, b, out, cap, st);
 }
 
 }  // namespace s3d
