@@ -531,22 +531,23 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		};
 #if S3D_DESC_SORT
 		const int nux = ((wx + 1) / 2 + kPX - 1) / kPX, nuy = (wy + kSH - 1) / kSH;  // units per unit row, unit rows
-		// (more than kPairCap pairs per strip row, or z ranges beyond a byte: only with windows far larger than the default parameters')
+		// (z ranges beyond a byte: only with windows far larger than the default parameters')
 		const bool chord_cached = z1 - z0 < 255 && !(dev_flags & 1);
-		const int rows_per_chunk = nux > 0 && nux * kUL <= kPairCap ? kPairCap / (nux * kUL) : 0;
-		for (int uy0 = 0; ncol > 0 && rows_per_chunk > 0 && uy0 < nuy; uy0 += rows_per_chunk) {
-		const int nch = min(nuy - uy0, rows_per_chunk) * nux;  // strips of this chunk
-		if (uy0 > 0) __syncthreads();                        // previous chunk's march is done with s_units / s_tile
+		constexpr int kChunkUnits = kPairCap / kUL;
+		const int nunits = ncol > 0 ? nux * nuy : 0;
+		for (int u0 = 0; u0 < nunits; u0 += kChunkUnits) {  // chunks of units in row-major order
+		const int nch = min(nunits - u0, kChunkUnits);
+		if (u0 > 0) __syncthreads();                         // previous chunk's march is done with s_units / s_tile
 		for (int i = tid; i < kLenBins; i += 256) s_cnt[i] = 0u;
 		if (tid == 0) s_tile = 0u;
 		__syncthreads();
 		for (int ps = tid; ps < nch * kUL; ps += 256) {  // pair slot = unit * kUL + position in the unit: kUL consecutive lanes per unit
 			const int uu = ps / kUL, spos = ps % kUL;
-			const int uyi = uu / nux, uxi = uu - uyi * nux;
+			const int uyi = (u0 + uu) / nux, uxi = (u0 + uu) - uyi * nux;
 			int rr[2], za[2], zb[2];
 			float px[2], py[2], pz[2];
 			bool colok[2];
-			setup_pair((uxi * kPX + spos % kPX) * 2, (uy0 + uyi) * kSH + spos / kPX, true, rr, za, zb, px, py, pz, colok);
+			setup_pair((uxi * kPX + spos % kPX) * 2, uyi * kSH + spos / kPX, true, rr, za, zb, px, py, pz, colok);
 			int lo = min(za[0], za[1]), hi = max(zb[0], zb[1]);  // empty columns: (2^28, -2^28)
 #pragma unroll
 			for (int o = kUL / 2; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
@@ -606,8 +607,8 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			const int uidx = tile * (64 / kUL) + lane / kUL, spos = lane % kUL;
 			const bool lane_ok = uidx < nnz;
 			const int uu = s_units[lane_ok ? uidx : 0];
-			const int uyi = uu / nux, uxi = uu - uyi * nux;
-			const int lxa = (uxi * kPX + spos % kPX) * 2, ly = (uy0 + uyi) * kSH + spos / kPX;
+			const int uyi = (u0 + uu) / nux, uxi = (u0 + uu) - uyi * nux;
+			const int lxa = (uxi * kPX + spos % kPX) * 2, ly = uyi * kSH + spos / kPX;
 #else
 			const int ty = tile / tiles_x, tx = tile - ty * tiles_x;  // (a centre-out order, longest chords first, measured no better)
 			const int lxa = tx * 2 * kLX + 2 * (lane % kLX), ly = ty * kTH + (lane / kLX);
