@@ -16,12 +16,17 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "sift3d_internal.h"
 
 namespace s3d {
 
 #ifndef S3D_DET_ROWS
 #define S3D_DET_ROWS 32  /* rows per block: 32 measured best (detect 0.93 -> 0.84 ms at 512^3; 64: 1.01) */
+#endif
+#ifndef S3D_DET_QUEUE
+#define S3D_DET_QUEUE 640  /* 640: the queue is drained after a batch of 8 ballot words; 128: after every word (1.06 vs 0.99 ms detection) */
 #endif
 constexpr int kRows = S3D_DET_ROWS;   // rows per block
 constexpr int kThreads = 256;
@@ -33,7 +38,7 @@ constexpr int kThreads = 256;
 // lanes fetch the 8 neighbours of one candidate each and OR their verdict into the wave's LDS copy of the mask words.
 // A per-word `if (candidate) { 8 loads }` issues those 8 load instructions for nearly every word (some lane usually is a
 // candidate) and the compiler drains them at each join: one memory round trip per word.
-constexpr int kQueue = 640;  // >= 63 left over + 8 words x 64 lanes pushed before the next drain
+constexpr int kQueue = S3D_DET_QUEUE;  // >= 63 left over + the lanes pushed before the next drain (one word: 64, a whole batch: 512)
 __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int ny, ZRange zr, int nyb, float peak_thresh,
                                                    unsigned long long *__restrict__ masks, unsigned *__restrict__ block_counts,
                                                    unsigned *__restrict__ prov, unsigned *__restrict__ prov_count, unsigned prov_cap,
@@ -41,7 +46,10 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	__shared__ unsigned s_cnt[kThreads / 64];
 	__shared__ float s_qv[kThreads / 64][kQueue];
 	__shared__ unsigned short s_qi[kThreads / 64][kQueue];
-	__shared__ unsigned long long s_mask[kThreads / 64][(kRows / 4) * 64];  // [row of the wave][word], wpr <= 64
+	// [wave][row of the wave][word of the segment]: dynamic, sized by the launcher for min(wpr, 64) words per row -- with the queue it
+	// is what limits the workgroups per CU, and the kernel is bound by memory latency x waves in flight
+	extern __shared__ unsigned long long s_mask_dyn[];
+	const int segw = min((nx + 63) >> 6, 64);
 	const int b = blockIdx.x;
 	const int nz = zr.zo1 - zr.zo0;                              // planes scanned by this launch (local range [zo0, zo1))
 	const int yb = b % nyb, zi = (b / nyb) % nz, lvl = b / (nyb * nz);
@@ -64,8 +72,8 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	const int r_lo = swid * (kRows / 4), r_hi = min(nrows, (swid + 1) * (kRows / 4));
 	float *qv = s_qv[swid];
 	unsigned short *qi = s_qi[swid];
-	unsigned long long *mloc = s_mask[swid];
-	for (int i = lane; i < (kRows / 4) * 64; i += 64) mloc[i] = 0ull;
+	unsigned long long *mloc = s_mask_dyn + (size_t)swid * (kRows / 4) * segw;
+	for (int i = lane; i < (kRows / 4) * segw; i += 64) mloc[i] = 0ull;
 	const unsigned long long lt = (1ull << lane) - 1ull;
 	const size_t plane0 = sz * (size_t)z + sy * (size_t)y0;
 	int qn = 0;  // wave-uniform
@@ -104,7 +112,7 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 		const float n7 = lazy_next ? (L.nextl_hi[ic] - L.nextl_lo[ic]) * (-1.0f) : next[ic];
 		const bool mn = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 && v < n7;
 		const bool mx = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 && v > n7;
-		if (act && (mn || mx)) atomicOr(&mloc[rr * 64 + xw], 1ull << bit);
+		if (act && (mn || mx)) atomicOr(&mloc[rr * segw + xw], 1ull << bit);
 	};
 	unsigned cnt = 0;
 	// rows wider than 64 ballot words (nx > 4096) are handled in segments of 64 words: the local mask copy holds one segment
@@ -134,6 +142,10 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 						qi[pos] = (unsigned short)(((ry - r_lo) << 12) | ((xw0 + bb - seg0) << 6) | lane);
 					}
 					qn += (int)__popcll(m);
+					if (kQueue < 63 + kBatch * 64 && qn >= 64) {  // small queue: drain after every word
+						qn -= 64;
+						evaluate(qn, 64, seg0);
+					}
 				}
 				// drain full waves of candidates (entries are consumed from the END so the front stays in place)
 				while (qn >= 64) {
@@ -148,10 +160,10 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 		for (int ry = r_lo; ry < r_hi; ry++) {
 			unsigned long long *mrow = masks + ((size_t)(lvl * nz + zi) * ny + (y0 + ry)) * wpr;
 			for (int xw = seg0 + lane; xw < seg1; xw += 64) {
-				const unsigned long long m = mloc[(ry - r_lo) * 64 + xw - seg0];
+				const unsigned long long m = mloc[(ry - r_lo) * segw + xw - seg0];
 				mrow[xw] = m;
 				cnt += (unsigned)__popcll(m);
-				mloc[(ry - r_lo) * 64 + xw - seg0] = 0ull;
+				mloc[(ry - r_lo) * segw + xw - seg0] = 0ull;
 			}
 		}
 	}
@@ -460,7 +472,8 @@ void launch_detect_mark(const DetectLevels &L, int nlevels, int nx, int ny, cons
 	if (nblocks == 0) return;
 	const bool lazy = L.lazy_src != nullptr && lazy_taps != nullptr && b.prov != nullptr;
 	if (lazy) (void)hipMemsetAsync(b.prov_count, 0, sizeof(unsigned), st);
-	hipLaunchKernelGGL(k_mark, dim3(nblocks), dim3(kThreads), 0, st, L, nx, ny, zr, nyb, peak_thresh, b.masks, b.block_counts, b.prov,
+	const size_t mask_lds = sizeof(unsigned long long) * (kThreads / 64) * (kRows / 4) * (size_t)std::min((nx + 63) >> 6, 64);
+	hipLaunchKernelGGL(k_mark, dim3(nblocks), dim3(kThreads), mask_lds, st, L, nx, ny, zr, nyb, peak_thresh, b.masks, b.block_counts, b.prov,
 	                   b.prov_count, b.prov_cap, b.total);
 	static const int lazy_grid = [] { const char *e = getenv("S3D_LAZY_GRID"); return e ? atoi(e) : 256 * 5; }();
 	if (lazy) hipLaunchKernelGGL(k_lazy_next, dim3(lazy_grid), dim3(256), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
