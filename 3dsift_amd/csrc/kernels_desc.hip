@@ -280,12 +280,6 @@ __device__ unsigned long long g_dstamp[64][4][10];
 #else
 #define S3D_DSTAMP(i)
 #endif
-#ifndef S3D_DESC_X3
-#define S3D_DESC_X3 1
-#endif
-#ifndef S3D_DESC_C2
-#define S3D_DESC_C2 1
-#endif
 #ifdef S3D_DDIAG  // timing-only builds (wrong results): 1 no histogram adds, 2 no heavy part, 4 / 16 no / only the 16-byte load, 8 no queue
 #define S3D_DDIAG_V S3D_DDIAG
 #if (S3D_DDIAG & 20) && (!defined(S3D_DESC_SH) || S3D_DESC_SH > 1)
@@ -337,7 +331,6 @@ __device__ __forceinline__ float dpp_from_lane_above(float v) {  // lane + N of 
 	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N), "0"(0.0f));
 	return r;
 }
-typedef float f3g __attribute__((ext_vector_type(3), aligned(4)));
 typedef float f4g __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2g __attribute__((ext_vector_type(2), aligned(4)));
 constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <= 64, a pop removes exactly 64
@@ -359,7 +352,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	__shared__ __attribute__((aligned(16))) float s_face[kFaces * kFaceStride];
 	__shared__ int s_fidx[kFaces * 4];
 	__shared__ float red[4];
-#if S3D_DESC_C2 && S3D_DESC_SORT
+#if S3D_DESC_SORT
 	__shared__ unsigned short s_units[kPairCap];  // the non-empty column pairs of the chunk, longest z range first
 	__shared__ unsigned s_chord[kPairCap];        // z ranges of a pair's two columns: (za0, zb0, za1, zb1) - z0, one byte each
 	__shared__ unsigned s_cnt[kLenBins];          // counting sort: pairs per length, then the running start of each length
@@ -472,22 +465,13 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		const gfloat_p lut_g = as_global(lutpool) + lut.off;
 		__syncthreads();
 
-#if defined(S3D_EXP) && S3D_EXP == 5
-		int exp_steps = 0, exp_lanes = 0, exp_pops = 0;
-#endif
 		S3D_DSTAMP(0)  // keypoint fetch, histogram clear, barriers
 		int qhead = 0, qcount = 0;  // wave-uniform (every lane executes every push / pop below)
 		// All control flow from here to the drain is wave-uniform: lanes without work are predicated, never branched
 		// away, because the queue bookkeeping must see every ballot.
-		// Columns are dealt to the waves as 8x8 tiles of the window's (x, y) footprint: chord lengths (and the cube clip)
-		// vary slowly across a tile, so the lanes of a wave finish their z-march together (a 64x1 row segment spans
-		// the circle from rim to centre and leaves ~40 % of the lane-steps idle)
-#if S3D_DESC_C2
-		// Two adjacent columns (x, x+1) per lane, 8 lanes x 8 rows per wave = a 16 x 8 footprint.  The march is bound by the ISSUE
-		// of its vector-memory instructions, so the stencil of both columns comes from three loads per step: one 16-byte row
-		// piece (x-1 .. x+2) that also carries the centre values, requested two planes ahead, and two 8-byte pieces of the rows
-		// y-1 and y+1 -- 1.5 instructions per voxel instead of 4.  Queue order differs from the one-column form, the integer
-		// histogram sums do not.
+		// Two adjacent columns (x, x+1) per lane: the stencil of both comes from one 16-byte row piece (x-1 .. x+2) that also carries
+		// the centre values, requested two planes ahead, plus the rows y-1 and y+1 (from the lanes beside this one, or an 8-byte load
+		// for the outer rows of a unit; see "Sorted units" above).  (One column per lane: 4 vector-memory instructions per voxel, 7.2 ms.)
 		// chord of the lane's two columns (xa, xa + 1) of window row ly: in-sphere range clipped to the rotated 4x4x4 cube
 		auto setup_pair = [&](int lxa, int ly, bool lane_ok, int (&rr)[2], int (&za)[2], int (&zb)[2], float (&px)[2], float (&py)[2],
 		                      float (&pz)[2], bool (&colok)[2]) {
@@ -770,124 +754,6 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			}
 		}
 		}  // chunk of unit rows (S3D_DESC_SORT) / plain block
-#else
-#ifndef S3D_DESC_TW
-#define S3D_DESC_TW 8
-#endif
-		constexpr int kTW = S3D_DESC_TW, kTH = 64 / kTW;  // (x, y) footprint of a wave's column tile
-		const int tiles_x = (wx + kTW - 1) / kTW, tiles_y = (wy + kTH - 1) / kTH;
-		const int ntiles = ncol > 0 ? tiles_x * tiles_y : 0;
-		for (int t0 = 0; t0 < ntiles; t0 += 4) {
-			const int tile = t0 + wid;                 // wave-uniform
-			const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-			const int lx = tx * kTW + (lane % kTW), ly = ty * kTH + (lane / kTW);
-			const int x = x0 + lx, y = y0 + ly;
-			const int dx = x - cxi, dy = y - cyi;
-			const int rr = dx * dx + dy * dy;
-			bool colok = tile < ntiles && lx < wx && ly < wy && rr <= nin;
-			int za = 0, zb = -1;
-			const float vxd = (float)dx * u, vyd = (float)dy * u;
-			// partial rotations: (R0*vx + R1*vy) is evaluated first in the reference's left-to-right sums
-			const float px = R0 * vxd + R1 * vyd, py = R3 * vxd + R4 * vyd, pz = R6 * vxd + R7 * vyd;
-			if (colok) {
-				// in-sphere chord: dz^2 <= nin - rr
-				int h = (int)__fsqrt_rn((float)(nin - rr));
-				while ((h + 1) * (h + 1) <= nin - rr) h++;
-				while (h * h > nin - rr) h--;
-				za = max(z0, czi - h); zb = min(z1, czi + h);
-				// clip the z range to the rotated 4x4x4 cube: in exact arithmetic a voxel is inside iff
-				// -hw < p_r + R_r2*dz*u < hw for the three rows r.  Only an iteration-count optimisation: it is
-				// widened by 2 voxels and the reference's exact fp32 test still runs on every visited voxel.
-				float lo = (float)(za - czi), hi = (float)(zb - czi);
-				const float pr[3] = {px, py, pz}, rr3[3] = {R2 * u, R5 * u, R8 * u};
-#pragma unroll
-				for (int r = 0; r < 3; r++) {
-					if (fabsf(rr3[r]) > 1e-6f * desc_hw) {
-						const float inv = __frcp_rn(rr3[r]);
-						const float t0 = (-desc_hw - pr[r]) * inv, t1 = (desc_hw - pr[r]) * inv;
-						lo = fmaxf(lo, fminf(t0, t1) - S3D_DESC_CLIPM);
-						hi = fminf(hi, fmaxf(t0, t1) + S3D_DESC_CLIPM);
-					} else if (fabsf(pr[r]) > desc_hw * 1.001f + 1.0f) {
-						hi = lo - 1.0f;  // this row never enters the cube
-					}
-				}
-				if (lo <= hi) { za = max(za, czi + (int)floorf(lo)); zb = min(zb, czi + (int)ceilf(hi)); }
-				else zb = za - 1;
-			}
-			const int zlen = (colok && zb >= za) ? zb - za + 1 : 0;
-			int maxlen = zlen;
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-			maxlen = __builtin_amdgcn_readfirstlane(maxlen);
-			S3D_DSTAMP(1)  // batch setup (chord, cube clip)
-			if (maxlen == 0) continue;  // wave-uniform
-#if defined(S3D_EXP) && S3D_EXP == 5
-			exp_steps += maxlen; exp_lanes += zlen;
-#endif
-			// lanes without a column march on the keypoint's own column (always in bounds) and are masked
-			gfloat_p c = zlen > 0 ? Ld + (size_t)x + (size_t)sy * (size_t)y + (size_t)sz * (size_t)(za - L.zoff) : centre;
-			float cm = *(c - sz), cc = *c, cp = c[sz];  // centre column at z-1, z, z+1
-			float nxm = c[-1], nxp = c[1], nym = *(c - sy), nyp = c[sy];  // in-plane neighbours of plane z
-			int dz = za - czi;
-			for (int step = 0; step < maxlen; step++) {
-				const bool in = step < zlen;
-				// software pipeline: everything the NEXT step needs (its in-plane neighbours and its z+1 value) is requested
-				// now and consumed one step later; the clamped addresses stay inside the window's plane range
-				const bool more = step + 1 < zlen;
-				const gfloat_p cn = more ? c + sz : c;
-				const float cpn = cn[sz];  // plane z+2 (<= zb+1 <= nz-1), or z+1 again on the last step
-#if S3D_DESC_X3
-				// the x neighbours of the next plane come with ONE 12-byte load (x-1, x, x+1; dword aligned): four VMEM instructions per
-				// step instead of five -- the march is bound by VMEM issue, not by bytes
-				const f3g x3 = *reinterpret_cast<const f3g __attribute__((address_space(1))) *>(cn - 1);
-				const float nxm1 = x3.x, nxp1 = x3.z, nym1 = *(cn - sy), nyp1 = cn[sy];
-#else
-				const float nxm1 = cn[-1], nxp1 = cn[1], nym1 = *(cn - sy), nyp1 = cn[sy];
-#endif
-				S3D_DSTAMP(2)  // back-edge + issue of the next step's loads
-				const float vzd = (float)dz * u;
-				float bx = px + R2 * vzd, by = py + R5 * vzd, bz = pz + R8 * vzd;
-				bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
-				bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
-				// inside the 4x4x4 cube: the reference's !(b <= -0.5 || b >= 3.5) per axis (Src/cSIFT3D.cc:1299-1303); the
-				// coordinates are finite, so min/max over the three axes gives the same predicate in two v_min3/v_max3
-				bool act = in && fminf(fminf(bx, by), bz) > -0.5f && fmaxf(fmaxf(bx, by), bz) < 3.5f;
-				const float w = LUT_LDS ? s_lut[in ? rr + dz * dz : 0] : lut_g[in ? rr + dz * dz : 0];
-				float gx = nxp - nxm;
-				float gy = nyp - nym;
-				float gz = cp - cm;
-				gx = gx * w; gy = gy * w; gz = gz * w;
-				const float rx = gx, ry = gy, rz = gz;  // rotated on the compacted voxels (accumulate_voxel)
-				const float g2 = gx * gx + gy * gy + gz * gz;
-				act = act && !(g2 < kBaryEps * 0.99f);
-				cm = cc; cc = cp; cp = cpn; nxm = nxm1; nxp = nxp1; nym = nym1; nyp = nyp1;
-				c = cn; dz += more ? 1 : 0;
-				S3D_DSTAMP(3)  // step arithmetic
-				// ---- push the active lanes into the wave's queue (compaction by ballot rank) ----
-				const unsigned long long m = __ballot(act);
-				if (m) {
-					if (act) {
-						const int pos = (qhead + qcount + (int)__popcll(m & ((1ull << lane) - 1ull))) & (kQCap - 1);
-						q[0][pos] = bx; q[1][pos] = by; q[2][pos] = bz; q[3][pos] = rx; q[4][pos] = ry; q[5][pos] = rz;
-					}
-					qcount += (int)__popcll(m);
-				}
-				S3D_DSTAMP(4)  // push
-				// ---- a full wave of active voxels is ready: run the heavy part on all 64 lanes ----
-				if (qcount >= 64) {
-					const int pos = (qhead + lane) & (kQCap - 1);
-					msum += accumulate_voxel(true, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale,
-					                 s_face, s_fidx, s_predn, s_predf, hist_rep, spread);
-					qhead = (qhead + 64) & (kQCap - 1);
-					qcount -= 64;
-#if defined(S3D_EXP) && S3D_EXP == 5
-					exp_pops++;
-#endif
-				}
-				S3D_DSTAMP(5)  // pop (accumulate 64 voxels)
-			}
-		}
-#endif
 		if (qcount > 0) {  // drain (wave-uniform)
 			const int pos = (qhead + lane) & (kQCap - 1);
 			const bool valid = lane < qcount;
@@ -948,14 +814,6 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 #if defined(S3D_EXP) && S3D_EXP == 6
 		__syncthreads();
 		if (tid == 0) { out[0] = exp_mass; out[1] = m_est; out[2] = (float)exp_attempts; out[3] = fix_scale; }
-#endif
-#if defined(S3D_EXP) && S3D_EXP == 5
-		{
-			int tl = exp_lanes;
-			for (int o = 32; o > 0; o >>= 1) tl += __shfl_xor(tl, o, 64);
-			__syncthreads();
-			if (tid == 0) { out[0] = (float)exp_steps; out[1] = (float)tl; out[2] = (float)exp_pops; }
-		}
 #endif
 	}
 #if defined(S3D_EXP) && S3D_EXP == 21
