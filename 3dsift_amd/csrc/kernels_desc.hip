@@ -699,12 +699,13 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 				bool actk[2];
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
-					const bool in = step < zlen && (unsigned)(z - za[k]) <= (unsigned)(zb[k] - za[k]);  // empty column: za = 2^28, zb = -2^28
+					const bool in = ((int)(step < zlen) & (int)((unsigned)(z - za[k]) <= (unsigned)(zb[k] - za[k]))) != 0;  // empty column: za = 2^28, zb = -2^28
 					float bx = px[k] + R2 * vzd, by = py[k] + R5 * vzd, bz = pz[k] + R8 * vzd;
 					bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
 					bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
 					// inside the 4x4x4 cube: the reference's !(b <= -0.5 || b >= 3.5) per axis (Src/cSIFT3D.cc:1299-1303)
-					bool act = in && fminf(fminf(bx, by), bz) > -0.5f && fmaxf(fmaxf(bx, by), bz) < 3.5f;
+					// (bitwise &: straight-line compares; && makes hipcc wrap each operand in an exec-mask branch)
+					const bool act = ((int)in & (int)(fminf(fminf(bx, by), bz) > -0.5f) & (int)(fmaxf(fmaxf(bx, by), bz) < 3.5f)) != 0;
 					const float w = LUT_LDS ? s_lut[in ? rr[k] + dz2 : 0] : lut_g[in ? rr[k] + dz2 : 0];
 					const float nxm = k ? rowC.y : rowC.x, nxp = k ? rowC.w : rowC.z;
 					const float nym = k ? ymC.y : ymC.x, nyp = k ? ypC.y : ypC.x;
@@ -716,7 +717,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 					// exact |R g|^2 >= eps test run on the compacted voxels; here a voxel is only dropped when it fails by a margin
 					gx = gx * w; gy = gy * w; gz = gz * w;
 					const float g2 = gx * gx + gy * gy + gz * gz;
-					actk[k] = act && !(g2 < kBaryEps * 0.99f);
+					actk[k] = ((int)act & (int)!(g2 < kBaryEps * 0.99f)) != 0;
 					bxk[k] = bx; byk[k] = by; bzk[k] = bz; rxk[k] = gx; ryk[k] = gy; rzk[k] = gz;
 				}
 #if S3D_DESC_SORT && S3D_DESC_SH > 1 && !(S3D_DDIAG_V & 20)
