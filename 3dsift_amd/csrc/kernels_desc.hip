@@ -81,6 +81,9 @@ constexpr int kFaceStride = 16;  // floats per face in the LDS table
 #ifndef S3D_DESC_SPREAD
 #define S3D_DESC_SPREAD 1
 #endif
+#ifndef S3D_DESC_LANEMAP
+#define S3D_DESC_LANEMAP 1
+#endif
 #ifndef S3D_DESC_BIN64
 #define S3D_DESC_BIN64 0
 #endif
@@ -91,17 +94,29 @@ typedef long long sbin_t;
 typedef unsigned bin_t;
 typedef int sbin_t;
 #endif
-constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = bin*kRep + lane % kRep)
-// Bank spreading (r02).  The voxels of a 64-lane batch are spatial neighbours: most of them share the cell AND the face, so every
-// one of the 24 adds sent all lanes to the SAME bin -- R replicas = R banks, 64/R lanes queued on each (an LDS atomic costs ~1.9
-// cycles per lane on the busiest bank; measured 16 cycles per ds_add with 8 replicas).  Now lane l walks the 8 cells of its voxel in
-// the order d ^ r, r = (l >> 2) & 7, so the lanes of a batch hit 8 different cells at every step, and the bin layout gives the three
-// cell strides the residues 1, 2, 4 modulo 8: 8 cells x 4 replicas = all 32 banks.  idx(ix, iy, iz, v) = 17 ix + 74 iy + 300 iz + v.
-constexpr int kSX = 17, kSY = 74, kSZ = 300, kBins = S3D_DESC_SPREAD ? 4 * kSZ : kDesc;
+constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = bin * kRep + replica of the lane)
+// Bank spreading (r02).  The voxels that leave the march side by side mostly share the cell AND the face, so every one of the 24 adds
+// sent all lanes to the SAME bin -- R replicas = R banks, 64/R lanes queued on each (an LDS atomic costs ~1.9 cycles per lane on the
+// busiest bank; measured 16 cycles per ds_add with 8 replicas).  Now lane l walks the 8 cells of its voxel in the order d ^ r,
+// r = l & 7, with the replica (l >> 3) & 3, and the bin layout gives the three cell strides the residues 1, 2, 4 modulo 8: the eight
+// lanes of a group (one unit of the march: one cell, as a rule) hit 8 different banks of their replica at every step, and groups with
+// different replicas never meet.  (r = (l >> 2) & 7, replica l & 3 -- neighbours on different replicas, lanes four apart on
+// different orders -- let voxels of different units, i.e. different cells, collide: +38 % conflict cycles, +0.15 ms.)
+#ifndef S3D_DESC_VMAJOR
+#define S3D_DESC_VMAJOR 1
+#endif
+#if S3D_DESC_VMAJOR
+// vertex-major: idx = 72 v + ix + 18 iy + 4 iz.  The cell strides have the residues 1, 2, 4 modulo 8 (and ix + 4 iz < 16 <= 18), the
+// vertex stride is 0 modulo 8: the bank of an add depends on the cell and the replica only, not on the face of the voxel
+// (864 bins = 13.8 KB with 4 replicas; the cell-major layout 17 ix + 74 iy + 300 iz + v: 1200 bins, 19.2 KB, 24 % more conflict cycles).
+constexpr int kSX = 1, kSY = 18, kSZ = 4, kSV = 72, kBins = 12 * kSV;
+#else
+constexpr int kSX = 17, kSY = 74, kSZ = 300, kSV = 1, kBins = S3D_DESC_SPREAD ? 4 * kSZ : kDesc;
+#endif
 __device__ __forceinline__ int bin_index(int j) {  // descriptor element j = (ix + 4 iy + 16 iz) * 12 + v  ->  histogram index
 	if (!S3D_DESC_SPREAD) return j;
 	const int c = j / 12, v = j - c * 12;
-	return (c & 3) * kSX + ((c >> 2) & 3) * kSY + (c >> 4) * kSZ + v;
+	return (c & 3) * kSX + ((c >> 2) & 3) * kSY + (c >> 4) * kSZ + v * kSV;
 }
 
 // reference Moller-Trumbore for ONE face whose constants sit at F[0..15]:
@@ -377,7 +392,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		s_face[i] = v;
 #endif
 	}
-	for (int i = tid; i < kFaces * 4; i += 256) s_fidx[i] = (i & 3) < 3 ? c_faces[i >> 2].idx[i & 3] : 0;
+	for (int i = tid; i < kFaces * 4; i += 256) s_fidx[i] = (i & 3) < 3 ? c_faces[i >> 2].idx[i & 3] * kSV : 0;  // vertex -> its first bin
 	if (tid < 12) s_predn[tid] = c_pred.n[tid / 3][tid % 3];
 	if (tid < 32) s_predf[tid] = c_pred.face[tid];
 	int cur_lut = -1;
@@ -385,8 +400,18 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
 #endif
 	float(*q)[kQCap] = s_q[wid];
+#if S3D_DESC_LANEMAP
+	// eight consecutive lanes (voxels that left the march side by side: one unit, mostly one cell) take the eight cell orders and share a
+	// replica; the next eight use the next replica.  Lanes from different units -- different cells -- then never meet on a bank.
+	bin_t *hist_rep = &hist[(lane >> 3) % kRep];
+#else
 	bin_t *hist_rep = &hist[lane % kRep];
+#endif
+#if S3D_DESC_LANEMAP
+	const int spread = lane & 7;
+#else
 	const int spread = (lane / kRep) & 7;
+#endif
 
 	// The accepted keypoints (slot -> extremum list from k_slots) are handed out one at a time through a global counter:
 	// window sizes differ 4x between keypoint levels, so a static deal leaves a long tail.  A partitioned run (multi-GPU
