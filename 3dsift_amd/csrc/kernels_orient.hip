@@ -141,6 +141,9 @@ __device__ int finish_orientation(DevKp &kp, const float T6[6], const float w3[3
 
 // LDS tiles of the orientation window: the default radius (3 * 1.5 * scale <= 11.43 voxels) gives <= 25 voxels per side,
 // + 2 for the central differences; larger windows (non-default sigma) take the global-load path
+#ifndef S3D_ORI_UN
+#define S3D_ORI_UN 2  /* window voxels per lane and pass */
+#endif
 constexpr int kTileW = 28, kTileH = 27;
 constexpr int kTilePc = ((kTileW / 4) * kTileH + 63) / 64;  // 16-byte pieces of a tile plane per lane (3)
 typedef float f4o __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte global piece at dword alignment
@@ -246,8 +249,10 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 			};
 			fetch_entries(z0 - czi);
 			for (int z = z0; z <= z1; z++) {
+#if !defined(S3D_ODIAG) || !(S3D_ODIAG & 2)  // (timing only: no tile traffic)
 				deposit(sp);                       // plane z+1 (requested one iteration ago)
 				request(min(z + 2, z1 + 1));       // in flight while plane z is processed
+#endif
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -255,7 +260,10 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 				const int dz = z - czi;
 				// kUn voxels per pass, all LDS reads (weights included) issued before the first use; inactive voxels read
 				// valid addresses and are masked, so the loop body is branch-free and pipelines
-				constexpr int kUn = 2;
+				constexpr int kUn = S3D_ORI_UN;
+#ifdef S3D_ODIAG
+				if (S3D_ODIAG & 1) { } else  // timing only: no window arithmetic
+#endif
 				if (use_list) {
 					// the lattice points of the window sphere in this plane come from a list (WinLut::list_off): 52 % of the box is
 					// outside the sphere, and the list also carries n = dx^2 + dy^2 + dz^2.  Windows clipped by the level border skip
@@ -276,7 +284,7 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 							const int lx = (int)(e & 255u) + ox, ly = (int)((e >> 8) & 255u) + oy;
 							const bool ok = (p0 + q) * 64 + lane < cnt && (unsigned)lx < (unsigned)wx && (unsigned)ly < (unsigned)wy;
 							w[q] = ok ? wl[e >> 16] : -1.0f;
-							const int o = ok ? (ly + 1) * kTileW + lx + 1 : kTileW + 1;
+							const int o = ok ? __mul24(ly + 1, kTileW) + lx + 1 : kTileW + 1;  // (24-bit multiply: full rate)
 							nb[q][0] = pc[o + 1]; nb[q][1] = pc[o - 1]; nb[q][2] = pc[o + kTileW]; nb[q][3] = pc[o - kTileW];
 							nb[q][4] = pp[o]; nb[q][5] = pm[o];
 						}
@@ -309,7 +317,7 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 						const int n = dx * dx + dy * dy + dz * dz;
 						const bool ok = v < plane && n < lut.len;
 						w[q] = ok ? wl[n] : -1.0f;
-						const int o = ok ? (ly + 1) * kTileW + lx + 1 : kTileW + 1;
+						const int o = ok ? __mul24(ly + 1, kTileW) + lx + 1 : kTileW + 1;  // (24-bit multiply: full rate)
 						nb[q][0] = pc[o + 1]; nb[q][1] = pc[o - 1]; nb[q][2] = pc[o + kTileW]; nb[q][3] = pc[o - kTileW];
 						nb[q][4] = pp[o]; nb[q][5] = pm[o];
 					}

@@ -10,7 +10,7 @@ for f in context kernels_pyramid kernels_fused kernels_march kernels_detect kern
   [ "$f" != "$src" ] && [ -f build/$f.o ] && cp -u build/$f.o build_$name/$f.o
 done
 FL="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value"
-{ [ "$src" = kernels_fused ] || [ "$src" = kernels_march ] || [ "$src" = kernels_desc ]; } && FL="$FL -fno-slp-vectorize"
+{ [ "$src" = kernels_fused ] || [ "$src" = kernels_march ] || [ "$src" = kernels_desc ] || [ "$src" = kernels_orient ]; } && FL="$FL -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $extra $FL -c $src.hip -o build_$name/$src.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../variants/libsift3d_hip_$name.so build_$name/*.o
 echo built variants/libsift3d_hip_$name.so
