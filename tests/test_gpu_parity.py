@@ -321,3 +321,25 @@ def test_descriptor_chord_cache_matches_recomputed_chords(capi, synth):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
     assert outs[0] == outs[1] and int(outs[0].split()[2]) > 20
+
+
+def test_two_stream_detection_matches_serial(capi, synth):
+    """Octaves >= 1 form their extremum masks on a second stream with their own scratch beside octave 0 (context.hip); the ordered
+    compaction is serial either way.  S3D_DET_SERIAL=1 runs everything on one stream with one scratch: same extrema (order
+    included), keypoints and descriptors, bit for bit."""
+    import subprocess, sys, os
+    code = (
+        "import importlib,hashlib,sys,numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "capi=importlib.import_module('3dsift_amd.capi'); synth=importlib.import_module('3dsift_amd.synth')\n"
+        "ex=capi.CreateCSIFT3D(synth.blobs((128,96,112),seed=9,noise=0.01)).KpSiftAlgorithm()\n"
+        "h=hashlib.sha1(); kp,d=ex.GetKeypoints(); h.update(np.ascontiguousarray(ex.extrema()).tobytes()); h.update(kp.tobytes()); h.update(d.tobytes())\n"
+        "print('HASH',h.hexdigest(),len(kp),ex.num_octaves)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    )
+    outs = []
+    for serial in ("0", "1"):
+        env = dict(os.environ, S3D_DET_SERIAL=serial)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
+    assert outs[0] == outs[1] and int(outs[0].split()[2]) > 20 and int(outs[0].split()[3]) >= 3
