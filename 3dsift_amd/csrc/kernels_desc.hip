@@ -853,11 +853,12 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
                      const unsigned *d_nkp, unsigned *d_work, hipStream_t st, bool lut_in_lds) {
 	(void)hipMemsetAsync(d_work, 0, sizeof(unsigned), st);
 	// development: S3D_DESC_DYNLDS=bytes of unused dynamic LDS per workgroup (occupancy experiments: fewer workgroups per CU)
+	static const int desc_grid = [] { const char *e = getenv("S3D_DESC_GRID"); return e ? atoi(e) : 256 * 8; }();  // persistent workgroups (work counter)
 	static const unsigned dyn_lds = [] { const char *e = getenv("S3D_DESC_DYNLDS"); return e ? (unsigned)atoi(e) : 0u; }();
 	// development / tests: S3D_DESC_NOCACHE=1 takes the path of windows whose z ranges do not fit the byte cache (recomputed chords)
 	static const int dev_flags = [] { const char *e = getenv("S3D_DESC_NOCACHE"); return e && e[0] == '1' ? 1 : 0; }();
 	if (lut_in_lds)
-		hipLaunchKernelGGL(k_describe<true>, dim3(256 * 8), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
+		hipLaunchKernelGGL(k_describe<true>, dim3(desc_grid), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
 		                   part_rank, part_world, order, d_nkp, d_work, dev_flags);
 	else
 		hipLaunchKernelGGL(k_describe<false>, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
