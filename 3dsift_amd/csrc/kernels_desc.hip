@@ -69,31 +69,14 @@ constexpr int kFaceStride = 16;  // floats per face in the LDS table
 #define S3D_DESC_REP 4
 #endif
 // (no waves-per-SIMD hint in __launch_bounds__: any value >= 2 makes hipcc schedule for occupancy and the kernel 10 % slower)
-#ifndef S3D_DESC_FASTMATH
-#define S3D_DESC_FASTMATH 0
-#endif
 #ifndef S3D_DESC_CLIPM
 #define S3D_DESC_CLIPM 0.25f /* widening of the cube clip of a column's z range, voxels */
 #endif
 #ifndef S3D_DESC_ATTR
 #define S3D_DESC_ATTR
 #endif
-#ifndef S3D_DESC_SPREAD
-#define S3D_DESC_SPREAD 1
-#endif
-#ifndef S3D_DESC_LANEMAP
-#define S3D_DESC_LANEMAP 1
-#endif
-#ifndef S3D_DESC_BIN64
-#define S3D_DESC_BIN64 0
-#endif
-#if S3D_DESC_BIN64
-typedef unsigned long long bin_t;   // A/B: 64-bit bins in 2^-29 units (never overflow, twice the LDS atomic cost)
-typedef long long sbin_t;
-#else
 typedef unsigned bin_t;
 typedef int sbin_t;
-#endif
 constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = bin * kRep + replica of the lane)
 // Bank spreading (r02).  The voxels that leave the march side by side mostly share the cell AND the face, so every one of the 24 adds
 // sent all lanes to the SAME bin -- R replicas = R banks, 64/R lanes queued on each (an LDS atomic costs ~1.9 cycles per lane on the
@@ -102,33 +85,18 @@ constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = 
 // lanes of a group (one unit of the march: one cell, as a rule) hit 8 different banks of their replica at every step, and groups with
 // different replicas never meet.  (r = (l >> 2) & 7, replica l & 3 -- neighbours on different replicas, lanes four apart on
 // different orders -- let voxels of different units, i.e. different cells, collide: +38 % conflict cycles, +0.15 ms.)
-#ifndef S3D_DESC_VMAJOR
-#define S3D_DESC_VMAJOR 1
-#endif
-#if S3D_DESC_VMAJOR
 // vertex-major: idx = 72 v + ix + 18 iy + 4 iz.  The cell strides have the residues 1, 2, 4 modulo 8 (and ix + 4 iz < 16 <= 18), the
 // vertex stride is 0 modulo 8: the bank of an add depends on the cell and the replica only, not on the face of the voxel
 // (864 bins = 13.8 KB with 4 replicas; the cell-major layout 17 ix + 74 iy + 300 iz + v: 1200 bins, 19.2 KB, 24 % more conflict cycles).
 constexpr int kSX = 1, kSY = 18, kSZ = 4, kSV = 72, kBins = 12 * kSV;
-#else
-constexpr int kSX = 17, kSY = 74, kSZ = 300, kSV = 1, kBins = S3D_DESC_SPREAD ? 4 * kSZ : kDesc;
-#endif
 __device__ __forceinline__ int bin_index(int j) {  // descriptor element j = (ix + 4 iy + 16 iz) * 12 + v  ->  histogram index
-	if (!S3D_DESC_SPREAD) return j;
 	const int c = j / 12, v = j - c * 12;
 	return (c & 3) * kSX + ((c >> 2) & 3) * kSY + (c >> 4) * kSZ + v * kSV;
 }
 
 // reference Moller-Trumbore for ONE face whose constants sit at F[0..15]:
 // e1(0..2) e2(3..5) t(6..8) q(9..11) qe2(12); returns pass/fail exactly like Check_intersect_faces' body
-#ifndef S3D_FACE_T
-#define S3D_FACE_T 1  /* face constants transposed in LDS ([constant][face]): lanes with different faces read different banks */
-#endif
-#if S3D_FACE_T
 #define FC(i) Fb[(i) * kFaceT]
-#else
-#define FC(i) Fb[i]
-#endif
 constexpr int kFaceT = 20;  // faces per constant row of the transposed table
 __device__ __forceinline__ bool face_test(const float *Fb, float gx, float gy, float gz, float &b0, float &b1, float &b2) {
 	const float F[13] = {FC(0), FC(1), FC(2), FC(3), FC(4), FC(5), FC(6), FC(7), FC(8), FC(9), FC(10), FC(11), FC(12)};
@@ -139,11 +107,7 @@ __device__ __forceinline__ bool face_test(const float *Fb, float gx, float gy, f
 	if (fabsf(det) < kBaryEps) return false;
 	// reference: (float)(1.0 / (double)det).  A correctly rounded fp32 division gives the same value: double
 	// rounding is innocuous for division when the wide format has >= 2p+2 = 50 bits (binary64 has 53)
-#if S3D_DESC_FASTMATH
-	const float det_inv = __builtin_amdgcn_rcpf(det);  // 1 ulp; decisions keep their 1e-4 margin, values move by <= 1e-7 relative
-#else
 	const float det_inv = __fdiv_rn(1.0f, det);
-#endif
 	b1 = det_inv * (px * F[6] + py * F[7] + pz * F[8]);
 	b2 = det_inv * (gx * F[9] + gy * F[10] + gz * F[11]);
 	b0 = 1.0f - b1 - b2;
@@ -212,22 +176,14 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 		}
 		const int bits = (rx < 0.f ? 1 : 0) | (ry < 0.f ? 2 : 0) | (rz < 0.f ? 4 : 0);
 		f = s_predf[kb * 8 + bits];
-#if S3D_FACE_T
 		const bool ok = face_test(&s_face[f], rx, ry, rz, b0, b1, b2);
-#else
-		const bool ok = face_test(&s_face[f * kFaceStride], rx, ry, rz, b0, b1, b2);
-#endif
 		slow = !(ok && b0 >= kFastMargin && b1 >= kFastMargin && b2 >= kFastMargin);
 	}
 	if (__any(slow)) {
 		if (slow) f = intersect_scan(rx, ry, rz, b0, b1, b2);
 	}
 	if (!valid || f < 0) return 0.0f;
-#if S3D_DESC_FASTMATH
-	const float mag = __builtin_amdgcn_sqrtf(g2);  // 1 ulp
-#else
 	const float mag = __fsqrt_rn(g2);
-#endif
 	const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
 	const int ix = (int)bx, iy = (int)by, iz = (int)bz;  // truncation toward zero, like the reference: 0..3
 	// Trilinear weights (Src/cSIFT3D.cc:1510-1512 forms them as double products rounded to fp32; fp32 products differ
@@ -237,7 +193,6 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 	const float m0 = ms * b0, m1 = ms * b1, m2 = ms * b2;
 	// cells ix+ddx etc. are >= 0 by construction; only the upper bound can fail (skip cells outside [0,3])
 	const bool okx = ix < 3, oky = iy < 3, okz = iz < 3;
-#if S3D_DESC_SPREAD
 	// step d of this lane is the cell offset d ^ r: weights and cell strides swap roles per axis where the bit of r is set
 	const bool qx = spread & 1, qy = spread & 2, qz = spread & 4;
 	const float ax[2] = {qx ? fx : wx0, qx ? wx0 : fx}, ay[2] = {qy ? fy : wy0, qy ? wy0 : fy}, az[2] = {qz ? fz : wz0, qz ? wz0 : fz};
@@ -265,26 +220,6 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h2) + off), (bin_t)(sbin_t)cvt_rpi(wgt * m2));
 #endif
 	}
-#else
-	const float pxy[4] = {wx0 * wy0, wx0 * fy, fx * wy0, fx * fy};  // index ddx*2 + ddy
-	const int base = (ix + iy * 4 + iz * 16) * 12;
-	bin_t *h0 = hist_rep + (base + s_fidx[f * 4]) * kRep;
-	bin_t *h1 = hist_rep + (base + s_fidx[f * 4 + 1]) * kRep;
-	bin_t *h2 = hist_rep + (base + s_fidx[f * 4 + 2]) * kRep;
-	// a barycentric coordinate can be negative by at most bary_eps (only after the exact face scan): the two's-complement add
-	// handles the sign
-#pragma unroll
-	for (int d = 0; d < 8; d++) {
-		const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;  // dx outer, dz inner (Src/cSIFT3D.cc:1492-1496)
-		if ((ddx && !okx) || (ddy && !oky) || (ddz && !okz)) continue;
-		const float wgt = pxy[ddx * 2 + ddy] * (ddz ? fz : wz0);
-		constexpr int kCell = 12 * kRep;
-		const int off = (ddx + ddy * 4 + ddz * 16) * kCell;  // compile-time: becomes the ds_add immediate offset
-		atomicAdd(h0 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m0));
-		atomicAdd(h1 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m1));
-		atomicAdd(h2 + off, (bin_t)(sbin_t)cvt_rpi(wgt * m2));
-	}
-#endif
 	return mag;
 }
 
@@ -295,19 +230,13 @@ __device__ unsigned long long g_dstamp[64][4][10];
 #else
 #define S3D_DSTAMP(i)
 #endif
-#ifdef S3D_DDIAG  // timing-only builds (wrong results): 1 no histogram adds, 2 no heavy part, 4 / 16 no / only the 16-byte load, 8 no queue
+#ifdef S3D_DDIAG  // timing-only builds (wrong results): 1 no histogram adds, 2 no heavy part, 32 one address per unit column, 64 no outer-row load
 #define S3D_DDIAG_V S3D_DDIAG
-#if (S3D_DDIAG & 20) && (!defined(S3D_DESC_SH) || S3D_DESC_SH > 1)
-#error "S3D_DDIAG bits 4 and 16 need -DS3D_DESC_SH=1"
-#endif
 #else
 #define S3D_DDIAG_V 0
 #endif
-#ifndef S3D_DESC_SORT
-#define S3D_DESC_SORT 1
-#endif
-// Sorted units (S3D_DESC_SORT).  A lane marches two adjacent columns (x, x+1).  A unit is a block of kPX such pairs by kSH rows on
-// kPX * kSH consecutive lanes.  The units of a window -- in chunks of kPairCap pairs, whole unit rows -- are sorted by the length of
+// Sorted units.  A lane marches two adjacent columns (x, x+1).  A unit is a block of kPX such pairs by kSH rows on
+// kPX * kSH consecutive lanes.  The units of a window -- in chunks of kPairCap pairs, row-major -- are sorted by the length of
 // their z range and dealt to the waves 64 lanes at a time, longest first: the lanes of a wave finish together.  (A fixed 16 x 8
 // tiling of the circular footprint leaves 35-45 % of the lane-steps idle: rim tiles march their longest chord with most lanes
 // outside the sphere.  Measured at 512^3, k_describe: tiles 4.92 ms, sorted single pairs 4.71, 1x4 units 4.39, 2x4 units 4.26,
@@ -318,7 +247,7 @@ __device__ unsigned long long g_dstamp[64][4][10];
 #ifndef S3D_DESC_LSHIFT
 #define S3D_DESC_LSHIFT 0
 #endif
-// Units higher than one row (S3D_DESC_SH > 1) march the union of their z ranges in lock step, so the y neighbours of a pair are
+// The lanes of a unit march the union of their z ranges in lock step, so the y neighbours of a pair are
 // the centre values the lanes kPX below / above hold in registers (DPP row shifts); only the first / last row of a unit loads its
 // outer row from memory: two vector-memory instructions per step, the second with a quarter of the lanes, instead of three.  The
 // march is bound by the cache lines its loads touch (timing-only builds, S3D_DDIAG): wider units share the lines of a row.
@@ -330,7 +259,7 @@ __device__ unsigned long long g_dstamp[64][4][10];
 #endif
 constexpr int kPairCap = S3D_DESC_UCAP, kLenBins = 128, kLenShift = S3D_DESC_LSHIFT, kSH = S3D_DESC_SH, kPX = S3D_DESC_PX;
 constexpr int kUL = kPX * kSH;  // lanes of a unit: kPX pairs wide, kSH rows high, row-major on consecutive lanes
-static_assert(kSH >= 1 && kPX >= 1 && kUL <= 16 && (kSH & (kSH - 1)) == 0 && (kPX & (kPX - 1)) == 0, "a unit is a power of two of lanes within a DPP row");
+static_assert(kSH >= 2 && kPX >= 1 && kUL <= 16 && (kSH & (kSH - 1)) == 0 && (kPX & (kPX - 1)) == 0, "a unit is a power of two of lanes within a DPP row");
 // value of the lane below / above in the 16-lane row.  Inline asm and volatile: hipcc sinks __builtin_amdgcn_update_dpp into the
 // branch it makes of a following select, where the source lanes are masked off and the DPP read returns 0.  (s_nop: a VALU
 // write of the source needs two wait states before a DPP read, and the hazard pass does not look into inline asm.)
@@ -367,12 +296,10 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	__shared__ __attribute__((aligned(16))) float s_face[kFaces * kFaceStride];
 	__shared__ int s_fidx[kFaces * 4];
 	__shared__ float red[4];
-#if S3D_DESC_SORT
 	__shared__ unsigned short s_units[kPairCap];  // the non-empty column pairs of the chunk, longest z range first
 	__shared__ unsigned s_chord[kPairCap];        // z ranges of a pair's two columns: (za0, zb0, za1, zb1) - z0, one byte each
 	__shared__ unsigned s_cnt[kLenBins];          // counting sort: pairs per length, then the running start of each length
 	__shared__ unsigned s_nnz;
-#endif
 	const unsigned count = min(d_count[0], cap);
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
@@ -386,11 +313,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		else if (j < 9) v = F.t[j - 6];
 		else if (j < 12) v = F.q[j - 9];
 		else if (j == 12) v = F.qe2;
-#if S3D_FACE_T
 		s_face[j * kFaceT + f] = v;  // j < 16 rows of 20 faces: same 320 floats
-#else
-		s_face[i] = v;
-#endif
 	}
 	for (int i = tid; i < kFaces * 4; i += 256) s_fidx[i] = (i & 3) < 3 ? c_faces[i >> 2].idx[i & 3] * kSV : 0;  // vertex -> its first bin
 	if (tid < 12) s_predn[tid] = c_pred.n[tid / 3][tid % 3];
@@ -400,18 +323,10 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
 #endif
 	float(*q)[kQCap] = s_q[wid];
-#if S3D_DESC_LANEMAP
 	// eight consecutive lanes (voxels that left the march side by side: one unit, mostly one cell) take the eight cell orders and share a
 	// replica; the next eight use the next replica.  Lanes from different units -- different cells -- then never meet on a bank.
 	bin_t *hist_rep = &hist[(lane >> 3) % kRep];
-#else
-	bin_t *hist_rep = &hist[lane % kRep];
-#endif
-#if S3D_DESC_LANEMAP
 	const int spread = lane & 7;
-#else
-	const int spread = (lane / kRep) & 7;
-#endif
 
 	// The accepted keypoints (slot -> extremum list from k_slots) are handed out one at a time through a global counter:
 	// window sizes differ 4x between keypoint levels, so a static deal leaves a long tail.  A partitioned run (multi-GPU
@@ -463,7 +378,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			const float p2 = __uint_as_float(__float_as_uint(q) & 0xFF800000u);
 			return fminf(fmaxf(p2, lut.fix_scale), 536870912.0f);
 		};
-		float fix_scale = S3D_DESC_BIN64 ? 536870912.0f : pick_scale(m_est * 4.0f);
+		float fix_scale = pick_scale(m_est * 4.0f);
 		int x0, x1, y0, y1, z0, z1;
 		win_bounds_d((float)cxi, win_radius, u, L.nx, x0, x1);
 		win_bounds_d((float)cyi, win_radius, u, L.ny, y0, y1);
@@ -538,7 +453,6 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 				if (!(colok[k] && zb[k] >= za[k])) { colok[k] = false; za[k] = 1 << 28; zb[k] = -(1 << 28); }  // empty column
 			}
 		};
-#if S3D_DESC_SORT
 		const int nux = ((wx + 1) / 2 + kPX - 1) / kPX, nuy = (wy + kSH - 1) / kSH;  // units per unit row, unit rows
 		// (z ranges beyond a byte: only with windows far larger than the default parameters')
 		const bool chord_cached = z1 - z0 < 255 && !(dev_flags & 1);
@@ -599,12 +513,6 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		}
 		__syncthreads();
 		const int nnz = (int)s_nnz, ntiles = (nnz * kUL + 63) / 64;
-#else
-		constexpr int kLX = 8, kTH = 8;
-		const int tiles_x = (wx + 2 * kLX - 1) / (2 * kLX), tiles_y = (wy + kTH - 1) / kTH;
-		const int ntiles = ncol > 0 ? tiles_x * tiles_y : 0;
-		{
-#endif
 		// groups of units (or tiles) are handed to the four waves through an LDS counter: they differ several-fold in work, so
 		// a static deal leaves waves idle at the barrier that closes the keypoint
 		for (;;) {
@@ -612,22 +520,15 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			if (lane == 0) tile = (int)atomicAdd(&s_tile, 1u);
 			tile = __builtin_amdgcn_readfirstlane(tile);  // wave-uniform
 			if (tile >= ntiles) break;
-#if S3D_DESC_SORT
 			const int uidx = tile * (64 / kUL) + lane / kUL, spos = lane % kUL;
 			const bool lane_ok = uidx < nnz;
 			const int uu = s_units[lane_ok ? uidx : 0];
 			const int uyi = (u0 + uu) / nux, uxi = (u0 + uu) - uyi * nux;
 			const int lxa = (uxi * kPX + spos % kPX) * 2, ly = uyi * kSH + spos / kPX;
-#else
-			const int ty = tile / tiles_x, tx = tile - ty * tiles_x;  // (a centre-out order, longest chords first, measured no better)
-			const int lxa = tx * 2 * kLX + 2 * (lane % kLX), ly = ty * kTH + (lane / kLX);
-			const bool lane_ok = true;
-#endif
 			const int xa = x0 + lxa, y = y0 + ly;
 			int rr[2], za[2], zb[2];
 			float px[2], py[2], pz[2];
 			bool colok[2];
-#if S3D_DESC_SORT
 			if (chord_cached) {  // block-uniform
 				const unsigned ch = s_chord[uu * kUL + spos];
 				const int dy = y - cyi;
@@ -643,9 +544,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 					za[k] = colok[k] ? z0 + a : 1 << 28; zb[k] = colok[k] ? z0 + b : -(1 << 28);
 				}
 			} else
-#endif
 				setup_pair(lxa, ly, lane_ok, rr, za, zb, px, py, pz, colok);
-#if S3D_DESC_SORT && S3D_DESC_SH > 1
 			// every lane of a strip marches the strip's z range: it holds the y neighbours of the lanes beside it, also where its own
 			// columns are outside the sphere.  Row wy (one past the window) is such a provider; rows beyond it are nobody's neighbour.
 			int zA = min(za[0], za[1]), zB = max(zb[0], zb[1]);
@@ -655,11 +554,6 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			const bool top = spos / kPX == 0, bot = spos / kPX == kSH - 1;
 			// the strip's first lane loads row y-1, its last lane row y+1 (when its own row is inside the window: y+1 <= ny-1)
 			const ptrdiff_t e_off = top ? -(ptrdiff_t)sy : (bot && ly < wy ? (ptrdiff_t)sy : (ptrdiff_t)0);
-#else
-			const bool anycol = colok[0] || colok[1];
-			const int zA = min(za[0], za[1]), zB = max(zb[0], zb[1]);  // the lane marches the union of its two chords
-			const int zlen = anycol ? zB - zA + 1 : 0;
-#endif
 			int maxlen = zlen;
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
@@ -677,27 +571,15 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			f4g rowC = *reinterpret_cast<g4p>(c - 1);         // plane z:   x-1, a, b, x+2
 			f4g rowN = *reinterpret_cast<g4p>(c + sz - 1);    // plane z+1 (centres of both columns in .y .z)
 			f2g cmv = *reinterpret_cast<g2p>(c - sz);         // centres of plane z-1
-#if S3D_DESC_SORT && S3D_DESC_SH > 1
 			f2g edC = f2g{0.f, 0.f};
 			if (top || bot) edC = *reinterpret_cast<g2p>(c + e_off);  // the strip's outer row of plane z
-#else
-			f2g ymC = *reinterpret_cast<g2p>(c - sy), ypC = *reinterpret_cast<g2p>(c + sy);
-#endif
 			int z = zA;
 			for (int step = 0; step < maxlen; step++) {
 				// software pipeline: the row piece of plane z+2 and the y rows of plane z+1 are requested now; clamped addresses stay
 				// inside the planes zA-1 .. zB+1 of the window
 				const bool more = step + 1 < zlen;
 				const gfloat_p cn = more ? c + sz : c;
-#if defined(S3D_DDIAG) && (S3D_DDIAG & 4)  // timing only: no vector-memory instructions in the step
-				f4g rowNN = rowN; f2g ymN = ypC, ypN = ymC;
-				asm volatile("" : "+v"(rowNN.x), "+v"(rowNN.y), "+v"(rowNN.z), "+v"(rowNN.w), "+v"(ymN.x), "+v"(ymN.y), "+v"(ypN.x), "+v"(ypN.y) : "v"(cn));
-#elif defined(S3D_DDIAG) && (S3D_DDIAG & 16)  // timing only: only the 16-byte load
-				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
-				f2g ymN = ypC, ypN = ymC;
-				asm volatile("" : "+v"(ymN.x), "+v"(ymN.y), "+v"(ypN.x), "+v"(ypN.y) : "v"(cn));
-#elif S3D_DESC_SORT && S3D_DESC_SH > 1
-#if S3D_DDIAG_V & 32  // timing only: the four lanes of a strip request ONE address (16 cache lines per instruction instead of 64)
+#if S3D_DDIAG_V & 32  // timing only: the lanes of a unit column request ONE address (fewer cache lines per instruction)
 				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1 - (ptrdiff_t)sy * (spos / kPX));
 #else
 				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
@@ -706,13 +588,9 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 #if !(S3D_DDIAG_V & 64)  // timing only: no outer-row load
 				if (top || bot) edN = *reinterpret_cast<g2p>(cn + e_off);
 #endif
-				// y neighbours of plane z: the centre values of the lanes beside this one (same strip, same plane)
+				// y neighbours of plane z: the centre values of the lanes beside this one (same unit, same plane)
 				const f2g dn = f2g{dpp_from_lane_below<kPX>(rowC.y), dpp_from_lane_below<kPX>(rowC.z)}, up = f2g{dpp_from_lane_above<kPX>(rowC.y), dpp_from_lane_above<kPX>(rowC.z)};
 				const f2g ymC = top ? edC : dn, ypC = bot ? edC : up;
-#else
-				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
-				const f2g ymN = *reinterpret_cast<g2p>(cn - sy), ypN = *reinterpret_cast<g2p>(cn + sy);
-#endif
 				S3D_DSTAMP(2)  // back-edge + issue of the next step's loads
 #if defined(S3D_EXP) && S3D_EXP == 21
 				st_acc[8]++;
@@ -745,18 +623,14 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 					actk[k] = ((int)act & (int)!(g2 < kBaryEps * 0.99f)) != 0;
 					bxk[k] = bx; byk[k] = by; bzk[k] = bz; rxk[k] = gx; ryk[k] = gy; rzk[k] = gz;
 				}
-#if S3D_DESC_SORT && S3D_DESC_SH > 1 && !(S3D_DDIAG_V & 20)
 				cmv = f2g{rowC.y, rowC.z}; rowC = rowN; rowN = rowNN; edC = edN;
-#else
-				cmv = f2g{rowC.y, rowC.z}; rowC = rowN; rowN = rowNN; ymC = ymN; ypC = ypN;
-#endif
 				c = cn; z += more ? 1 : 0;
 				S3D_DSTAMP(3)  // step arithmetic
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
 					// ---- push the active lanes into the wave's queue (compaction by ballot rank) ----
 					const unsigned long long m = __ballot(actk[k]);
-					if (m && !(S3D_DDIAG_V & 8)) {
+					if (m) {
 						if (actk[k]) {
 							const int pos = (qhead + qcount + (int)__popcll(m & ((1ull << lane) - 1ull))) & (kQCap - 1);
 							q[0][pos] = bxk[k]; q[1][pos] = byk[k]; q[2][pos] = bzk[k]; q[3][pos] = rxk[k]; q[4][pos] = ryk[k]; q[5][pos] = rzk[k];
@@ -779,7 +653,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 				}
 			}
 		}
-		}  // chunk of unit rows (S3D_DESC_SORT) / plain block
+		}  // chunk of units
 		if (qcount > 0) {  // drain (wave-uniform)
 			const int pos = (qhead + lane) & (kQCap - 1);
 			const bool valid = lane < qcount;
@@ -795,7 +669,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		__syncthreads();
 		const float mass = ((red[0] + red[1]) + (red[2] + red[3])) * 1.001f;
 		// every bin (and replica) sum is <= mass * fix_scale + half a unit per contribution (< 2^20 contributions)
-		if (S3D_DESC_BIN64 || attempt == 1 || mass * fix_scale + 1048576.0f < 2147483648.0f) {
+		if (attempt == 1 || mass * fix_scale + 1048576.0f < 2147483648.0f) {
 #if defined(S3D_EXP) && S3D_EXP == 6
 			exp_mass = mass; exp_attempts = attempt + 1;
 #endif
