@@ -413,6 +413,8 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		// the centre values, requested two planes ahead, plus the rows y-1 and y+1 (from the lanes beside this one, or an 8-byte load
 		// for the outer rows of a unit; see "Sorted units" above).  (One column per lane: 4 vector-memory instructions per voxel, 7.2 ms.)
 		// chord of the lane's two columns (xa, xa + 1) of window row ly: in-sphere range clipped to the rotated 4x4x4 cube
+		const float rr3[3] = {R2 * u, R5 * u, R8 * u};  // z step of the three rotated coordinates (per keypoint)
+		const float rr3_inv[3] = {__frcp_rn(rr3[0]), __frcp_rn(rr3[1]), __frcp_rn(rr3[2])};
 		auto setup_pair = [&](int lxa, int ly, bool lane_ok, int (&rr)[2], int (&za)[2], int (&zb)[2], float (&px)[2], float (&py)[2],
 		                      float (&pz)[2], bool (&colok)[2]) {
 			const int dy = y0 + ly - cyi;
@@ -428,18 +430,18 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 				za[k] = 0; zb[k] = -1;
 				if (colok[k]) {
 					// in-sphere chord: dz^2 <= nin - rr
-					int h = (int)__fsqrt_rn((float)(nin - rr[k]));
-					while ((h + 1) * (h + 1) <= nin - rr[k]) h++;
-					while (h * h > nin - rr[k]) h--;
+					int h = (int)__fsqrt_rn((float)(nin - rr[k]));  // within 1 of the integer square root (nin < 2^23): one correction each way
+					h += (h + 1) * (h + 1) <= nin - rr[k] ? 1 : 0;
+					h -= h * h > nin - rr[k] ? 1 : 0;
 					za[k] = max(z0, czi - h); zb[k] = min(z1, czi + h);
 					// clip the z range to the rotated 4x4x4 cube (iteration-count optimisation only, widened by S3D_DESC_CLIPM voxels:
 					// the reference's exact fp32 test still runs on every visited voxel)
 					float lo = (float)(za[k] - czi), hi = (float)(zb[k] - czi);
-					const float pr[3] = {px[k], py[k], pz[k]}, rr3[3] = {R2 * u, R5 * u, R8 * u};
+					const float pr[3] = {px[k], py[k], pz[k]};
 #pragma unroll
 					for (int r = 0; r < 3; r++) {
 						if (fabsf(rr3[r]) > 1e-6f * desc_hw) {
-							const float inv = __frcp_rn(rr3[r]);
+							const float inv = rr3_inv[r];
 							const float t0 = (-desc_hw - pr[r]) * inv, t1 = (desc_hw - pr[r]) * inv;
 							lo = fmaxf(lo, fminf(t0, t1) - S3D_DESC_CLIPM);
 							hi = fminf(hi, fmaxf(t0, t1) + S3D_DESC_CLIPM);
