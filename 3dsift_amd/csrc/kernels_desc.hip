@@ -10,31 +10,31 @@
 // reference's eps tolerances) -> barycentric weights; trilinear scatter of |g| into 8 cells x 3
 // face vertices of the 768-bin histogram.  Then L2-normalise, clamp at 0.2*128/768, normalise.
 //
-// MI355X mapping (256 threads per keypoint, window data is L2 resident):
-//   * threads own (x,y) COLUMNS of the window (lanes along x => coalesced) and march along z over the
-//     in-sphere chord only; the centre column is carried in registers (z-1, z, z+1)
+// MI355X mapping (256 threads per keypoint, keypoints handed out through a global counter, large windows first):
+//   * a lane owns two adjacent (x, y) COLUMNS of the window and marches along z over their in-sphere, cube-clipped chord; eight lanes
+//     (2 column pairs x 4 rows) form a unit that marches in lock step, the units of a window are sorted by the length of their z
+//     range and dealt to the four waves longest first ("Sorted units" below)
+//   * per step a lane loads one 16-byte row piece (x-1 .. x+2, two planes ahead); the rows y-1 / y+1 come from the lanes beside it
+//     (DPP row shifts), only the outer rows of a unit from memory; the centre column is carried in registers (z-1, z, z+1)
 //   * the Gaussian weight / in-sphere test come from the host-built table indexed by the integer
 //     squared offset, staged in LDS (bit-identical to the CPU expf; no device exp on the path)
+//   * lane compaction: chords are ragged and many voxels are inactive, so each wave pushes its ACTIVE voxels
+//     (bin coordinates + weighted gradient) into a small LDS queue by ballot rank and runs the heavy part (rotation, face
+//     test, trilinear weights, 24 atomics) only on full 64-lane batches; all loops are wave-uniform
 //   * face lookup: the face is PREDICTED from |g| (4 dot products + sign bits -> table), verified with
 //     the reference's exact Moller-Trumbore arithmetic for that face and accepted only when all three
 //     barycentrics clear a 1e-4 margin (then no other face can pass the reference's -1.19e-6 test, so
 //     "first passing face in mesh order" is this face); otherwise the literal 20-face ordered scan runs
-//   * the 24 products of a voxel go straight to an LDS histogram kept in 32-BIT FIXED POINT and are added with ds_add_u32: on gfx950
+//   * the 24 products of a voxel go to an LDS histogram kept in 32-BIT FIXED POINT and are added with ds_add_u32: on gfx950
 //     an LDS float atomic (ds_add_f32) costs ~190 cycles per wave instruction, ds_add_u32 4.3 + 3.8 per extra lane on the same
 //     address, ds_add_u64 6.4 + 7.5 (scripts/microbench/lds_atomics.hip), and integer sums are order independent, so descriptors
-//     are bitwise reproducible run to run.  The unit 2^-k is chosen per (octave, level) on the host so that no bin can leave the
-//     int32 range for that window size (WinLut::fix_scale; 2^-17 .. 2^-20 for the default scales: the rounding of a contribution
-//     is < 4e-6 absolute, ~1e-5 of a bin sum and far inside the 1e-4 RMS bar).  The fp32 product mag*w*bary is formed exactly like
-//     the reference, scaled by the power of two and converted with one v_cvt_i32_f32 (round to nearest even).  R replicas
-//     (replica = lane & (R-1), bin-major) keep neighbouring lanes that hit the same bin on different addresses; they are summed
-//     once per keypoint
-//   * the four in-plane neighbour loads of the next z step are issued unconditionally one step ahead
-//     (software pipelining; a load behind the activity branch would be waited for at the join)
-//   * lane compaction: chords are ragged and many voxels are inactive, so each wave pushes its ACTIVE voxels
-//     (bin coordinates + rotated gradient) into a small LDS queue by ballot rank and runs the heavy part (face
-//     test, trilinear weights, 24 atomics) only on full 64-lane batches; all loops are wave-uniform
-// Every per-voxel contribution is bit-identical to the reference; only the ORDER of the fp32
-// histogram additions differs, i.e. ~1e-7 relative -- tolerance 1e-4 RMS (BASELINE.json).
+//     are bitwise reproducible whatever the schedule.  The unit 2^-k is chosen PER KEYPOINT from the gradient mass of its window
+//     (estimate first, exact bound and one redo if the estimate was too small; WinLut::fix_scale is the coarsest unit ever used):
+//     a contribution is rounded to < 1e-6 of the mass.  The fp32 product mag*w*bary is formed like the reference, scaled by the
+//     power of two and converted with one v_cvt_rpi_i32_f32.  Four replicas and a per-lane cell order spread the adds over the
+//     banks ("Bank spreading" below); the replicas are summed once per keypoint
+// Every per-voxel contribution equals the reference's up to that rounding; the ORDER of the additions is free (integers).
+// Measured differences to the oracle: 1e-6 .. 4e-6 RMS -- tolerance 1e-4 RMS (BASELINE.json).
 #include <float.h>
 
 #include <stdio.h>
