@@ -8,11 +8,15 @@
 // The reference emits extrema in (octave, level, z, y, x) scan order and the matcher output order
 // depends on it, so instead of an atomic append + sort the scan is made order-preserving.  One launch
 // of each kernel covers the THREE keypoint levels of an octave:
-//   k_mark : block = (level, z, 16 rows) -- a contiguous range in scan order; lanes run along x (coalesced, no
-//            index divisions); each wave stores the 64-bit ballot of its 64 voxels, each block its hit count
+//   k_mark : block = (level, z, kRows rows) -- a contiguous range in scan order; lanes run along x (coalesced, no
+//            index divisions); voxels above the peak threshold are queued per wave and their eight neighbours gathered 64
+//            candidates at a time; each wave stores the 64-bit ballots of its rows, each block its hit count
+//   k_lazy_next : the last Gaussian level of an octave is not built; the candidates of the last keypoint level that passed seven
+//            tests are parked by k_mark and get the missing neighbour value here (one workgroup per candidate)
 //   k_scan : one workgroup turns the block counts into exclusive offsets on top of the running total
 //   k_emit : one thread per ballot word; words with hits (rare) write their extrema at offset + rank
-// No host synchronisation anywhere; the running total stays on the device.
+// k_mark + k_lazy_next of octaves >= 1 may run on a second stream with their own scratch (launch_detect_mark); k_scan + k_emit
+// (launch_detect_emit) run in octave order on one stream.  No host synchronisation anywhere; the running total stays on the device.
 #include <stdio.h>
 #include <stdlib.h>
 

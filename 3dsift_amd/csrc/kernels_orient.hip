@@ -5,12 +5,14 @@
 // sphere r = 3*(1.5*scale) around the extremum on G[octave][level], symmetric 3x3 eigen-decomposition
 // in fp64, eigen-ratio / distinctness / corner rejects, sign alignment, R = [v_max | v_mid | v_max x v_mid].
 //
-// MI355X mapping: the window (<= 25^3 voxels) is L2 resident; lanes sweep (y,x) planes, the Gaussian
-// weight comes from a host-built table indexed by the integer squared offset (bit-identical to the
-// CPU expf, no device exp), the nine fp32 sums are reduced across the wave with DPP shuffles, lane 0
-// runs the fp64 Jacobi eigen-solve.  Per-voxel terms are bit-identical to the reference; only the
-// ORDER of the fp32 additions differs (lane-strided + butterfly instead of sequential), which moves
-// the tensor by ~1e-7 relative -- inside the stated descriptor tolerance (1e-4 RMS).
+// MI355X mapping (k_orient): one wave per extremum, many short workgroups (window volumes differ 3x between the levels).  Three
+// consecutive planes of the window footprint live in the wave's LDS slots (16-byte pieces global -> LDS, the plane after next in
+// flight); the lanes walk the lattice points of the window SPHERE of the plane from a per-level list (WinLut::list_off, entries
+// requested a plane ahead) -- windows larger than the default take the box scan over LDS tiles or global memory.  The Gaussian
+// weight comes from a host-built table indexed by the integer squared offset (bit-identical to the CPU expf, no device exp), the
+// nine fp32 sums are reduced across the wave with shuffles; k_orient_finish runs the fp64 Jacobi eigen-solve with one LANE per
+// extremum.  Per-voxel terms are bit-identical to the reference; only the ORDER of the fp32 additions differs (lane-strided +
+// butterfly instead of sequential), which moves the tensor by ~1e-7 relative -- inside the stated descriptor tolerance (1e-4 RMS).
 #include <float.h>
 
 #include "sift3d_internal.h"
