@@ -356,14 +356,9 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 				const float w = wtab[n];
 				if (w < 0.0f) continue;  // outside the sphere
 				const gfloat_p c = Ld + (size_t)x + sy * (size_t)y + sz * (size_t)(z - L.zoff);
-#if defined(S3D_EXP) && S3D_EXP == 10  // experiment: one load per voxel
-				const float c0 = c[0];
-				float vx = 0.5f * (c0 * 1.1f - c0), vy = 0.5f * (c0 * 1.2f - c0), vz = 0.5f * (c0 * 1.3f - c0);
-#else
 				float vx = 0.5f * (c[1] - c[-1]);
 				float vy = 0.5f * (c[sy] - *(c - sy));
 				float vz = 0.5f * (c[sz] - *(c - sz));
-#endif
 				vx = vx * inv_u; vy = vy * inv_u; vz = vz * inv_u;
 				t00 = t00 + vx * vx * w;
 				t01 = t01 + vx * vy * w;
