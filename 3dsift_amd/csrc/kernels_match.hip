@@ -78,8 +78,8 @@ __device__ __forceinline__ void topk_bubble(float (&bs)[TOPK], int (&bj)[TOPK], 
 // are four consecutive floats of a plain row-major LDS tile (one ds_read_b128).  The summation order over k is free here:
 // the scores only SELECT candidates, k_rescore recomputes them exactly.
 __global__ void __launch_bounds__(256, 2) k_scores_top4(const float *__restrict__ A, const int *__restrict__ row_ids, int nrows,
-                                                        const float *__restrict__ B, int m, int tiles_per_split,
-                                                        Cand *__restrict__ part /*[nrows][gridDim.y][TOPK]*/) {
+                                                        const float *__restrict__ B, int m, int slots,
+                                                        Cand *__restrict__ part /*[nrows][slots][TOPK]*/) {
 	// [A buf0 | A buf1 | B buf0 | B buf1]; after the MFMAs of a tile the same memory holds the tile's 128 x 128 scores
 	__shared__ __attribute__((aligned(16))) float smem[4 * BM * PITCH];
 	float(*As)[BM * PITCH] = reinterpret_cast<float(*)[BM * PITCH]>(smem);
@@ -87,9 +87,22 @@ __global__ void __launch_bounds__(256, 2) k_scores_top4(const float *__restrict_
 	static_assert(4 * 32 * SP <= 4 * BM * PITCH, "score tile must fit the staging buffers");
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 	const int li = lane & 31, lh = lane >> 5;
-	const int row0 = blockIdx.x * BM;
 	const int ntiles = (m + BN - 1) / BN;
-	const int tile_lo = blockIdx.y * tiles_per_split, tile_hi = min(ntiles, tile_lo + tiles_per_split);
+	// The (row block, column tile) pairs, row-block major, are dealt to the workgroups in equal contiguous shares (one residency
+	// round; a share may end in the middle of a row block and go on in the next one): with whole column splits per row block
+	// 89 x 89 tiles gave 445 workgroups of 18 tiles for 512 slots -- now 512 of 15-16.  A row block is covered by at most
+	// `slots` workgroups; each leaves one partial list per row (k_merge_top4 joins them, unused slots stay empty).
+	const long long total = (long long)((nrows + BM - 1) / BM) * ntiles;
+	const long long L0 = (long long)blockIdx.x * total / gridDim.x, L1 = (long long)(blockIdx.x + 1) * total / gridDim.x;
+	for (long long L = L0; L < L1;) {
+	const int rbi = (int)(L / ntiles);
+	const int tile_lo = (int)(L - (long long)rbi * ntiles), tile_hi = (int)min((long long)ntiles, tile_lo + (L1 - L));
+	L += tile_hi - tile_lo;
+	// index of this workgroup among those that cover row block rbi: the first one is the largest w with L0(w) <= rbi * ntiles
+	const long long X = (long long)rbi * ntiles;
+	const int wfirst = (int)(((X + 1) * gridDim.x + total - 1) / total) - 1;
+	const int slot = (int)blockIdx.x - wfirst;
+	const int row0 = rbi * BM;
 
 	// staging: 8 consecutive lanes load one 128-B row piece (32 floats) as float4s; 32 rows per pass, 4 passes
 	const int srow = tid >> 3, spiece = (tid & 7) * 4;
@@ -190,11 +203,12 @@ __global__ void __launch_bounds__(256, 2) k_scores_top4(const float *__restrict_
 		const int oj = __shfl(bj[t], li + 32, 64);
 		if (lane < 32 && oj >= 0) top4_insert(bs, bj, os, oj);
 	}
-	if (lane < 32 && my_row_ok) {
-		Cand *o = part + ((size_t)(row0 + wid * 32 + lane) * gridDim.y + blockIdx.y) * TOPK;
+	if (lane < 32 && my_row_ok && slot < slots) {
+		Cand *o = part + ((size_t)(row0 + wid * 32 + lane) * slots + slot) * TOPK;
 #pragma unroll
 		for (int t = 0; t < TOPK; t++) o[t] = Cand{bs[t], bj[t]};
 	}
+	}  // next row block of this workgroup's share
 }
 
 // merge the per-split partial lists of a row into its global top-4 (score desc, column asc)
@@ -335,13 +349,16 @@ __global__ void __launch_bounds__(256) k_exact_rows(const float *__restrict__ A,
 int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const float *d_b, int m, int *d_cand, void *d_part,
                       float *d_gd, float *d_sd, int *d_gi, int *d_si, const MatchGuard &g, hipStream_t st) {
 	if (nrows <= 0) return SIFT3D_OK;
-	// column splits: as many workgroups as fit ONE residency round (two per CU), never more than the tiles there are
+	// as many workgroups as fit ONE residency round (two per CU), each with an equal share of the (row block, column tile) pairs;
+	// at most kMaxSplits - 1 workgroups per row block (plus the one that straddles its start)
 	const int rb = (nrows + BM - 1) / BM, ntiles = (m + BN - 1) / BN;
-	int splits = std::min(std::min(kMaxSplits, ntiles), std::max(1, (2 * 256) / rb));
-	const int tps = (ntiles + splits - 1) / splits;
-	splits = (ntiles + tps - 1) / tps;
-	hipLaunchKernelGGL(k_scores_top4, dim3(rb, splits), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, tps, (Cand *)d_part);
-	hipLaunchKernelGGL(k_merge_top4, dim3((nrows + 255) / 256), dim3(256), 0, st, (const Cand *)d_part, nrows, splits, d_cand, g.s4);
+	const long long total = (long long)rb * ntiles;
+	const int nwg = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(2 * 256, total), (long long)(kMaxSplits - 1) * rb));
+	// workgroups that can touch one row block: those starting inside it plus the one running into it
+	const int slots = std::min(kMaxSplits, (int)(((long long)ntiles * nwg + total - 1) / total) + 1);
+	(void)hipMemsetAsync(d_part, 0xFF, sizeof(Cand) * (size_t)TOPK * slots * nrows, st);  // j = -1: empty
+	hipLaunchKernelGGL(k_scores_top4, dim3(nwg), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, slots, (Cand *)d_part);
+	hipLaunchKernelGGL(k_merge_top4, dim3((nrows + 255) / 256), dim3(256), 0, st, (const Cand *)d_part, nrows, slots, d_cand, g.s4);
 	(void)hipMemsetAsync(g.redo, 0, sizeof(int), st);
 	hipLaunchKernelGGL(k_rescore, dim3((nrows + 3) / 4), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, d_cand, d_gd, d_sd, d_gi, d_si,
 	                   g.s4, g.a_n2, g.b_n2max, g.redo);
