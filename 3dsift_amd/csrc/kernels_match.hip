@@ -19,6 +19,7 @@
 // gfx950 only: 64-lane waves, MFMA C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include <float.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -77,6 +78,21 @@ __device__ __forceinline__ void topk_bubble(float (&bs)[TOPK], int (&bj)[TOPK], 
 // lanes 0-31 feed k = s, lanes 32-63 feed k = s + 16 of the 32-wide chunk, so a lane's operands for four consecutive steps
 // are four consecutive floats of a plain row-major LDS tile (one ds_read_b128).  The summation order over k is free here:
 // the scores only SELECT candidates, k_rescore recomputes them exactly.
+// LDS-DMA: lane l's 16 bytes at base + voff land at lds_dst + 16*l (global_load_lds_dwordx4).  M0 carries the wave-uniform LDS byte
+// address (restored).  Counted by vmcnt like any load.
+__device__ __forceinline__ void x_dma16(const float *base, unsigned voff, unsigned lds_dst) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+
+// DMA = true (every byte offset into A and B fits 32 bits): the 32-wide k chunks travel global -> LDS by LDS-DMA instead of through
+// registers (no staging registers, no ds_write, no VALU).  A wave's instruction fills 8 rows x 128 B contiguously, so the rows are
+// NOT padded; instead the 16-byte piece g of tile row r is stored at slot g ^ ((r >> 1) & 7) -- the lane that owns slot c of row r
+// simply requests piece c ^ ((r >> 1) & 7) -- which makes the ds_read_b128 fragment reads of 16 consecutive rows hit the 16
+// distinct 4-bank groups (also in the lane groups the hardware serves a b128 read in).  Rows / columns past the end request row 0:
+// their scores are never looked at.
+template <bool DMA>
 __global__ void __launch_bounds__(256, 2) k_scores_top4(const float *__restrict__ A, const int *__restrict__ row_ids, int nrows,
                                                         const float *__restrict__ B, int m, int slots,
                                                         Cand *__restrict__ part /*[nrows][slots][TOPK]*/) {
@@ -112,6 +128,17 @@ __global__ void __launch_bounds__(256, 2) k_scores_top4(const float *__restrict_
 		const int r = row0 + srow + 32 * p;
 		Ap[p] = r < nrows ? A + (size_t)(row_ids ? row_ids[r] : r) * KD + spiece : nullptr;
 	}
+	// DMA staging: byte offset of this lane's piece of tile row srow + 32 p (k = 0) and the LDS address of the wave's 8-row slab
+	const unsigned swz = (unsigned)((tid & 7) ^ ((srow >> 1) & 7)) * 16u;  // (row + 32 p) >> 1 has the same low three bits
+	unsigned aoff[4];
+#pragma unroll
+	for (int p = 0; p < 4; p++) {
+		const int r = row0 + srow + 32 * p;
+		aoff[p] = (unsigned)(r < nrows ? (row_ids ? row_ids[r] : r) : (row_ids ? row_ids[0] : 0)) * (unsigned)(KD * 4) + swz;
+	}
+	const unsigned lds_a = (unsigned)(unsigned long long)&As[0][0], lds_b = (unsigned)(unsigned long long)&Bs[0][0];
+	const unsigned slab = (unsigned)__builtin_amdgcn_readfirstlane(wid) * (8u * 32u * 4u);  // this wave's rows 8 wid .. 8 wid + 7 of a 32-row pass
+	const unsigned fswz = (unsigned)((li >> 1) & 7);  // fragment reads: tile rows wid*32 + li and li + 32 nb share (row >> 1) & 7
 	float bs[TOPK];
 	int bj[TOPK];
 #pragma unroll
@@ -147,29 +174,55 @@ __global__ void __launch_bounds__(256, 2) k_scores_top4(const float *__restrict_
 				*reinterpret_cast<f32x4 *>(&Bs[buf][(srow + 32 * p) * PITCH + spiece]) = pb[p];
 			}
 		};
-		fetch(0);
-		__syncthreads();  // every wave is done with both buffers of the previous tile
-		stash(0);
-		__syncthreads();
+		unsigned boff[4];
+#pragma unroll
+		for (int p = 0; p < 4; p++) {
+			const int c = col0 + srow + 32 * p;
+			boff[p] = (unsigned)(c < m ? c : 0) * (unsigned)(KD * 4) + swz;
+		}
+		auto dma = [&](int buf, int k0) {  // chunk k0 .. k0 + 31 of both tiles -> buffer buf
+#pragma unroll
+			for (int p = 0; p < 4; p++) {
+				x_dma16(A, aoff[p] + (unsigned)(k0 * 4), lds_a + (unsigned)(buf * BM * PITCH * 4) + (unsigned)(p * 32 * 32 * 4) + slab);
+				x_dma16(B, boff[p] + (unsigned)(k0 * 4), lds_b + (unsigned)(buf * BN * PITCH * 4) + (unsigned)(p * 32 * 32 * 4) + slab);
+			}
+		};
 		constexpr int NCH = KD / BK;
+		if (DMA) {
+			__syncthreads();  // every wave is done with both buffers (and the score tile) of the previous tile
+			dma(0, 0);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__syncthreads();
+		} else {
+			fetch(0);
+			__syncthreads();  // every wave is done with both buffers of the previous tile
+			stash(0);
+			__syncthreads();
+		}
 		for (int ch = 0; ch < NCH; ch++) {
 			const int buf = ch & 1;
-			if (ch + 1 < NCH) fetch((ch + 1) * BK);  // in flight during the MFMAs of this chunk
-			const float *ar = &As[buf][(wid * 32 + li) * PITCH + lh * 16];
-			const float *br = &Bs[buf][li * PITCH + lh * 16];
+			if (ch + 1 < NCH) {  // in flight during the MFMAs of this chunk (the other buffer was last read in chunk ch-1, a barrier ago)
+				if (DMA) dma(buf ^ 1, (ch + 1) * BK);
+				else fetch((ch + 1) * BK);
+			}
+			constexpr int RP = DMA ? 32 : PITCH;  // row pitch of the staged tiles
+			const float *ar = &As[buf][(wid * 32 + li) * RP];
+			const float *br = &Bs[buf][li * RP];
 #pragma unroll
 			for (int q = 0; q < 4; q++) {
-				const f32x4 a4 = *reinterpret_cast<const f32x4 *>(ar + 4 * q);
+				const int po = DMA ? (int)((((unsigned)lh << 2 | (unsigned)q) ^ fswz) * 4u) : lh * 16 + 4 * q;  // piece lh*4 + q of the row
+				const f32x4 a4 = *reinterpret_cast<const f32x4 *>(ar + po);
 				f32x4 b4[4];
 #pragma unroll
-				for (int nb = 0; nb < 4; nb++) b4[nb] = *reinterpret_cast<const f32x4 *>(br + nb * 32 * PITCH + 4 * q);
+				for (int nb = 0; nb < 4; nb++) b4[nb] = *reinterpret_cast<const f32x4 *>(br + nb * 32 * RP + po);
 #pragma unroll
 				for (int e = 0; e < 4; e++)
 #pragma unroll
 					for (int nb = 0; nb < 4; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[nb][e], acc[nb], 0, 0, 0);
 			}
 			if (ch + 1 < NCH) {
-				stash(buf ^ 1);   // the other buffer was last read in chunk ch-1, a barrier ago
+				if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				else stash(buf ^ 1);
 				__syncthreads();
 			}
 		}
@@ -357,7 +410,12 @@ int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const f
 	// workgroups that can touch one row block: those starting inside it plus the one running into it
 	const int slots = std::min(kMaxSplits, (int)(((long long)ntiles * nwg + total - 1) / total) + 1);
 	(void)hipMemsetAsync(d_part, 0xFF, sizeof(Cand) * (size_t)TOPK * slots * nrows, st);  // j = -1: empty
-	hipLaunchKernelGGL(k_scores_top4, dim3(nwg), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, slots, (Cand *)d_part);
+	// (the DMA form addresses A and B with 32-bit byte offsets; row_ids index the caller's whole A, whose size is not known here:
+	// the caller says whether both matrices stay below 4 GB)
+	if (g.small_offsets)
+		hipLaunchKernelGGL(k_scores_top4<true>, dim3(nwg), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, slots, (Cand *)d_part);
+	else
+		hipLaunchKernelGGL(k_scores_top4<false>, dim3(nwg), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, slots, (Cand *)d_part);
 	hipLaunchKernelGGL(k_merge_top4, dim3((nrows + 255) / 256), dim3(256), 0, st, (const Cand *)d_part, nrows, slots, d_cand, g.s4);
 	(void)hipMemsetAsync(g.redo, 0, sizeof(int), st);
 	hipLaunchKernelGGL(k_rescore, dim3((nrows + 3) / 4), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, d_cand, d_gd, d_sd, d_gi, d_si,
@@ -437,7 +495,10 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 		MCHK(hipMemsetAsync(d_nmax, 0, 2 * sizeof(unsigned), nullptr));
 		if (n) hipLaunchKernelGGL(k_row_norm2, dim3((n + 3) / 4), dim3(256), 0, nullptr, d_a, n, d_an2, d_nmax);
 		if (m) hipLaunchKernelGGL(k_row_norm2, dim3((m + 3) / 4), dim3(256), 0, nullptr, d_b, m, d_bn2, d_nmax + 1);
-		const MatchGuard g_fwd{d_s4, d_an2, d_nmax + 1, d_redo}, g_rev{d_s4, d_bn2, d_nmax, d_redo};
+		// (S3D_MATCH_NODMA=1: the register-staged form, which matrices of 4 GB and more take, on any size -- for tests)
+		static const bool no_dma = [] { const char *e = getenv("S3D_MATCH_NODMA"); return e && e[0] == '1'; }();
+		const bool small = !no_dma && (size_t)std::max(n, m) * KD * sizeof(float) < ((size_t)1 << 32);
+		const MatchGuard g_fwd{d_s4, d_an2, d_nmax + 1, d_redo, small}, g_rev{d_s4, d_bn2, d_nmax, d_redo, small};
 		MCHK(hipEventCreate(&e0));
 		MCHK(hipEventCreate(&e1));
 		MCHK(hipEventRecord(e0, nullptr));

@@ -212,7 +212,10 @@ void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, in
 // d_part: scratch for the per-column-split partial top-4 lists, 8 B * 4 * 16 * nrows
 // near-tie guard scratch (see kernels_match.hip): s4[nrows], squared norms of the A rows (indexed by ORIGINAL row id), the maximal
 // squared norm of the B rows (bits), redo list [1 + nrows]
-struct MatchGuard { float *s4; const float *a_n2; const unsigned *b_n2max; int *redo; };
+struct MatchGuard {
+	float *s4; const float *a_n2; const unsigned *b_n2max; int *redo;
+	bool small_offsets = false;  // both descriptor matrices are smaller than 4 GB: k_scores_top4 may stage them by LDS-DMA (32-bit offsets)
+};
 int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const float *d_b, int m, int *d_cand /*nrows*4*/,
                       void *d_part, float *d_gd, float *d_sd, int *d_gi, int *d_si, const MatchGuard &g, hipStream_t st);
 
