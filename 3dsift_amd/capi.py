@@ -43,7 +43,11 @@ SYMBOLS = [
     "sift3d_export_device", "sift3d_import_descriptors_device", "sift3d_run_partial_orientation",
     "sift3d_export_orientation_device", "sift3d_import_orientation_device", "sift3d_run_describe",
     "sift3d_set_stream", "sift3d_slab_export_dogmax_device", "sift3d_slab_import_dogmax_device", "sift3d_slab_decimate_async",
+    # test hooks / debug accessors / matcher timing
+    "sift3d_test_hook", "sift3d_debug_counters", "sift3d_debug_face_lookup", "sift3d_match_times", "sift3d_debug_copy_bandwidth",
 ]
+HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "desc_nocache": 4, "match_nodma": 5, "one_stream": 6,
+         "desc_mass_shift": 7, "list_cap": 8}
 ORIENT_WORDS = 34
 
 
@@ -130,10 +134,20 @@ def lib():
         L.sift3d_import_orientation_device.argtypes = [C.c_void_p, C.c_void_p]
         L.sift3d_run_describe.argtypes = [C.c_void_p]
         L.sift3d_import_descriptors_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_test_hook.argtypes = [C.c_int, C.c_int]
+        L.sift3d_debug_counters.argtypes = [C.c_void_p, _ip]
+        L.sift3d_debug_face_lookup.argtypes = [_fp, C.c_int, C.c_int, _ip, _fp, C.c_int]
+        L.sift3d_debug_copy_bandwidth.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.sift3d_match_times.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.sift3d_error_string.argtypes = [C.c_int]
         L.sift3d_error_string.restype = C.c_char_p
         L.sift3d_last_error.restype = C.c_char_p
         _lib = L
+        # measurement scripts: S3D_HOOKS="one_stream=1,det_serial=1" sets test hooks of the library from the environment of the
+        # PYTHON driver (the library itself never reads the environment)
+        for item in filter(None, os.environ.get("S3D_HOOKS", "").split(",")):
+            k, _, v = item.partition("=")
+            L.sift3d_test_hook(HOOKS[k.strip()], int(v or 1))
     return _lib
 
 
@@ -160,6 +174,36 @@ def kernel_source_sha():
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+class hook:
+    """with capi.hook("list_cap", 64): ...  -- sets a test hook of the library (include/sift3d_hip.h) and restores it"""
+
+    def __init__(self, name, value):
+        self.which, self.value = HOOKS[name], int(value)
+
+    def __enter__(self):
+        self.prev = lib().sift3d_test_hook(self.which, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        lib().sift3d_test_hook(self.which, self.prev)
+        return False
+
+
+def copy_bandwidth(nbytes=1 << 30, iters=5, device=0):
+    """GB/s of the library's float4 device copy kernel (read + write)"""
+    g = C.c_double(0)
+    _check(lib().sift3d_debug_copy_bandwidth(nbytes, iters, device, C.byref(g)))
+    return g.value
+
+
+def face_lookup(grad3, route=0, device=0):
+    """Check_intersect_faces of k_describe on [n, 3] gradients: (face [n] int32, bary [n, 3]); route 0 predicted+verified, 1 literal scan"""
+    g = np.ascontiguousarray(grad3, np.float32).reshape(-1, 3)
+    face = np.zeros(len(g), np.int32); bary = np.zeros((len(g), 3), np.float32)
+    _check(lib().sift3d_debug_face_lookup(_f(g), len(g), int(route), face.ctypes.data_as(_ip), _f(bary), device))
+    return face, bary
 
 
 def device_count():
@@ -278,6 +322,16 @@ class CSIFT3D:
         _check(lib().sift3d_device_results(self._h, C.byref(d), C.byref(x), C.byref(n)))
         return d.value, x.value, n.value
 
+    def export_device(self, desc_ptr, xyz_ptr=None):
+        """D2D copy of the results into caller-owned device buffers (n*768, n*3 floats)"""
+        _check(lib().sift3d_export_device(self._h, C.c_void_p(int(desc_ptr)), C.c_void_p(int(xyz_ptr)) if xyz_ptr else None))
+
+    def debug_counters(self):
+        """{list_regrows, desc_second_passes, match_exact_rows}: how often the rare paths ran (sift3d_debug_counters)"""
+        a = (C.c_int * 4)()
+        _check(lib().sift3d_debug_counters(self._h, a))
+        return {"list_regrows": a[0], "desc_second_passes": a[1], "match_exact_rows": a[2]}
+
 
 def _params(kw):
     return Params(kw.get("num_kp_levels", 3), kw.get("sigma_default", 1.6), kw.get("sigma_n_default", 1.15),
@@ -328,9 +382,6 @@ class SeededCSIFT3D(CSIFT3D):
         n = C.c_int(0)
         _check(lib().sift3d_num_extrema(self._h, C.byref(n)))
         return n.value
-
-    def export_device(self, desc_ptr, xyz_ptr=None):
-        _check(lib().sift3d_export_device(self._h, C.c_void_p(int(desc_ptr)), C.c_void_p(int(xyz_ptr)) if xyz_ptr else None))
 
     def import_descriptors(self, desc_ptr):
         _check(lib().sift3d_import_descriptors_device(self._h, C.c_void_p(int(desc_ptr))))
@@ -447,7 +498,9 @@ class muBruteMatcher:
 
     def __init__(self, device=0):
         self.device = device
-        self.totalTime = 0.0
+        self.totalTime = 0.0   # device time of the last call (HIP events on the matcher's stream)
+        self.wallTime = 0.0    # host clock around the last call
+        self.exact_rows = 0    # rows the near-tie guard re-scored exactly in the last call
         self._last = None
 
     def _match(self, ref_desc, ref_xyz, tar_desc, tar_xyz, thresHold, mode, on_device=False, n=None, m=None):
@@ -467,6 +520,12 @@ class muBruteMatcher:
         _check(L.sift3d_match(pa, px, n, pb, py, m, float(thresHold), int(mode), int(bool(on_device)), self.device,
                               gi.ctypes.data_as(_ip), si.ctypes.data_as(_ip), _f(gd), _f(sd), _f(pairs), C.byref(k), C.byref(sec)))
         self.totalTime = sec.value
+        dv = C.c_double(0); wl = C.c_double(0)
+        L.sift3d_match_times(C.byref(dv), C.byref(wl))
+        self.wallTime = wl.value
+        a = (C.c_int * 4)()
+        L.sift3d_debug_counters(None, a)
+        self.exact_rows = a[2]
         self._last = dict(gIdx=gi[:n], sIdx=si[:n], gDist=gd[:n], sDist=sd[:n], pairs=pairs[:k.value].copy())
         return self._last
 

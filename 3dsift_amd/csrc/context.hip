@@ -20,6 +20,24 @@ namespace s3d {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &s) { g_last_error = s; }
 
+// test hooks (include/sift3d_hip.h) and development switches (sift3d_internal.h)
+static int g_hooks[SIFT3D_HOOK_COUNT] = {0};
+int hook(int which) { return which >= 0 && which < SIFT3D_HOOK_COUNT ? g_hooks[which] : 0; }
+#ifdef S3D_DEV_SWITCHES
+// measurement builds only (scripts/build_variant.sh): the old environment switches
+int dev_tune_i(const char *env_name, int dflt) { const char *e = getenv(env_name); return e ? atoi(e) : dflt; }
+double dev_tune_d(const char *env_name, double dflt) { const char *e = getenv(env_name); return e ? atof(e) : dflt; }
+static const bool g_env_hooks = [] {
+	static const char *names[SIFT3D_HOOK_COUNT] = {"S3D_DOG_EAGER", "S3D_GLAST_EAGER", "S3D_DET_SERIAL", "S3D_SEPARABLE", "S3D_DESC_NOCACHE",
+	                                               "S3D_MATCH_NODMA", "S3D_ONE_STREAM", "S3D_DESC_MASS_SHIFT", "S3D_LIST_CAP"};
+	for (int i = 0; i < SIFT3D_HOOK_COUNT; i++) { const char *e = getenv(names[i]); if (e) g_hooks[i] = atoi(e); }
+	return true;
+}();
+#else
+int dev_tune_i(const char *, int dflt) { return dflt; }
+double dev_tune_d(const char *, double dflt) { return dflt; }
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // host-side constant builders (each mirrors a reference routine; same fp32/fp64 mix)
 // ---------------------------------------------------------------------------------------------
@@ -189,7 +207,8 @@ struct sift3d_ctx {
 	std::vector<Taps> taps;  // per GSS level index within an octave
 	Taps base_taps{};
 
-	bool use_fused = true;  // S3D_SEPARABLE=1 forces the generic three-pass kernels (A/B + parity cross-check)
+	bool use_fused = true;  // SIFT3D_HOOK_SEPARABLE forces the generic three-pass kernels (parity cross-check)
+	int n_regrow = 0, n_desc_redo = 0;  // sift3d_debug_counters: list regrows / second descriptor passes of the last run
 
 	// results / state
 	int stage = 0;  // highest stage run
@@ -243,6 +262,13 @@ static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
 		}
 	}
 	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_test_hook(int which, int value) {
+	if (which < 0 || which >= SIFT3D_HOOK_COUNT) return -1;
+	const int prev = g_hooks[which];
+	g_hooks[which] = value;
+	return prev;
 }
 
 extern "C" void sift3d_default_params(sift3d_params *p) {
@@ -442,7 +468,7 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	c->nx = cfg.nx; c->ny = cfg.ny; c->nz = cfg.nz;
 	c->octave_base = cfg.octave_base; c->seeded = cfg.seeded;
 	c->slab = cfg.slab; c->own0 = cfg.z0; c->own1 = cfg.z1; c->halo = cfg.halo;
-	{ const char *e = getenv("S3D_SEPARABLE"); c->use_fused = !(e && e[0] == '1'); }
+	c->use_fused = !hook(SIFT3D_HOOK_SEPARABLE);
 	plan_pyramid(c, cfg.noct_total);
 	c->in.nx = cfg.nx; c->in.ny = cfg.ny; c->in.nz = cfg.nz; c->in.unit = (float)(1 << c->octave_base); c->in.scale = 1.f;
 	if (c->slab) { c->in.bz = c->own1 - c->own0 + 2 * c->halo; c->in.zoff = c->own0 - c->halo; }
@@ -467,8 +493,8 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	c->ev_done.assign(c->ostream.size(), nullptr);
 	c->own_stream = c->stream;
 	c->ostream[0] = c->stream;
-	// S3D_ONE_STREAM=1 (profiling): every octave on the main stream, so a kernel trace shows isolated launch durations
-	const bool one_stream = [] { const char *e = getenv("S3D_ONE_STREAM"); return e && e[0] == '1'; }();
+	// SIFT3D_HOOK_ONE_STREAM (profiling): every octave on the main stream, so a kernel trace shows isolated launch durations
+	const bool one_stream = hook(SIFT3D_HOOK_ONE_STREAM) != 0;
 	for (size_t o = 0; o < c->ostream.size(); o++) {
 		if (o > 0 && one_stream) c->ostream[o] = c->stream;
 		else if (o > 0) CHECKED(hipStreamCreateWithFlags(&c->ostream[o], hipStreamNonBlocking));
@@ -498,7 +524,7 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	for (auto &L : c->gss) { L.d = p; p += al64(L.n()); }
 	for (auto &L : c->dog) { L.d = p; p += al64(L.n()); }
 
-	const size_t nwords = 1 + (size_t)std::max(1, c->noct * c->nd) + 4;
+	const size_t nwords = 1 + (size_t)std::max(1, c->noct * c->nd) + 8;  // ... + total, overflow, nkp, describe work counter, describe redo counter, orientation redo counter
 	CHECKED(hipMalloc(&c->d_words, sizeof(unsigned) * nwords));
 	CHECKED(hipMemset(c->d_words, 0, sizeof(unsigned) * nwords));
 	c->d_inmax = c->d_words;
@@ -518,7 +544,7 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	}
 	c->det.total = c->d_total;
 	{
-		static const bool det_serial = [] { const char *e = getenv("S3D_DET_SERIAL"); return e && e[0] == '1'; }();
+		const bool det_serial = hook(SIFT3D_HOOK_DET_SERIAL) != 0;
 		if (!c->slab && c->noct > 1 && !det_serial && c->ostream.size() > 1 && c->ostream[1] != c->stream) {
 			const size_t kl = (size_t)c->p.num_kp_levels;
 			c->det_o.assign((size_t)c->noct, DetectBufs{});
@@ -563,6 +589,7 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	// keypoint lists: synthetic blob volumes give ~6e-4*V extrema; leave 8x headroom, regrow on overflow
 	const size_t V0 = (size_t)cfg.nx * cfg.ny * scan_planes;
 	unsigned cap = (unsigned)std::min<size_t>(std::max<size_t>(4096, V0 / 256), 4u << 20);
+	if (hook(SIFT3D_HOOK_LIST_CAP) > 0) cap = (unsigned)hook(SIFT3D_HOOK_LIST_CAP);  // tests: overflow -> regrow -> rerun
 	rc = alloc_lists(c, cap);
 	if (rc) { sift3d_destroy(c); return rc; }
 	CHECKED(hipStreamSynchronize(c->stream));
@@ -582,7 +609,9 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 	sift3d_ctx *c = *out;
 	// ---- constructor work proper: copy + data_scale (Src/cSIFT3D.cc:161-162) ----
 	const size_t V0 = (size_t)nx * ny * nz;
-	hipError_t e = hipMemcpyAsync(c->in.d, volume, sizeof(float) * V0, volume_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream);
+	hipError_t e = hipSuccess;
+	if (volume_on_device) e = hipMemcpyAsync(c->in.d, volume, sizeof(float) * V0, hipMemcpyDeviceToDevice, c->stream);
+	else if ((rc = staged_h2d(c->in.d, volume, sizeof(float) * V0, device, c->stream)) != SIFT3D_OK) { sift3d_destroy(c); *out = nullptr; return rc; }
 	if (e == hipSuccess) {
 		launch_absmax(c->in.d, V0, c->d_inmax, c->stream);
 		launch_scale_by_max(c->in.d, V0, c->d_inmax, c->stream);
@@ -609,16 +638,16 @@ static void smooth_level(sift3d_ctx *c, int o, const float *src, const Level &ds
 	// Slot planning across the octave streams (single-round launches keep every slot they take until they end): the levels of
 	// octave 0 behind the seed level G[0][num_kp_levels] leave a third of the machine to the chains of the smaller octaves, which
 	// are planned for that third; otherwise those chains starve and run as a tail after octave 0 has finished.
-	static const int tail_slots = [] { const char *e = getenv("S3D_O0_TAIL_SLOTS"); return e ? atoi(e) : S3D_O0_TAIL_SLOTS_DEFAULT; }();
-	static const int bg_slots = [] { const char *e = getenv("S3D_BG_SLOTS"); return e ? atoi(e) : S3D_BG_SLOTS_DEFAULT; }();
+	static const int tail_slots = dev_tune_i("S3D_O0_TAIL_SLOTS", S3D_O0_TAIL_SLOTS_DEFAULT);
+	static const int bg_slots = dev_tune_i("S3D_BG_SLOTS", S3D_BG_SLOTS_DEFAULT);
 	// wave priority: the launches of octaves >= 2 (1/64 of the work, but each octave waits for level 3 of the one above, and beside the
 	// big launches their workgroups crawl) run at the highest wave priority: 2.82 -> 2.71 ms per 512^3 pyramid.  Raising octave 1 too
 	// (S3D_PRIO=1) costs octave 0 as much as it gains.
-	static const int prio_mode = [] { const char *e = getenv("S3D_PRIO"); return e ? atoi(e) : 2; }();
+	static const int prio_mode = dev_tune_i("S3D_PRIO", 2);
 	const int prio = (prio_mode && c->noct > 1) ? (o >= 2 ? 2 : (o == 1 && prio_mode == 1 ? 1 : 0)) : 0;
 	const int plan_slots = c->noct > 1 ? (o == 0 ? (level > c->p.num_kp_levels ? tail_slots : 0) : bg_slots) : 0;
 	// hot path: one fused pass (x, y, z blur + DoG + abs-max); prev == src for every DoG-producing level
-	static const int fused_min = [] { const char *e = getenv("S3D_FUSED_MIN"); return e ? atoi(e) : S3D_FUSED_MIN_DEFAULT; }();
+	static const int fused_min = dev_tune_i("S3D_FUSED_MIN", S3D_FUSED_MIN_DEFAULT);
 	if (c->use_fused && (prev == nullptr || prev == src) && std::min(dst.nx, std::min(dst.ny, dst.nz)) >= fused_min &&
 	    launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.zr_all(), t, st, plan_slots, prio))
 		return;
@@ -634,16 +663,17 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 	if (upto < 1) upto = 1;
 	if (upto > 5) upto = 5;
 	hipStream_t st = c->stream;
-	// S3D_DOG_EAGER=1: write every DoG level (A/B; the z-slab path always does)
-	static const bool dog_eager = [] { const char *e = getenv("S3D_DOG_EAGER"); return e && e[0] == '1'; }();
+	// SIFT3D_HOOK_DOG_EAGER: write every DoG level
+	const bool dog_eager = hook(SIFT3D_HOOK_DOG_EAGER) != 0;
 	c->dog_elide = !dog_eager && c->nd >= 3;
 	// the last Gaussian level is only ever read at the voxels that pass seven of the eight extremum tests of the last keypoint level:
-	// it is not built at all; those voxels get the value from k_lazy_next (DetectLevels::lazy_src).  S3D_GLAST_EAGER=1 builds it.
-	static const bool glast_eager = [] { const char *e = getenv("S3D_GLAST_EAGER"); return e && e[0] == '1'; }();
+	// it is not built at all; those voxels get the value from k_lazy_next (DetectLevels::lazy_src).  SIFT3D_HOOK_GLAST_EAGER builds it.
+	const bool glast_eager = hook(SIFT3D_HOOK_GLAST_EAGER) != 0;
 	c->g_last_elide = c->dog_elide && !glast_eager && c->use_fused && 2 * (2 * c->taps[c->ng - 1].hw + 1) <= kLazySlots;
 	c->g_last_built.assign((size_t)std::max(1, c->noct), 0);
-	for (int attempt = 0; attempt < 4; attempt++) {
-		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(std::max(1, c->noct * c->nd) + 4), st));
+	c->n_regrow = 0;
+	for (int attempt = 0; attempt < 8; attempt++) {
+		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(std::max(1, c->noct * c->nd) + 6), st));
 		S3D_HIP(hipEventRecord(c->ev[0], st));
 		// ---- Build_Gaussian_Scale_Space (Src/cSIFT3D.cc:268-319) with the DoG (346-360) fused into the z pass ----
 		// fork: every octave stream starts after the main stream reached this point; octave o is seeded by
@@ -723,7 +753,7 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		// ---- Assign_Orientation (Src/cSIFT3D.cc:427-482) ----
 		if (upto >= 4) {
 			launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
-			              c->p.corner_thresh, part_orient ? c->part_rank : 0, part_orient ? c->part_world : 1, st);
+			              c->p.corner_thresh, part_orient ? c->part_rank : 0, part_orient ? c->part_world : 1, c->d_order, c->d_nkp + 3, st);
 			launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, st);
 		}
 		S3D_HIP(hipEventRecord(c->ev[4], st));
@@ -734,19 +764,22 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		}
 		if (upto >= 4) launch_finalize(c->d_ext, c->d_total, c->ext_cap, upto >= 5, c->d_kpout, c->d_xyz, c->kp_cap, st);
 		S3D_HIP(hipEventRecord(c->ev[5], st));
-		unsigned host_words[3] = {0, 0, 0};  // total, overflow, nkp
-		S3D_HIP(hipMemcpyAsync(host_words, c->d_total, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, st));
+		unsigned host_words[5] = {0, 0, 0, 0, 0};  // total, overflow, nkp, describe work counter, describe second passes
+		S3D_HIP(hipMemcpyAsync(host_words, c->d_total, sizeof(unsigned) * 5, hipMemcpyDeviceToHost, st));
 		S3D_HIP(hipStreamSynchronize(st));
 		S3D_HIP(hipGetLastError());
 		if (host_words[1] != 0 || host_words[0] > c->ext_cap) {
-			// list overflow: regrow to fit and rerun (rare; sizes are generous)
+			// list overflow: regrow to fit and rerun (rare; sizes are generous).  The detection kernels keep counting past the
+			// capacity, so host_words[0] is the number of extrema of the volume (short of candidates dropped from a full parking list).
 			const unsigned need = std::max(host_words[0], c->ext_cap) * 2u;
 			rc = alloc_lists(c, need);
 			if (rc) return rc;
+			c->n_regrow++;
 			continue;
 		}
 		c->n_ext = host_words[0];
 		c->n_kp = upto >= 4 ? host_words[2] : 0;
+		c->n_desc_redo = upto >= 5 ? (int)host_words[4] : 0;
 		c->stage = upto;
 		float ms = 0;
 		auto dt = [&](int a, int b) { hipEventElapsedTime(&ms, c->ev[a], c->ev[b]); return (double)ms * 1e-3; };
@@ -786,11 +819,10 @@ extern "C" int sift3d_get_keypoints(sift3d_handle c, sift3d_keypoint *out, float
 	if (c->stage < 4 || c->n_kp == 0) return SIFT3D_OK;
 	int rc = set_device(c->device);
 	if (rc) return rc;
-	if (out) S3D_HIP(hipMemcpy(out, c->d_kpout, sizeof(sift3d_keypoint) * (size_t)c->n_kp, hipMemcpyDeviceToHost));
-	if (desc) {
-		if (c->stage < 5) return SIFT3D_ERR_STATE;
-		S3D_HIP(hipMemcpy(desc, c->d_desc, sizeof(float) * kDesc * (size_t)c->n_kp, hipMemcpyDeviceToHost));
-	}
+	if (desc && c->stage < 5) return SIFT3D_ERR_STATE;
+	// results were complete when the run returned; the copies go through the pinned staging pool on the handle's own stream
+	if (out && (rc = staged_d2h(out, c->d_kpout, sizeof(sift3d_keypoint) * (size_t)c->n_kp, c->device, c->own_stream))) return rc;
+	if (desc && (rc = staged_d2h(desc, c->d_desc, sizeof(float) * kDesc * (size_t)c->n_kp, c->device, c->own_stream))) return rc;
 	return SIFT3D_OK;
 }
 
@@ -859,16 +891,14 @@ extern "C" int sift3d_copy_level(sift3d_handle c, int is_dog, int idx, float *ou
 		launch_dog_from_gss(c->gss[(size_t)o * c->ng + i + 1].d, c->gss[(size_t)o * c->ng + i].d, L->d, L->n(), c->stream);
 		S3D_HIP(hipStreamSynchronize(c->stream));
 	}
-	S3D_HIP(hipMemcpy(out, L->d, sizeof(float) * L->n(), hipMemcpyDeviceToHost));
-	return SIFT3D_OK;
+	return staged_d2h(out, L->d, sizeof(float) * L->n(), c->device, c->own_stream);
 }
 
 extern "C" int sift3d_copy_input(sift3d_handle c, float *out) {
 	if (!c || !out) return SIFT3D_ERR_ARG;
 	int rc = set_device(c->device);
 	if (rc) return rc;
-	S3D_HIP(hipMemcpy(out, c->in.d, sizeof(float) * c->in.n(), hipMemcpyDeviceToHost));
-	return SIFT3D_OK;
+	return staged_d2h(out, c->in.d, sizeof(float) * c->in.n(), c->device, c->own_stream);
 }
 
 extern "C" int sift3d_num_extrema(sift3d_handle c, int *n) {
@@ -934,6 +964,72 @@ extern "C" int sift3d_gaussian_smooth(const float *src, int nx, int ny, int nz, 
 	}
 	if (e == hipSuccess) e = hipMemcpy(dst, d, sizeof(float) * n, hipMemcpyDeviceToHost);
 	hipFree(d);
+	if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return SIFT3D_ERR_HIP; }
+	return SIFT3D_OK;
+}
+
+
+// best-of-iters bandwidth (GB/s, read + write) of a float4 device-to-device copy of `bytes` bytes: the achievable HBM ceiling
+// bench.py reports beside the 8 TB/s spec peak
+extern "C" int sift3d_debug_copy_bandwidth(size_t bytes, int iters, int device, double *gbs) {
+	if (!gbs || bytes < 4096 || iters < 1) return SIFT3D_ERR_ARG;
+	int rc = set_device(device);
+	if (rc) return rc;
+	const size_t nf = (bytes / 16) * 4;
+	float *d = nullptr;
+	S3D_HIP(hipMalloc(&d, sizeof(float) * nf * 2));
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	hipError_t e = hipMemset(d, 0, sizeof(float) * nf * 2);
+	if (e == hipSuccess) e = hipEventCreate(&e0);
+	if (e == hipSuccess) e = hipEventCreate(&e1);
+	double best = 0.0;
+	for (int i = 0; i < iters + 1 && e == hipSuccess; i++) {  // first pass warms up
+		(void)hipEventRecord(e0, nullptr);
+		launch_copy16(d, d + nf, nf, nullptr);
+		(void)hipEventRecord(e1, nullptr);
+		e = hipEventSynchronize(e1);
+		float ms = 0;
+		if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+		if (i > 0 && ms > 0) best = std::max(best, 2.0 * (double)nf * 4.0 / ((double)ms * 1e-3) / 1e9);
+	}
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	(void)hipFree(d);
+	if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return SIFT3D_ERR_HIP; }
+	*gbs = best;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_debug_counters(sift3d_handle c, int out[4]) {
+	if (!out) return SIFT3D_ERR_ARG;
+	out[0] = c ? c->n_regrow : 0;
+	out[1] = c ? c->n_desc_redo : 0;
+	out[2] = match_redo_rows();
+	out[3] = 0;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_debug_face_lookup(const float *grad3, int n, int route, int *face, float *bary3, int device) {
+	if (!grad3 || !face || !bary3 || n < 0) return SIFT3D_ERR_ARG;
+	int rc = set_device(device);
+	if (rc) return rc;
+	if (n == 0) return SIFT3D_OK;
+	FaceConst faces[kFaces];
+	build_faces(faces);
+	FacePredict pred;
+	build_predict(faces, &pred);
+	S3D_HIP(upload_faces(faces, &pred));
+	float *d = nullptr;
+	S3D_HIP(hipMalloc(&d, sizeof(float) * (size_t)n * 7));
+	int *d_face = reinterpret_cast<int *>(d + (size_t)n * 6);
+	hipError_t e = hipMemcpy(d, grad3, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		launch_face_lookup(d, n, route, d_face, d + (size_t)n * 3, nullptr);
+		e = hipDeviceSynchronize();
+	}
+	if (e == hipSuccess) e = hipMemcpy(bary3, d + (size_t)n * 3, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(face, d_face, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost);
+	(void)hipFree(d);
 	if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return SIFT3D_ERR_HIP; }
 	return SIFT3D_OK;
 }
@@ -1240,8 +1336,7 @@ extern "C" int sift3d_slab_level(sift3d_handle c, int i) {
 	} else {
 		// like the single-volume path, the first and last DoG level of the octave are not materialised (read only as the centre-voxel
 		// neighbour of extremum candidates: no halo, no abs-max)
-		static const bool dog_eager = [] { const char *e = getenv("S3D_DOG_EAGER"); return e && e[0] == '1'; }();
-		static const bool glast_eager = [] { const char *e = getenv("S3D_GLAST_EAGER"); return e && e[0] == '1'; }();
+		const bool dog_eager = hook(SIFT3D_HOOK_DOG_EAGER) != 0, glast_eager = hook(SIFT3D_HOOK_GLAST_EAGER) != 0;
 		c->dog_elide = !dog_eager && c->nd >= 3;
 		// ... and the last Gaussian level is not built at all (k_lazy_next evaluates it at the parked extremum candidates; its source
 		// level G[nd-1] holds the hw+1 halo planes the caller exchanged for this level)
@@ -1296,6 +1391,7 @@ static int slab_count_and_regrow(sift3d_ctx *c, bool &again) {
 	if (host_words[1] != 0 || host_words[0] > c->ext_cap) {
 		int rc = alloc_lists(c, std::max(host_words[0], c->ext_cap) * 2u);
 		if (rc) return rc;
+		c->n_regrow++;
 		again = true;
 		return SIFT3D_OK;
 	}
@@ -1343,7 +1439,7 @@ extern "C" int sift3d_slab_describe(sift3d_handle c) {
 	if (rc) return rc;
 	hipStream_t st = c->stream;
 	launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
-	              c->p.corner_thresh, 0, 1, st);
+	              c->p.corner_thresh, 0, 1, c->d_order, c->d_nkp + 3, st);
 	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, st);
 	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, 0, 1, c->d_order, c->d_nkp,
 	                c->d_nkp + 1, st, c->desc_lut_lds);

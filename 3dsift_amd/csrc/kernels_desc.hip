@@ -39,6 +39,8 @@
 
 #include <stdio.h>
 
+#include <algorithm>
+
 #include "sift3d_internal.h"
 
 namespace s3d {
@@ -137,6 +139,51 @@ __device__ __forceinline__ int intersect_scan(float gx, float gy, float gz, floa
 	return found;
 }
 
+// face constants -> LDS (per-lane face index => LDS gather instead of a 20-way constant waterfall); 256 threads, caller syncs
+__device__ __forceinline__ void stage_face_tables(int tid, float *s_face, int *s_fidx, float *s_predn, int *s_predf) {
+	for (int i = tid; i < kFaces * kFaceStride; i += 256) {
+		const int f = i / kFaceStride, j = i - f * kFaceStride;
+		const FaceConst &F = c_faces[f];
+		float v = 0.f;
+		if (j < 3) v = F.e1[j];
+		else if (j < 6) v = F.e2[j - 3];
+		else if (j < 9) v = F.t[j - 6];
+		else if (j < 12) v = F.q[j - 9];
+		else if (j == 12) v = F.qe2;
+		s_face[j * kFaceT + f] = v;  // j < 16 rows of 20 faces: same 320 floats
+	}
+	for (int i = tid; i < kFaces * 4; i += 256) s_fidx[i] = (i & 3) < 3 ? c_faces[i >> 2].idx[i & 3] * kSV : 0;  // vertex -> its first bin
+	if (tid < 12) s_predn[tid] = c_pred.n[tid / 3][tid % 3];
+	if (tid < 32) s_predf[tid] = c_pred.face[tid];
+}
+
+// Check_intersect_faces for one gradient (Src/cSIFT3D.cc:1542-1573): the face is PREDICTED (best of the 4 face normals of the
+// positive octant, then the sign bits), verified with the reference's exact arithmetic for that face and accepted when all three
+// barycentrics clear kFastMargin; otherwise the literal ordered 20-face scan decides.  Wave-uniform control flow.
+__device__ __forceinline__ int face_lookup(bool valid, float rx, float ry, float rz, const float *s_face, const float *s_predn,
+                                           const int *s_predf, float &b0, float &b1, float &b2, bool scan_only = false) {
+	int f = -1;
+	bool slow = false;
+	if (valid) {
+		const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
+		float best = ax * s_predn[0] + ay * s_predn[1] + az * s_predn[2];
+		int kb = 0;
+#pragma unroll
+		for (int t = 1; t < 4; t++) {
+			const float sc = ax * s_predn[3 * t] + ay * s_predn[3 * t + 1] + az * s_predn[3 * t + 2];
+			if (sc > best) { best = sc; kb = t; }
+		}
+		const int bits = (rx < 0.f ? 1 : 0) | (ry < 0.f ? 2 : 0) | (rz < 0.f ? 4 : 0);
+		f = s_predf[kb * 8 + bits];
+		const bool ok = face_test(&s_face[f], rx, ry, rz, b0, b1, b2);
+		slow = scan_only || !(ok && b0 >= kFastMargin && b1 >= kFastMargin && b2 >= kFastMargin);
+	}
+	if (__any(slow)) {
+		if (slow) f = intersect_scan(rx, ry, rz, b0, b1, b2);
+	}
+	return f;
+}
+
 // heavy part of one ACTIVE voxel (inside sphere and cube, |g|^2 >= eps): face lookup, trilinear weights,
 // 24 fixed-point adds.  Runs on compacted full waves (see the queue in k_describe).
 // fp32 -> int32, round to nearest (ties up): ONE instruction (__float2int_rn is v_rndne_f32 + v_cvt_i32_f32)
@@ -162,26 +209,7 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 	const float g2 = rx * rx + ry * ry + rz * rz;
 	valid = valid && !(g2 < kBaryEps);
 	float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-	int f = -1;
-	bool slow = false;
-	if (valid) {
-		// predicted face: best of the 4 face normals of the positive octant, then the sign bits
-		const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
-		float best = ax * s_predn[0] + ay * s_predn[1] + az * s_predn[2];
-		int kb = 0;
-#pragma unroll
-		for (int t = 1; t < 4; t++) {
-			const float sc = ax * s_predn[3 * t] + ay * s_predn[3 * t + 1] + az * s_predn[3 * t + 2];
-			if (sc > best) { best = sc; kb = t; }
-		}
-		const int bits = (rx < 0.f ? 1 : 0) | (ry < 0.f ? 2 : 0) | (rz < 0.f ? 4 : 0);
-		f = s_predf[kb * 8 + bits];
-		const bool ok = face_test(&s_face[f], rx, ry, rz, b0, b1, b2);
-		slow = !(ok && b0 >= kFastMargin && b1 >= kFastMargin && b2 >= kFastMargin);
-	}
-	if (__any(slow)) {
-		if (slow) f = intersect_scan(rx, ry, rz, b0, b1, b2);
-	}
+	const int f = face_lookup(valid, rx, ry, rz, s_face, s_predn, s_predf, b0, b1, b2);
 	if (!valid || f < 0) return 0.0f;
 	const float mag = __fsqrt_rn(g2);
 	const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
@@ -287,6 +315,8 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap,
                                                   int part_rank, int part_world, const int *__restrict__ order,
                                                   const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work, int dev_flags) {
+	// d_work[0] = the work counter, d_work[1] = keypoints that took the second pass (sift3d_debug_counters)
+	// dev_flags (test hooks): bit 0 = recompute the chords (SIFT3D_HOOK_DESC_NOCACHE), bits 8.. = s of SIFT3D_HOOK_DESC_MASS_SHIFT
 	__shared__ unsigned s_item, s_tile;
 	__shared__ bin_t hist[kBins * kRep];  // [bin][replica], two's-complement fixed point, units of 1 / lut.fix_scale
 	__shared__ float s_lut[LUT_LDS ? kMaxDescLut : 1];
@@ -303,21 +333,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	const unsigned count = min(d_count[0], cap);
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
-	// face constants -> LDS (per-lane face index => LDS gather instead of a 20-way constant waterfall)
-	for (int i = tid; i < kFaces * kFaceStride; i += 256) {
-		const int f = i / kFaceStride, j = i - f * kFaceStride;
-		const FaceConst &F = c_faces[f];
-		float v = 0.f;
-		if (j < 3) v = F.e1[j];
-		else if (j < 6) v = F.e2[j - 3];
-		else if (j < 9) v = F.t[j - 6];
-		else if (j < 12) v = F.q[j - 9];
-		else if (j == 12) v = F.qe2;
-		s_face[j * kFaceT + f] = v;  // j < 16 rows of 20 faces: same 320 floats
-	}
-	for (int i = tid; i < kFaces * 4; i += 256) s_fidx[i] = (i & 3) < 3 ? c_faces[i >> 2].idx[i & 3] * kSV : 0;  // vertex -> its first bin
-	if (tid < 12) s_predn[tid] = c_pred.n[tid / 3][tid % 3];
-	if (tid < 32) s_predf[tid] = c_pred.face[tid];
+	stage_face_tables(tid, s_face, s_fidx, s_predn, s_predf);
 	int cur_lut = -1;
 #if defined(S3D_EXP) && S3D_EXP == 21
 	unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
@@ -378,7 +394,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			const float p2 = __uint_as_float(__float_as_uint(q) & 0xFF800000u);
 			return fminf(fmaxf(p2, lut.fix_scale), 536870912.0f);
 		};
-		float fix_scale = pick_scale(m_est * 4.0f);
+		float fix_scale = pick_scale(m_est * 4.0f * __uint_as_float((unsigned)(127 - ((dev_flags >> 8) & 63)) << 23));  // hook: estimate / 2^s
 		int x0, x1, y0, y1, z0, z1;
 		win_bounds_d((float)cxi, win_radius, u, L.nx, x0, x1);
 		win_bounds_d((float)cyi, win_radius, u, L.ny, y0, y1);
@@ -671,12 +687,18 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		__syncthreads();
 		const float mass = ((red[0] + red[1]) + (red[2] + red[3])) * 1.001f;
 		// every bin (and replica) sum is <= mass * fix_scale + half a unit per contribution (< 2^20 contributions)
-		if (attempt == 1 || mass * fix_scale + 1048576.0f < 2147483648.0f) {
+		// ... and a first guess far ABOVE the mass (a sharp structure inside the orientation window, a flat descriptor window: the
+		// zero background of CT / MR volumes) leaves a unit that much coarser than necessary: below 1/64 of the range the keypoint is
+		// redone as well, whenever the exact bound gives a finer unit (rounding noise per bin stays < 1e-5 of the descriptor norm)
+		const bool overflow = !(mass * fix_scale + 1048576.0f < 2147483648.0f);
+		const bool coarse = mass * fix_scale < 2147483648.0f / 64.0f && pick_scale(mass) > fix_scale;
+		if (attempt == 1 || !(overflow || coarse)) {
 #if defined(S3D_EXP) && S3D_EXP == 6
 			exp_mass = mass; exp_attempts = attempt + 1;
 #endif
 			break;
 		}
+		if (tid == 0) atomicAdd(d_work + 1, 1u);
 		fix_scale = pick_scale(mass);  // exact bound: this pass cannot overflow
 		}
 		const double fix_inv = 1.0 / (double)fix_scale;
@@ -724,15 +746,36 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 #endif
 }
 
+// sift3d_debug_face_lookup: the face lookup of k_describe on caller-provided gradients (unit parity against golden g7)
+__global__ void __launch_bounds__(256) k_face_lookup(const float *__restrict__ g3, int n, int route, int *__restrict__ face, float *__restrict__ bary3) {
+	__shared__ float s_predn[12];
+	__shared__ int s_predf[32];
+	__shared__ __attribute__((aligned(16))) float s_face[kFaces * kFaceStride];
+	__shared__ int s_fidx[kFaces * 4];
+	stage_face_tables(threadIdx.x, s_face, s_fidx, s_predn, s_predf);
+	__syncthreads();
+	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {  // wave-uniform trip count (face_lookup votes)
+		const int i = base + threadIdx.x;
+		const bool valid = i < n;
+		const float gx = valid ? g3[3 * i] : 1.f, gy = valid ? g3[3 * i + 1] : 0.f, gz = valid ? g3[3 * i + 2] : 0.f;
+		float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+		// |g|^2 < eps rejects first, like Check_intersect_faces (Src/cSIFT3D.cc:1546) and accumulate_voxel
+		const float g2 = gx * gx + gy * gy + gz * gz;
+		const int f = face_lookup(valid && !(g2 < kBaryEps), gx, gy, gz, s_face, s_predn, s_predf, b0, b1, b2, route != 0);
+		if (valid) { face[i] = f; bary3[3 * i] = b0; bary3[3 * i + 1] = b1; bary3[3 * i + 2] = b2; }
+	}
+}
+void launch_face_lookup(const float *d_g3, int n, int route, int *d_face, float *d_bary3, hipStream_t st) {
+	hipLaunchKernelGGL(k_face_lookup, dim3(std::max(1, std::min((n + 255) / 256, 1024))), dim3(256), 0, st, d_g3, n, route, d_face, d_bary3);
+}
+
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels, const WinLut *d_luts,
                      const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world, const int *order,
                      const unsigned *d_nkp, unsigned *d_work, hipStream_t st, bool lut_in_lds) {
-	(void)hipMemsetAsync(d_work, 0, sizeof(unsigned), st);
-	// development: S3D_DESC_DYNLDS=bytes of unused dynamic LDS per workgroup (occupancy experiments: fewer workgroups per CU)
-	static const int desc_grid = [] { const char *e = getenv("S3D_DESC_GRID"); return e ? atoi(e) : 256 * 8; }();  // persistent workgroups (work counter)
-	static const unsigned dyn_lds = [] { const char *e = getenv("S3D_DESC_DYNLDS"); return e ? (unsigned)atoi(e) : 0u; }();
-	// development / tests: S3D_DESC_NOCACHE=1 takes the path of windows whose z ranges do not fit the byte cache (recomputed chords)
-	static const int dev_flags = [] { const char *e = getenv("S3D_DESC_NOCACHE"); return e && e[0] == '1' ? 1 : 0; }();
+	(void)hipMemsetAsync(d_work, 0, 2 * sizeof(unsigned), st);
+	static const int desc_grid = dev_tune_i("S3D_DESC_GRID", 256 * 8);  // persistent workgroups (work counter)
+	static const unsigned dyn_lds = (unsigned)dev_tune_i("S3D_DESC_DYNLDS", 0);  // unused dynamic LDS per workgroup (occupancy experiments)
+	const int dev_flags = (hook(SIFT3D_HOOK_DESC_NOCACHE) ? 1 : 0) | (hook(SIFT3D_HOOK_DESC_MASS_SHIFT) & 63) << 8;
 	if (lut_in_lds)
 		hipLaunchKernelGGL(k_describe<true>, dim3(desc_grid), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
 		                   part_rank, part_world, order, d_nkp, d_work, dev_flags);

@@ -479,10 +479,10 @@ void launch_detect_mark(const DetectLevels &L, int nlevels, int nx, int ny, cons
 	const size_t mask_lds = sizeof(unsigned long long) * (kThreads / 64) * (kRows / 4) * (size_t)std::min((nx + 63) >> 6, 64);
 	hipLaunchKernelGGL(k_mark, dim3(nblocks), dim3(kThreads), mask_lds, st, L, nx, ny, zr, nyb, peak_thresh, b.masks, b.block_counts, b.prov,
 	                   b.prov_count, b.prov_cap, b.total);
-	static const int lazy_grid = [] { const char *e = getenv("S3D_LAZY_GRID"); return e ? atoi(e) : 256 * 2; }();  // = the resident workgroups (201 VGPRs: two per CU); 512 / 1280 / 5120: detection 0.95 / 0.99 / 1.02 ms
+	static const int lazy_grid = dev_tune_i("S3D_LAZY_GRID", 256 * 2);  // = the resident workgroups (201 VGPRs: two per CU); 512 / 1280 / 5120: detection 0.95 / 0.99 / 1.02 ms
 	if (lazy) hipLaunchKernelGGL(k_lazy_next, dim3(lazy_grid), dim3(256), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
 	                             b.masks, b.block_counts);
-	static const bool dbg = [] { const char *e = getenv("S3D_LAZY_DEBUG"); return e && e[0] == '1'; }();
+	static const bool dbg = dev_tune_i("S3D_LAZY_DEBUG", 0) != 0;
 	if (lazy && dbg) {
 		unsigned n = 0;
 		hipStreamSynchronize(st);

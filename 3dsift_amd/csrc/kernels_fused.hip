@@ -744,7 +744,7 @@ static void launch_hw(const float *src, float *dst, float *dog, unsigned *dogmax
 	double best_cost = 1e300;
 	// Levels with few tiles (octaves >= 1) run beside the big octave-0 launches on their own streams: what they cost the
 	// machine is their total work (workgroup-planes), not their latency, so their chunks are kept >= bg_k ramps long
-	static const double bg_k = [] { const char *e = getenv("S3D_BG_K"); return e ? atof(e) : S3D_BG_K_DEFAULT; }();
+	static const double bg_k = dev_tune_d("S3D_BG_K", S3D_BG_K_DEFAULT);
 	const bool background = ntiles * 4 <= slots;
 	for (int n = 1; n <= nz && n <= 64; n++) {
 		const int czn = (nz + n - 1) / n;

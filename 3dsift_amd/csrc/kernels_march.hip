@@ -480,7 +480,7 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 // instantiation): the caller falls through to kernels_fused.hip / kernels_pyramid.hip
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
                         hipStream_t st, int plan_slots, int prio) {
-	static const bool off = [] { const char *e = getenv("S3D_MARCH"); return e && e[0] == '0'; }();
+	static const bool off = dev_tune_i("S3D_MARCH", 1) == 0;
 	if (off) return false;
 	if ((nx % 32) || (ny % 32) || nx < 2 * t.hw + 2 || ny < 2 * t.hw + 2 || zr.nzg < 2 * t.hw + 2) return false;
 	switch (t.hw) {

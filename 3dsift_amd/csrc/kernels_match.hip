@@ -20,6 +20,7 @@
 #include <float.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -444,73 +445,151 @@ static void ratio_filter(std::vector<int> &gi, const std::vector<float> &gd, con
 	}
 }
 
+// Per-device matcher state, created on first use and reused by every later call (r03: a call used to do 3-5 hipMalloc / hipFree and
+// ran on the null stream): a grow-only device scratch, a pinned host block for the results, the matcher's own non-blocking stream
+// and its timing events.  One call at a time per device (the mutex is held for the whole call).
+#include <chrono>
+#include <mutex>
+
+namespace {
+struct MatchState {
+	std::mutex mu;
+	bool ready = false;
+	hipStream_t stream = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr, e_in = nullptr;
+	char *d_scratch = nullptr; size_t d_bytes = 0;   // device: everything but the descriptor matrices
+	float *d_ab = nullptr; size_t ab_floats = 0;     // device copies of host-resident descriptor matrices
+	char *h_pin = nullptr; size_t h_bytes = 0;       // pinned host: results of a pass (+ the coordinates of device-resident inputs)
+	int last_redo = 0;
+};
+constexpr int kMaxDev = 64;
+MatchState g_match[kMaxDev];
+thread_local double t_match_dev = 0.0, t_match_wall = 0.0;
+int g_match_redo_rows = 0;  // rows re-scored exactly by the last call (sift3d_debug_counters)
+
+int ensure(MatchState &S, size_t d_bytes, size_t ab_floats, size_t h_bytes) {
+	if (!S.ready) {
+		S3D_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+		S3D_HIP(hipEventCreate(&S.e0));
+		S3D_HIP(hipEventCreate(&S.e1));
+		S3D_HIP(hipEventCreateWithFlags(&S.e_in, hipEventDisableTiming));
+		S.ready = true;
+	}
+	auto grow = [](size_t want) { return want + want / 4 + 4096; };  // head room: sets of similar size do not reallocate
+	if (d_bytes > S.d_bytes) {
+		S3D_HIP(hipStreamSynchronize(S.stream));
+		if (S.d_scratch) (void)hipFree(S.d_scratch);
+		S.d_scratch = nullptr; S.d_bytes = 0;
+		S3D_HIP(hipMalloc(&S.d_scratch, grow(d_bytes)));
+		S.d_bytes = grow(d_bytes);
+	}
+	if (ab_floats > S.ab_floats) {
+		S3D_HIP(hipStreamSynchronize(S.stream));
+		if (S.d_ab) (void)hipFree(S.d_ab);
+		S.d_ab = nullptr; S.ab_floats = 0;
+		S3D_HIP(hipMalloc(&S.d_ab, sizeof(float) * grow(ab_floats)));
+		S.ab_floats = grow(ab_floats);
+	}
+	if (h_bytes > S.h_bytes) {
+		if (S.h_pin) (void)hipHostFree(S.h_pin);
+		S.h_pin = nullptr; S.h_bytes = 0;
+		S3D_HIP(hipHostMalloc(&S.h_pin, grow(h_bytes), hipHostMallocDefault));
+		S.h_bytes = grow(h_bytes);
+	}
+	return SIFT3D_OK;
+}
+size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+}  // namespace
+
+namespace s3d { int match_redo_rows() { return g_match_redo_rows; } }
+
+extern "C" int sift3d_match_times(double *device_seconds, double *wall_seconds) {
+	if (device_seconds) *device_seconds = t_match_dev;
+	if (wall_seconds) *wall_seconds = t_match_wall;
+	return SIFT3D_OK;
+}
+
 extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, const float *tar_desc, const float *tar_xyz, int m,
                             double thresHold, int mode, int on_device, int device, int *gIdx, int *sIdx, float *gDist,
                             float *sDist, float *pairs6, int *npairs, double *seconds) {
+	const auto wall0 = std::chrono::steady_clock::now();
 	if (n < 0 || m < 0 || mode < 1 || mode > 3 || (n > 0 && (!ref_desc || !ref_xyz)) || (m > 0 && (!tar_desc || !tar_xyz))) {
 		set_last_error("sift3d_match: bad argument");
 		return SIFT3D_ERR_ARG;
 	}
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_last_error("no HIP device visible: no CPU fallback"); return SIFT3D_ERR_NO_DEVICE; }
-	if (device < 0 || device >= ndev) return SIFT3D_ERR_ARG;
+	if (device < 0 || device >= ndev || device >= kMaxDev) return SIFT3D_ERR_ARG;
 	S3D_HIP(hipSetDevice(device));
 	if (npairs) *npairs = 0;
 	if (seconds) *seconds = 0;
+	t_match_dev = t_match_wall = 0.0;
+
+	MatchState &S = g_match[device];
+	std::lock_guard<std::mutex> lock(S.mu);
+	const size_t nn = (size_t)std::max(n, 1), mm = (size_t)std::max(m, 1), big = std::max(nn, mm);
+	// device scratch layout (256-B aligned pieces): results [gd | sd | gi | si] of a pass (ONE D2H copy), then the working arrays
+	const size_t o_res = 0, res_bytes = al256(4 * 4 * big);
+	const size_t o_cand = o_res + res_bytes, o_rows = o_cand + al256(4 * (size_t)TOPK * big), o_redo = o_rows + al256(4 * big);
+	const size_t o_s4 = o_redo + al256(4 * (big + 1)), o_an2 = o_s4 + al256(4 * big), o_bn2 = o_an2 + al256(4 * nn);
+	const size_t o_nmax = o_bn2 + al256(4 * mm), o_part = o_nmax + 256, d_bytes = o_part + al256(sizeof(Cand) * TOPK * kMaxSplits * big);
+	const size_t h_res = 0, h_xyz = res_bytes + 256, h_bytes = h_xyz + (on_device ? 4 * 3 * (nn + mm) : 0);
+	int rc = ensure(S, d_bytes, on_device ? 0 : (size_t)kDesc * (nn + mm), h_bytes);
+	if (rc) return rc;
+	hipStream_t st = S.stream;
 
 	std::vector<float> gd(n, 0.f), sd(n, 0.f), gd2(m, 0.f), sd2(m, 0.f);
 	std::vector<int> gi(n, -1), si(n, -1), gi2(m, -1), si2(m, -1);
-	std::vector<float> hx, hy;  // host copies of coordinates when inputs are device resident
 	const float *rx = ref_xyz, *tx = tar_xyz;
-
-	float *d_a = nullptr, *d_b = nullptr, *d_f = nullptr;
-	void *d_part = nullptr;
-	int *d_i = nullptr;
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	int rc = SIFT3D_OK;
-#define MCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); rc = SIFT3D_ERR_HIP; goto done; } } while (0)
+	int redo_rows = 0;
+#define MCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); (void)hipStreamSynchronize(st); return SIFT3D_ERR_HIP; } } while (0)
+	float *d_a, *d_b;
+	if (on_device) {
+		// device-resident inputs: work the caller queued on the legacy default stream (torch's default stream is that one) is
+		// ordered in front of the matcher; inputs produced on other streams must be complete when the call is made (sift3d_run is)
+		MCHK(hipEventRecord(S.e_in, nullptr));
+		MCHK(hipStreamWaitEvent(st, S.e_in, 0));
+		d_a = const_cast<float *>(ref_desc); d_b = const_cast<float *>(tar_desc);
+		float *hx = reinterpret_cast<float *>(S.h_pin + h_xyz), *hy = hx + 3 * nn;
+		if (n) MCHK(hipMemcpyAsync(hx, ref_xyz, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
+		if (m) MCHK(hipMemcpyAsync(hy, tar_xyz, sizeof(float) * 3 * m, hipMemcpyDeviceToHost, st));
+		rx = hx; tx = hy;  // read after the first synchronisation below
+	} else {
+		d_a = S.d_ab; d_b = S.d_ab + (size_t)kDesc * nn;
+		if (n) MCHK(hipMemcpyAsync(d_a, ref_desc, sizeof(float) * kDesc * n, hipMemcpyHostToDevice, st));
+		if (m) MCHK(hipMemcpyAsync(d_b, tar_desc, sizeof(float) * kDesc * m, hipMemcpyHostToDevice, st));
+	}
 	{
-		const size_t nn = (size_t)std::max(n, 1), mm = (size_t)std::max(m, 1), big = std::max(nn, mm);
-		if (on_device) {
-			d_a = const_cast<float *>(ref_desc); d_b = const_cast<float *>(tar_desc);
-			hx.resize((size_t)n * 3); hy.resize((size_t)m * 3);
-			if (n) MCHK(hipMemcpy(hx.data(), ref_xyz, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
-			if (m) MCHK(hipMemcpy(hy.data(), tar_xyz, sizeof(float) * 3 * m, hipMemcpyDeviceToHost));
-			rx = hx.data(); tx = hy.data();
-		} else {
-			MCHK(hipMalloc(&d_a, sizeof(float) * kDesc * nn));
-			MCHK(hipMalloc(&d_b, sizeof(float) * kDesc * mm));
-			if (n) MCHK(hipMemcpy(d_a, ref_desc, sizeof(float) * kDesc * n, hipMemcpyHostToDevice));
-			if (m) MCHK(hipMemcpy(d_b, tar_desc, sizeof(float) * kDesc * m, hipMemcpyHostToDevice));
-		}
-		MCHK(hipMalloc(&d_f, sizeof(float) * (3 * big + nn + mm + 2)));
-		MCHK(hipMalloc(&d_i, sizeof(int) * ((2 + TOPK + 2) * big + 1)));
-		MCHK(hipMalloc(&d_part, sizeof(Cand) * TOPK * kMaxSplits * big));
-		float *d_gd = d_f, *d_sd = d_f + big;
-		int *d_gi = d_i, *d_si = d_i + big, *d_cand = d_i + 2 * big, *d_rows = d_i + (2 + TOPK) * big;
-		// near-tie guard scratch: 4th fp32 score per row, squared row norms of both sets and their maxima, redo list
-		float *d_s4 = d_f + 2 * big, *d_an2 = d_f + 3 * big, *d_bn2 = d_an2 + nn;
-		unsigned *d_nmax = reinterpret_cast<unsigned *>(d_bn2 + mm);
-		int *d_redo = d_i + (2 + TOPK + 1) * big;
-		MCHK(hipMemsetAsync(d_nmax, 0, 2 * sizeof(unsigned), nullptr));
-		if (n) hipLaunchKernelGGL(k_row_norm2, dim3((n + 3) / 4), dim3(256), 0, nullptr, d_a, n, d_an2, d_nmax);
-		if (m) hipLaunchKernelGGL(k_row_norm2, dim3((m + 3) / 4), dim3(256), 0, nullptr, d_b, m, d_bn2, d_nmax + 1);
-		// (S3D_MATCH_NODMA=1: the register-staged form, which matrices of 4 GB and more take, on any size -- for tests)
-		static const bool no_dma = [] { const char *e = getenv("S3D_MATCH_NODMA"); return e && e[0] == '1'; }();
-		const bool small = !no_dma && (size_t)std::max(n, m) * KD * sizeof(float) < ((size_t)1 << 32);
+		char *D = S.d_scratch;
+		float *d_gd = reinterpret_cast<float *>(D + o_res), *d_sd = d_gd + big;
+		int *d_gi = reinterpret_cast<int *>(d_sd + big), *d_si = d_gi + big;
+		int *d_cand = reinterpret_cast<int *>(D + o_cand), *d_rows = reinterpret_cast<int *>(D + o_rows), *d_redo = reinterpret_cast<int *>(D + o_redo);
+		float *d_s4 = reinterpret_cast<float *>(D + o_s4), *d_an2 = reinterpret_cast<float *>(D + o_an2), *d_bn2 = reinterpret_cast<float *>(D + o_bn2);
+		unsigned *d_nmax = reinterpret_cast<unsigned *>(D + o_nmax);
+		void *d_part = D + o_part;
+		float *h_gd = reinterpret_cast<float *>(S.h_pin + h_res), *h_sd = h_gd + big;
+		int *h_gi = reinterpret_cast<int *>(h_sd + big), *h_si = h_gi + big;
+		int *h_redo = reinterpret_cast<int *>(S.h_pin + res_bytes);
+
+		MCHK(hipEventRecord(S.e0, st));
+		MCHK(hipMemsetAsync(d_nmax, 0, 2 * sizeof(unsigned), st));
+		if (n) hipLaunchKernelGGL(k_row_norm2, dim3((n + 3) / 4), dim3(256), 0, st, d_a, n, d_an2, d_nmax);
+		if (m) hipLaunchKernelGGL(k_row_norm2, dim3((m + 3) / 4), dim3(256), 0, st, d_b, m, d_bn2, d_nmax + 1);
+		// matrices of 4 GB and more take the register-staged form (SIFT3D_HOOK_MATCH_NODMA forces it on any size, for the tests)
+		const bool small = !hook(SIFT3D_HOOK_MATCH_NODMA) && (size_t)std::max(n, m) * KD * sizeof(float) < ((size_t)1 << 32);
 		const MatchGuard g_fwd{d_s4, d_an2, d_nmax + 1, d_redo, small}, g_rev{d_s4, d_bn2, d_nmax, d_redo, small};
-		MCHK(hipEventCreate(&e0));
-		MCHK(hipEventCreate(&e1));
-		MCHK(hipEventRecord(e0, nullptr));
 
 		// ---- ref -> tar ----
 		if (n > 0 && m > 0) {
-			match_rows_device(d_a, nullptr, n, d_b, m, d_cand, d_part, d_gd, d_sd, d_gi, d_si, g_fwd, nullptr);
-			MCHK(hipMemcpy(gd.data(), d_gd, sizeof(float) * n, hipMemcpyDeviceToHost));
-			MCHK(hipMemcpy(sd.data(), d_sd, sizeof(float) * n, hipMemcpyDeviceToHost));
-			MCHK(hipMemcpy(gi.data(), d_gi, sizeof(int) * n, hipMemcpyDeviceToHost));
-			MCHK(hipMemcpy(si.data(), d_si, sizeof(int) * n, hipMemcpyDeviceToHost));
-		} else if (n > 0) {
+			match_rows_device(d_a, nullptr, n, d_b, m, d_cand, d_part, d_gd, d_sd, d_gi, d_si, g_fwd, st);
+			MCHK(hipMemcpyAsync(h_gd, d_gd, 4 * 4 * big, hipMemcpyDeviceToHost, st));
+			MCHK(hipMemcpyAsync(h_redo, d_redo, sizeof(int), hipMemcpyDeviceToHost, st));
+			MCHK(hipStreamSynchronize(st));
+			memcpy(gd.data(), h_gd, sizeof(float) * n); memcpy(sd.data(), h_sd, sizeof(float) * n);
+			memcpy(gi.data(), h_gi, sizeof(int) * n); memcpy(si.data(), h_si, sizeof(int) * n);
+			redo_rows += h_redo[0];
+		} else {
+			MCHK(hipStreamSynchronize(st));
 			// no targets: every dot loop is empty -> d = 2 - 2*FLT_MIN, idx -1
 			for (int i = 0; i < n; i++) { gd[i] = sd[i] = (float)(2 - 2 * (double)FLT_MIN); }
 		}
@@ -524,15 +603,13 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 			for (int j = 0; j < m; j++) { cnt[j] = cnt[j] > mask_thres ? 1 : 0; if (cnt[j]) rows.push_back(j); }  // toMask :122-131
 			// ---- tar -> ref over the masked targets only (masked-out rows keep gIdx2 = -1) ----
 			if (!rows.empty() && n > 0) {
-				MCHK(hipMemcpy(d_rows, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
-				match_rows_device(d_b, d_rows, (int)rows.size(), d_a, n, d_cand, d_part, d_gd, d_sd, d_gi, d_si, g_rev, nullptr);
-				std::vector<float> tg(m), ts(m);
-				std::vector<int> ti(m), tsi(m);
-				MCHK(hipMemcpy(tg.data(), d_gd, sizeof(float) * m, hipMemcpyDeviceToHost));
-				MCHK(hipMemcpy(ts.data(), d_sd, sizeof(float) * m, hipMemcpyDeviceToHost));
-				MCHK(hipMemcpy(ti.data(), d_gi, sizeof(int) * m, hipMemcpyDeviceToHost));
-				MCHK(hipMemcpy(tsi.data(), d_si, sizeof(int) * m, hipMemcpyDeviceToHost));
-				for (int j : rows) { gd2[j] = tg[j]; sd2[j] = ts[j]; gi2[j] = ti[j]; si2[j] = tsi[j]; }
+				MCHK(hipMemcpyAsync(d_rows, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice, st));
+				match_rows_device(d_b, d_rows, (int)rows.size(), d_a, n, d_cand, d_part, d_gd, d_sd, d_gi, d_si, g_rev, st);
+				MCHK(hipMemcpyAsync(h_gd, d_gd, 4 * 4 * big, hipMemcpyDeviceToHost, st));
+				MCHK(hipMemcpyAsync(h_redo, d_redo, sizeof(int), hipMemcpyDeviceToHost, st));
+				MCHK(hipStreamSynchronize(st));
+				for (int j : rows) { gd2[j] = h_gd[j]; sd2[j] = h_sd[j]; gi2[j] = h_gi[j]; si2[j] = h_si[j]; }
+				redo_rows += h_redo[0];
 			}
 			ratio_filter(gi2, gd2, sd2, thresHold);
 			for (int i = 0; i < n; i++) {                                              // bijectFilter :133-144
@@ -541,11 +618,12 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 				if (gi2[j] != i) gi[i] *= -1;
 			}
 		}
-		MCHK(hipEventRecord(e1, nullptr));
-		MCHK(hipEventSynchronize(e1));
+		MCHK(hipEventRecord(S.e1, st));
+		MCHK(hipEventSynchronize(S.e1));
 		float ms = 0;
-		hipEventElapsedTime(&ms, e0, e1);
-		if (seconds) *seconds = (double)ms * 1e-3;
+		hipEventElapsedTime(&ms, S.e0, S.e1);
+		t_match_dev = (double)ms * 1e-3;
+		if (seconds) *seconds = t_match_dev;
 
 		int np = 0;
 		for (int i = 0; i < n; i++) {                                                  // toCvec :99-112
@@ -564,13 +642,8 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 			if (sDist) sDist[i] = sd[i];
 		}
 	}
-done:
 #undef MCHK
-	if (e0) hipEventDestroy(e0);
-	if (e1) hipEventDestroy(e1);
-	if (!on_device) { hipFree(d_a); hipFree(d_b); }
-	hipFree(d_f);
-	hipFree(d_i);
-	hipFree(d_part);
-	return rc;
+	g_match_redo_rows = redo_rows;
+	t_match_wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+	return SIFT3D_OK;
 }

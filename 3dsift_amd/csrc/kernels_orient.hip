@@ -11,8 +11,17 @@
 // requested a plane ahead) -- windows larger than the default take the box scan over LDS tiles or global memory.  The Gaussian
 // weight comes from a host-built table indexed by the integer squared offset (bit-identical to the CPU expf, no device exp), the
 // nine fp32 sums are reduced across the wave with shuffles; k_orient_finish runs the fp64 Jacobi eigen-solve with one LANE per
-// extremum.  Per-voxel terms are bit-identical to the reference; only the ORDER of the fp32 additions differs (lane-strided +
-// butterfly instead of sequential), which moves the tensor by ~1e-7 relative -- inside the stated descriptor tolerance (1e-4 RMS).
+// extremum.  Per-voxel terms are bit-identical to the reference; the ORDER of the fp32 additions of this first pass differs
+// (lane-strided + butterfly instead of sequential), which moves the tensor by ~1e-6 relative.
+//
+// r03 -- the window sums of every ACCEPTED keypoint are bit-identical to the reference's.  The descriptor is a discontinuous function
+// of the rotation matrix (a window voxel is in or out of the rotated 4x4x4 cube, Src/cSIFT3D.cc:1299-1303): a last-bit difference
+// of R flips single voxels, and where such a voxel carries a large gradient (small blobs at octave >= 1) one descriptor element
+// moved by up to 1.5e-3 (512^3: 15 of 11 292 keypoints above 8e-4; global RMS 4e-6).  So the parallel sums only SCREEN:
+// k_orient_finish flags every extremum that is accepted or within a margin of any threshold, k_orient<true> recomputes the
+// flagged ones (21 % of the extrema) with the reference's summation order -- the 9 terms of 64 consecutive lattice points go to
+// LDS and nine lanes add them one after the other, exactly like the sequential loop of Src/cSIFT3D.cc:958-998 (points the
+// reference skips contribute +0, which leaves an accumulator unchanged) -- and k_orient_finish runs again on them.
 #include <float.h>
 
 #include "sift3d_internal.h"
@@ -83,12 +92,18 @@ __device__ void eig_sym3(const double A[9], double w[3], double V[9]) {
 __device__ __forceinline__ float dot3f(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
 // everything after the window sums (Src/cSIFT3D.cc:1000-1137), executed by one lane
-__device__ int finish_orientation(DevKp &kp, const float T6[6], const float w3[3], float max_eig_ratio, float corner_thresh) {
+// *near (may be null): set when the extremum is accepted or any test lies within a margin of its threshold -- the fast sums carry
+// a relative error of ~1e-6, the margins are 100x that
+__device__ int finish_orientation(DevKp &kp, const float T6[6], const float w3[3], float max_eig_ratio, float corner_thresh, bool *near = nullptr) {
+	bool nr = false;
 	float T[9] = {T6[0], T6[1], T6[2], T6[1], T6[3], T6[4], T6[2], T6[4], T6[5]};
 #pragma unroll
 	for (int i = 0; i < 9; i++) kp.st[i] = T[i];
 	kp.win[0] = w3[0]; kp.win[1] = w3[1]; kp.win[2] = w3[2];
-	if (dot3f(w3, w3) < 1E-10f) return -1;  // ori_grad_thresh, Src/cSIFT3D.cc:22
+	const float gg = dot3f(w3, w3);
+	nr = fabsf(gg - 1E-10f) <= 1E-13f;
+	if (near) *near = nr;
+	if (gg < 1E-10f) return -1;  // ori_grad_thresh, Src/cSIFT3D.cc:22
 
 	double A[9], wv[3], V[9];
 #pragma unroll
@@ -113,7 +128,10 @@ __device__ int finish_orientation(DevKp &kp, const float T6[6], const float w3[3
 		kp.eigvalue[j] = val[j];
 		kp.eigvector[3 * j] = vec[j][0]; kp.eigvector[3 * j + 1] = vec[j][1]; kp.eigvector[3 * j + 2] = vec[j][2];
 	}
-	if (fabsf(__fdiv_rn(val[0], val[1])) > max_eig_ratio || fabsf(__fdiv_rn(val[1], val[2])) > max_eig_ratio) return -2;
+	const float r01 = fabsf(__fdiv_rn(val[0], val[1])), r12 = fabsf(__fdiv_rn(val[1], val[2]));
+	nr = nr || fabsf(r01 - max_eig_ratio) <= 1e-4f || fabsf(r12 - max_eig_ratio) <= 1e-4f || !(r01 == r01) || !(r12 == r12);
+	if (near) *near = nr;
+	if (r01 > max_eig_ratio || r12 > max_eig_ratio) return -2;
 	if ((double)fabsf(val[0] - val[1]) < DBL_EPSILON || (double)fabsf(val[0] - val[2]) < DBL_EPSILON ||
 	    (double)fabsf(val[2] - val[1]) < DBL_EPSILON)
 		return -2;
@@ -129,7 +147,10 @@ __device__ int finish_orientation(DevKp &kp, const float T6[6], const float w3[3
 		const float sgn = d > 0.0f ? 1.0f : -1.0f;
 		vec[i][0] *= sgn; vec[i][1] *= sgn; vec[i][2] *= sgn;
 	}
+	nr = nr || fabsf(corner - corner_thresh) <= 1e-4f;
+	if (near) *near = nr;
 	if (corner < corner_thresh) return -3;
+	if (near) *near = true;  // accepted: its sums are recomputed in the reference's order
 	const float *v1 = vec[2], *v2 = vec[1];
 	float vr[3];
 	vr[0] = v1[1] * v2[2] - v1[2] * v2[1];
@@ -151,24 +172,32 @@ constexpr int kTilePc = ((kTileW / 4) * kTileH + 63) / 64;  // 16-byte pieces of
 typedef float f4o __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte global piece at dword alignment
 constexpr int kOriLut = 256;  // squared-offset weight table of the orientation window (r^2 <= 131 by default)
 
+// EXACT = false: every owned extremum, parallel sums (lane-strided + butterfly).  EXACT = true: the extrema of redo_list, sums in
+// the reference's order (see the header): a pass hands 64 consecutive window points -- in the reference's (z, y, x) loop order -- to
+// the lanes, the nine products of every point go to the wave's term buffer in LDS and lanes 0..8 add the 64 values of "their" sum
+// one after the other.  Points the reference skips (outside the sphere / the clipped box) contribute +0.0f: acc + 0 == acc.
+constexpr int kTermPitch = 68;  // floats per term row: rows start 4 banks apart, the chain's 16-byte reads do not collide
+template <bool EXACT>
 __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__restrict__ codes, const unsigned *__restrict__ d_count, unsigned cap,
                                                 const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                 const float *__restrict__ lutpool, float max_eig, float corner, int part_rank,
-                                                int part_world) {
+                                                int part_world, const int *__restrict__ redo_list, const unsigned *__restrict__ redo_count) {
 	__shared__ __attribute__((aligned(16))) float s_tile[4 * 3 * kTileW * kTileH];  // per wave: planes z-1, z, z+1 of the window footprint
 	__shared__ float s_wlut[4 * kOriLut];
+	__shared__ __attribute__((aligned(16))) float s_terms[EXACT ? 4 * 9 * kTermPitch : 4];
 	const unsigned count = min(d_count[0], cap);
 	const int lane = threadIdx.x & 63;
 	const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
 	// partitioned run: this rank orients the extrema k = j * world + rank (dealt densely to the waves); the others get code 0
 	const unsigned pw = part_world > 1 ? (unsigned)part_world : 1u, pr = part_world > 1 ? (unsigned)part_rank : 0u;
-	if (pw > 1)
+	if (!EXACT && pw > 1)
 		for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x)
 			if (k % pw != pr) { kps[k].code = 0; codes[k] = 0; }
-	const unsigned owned = count > pr ? (count - pr + pw - 1) / pw : 0u;
+	const unsigned owned = EXACT ? min(redo_count[0], cap) : (count > pr ? (count - pr + pw - 1) / pw : 0u);
+	float *tb = &s_terms[EXACT ? (threadIdx.x >> 6) * 9 * kTermPitch : 0];
 	for (unsigned j = wave; j < owned; j += nwaves) {
-		const unsigned k = j * pw + pr;
+		const unsigned k = EXACT ? (unsigned)redo_list[j] : j * pw + pr;
 		const int cxi = kps[k].x, cyi = kps[k].y, czi = kps[k].z;
 		const int li = kps[k].octave * 8 + kps[k].level;
 		const LevelRef L = levels[li];
@@ -185,12 +214,59 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 		const size_t sy = (size_t)L.nx, sz = (size_t)L.nx * L.ny;
 		const gfloat_p Ld = as_global(L.d);  // global_load instead of flat_load (see sift3d_internal.h)
 		float t00 = 0.f, t01 = 0.f, t02 = 0.f, t11 = 0.f, t12 = 0.f, t22 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+		float chain = 0.f;  // EXACT: lane a < 9 carries sum a (t00 t01 t02 t11 t12 t22 g0 g1 g2)
+		// one window point per lane: fast form = nine partial sums per lane; exact form = the 64 points of the pass, which are
+		// consecutive in the reference's loop order, are added one after the other (nvalid: wave-uniform bound on the leading
+		// points of the pass that can be valid)
+		auto emit = [&](bool ok, float c1p, float c1m, float c2p, float c2m, float c3p, float c3m, float ww, int nvalid) {
+			float vx = 0.5f * (c1p - c1m);
+			float vy = 0.5f * (c2p - c2m);
+			float vz = 0.5f * (c3p - c3m);
+			vx = vx * inv_u; vy = vy * inv_u; vz = vz * inv_u;
+			if (!EXACT) {
+				if (ok) {
+					t00 = t00 + vx * vx * ww;
+					t01 = t01 + vx * vy * ww;
+					t02 = t02 + vx * vz * ww;
+					t11 = t11 + vy * vy * ww;
+					t12 = t12 + vy * vz * ww;
+					t22 = t22 + vz * vz * ww;
+					g0 = g0 + vx * ww; g1 = g1 + vy * ww; g2 = g2 + vz * ww;
+				}
+			} else {
+				tb[0 * kTermPitch + lane] = ok ? vx * vx * ww : 0.0f;
+				tb[1 * kTermPitch + lane] = ok ? vx * vy * ww : 0.0f;
+				tb[2 * kTermPitch + lane] = ok ? vx * vz * ww : 0.0f;
+				tb[3 * kTermPitch + lane] = ok ? vy * vy * ww : 0.0f;
+				tb[4 * kTermPitch + lane] = ok ? vy * vz * ww : 0.0f;
+				tb[5 * kTermPitch + lane] = ok ? vz * vz * ww : 0.0f;
+				tb[6 * kTermPitch + lane] = ok ? vx * ww : 0.0f;
+				tb[7 * kTermPitch + lane] = ok ? vy * ww : 0.0f;
+				tb[8 * kTermPitch + lane] = ok ? vz * ww : 0.0f;
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				if (lane < 9) {
+					// (eight 16-byte reads in flight, then their 32 dependent adds: the loop is bound by the add chain, not by LDS latency)
+					const float4 *row = reinterpret_cast<const float4 *>(tb + lane * kTermPitch);
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						if (h * 32 >= nvalid) break;  // wave-uniform
+						float4 v[8];
+#pragma unroll
+						for (int i = 0; i < 8; i++) v[i] = row[h * 8 + i];
+#pragma unroll
+						for (int i = 0; i < 8; i++) { chain = chain + v[i].x; chain = chain + v[i].y; chain = chain + v[i].z; chain = chain + v[i].w; }
+					}
+				}
+				__builtin_amdgcn_wave_barrier();  // the term rows are free again
+			}
+		};
 		const int tw = wx + 2, th = wy + 2;  // window footprint plus the central-difference border
 		if (plane > 0 && z1 >= z0 && tw <= kTileW && th <= kTileH && lut.len <= kOriLut) {
 			// ---- LDS path: three consecutive (tw x th) planes of the level live in this wave's LDS slots, so a window
 			// voxel costs one global load (plus border) instead of six; plane z+2 is requested into registers while plane
-			// z is processed and written to its slot one iteration later.  Same voxel -> lane mapping and accumulation
-			// order as the global path below.
+			// z is processed and written to its slot one iteration later.  Same voxel -> lane mapping as the global path below.
 			float *tile = &s_tile[(threadIdx.x >> 6) * 3 * kTileW * kTileH];
 			float *wl = &s_wlut[(threadIdx.x >> 6) * kOriLut];   // this wave's copy of the window weights
 			for (int i = lane; i < lut.len && i < kOriLut; i += 64) wl[i] = wtab[i];
@@ -270,7 +346,7 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 					// the lattice points of the window sphere in this plane come from a list (WinLut::list_off): 52 % of the box is
 					// outside the sphere, and the list also carries n = dx^2 + dy^2 + dz^2.  Windows clipped by the level border skip
 					// the entries outside their box.  This plane's entries were requested one plane ago (a load inside the pass loop
-					// would put a memory round trip in front of every pass).
+					// would put a memory round trip in front of every pass).  The list is in (dy, dx) order: the reference's loop order.
 					unsigned E[kEL];
 #pragma unroll
 					for (int i = 0; i < kEL; i++) E[i] = En[i];
@@ -292,20 +368,22 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 						}
 #pragma unroll
 						for (int q = 0; q < kUn; q++) {
-							if (w[q] < 0.0f) continue;  // outside the clipped box / past the end of the plane's list
-							float vx = 0.5f * (nb[q][0] - nb[q][1]);
-							float vy = 0.5f * (nb[q][2] - nb[q][3]);
-							float vz = 0.5f * (nb[q][4] - nb[q][5]);
-							vx = vx * inv_u; vy = vy * inv_u; vz = vz * inv_u;
-							const float ww = w[q];
-							t00 = t00 + vx * vx * ww;
-							t01 = t01 + vx * vy * ww;
-							t02 = t02 + vx * vz * ww;
-							t11 = t11 + vy * vy * ww;
-							t12 = t12 + vy * vz * ww;
-							t22 = t22 + vz * vz * ww;
-							g0 = g0 + vx * ww; g1 = g1 + vy * ww; g2 = g2 + vz * ww;
+							if (EXACT && (p0 + q) * 64 >= cnt) break;  // wave-uniform: nothing left in this plane
+							// w < 0: outside the clipped box / past the end of the plane's list
+							emit(!(w[q] < 0.0f), nb[q][0], nb[q][1], nb[q][2], nb[q][3], nb[q][4], nb[q][5], w[q], min(64, cnt - (p0 + q) * 64));
 						}
+					}
+				} else if (EXACT) {
+					for (int vb = 0; vb < plane; vb += 64) {  // wave-uniform passes of 64 consecutive box voxels
+						const int v = vb + lane;
+						const int ly = (int)(((float)v + 0.5f) * inv_wx);
+						const int lx = v - ly * wx;
+						const int dx = x0 + lx - cxi, dy = y0 + ly - cyi;
+						const int n = dx * dx + dy * dy + dz * dz;
+						const bool in = v < plane && n < lut.len;
+						const float ww = in ? wl[n] : -1.0f;
+						const int o = in ? __mul24(ly + 1, kTileW) + lx + 1 : kTileW + 1;
+						emit(!(ww < 0.0f), pc[o + 1], pc[o - 1], pc[o + kTileW], pc[o - kTileW], pp[o], pm[o], ww, min(64, plane - vb));
 					}
 				} else
 				for (int v0 = lane; v0 < plane; v0 += 64 * kUn) {
@@ -324,21 +402,8 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 						nb[q][4] = pp[o]; nb[q][5] = pm[o];
 					}
 #pragma unroll
-					for (int q = 0; q < kUn; q++) {
-						if (w[q] < 0.0f) continue;  // outside the sphere / past the end of the plane
-						float vx = 0.5f * (nb[q][0] - nb[q][1]);
-						float vy = 0.5f * (nb[q][2] - nb[q][3]);
-						float vz = 0.5f * (nb[q][4] - nb[q][5]);
-						vx = vx * inv_u; vy = vy * inv_u; vz = vz * inv_u;
-						const float ww = w[q];
-						t00 = t00 + vx * vx * ww;
-						t01 = t01 + vx * vy * ww;
-						t02 = t02 + vx * vz * ww;
-						t11 = t11 + vy * vy * ww;
-						t12 = t12 + vy * vz * ww;
-						t22 = t22 + vz * vz * ww;
-						g0 = g0 + vx * ww; g1 = g1 + vy * ww; g2 = g2 + vz * ww;
-					}
+					for (int q = 0; q < kUn; q++)  // w < 0: outside the sphere / past the end of the plane
+						emit(!(w[q] < 0.0f), nb[q][0], nb[q][1], nb[q][2], nb[q][3], nb[q][4], nb[q][5], w[q], 64);
 				}
 				__builtin_amdgcn_wave_barrier();   // every lane is done with plane z-1 before its slot is overwritten
 				const int tmp = sm; sm = sc; sc = sp; sp = tmp;
@@ -346,66 +411,82 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 		} else
 		for (int z = z0; z <= z1; z++) {
 			const int dz = z - czi;
-			for (int v = lane; v < plane; v += 64) {
+			for (int vb = 0; vb < plane; vb += 64) {  // wave-uniform passes (EXACT needs every lane at the term buffer)
+				const int v = vb + lane;
 				const int ly = (int)(((float)v + 0.5f) * inv_wx);
 				const int lx = v - ly * wx;
 				const int x = x0 + lx, y = y0 + ly;
 				const int dx = x - cxi, dy = y - cyi;
 				const int n = dx * dx + dy * dy + dz * dz;
-				if (n >= lut.len) continue;
-				const float w = wtab[n];
-				if (w < 0.0f) continue;  // outside the sphere
-				const gfloat_p c = Ld + (size_t)x + sy * (size_t)y + sz * (size_t)(z - L.zoff);
-				float vx = 0.5f * (c[1] - c[-1]);
-				float vy = 0.5f * (c[sy] - *(c - sy));
-				float vz = 0.5f * (c[sz] - *(c - sz));
-				vx = vx * inv_u; vy = vy * inv_u; vz = vz * inv_u;
-				t00 = t00 + vx * vx * w;
-				t01 = t01 + vx * vy * w;
-				t02 = t02 + vx * vz * w;
-				t11 = t11 + vy * vy * w;
-				t12 = t12 + vy * vz * w;
-				t22 = t22 + vz * vz * w;
-				g0 = g0 + vx * w; g1 = g1 + vy * w; g2 = g2 + vz * w;
+				const bool in = v < plane && n < lut.len;
+				const float w = in ? wtab[n] : -1.0f;  // < 0: outside the sphere
+				const bool ok = !(w < 0.0f);
+				const gfloat_p c = ok ? Ld + (size_t)x + sy * (size_t)y + sz * (size_t)(z - L.zoff)
+				                      : Ld + (size_t)cxi + sy * (size_t)cyi + sz * (size_t)(czi - L.zoff);  // masked lanes read the centre
+				emit(ok, c[1], c[-1], c[sy], *(c - sy), c[sz], *(c - sz), w, min(64, plane - vb));
 			}
 		}
-		float T6[6] = {wave_sum(t00), wave_sum(t01), wave_sum(t02), wave_sum(t11), wave_sum(t12), wave_sum(t22)};
-		float w3[3] = {wave_sum(g0), wave_sum(g1), wave_sum(g2)};
-		if (lane == 0) {
-			// window sums only: the eigen decomposition runs in k_orient_finish, one LANE per extremum (here it would
-			// occupy one lane of the wave and idle the other 63)
-			kps[k].st[0] = T6[0]; kps[k].st[1] = T6[1]; kps[k].st[2] = T6[2]; kps[k].st[4] = T6[3]; kps[k].st[5] = T6[4]; kps[k].st[8] = T6[5];
-			kps[k].win[0] = w3[0]; kps[k].win[1] = w3[1]; kps[k].win[2] = w3[2];
+		if (EXACT) {
+			if (lane < 9) {
+				const int slot = lane < 3 ? lane : (lane == 3 ? 4 : (lane == 4 ? 5 : 8));  // t00 t01 t02 t11 t12 t22 -> st[0 1 2 4 5 8]
+				if (lane < 6) kps[k].st[slot] = chain;
+				else kps[k].win[lane - 6] = chain;
+			}
+		} else {
+			float T6[6] = {wave_sum(t00), wave_sum(t01), wave_sum(t02), wave_sum(t11), wave_sum(t12), wave_sum(t22)};
+			float w3[3] = {wave_sum(g0), wave_sum(g1), wave_sum(g2)};
+			if (lane == 0) {
+				// window sums only: the eigen decomposition runs in k_orient_finish, one LANE per extremum (here it would
+				// occupy one lane of the wave and idle the other 63)
+				kps[k].st[0] = T6[0]; kps[k].st[1] = T6[1]; kps[k].st[2] = T6[2]; kps[k].st[4] = T6[3]; kps[k].st[5] = T6[4]; kps[k].st[8] = T6[5];
+				kps[k].win[0] = w3[0]; kps[k].win[1] = w3[1]; kps[k].win[2] = w3[2];
+			}
 		}
 	}
 }
 
 // second phase of Assign_Orientation_Imp (Src/cSIFT3D.cc:1000-1137): eigen decomposition, rejection tests, rotation
 // matrix; one thread per extremum
+// pass 0: every owned extremum, from the parallel sums; extrema that are accepted or close to a threshold are appended to
+// redo_list.  pass 1: the extrema of redo_list, from the sums in the reference's order.
 __global__ void __launch_bounds__(64) k_orient_finish(DevKp *__restrict__ kps, int *__restrict__ codes, const unsigned *__restrict__ d_count,
-                                                      unsigned cap, float max_eig, float corner, int part_rank, int part_world) {
+                                                      unsigned cap, float max_eig, float corner, int part_rank, int part_world, int pass,
+                                                      int *__restrict__ redo_list, unsigned *__restrict__ redo_count) {
 	const unsigned count = min(d_count[0], cap);
 	const unsigned pw = part_world > 1 ? (unsigned)part_world : 1u, pr = part_world > 1 ? (unsigned)part_rank : 0u;
-	const unsigned owned = count > pr ? (count - pr + pw - 1) / pw : 0u;
+	const unsigned owned = pass ? min(redo_count[0], cap) : (count > pr ? (count - pr + pw - 1) / pw : 0u);
 	for (unsigned j = blockIdx.x * blockDim.x + threadIdx.x; j < owned; j += gridDim.x * blockDim.x) {
-		const unsigned k = j * pw + pr;
+		const unsigned k = pass ? (unsigned)redo_list[j] : j * pw + pr;
 		DevKp kp = kps[k];
 		const float T6[6] = {kp.st[0], kp.st[1], kp.st[2], kp.st[4], kp.st[5], kp.st[8]};
 		const float w3[3] = {kp.win[0], kp.win[1], kp.win[2]};
-		kp.code = finish_orientation(kp, T6, w3, max_eig, corner);
+		bool near = false;
+		kp.code = finish_orientation(kp, T6, w3, max_eig, corner, &near);
 		kps[k] = kp;
 		codes[k] = kp.code == 1 ? ((kp.level << 4) | 1) : kp.code;  // dense copy for the compaction scan (level in the high bits)
+		if (!pass && near) {
+			const unsigned pos = atomicAdd(redo_count, 1u);
+			if (pos < cap) redo_list[pos] = (int)k;
+		}
 	}
 }
 
 void launch_orient(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap, const LevelRef *d_levels, const WinLut *d_luts,
-                   const float *d_lutpool, float max_eig, float corner, int part_rank, int part_world, hipStream_t st) {
+                   const float *d_lutpool, float max_eig, float corner, int part_rank, int part_world, int *redo_list, unsigned *redo_count,
+                   hipStream_t st) {
 	// windows differ 3x in volume between the keypoint levels: many short-lived workgroups (1-2 windows per wave) balance better than a
 	// resident-sized grid (0.70 vs 0.75 ms at 512^3; S3D_ORI_GRID to measure)
-	static const int ori_grid = [] { const char *e = getenv("S3D_ORI_GRID"); return e ? atoi(e) : 256 * 32; }();
-	hipLaunchKernelGGL(k_orient, dim3(ori_grid), dim3(256), 0, st, kps, codes, d_count, cap, d_levels, d_luts, d_lutpool, max_eig, corner,
-	                   part_rank, part_world);
-	hipLaunchKernelGGL(k_orient_finish, dim3(256 * 8), dim3(64), 0, st, kps, codes, d_count, cap, max_eig, corner, part_rank, part_world);
+	static const int ori_grid = dev_tune_i("S3D_ORI_GRID", 256 * 32);
+	(void)hipMemsetAsync(redo_count, 0, sizeof(unsigned), st);
+	hipLaunchKernelGGL(k_orient<false>, dim3(ori_grid), dim3(256), 0, st, kps, codes, d_count, cap, d_levels, d_luts, d_lutpool, max_eig, corner,
+	                   part_rank, part_world, (const int *)redo_list, (const unsigned *)redo_count);
+	hipLaunchKernelGGL(k_orient_finish, dim3(256 * 8), dim3(64), 0, st, kps, codes, d_count, cap, max_eig, corner, part_rank, part_world, 0,
+	                   redo_list, redo_count);
+	// accepted and borderline extrema again, with the sums in the reference's order (see the header)
+	hipLaunchKernelGGL(k_orient<true>, dim3(ori_grid), dim3(256), 0, st, kps, codes, d_count, cap, d_levels, d_luts, d_lutpool, max_eig, corner,
+	                   part_rank, part_world, (const int *)redo_list, (const unsigned *)redo_count);
+	hipLaunchKernelGGL(k_orient_finish, dim3(256 * 2), dim3(64), 0, st, kps, codes, d_count, cap, max_eig, corner, part_rank, part_world, 1,
+	                   redo_list, redo_count);
 }
 
 // Orientation results as kOrientWords int32 words per extremum (code, then the bit patterns of win, eigvalue, eigvector,

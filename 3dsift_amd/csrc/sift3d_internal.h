@@ -127,6 +127,7 @@ bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogm
 // tile-aligned levels (kernels_march.hip): descending z-march with scatter accumulators; false => not applicable, use the above
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
                         hipStream_t st, int plan_slots = 0, int prio = 0 /* wave priority class: 0 normal, 1, 2 */);
+void launch_copy16(const float *src, float *dst, size_t nfloats, hipStream_t st);  // float4 copy (bandwidth ceiling probe)
 void launch_downsample(const float *src, int snx, int sny, float *dst, int nx, int ny, int nz, hipStream_t st);
 
 // ---- kernels_detect.hip --------------------------------------------------------------------
@@ -187,6 +188,7 @@ struct LevelRef {
 // part_rank / part_world: only extrema with index % part_world == part_rank are oriented (the others get code 0)
 void launch_orient(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap, const LevelRef *d_levels /*[noct*8]*/,
                    const WinLut *d_luts, const float *d_lutpool, float max_eig, float corner, int part_rank, int part_world,
+                   int *redo_list /* cap ints: the extrema whose sums are redone in the reference's order */, unsigned *redo_count,
                    hipStream_t st);
 constexpr int kOrientWords = 34;  // code + win[3] + eigvalue[3] + eigvector[9] + rot[9] + st[9]  (== SIFT3D_ORIENT_WORDS)
 void launch_orient_pack(const DevKp *kps, const unsigned *d_count, unsigned cap, int *dst, int part_rank, int part_world, hipStream_t st);
@@ -203,6 +205,7 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
                      const WinLut *d_luts, const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world,
                      const int *order, const unsigned *d_nkp, unsigned *d_work /* device counter, zeroed by the launch */,
                      hipStream_t st, bool lut_in_lds = true);
+void launch_face_lookup(const float *d_g3, int n, int route, int *d_face, float *d_bary3, hipStream_t st);  // sift3d_debug_face_lookup
 void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, int transposed,
                      sift3d_keypoint *d_out, float *d_xyz, unsigned kp_cap, hipStream_t st);
 
@@ -218,6 +221,20 @@ struct MatchGuard {
 };
 int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const float *d_b, int m, int *d_cand /*nrows*4*/,
                       void *d_part, float *d_gd, float *d_sd, int *d_gi, int *d_si, const MatchGuard &g, hipStream_t st);
+int match_redo_rows();  // rows the last sift3d_match re-scored exactly (near-tie guard)
+
+// ---- test hooks and development switches --------------------------------------------------------
+// Test hooks (include/sift3d_hip.h, sift3d_test_hook): process-wide integers that force code paths ordinary inputs rarely
+// reach, so that the parity tests execute every branch of the product.  hook(SIFT3D_HOOK_x) reads the current value.
+int hook(int which);
+// Tuning values of the launch planning: compile-time defaults.  Only a -DS3D_DEV_SWITCHES build (scripts/build_variant.sh, the
+// A/B measurement scripts) lets an environment variable override them; the product library never reads the environment.
+int dev_tune_i(const char *env_name, int dflt);
+double dev_tune_d(const char *env_name, double dflt);
+
+// ---- staging.hip: pageable host memory <-> device through pinned, double-buffered chunks --------
+int staged_h2d(void *d_dst, const void *h_src, size_t bytes, int device, hipStream_t st);  // stream-ordered on return
+int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStream_t st);  // complete on return
 
 // error plumbing
 void set_last_error(const std::string &s);

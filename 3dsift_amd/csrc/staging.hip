@@ -1,0 +1,108 @@
+// staging.hip -- host <-> device copies of pageable host memory through a small pinned, double-buffered staging pool.
+//
+// CreateCSIFT3D(float*) hands over a pageable volume (Src/cSIFT3D.cc:146-163 copies it with memcpy) and GetKeypoints returns
+// pageable vectors (Src/cSIFT3D.cc:1686-1688).  One hipMemcpy of pageable memory moved 0.5-0.8 GB/s on the MI355X boxes (r02:
+// 650-990 ms for the 512 MB of a 512^3 volume); here the host side of the copy is a multi-threaded memcpy into / out of pinned
+// chunks that overlap with the DMA of the previous chunk.  Host only, no kernels.
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "sift3d_internal.h"
+
+namespace s3d {
+
+namespace {
+constexpr size_t kChunk = (size_t)16 << 20;  // bytes per pinned buffer
+constexpr int kBufs = 2;
+struct Pool {
+	std::mutex mu;
+	char *buf[kBufs] = {nullptr, nullptr};
+	hipEvent_t ev[kBufs] = {nullptr, nullptr};
+	int device = -1;  // events belong to a device
+};
+Pool g_pool;
+
+int pool_ready(Pool &P, int device) {
+	for (int i = 0; i < kBufs; i++)
+		if (!P.buf[i]) S3D_HIP(hipHostMalloc(reinterpret_cast<void **>(&P.buf[i]), kChunk, hipHostMallocPortable));
+	if (P.device != device) {
+		for (int i = 0; i < kBufs; i++) {
+			if (P.ev[i]) (void)hipEventDestroy(P.ev[i]);
+			P.ev[i] = nullptr;
+			S3D_HIP(hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming));
+		}
+		P.device = device;
+	}
+	return SIFT3D_OK;
+}
+
+// memcpy with a few helper threads (a single core moves 8-12 GB/s; PCIe 5 x16 wants ~50)
+void par_memcpy(char *dst, const char *src, size_t bytes) {
+	const unsigned hc = std::thread::hardware_concurrency();
+	const int nt = (int)std::min<size_t>(std::max(1u, std::min(4u, hc ? hc / 2 : 1u)), std::max<size_t>(1, bytes >> 20));
+	if (nt <= 1) { memcpy(dst, src, bytes); return; }
+	const size_t part = ((bytes / nt) + 4095) & ~(size_t)4095;
+	std::vector<std::thread> th;
+	for (int t = 1; t < nt; t++) {
+		const size_t o = std::min(bytes, part * (size_t)t), e = std::min(bytes, o + part);
+		if (e > o) th.emplace_back([=] { memcpy(dst + o, src + o, e - o); });
+	}
+	memcpy(dst, src, std::min(bytes, part));
+	for (auto &t : th) t.join();
+}
+}  // namespace
+
+// host (pageable) -> device; returns after every byte has been handed to the stream (the copies are still in flight: stream-ordered)
+int staged_h2d(void *d_dst, const void *h_src, size_t bytes, int device, hipStream_t st) {
+	if (bytes == 0) return SIFT3D_OK;
+	if (bytes < ((size_t)1 << 20)) { S3D_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st)); return SIFT3D_OK; }
+	std::lock_guard<std::mutex> lock(g_pool.mu);
+	int rc = pool_ready(g_pool, device);
+	if (rc) return rc;
+	size_t off = 0;
+	for (int i = 0; off < bytes; i++) {
+		const int b = i % kBufs;
+		const size_t n = std::min(kChunk, bytes - off);
+		if (i >= kBufs) S3D_HIP(hipEventSynchronize(g_pool.ev[b]));  // the DMA that last read this buffer is done
+		par_memcpy(g_pool.buf[b], static_cast<const char *>(h_src) + off, n);
+		S3D_HIP(hipMemcpyAsync(static_cast<char *>(d_dst) + off, g_pool.buf[b], n, hipMemcpyHostToDevice, st));
+		S3D_HIP(hipEventRecord(g_pool.ev[b], st));
+		off += n;
+	}
+	for (int b = 0; b < kBufs; b++) S3D_HIP(hipEventSynchronize(g_pool.ev[b]));  // the pool is free for the next caller
+	return SIFT3D_OK;
+}
+
+// device -> host (pageable); synchronous: the data is in h_dst on return
+int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStream_t st) {
+	if (bytes == 0) return SIFT3D_OK;
+	if (bytes < ((size_t)1 << 20)) {
+		S3D_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+		S3D_HIP(hipStreamSynchronize(st));
+		return SIFT3D_OK;
+	}
+	std::lock_guard<std::mutex> lock(g_pool.mu);
+	int rc = pool_ready(g_pool, device);
+	if (rc) return rc;
+	const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+	auto issue = [&](size_t i) -> hipError_t {
+		const size_t off = i * kChunk, n = std::min(kChunk, bytes - off);
+		hipError_t e = hipMemcpyAsync(g_pool.buf[i % kBufs], static_cast<const char *>(d_src) + off, n, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipEventRecord(g_pool.ev[i % kBufs], st);
+		return e;
+	};
+	for (size_t i = 0; i < std::min<size_t>(kBufs, nchunks); i++) S3D_HIP(issue(i));
+	for (size_t i = 0; i < nchunks; i++) {
+		const size_t off = i * kChunk, n = std::min(kChunk, bytes - off);
+		S3D_HIP(hipEventSynchronize(g_pool.ev[i % kBufs]));
+		par_memcpy(static_cast<char *>(h_dst) + off, g_pool.buf[i % kBufs], n);
+		if (i + kBufs < nchunks) S3D_HIP(issue(i + kBufs));  // the buffer is free again
+	}
+	return SIFT3D_OK;
+}
+
+}  // namespace s3d

@@ -59,6 +59,11 @@ def my_pairs(rank, world):
     return [p for k, p in enumerate(ordered_pairs(world)) if k % world == rank]
 
 
+def match_pairs(descs, xyzs, match_fn, rank, world):
+    """run match_fn on the ordered pairs dealt to `rank` of `world`, from the gathered per-volume lists"""
+    return {(i, j): match_fn(descs[i], xyzs[i], descs[j], xyzs[j]) for (i, j) in my_pairs(rank, world)}
+
+
 def allpairs_match(desc, xyz, match_fn):
     """BASELINE configs[4] matching step: all-gather every rank's (ragged) descriptors and coordinates, then run
     `match_fn(desc_i, xyz_i, desc_j, xyz_j)` (enhancedMatch) on this rank's share of the ordered volume pairs.
@@ -67,4 +72,4 @@ def allpairs_match(desc, xyz, match_fn):
     xyzs = allgather_ragged(xyz)
     world = len(descs)
     rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
-    return {(i, j): match_fn(descs[i], xyzs[i], descs[j], xyzs[j]) for (i, j) in my_pairs(rank, world)}
+    return match_pairs(descs, xyzs, match_fn, rank, world)

@@ -17,9 +17,12 @@ exchange + all-reduce over RCCL; strong scaling, N=1 is the plain single-GPU ext
 A default N>1 run appends the slab measurement as "slab": {...} to its JSON line, behind a watchdog.
 
 The JSON line also carries
-  roofline      pyramid build (the HBM-bound part north_star sets a target for): algorithmic bytes
-                68 B x pyramid voxels / HIP-event time of that stage on the library's own
-                stream, against the 8 TB/s HBM3E peak
+  roofline      pyramid build (the HBM-bound part north_star sets a target for): the bytes its kernels MOVE
+                (52 B x pyramid voxels: two DoG levels per octave and the last Gaussian level are not built)
+                / HIP-event time of that stage on the library's own stream, against the 8 TB/s HBM3E peak;
+                frac_survey is the same time priced with SURVEY.md 8d's 68 B per voxel
+  descriptor    the descriptor stage (half of the step): keypoints/s, window voxels/s, and the VALU-issue roofline
+                of k_describe (wave-instructions from the committed PMC profile of the same kernel sources)
   cpu_baseline  the CPU oracle (our restatement of the reference, OpenMP) timed on this host on a
                 bounded sample of the same workload
   parity        the GPU result on that sample checked against the oracle
@@ -49,6 +52,26 @@ def pyramid_voxels(shape, levels=3):
         tot += nx * ny * nz
         nx, ny, nz = nx // 2, ny // 2, nz // 2
     return tot, noct
+
+
+def sphere_lattice_points(r2_over_u2):
+    """number of integer offsets (dx, dy, dz) with dx^2 + dy^2 + dz^2 <= r2_over_u2"""
+    R = int(np.floor(np.sqrt(r2_over_u2)))
+    a = np.arange(-R, R + 1, dtype=np.int64) ** 2
+    return int((a[:, None, None] + a[None, :, None] + a[None, None, :] <= r2_over_u2).sum())
+
+
+def descriptor_window_voxels(kp):
+    """voxels of the descriptor windows of a keypoint set: lattice points of the sphere r = 2 * 7.0711 * scale at the keypoint's
+    octave (Src/cSIFT3D.cc:1155-1156, 1276-1296), not clipped at the volume border"""
+    tot = 0
+    for o in np.unique(kp["octave"]):
+        for lv in np.unique(kp["level"][kp["octave"] == o]):
+            sel = kp[(kp["octave"] == o) & (kp["level"] == lv)]
+            r = np.float32(2.0) * (sel["scale"][0] * np.float32(7.071067812))
+            u = np.float32(2.0 ** int(o))
+            tot += len(sel) * sphere_lattice_points(float(r * r) / float(u * u))
+    return tot
 
 
 def parse_dims(txt):
@@ -152,6 +175,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=512, help="edge of the CPU-baseline sample crop (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-match", action="store_true", help="skip the configs[2] matcher leg")
+    ap.add_argument("--no-nonaligned", action="store_true", help="skip the non-tile-aligned volume leg")
+    ap.add_argument("--nonaligned-dims", default="480x500x300", help="nx x ny x nz of the non-aligned leg")
     ap.add_argument("--allpairs", action="store_true", help="N>1: all-gather descriptors + all-pairs enhancedMatch (configs[4])")
     ap.add_argument("--workload", choices=["volumes", "slab"], default="volumes")
     ap.add_argument("--slab-dims", default="1024x1024x512", help="nx x ny x nz of the sharded volume (configs[3])")
@@ -230,8 +255,13 @@ def main():
         except Exception:
             traffic = None
     t_pyr = stage["d_BuildGSS"] + stage["d_BuildDOG"]
-    alg_bytes = 68.0 * pv
-    achieved = alg_bytes / t_pyr / 1e9
+    # What the pyramid kernels MOVE: per octave 5 Gaussian levels read + written (40 B per voxel) + 3 DoG levels written (12 B) = 52 B.
+    # Not built at all: DoG[0] and DoG[nd-1] (only candidate voxels ever read them; the extrema test forms those values from the two
+    # Gaussian levels) and the last Gaussian level G[nd] (k_lazy_next evaluates it at the few thousand voxels that pass seven of the
+    # eight tests of the last keypoint level -- that kernel's time is in d_Detect, its reads are 17^3 samples per parked voxel out
+    # of the L2).  SURVEY 8d's accounting of an unfused build is 68 B; `frac_survey` prices the same seconds with it.
+    moved_bytes = 52.0 * pv
+    achieved = moved_bytes / t_pyr / 1e9
     out = {
         "metric": "Mvoxels/s end-to-end KpSiftAlgorithm on 512^3 fp32",
         "value": world * n ** 3 * args.steps / dt / 1e6,
@@ -250,27 +280,41 @@ def main():
                    "volumes_per_gpu": 1, "parallelism": f"independent volumes x{world}"},
         "stage_ms": {k: round(v * 1e3, 4) for k, v in stage.items()},
         "descriptor_keypoints_per_s": (nkp / stage["d_Extraction"]) if stage["d_Extraction"] > 0 else None,
-        "roofline": {"bound": "hbm", "kernel": "pyramid build (all Gaussian/DoG level kernels of one KpSiftAlgorithm)",
+        "roofline": {"bound": "hbm", "kernel": "pyramid build (all Gaussian/DoG level kernels of one KpSiftAlgorithm: k_march_level / k_conv_axis / k_downsample)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "algorithmic_bytes": alg_bytes, "seconds": t_pyr, "traffic": traffic, "traffic_note": traffic_note,
-                     # not everything SURVEY's 68 B/voxel counts is moved any more: the first and last DoG level of every octave are
-                     # not written (only candidate voxels ever read them; the extrema test forms those values from the two Gaussian
-                     # levels: 60 B), and since r02 the last Gaussian level is not built at all (it is read at the few thousand voxels
-                     # that pass seven of the eight extremum tests of the last keypoint level, where k_lazy_next evaluates it: 52 B)
-                     "algorithmic_bytes_moved": 52.0 * pv, "frac_moved": 52.0 * pv / t_pyr / 1e9 / HBM_PEAK_GBS},
+                     "algorithmic_bytes": moved_bytes, "bytes_per_pyramid_voxel": 52, "seconds": t_pyr,
+                     "traffic": traffic, "traffic_note": traffic_note,
+                     "frac_survey": 68.0 * pv / t_pyr / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_survey": 68.0 * pv},
     }
+    # ---- descriptor stage (keypoints/s and window-voxels/s, not an HBM fraction) + the VALU-issue roofline of k_describe
+    if stage["d_Extraction"] > 0 and nkp:
+        wv = descriptor_window_voxels(kp)
+        dsc = {"keypoints": nkp, "seconds": stage["d_Extraction"], "keypoints_per_s": nkp / stage["d_Extraction"],
+               "window_voxels": wv, "window_voxels_per_s": wv / stage["d_Extraction"]}
+        # wave-instructions of k_describe from the committed SQ-counter profile of the same kernel sources (rocprofv3 cannot run inside
+        # this process); issue peak = 1024 SIMDs x one fp32 wave-instruction per 1.0 ns (scripts/microbench/valu_chains.hip, r01)
+        pfile = os.path.join(ROOT, "profiles", f"pmc_k_describe_{n}.json")
+        if os.path.exists(pfile):
+            try:
+                pj = json.load(open(pfile))
+                if pj.get("kernel_source_sha") == capi.kernel_source_sha():
+                    valu = float(pj["SQ_INSTS_VALU"])
+                    peak = 1024 * 1.0e9
+                    dsc["roofline"] = {"bound": "valu-issue", "kernel": "k_describe", "achieved": valu / stage["d_Extraction"] / 1e9, "peak": peak / 1e9,
+                                       "unit": "G wave-instructions/s", "frac": valu / stage["d_Extraction"] / peak,
+                                       "valu_wave_instructions": valu, "per_keypoint": valu / nkp,
+                                       "lds_bank_conflict_share": (pj["SQ_LDS_BANK_CONFLICT"] / pj["SQ_LDS_IDX_ACTIVE"]) if pj.get("SQ_LDS_IDX_ACTIVE") else None}
+                else:
+                    dsc["roofline_note"] = "profiles/pmc_k_describe file was measured on other kernel sources: not reported"
+            except Exception:
+                pass
+        out["descriptor"] = dsc
+    out["debug_counters"] = ex.debug_counters()
 
     if rank == 0 and world == 1:
-        # ---- measured device-copy ceiling beside the spec peak: 1 GiB fp32 copied device to device, read + write counted
-        src = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
-        dst = torch.empty_like(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        best = 1e9
-        for _ in range(5):
-            e0.record(); dst.copy_(src); e1.record(); torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) * 1e-3)
-        copy_gbs = 2.0 * src.numel() * 4 / best / 1e9
-        del src, dst
+        # ---- measured device-copy ceiling beside the spec peak: the library's float4 copy kernel on 1 GiB, read + write counted
+        # (the MI355X guide measures 6.29 TB/s with such a kernel)
+        copy_gbs = capi.copy_bandwidth(1 << 30, 5, local)
         out["roofline"]["copy_ceiling_GBs"] = copy_gbs
         out["roofline"]["frac_of_copy_ceiling"] = achieved / copy_gbs
         # ---- constructor (never part of `value`): D2D copy + max-abs normalise from a device-resident volume, and the same from
@@ -284,7 +328,33 @@ def main():
         t_h2d = time.perf_counter() - tc0
         exc.close(); del host_vol
         out["ctor_ms"] = {"device_resident_volume": round(min(tcs) * 1e3, 3), "host_volume_incl_H2D": round(t_h2d * 1e3, 3),
-                          "note": "arena allocation + copy + data_scale; outside KpSiftAlgorithm in the reference too (Src/cSIFT3D.cc:146-163)"}
+                          "note": "arena allocation + copy + data_scale; outside KpSiftAlgorithm in the reference too (Src/cSIFT3D.cc:146-163); "
+                                  "the host volume is pageable memory, staged through pinned chunks (csrc/staging.hip)"}
+        tg = []
+        for _ in range(3):
+            tc0 = time.perf_counter(); ex.GetKeypoints(); tg.append(time.perf_counter() - tc0)
+        out["get_keypoints_ms"] = {"with_descriptors_D2H": round(min(tg) * 1e3, 3), "bytes": int(nkp * (768 * 4 + 168))}
+    if rank == 0 and world == 1 and not args.no_nonaligned:
+        # ---- a volume whose width and height are NOT multiples of the 32 x 32 tile of the level kernel (not part of `value`): the
+        # pyramid stage priced like the headline's, per pyramid voxel
+        nx2, ny2, nz2 = parse_dims(args.nonaligned_dims)
+        shape2 = (nz2, ny2, nx2)
+        v2 = synth.blobs_torch(shape2, dev, seed=4242)
+        torch.cuda.synchronize()
+        e2 = capi.CSIFT3D(None, device=local, device_ptr=v2.data_ptr(), shape=shape2)
+        e2.KpSiftAlgorithm()
+        st2, t2 = {}, []
+        for _ in range(3):
+            tc0 = time.perf_counter(); e2.KpSiftAlgorithm(); t2.append(time.perf_counter() - tc0)
+            for k, v in e2.m_timer.items():
+                st2[k] = st2.get(k, 0.0) + v / 3
+        pv2, noct2 = pyramid_voxels(shape2)
+        tp2 = st2["d_BuildGSS"] + st2["d_BuildDOG"]
+        out["nonaligned"] = {"workload": f"{nx2}x{ny2}x{nz2} fp32 synthetic blob volume ({noct2} octaves)", "ms_per_step": float(np.median(t2)) * 1e3,
+                             "Mvoxels_per_s": nx2 * ny2 * nz2 / float(np.median(t2)) / 1e6, "stage_ms": {k: round(v * 1e3, 4) for k, v in st2.items()},
+                             "pyramid_frac": 52.0 * pv2 / tp2 / 1e9 / HBM_PEAK_GBS,
+                             "pyramid_ns_per_pyramid_voxel": tp2 / pv2 * 1e9, "aligned_pyramid_ns_per_pyramid_voxel": t_pyr / pv * 1e9}
+        e2.close(); del v2
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
         # ---- CPU baseline + parity on a bounded sample: the [0:s]^3 crop of the same volume ----
         import oracle_lib as ol  # test infrastructure, used here ONLY as the timed baseline / checker
@@ -319,9 +389,11 @@ def main():
         g = capi.CSIFT3D(crop, device=local).KpSiftAlgorithm()
         gkp, gdesc = g.GetKeypoints()
         same = len(gkp) == len(okp) and all(np.array_equal(gkp[f], okp[f]) for f in ("x", "y", "z", "octave", "level"))
-        rms = float(np.sqrt(np.mean((gdesc.astype(np.float64) - odesc) ** 2))) if same and len(okp) else None
+        from hipcheck import descriptor_errors
+        rms, worst_kp, worst_abs = descriptor_errors(gdesc, odesc) if same and len(okp) else (None, None, None)
         out["parity"] = {"sample_keypoints_gpu": len(gkp), "sample_keypoints_cpu": len(okp), "same_keypoint_set": bool(same),
-                         "descriptor_rms": rms}
+                         "descriptor_rms": rms, "worst_keypoint_rms": worst_kp, "worst_element_abs": worst_abs,
+                         "bars": "1e-4 RMS per keypoint, 5e-4 per element (tests/hipcheck.py)"}
     if rank == 0 and world == 1 and not args.no_match:
         # ---- BASELINE configs[2] leg (not part of `value`): second volume = the same blobs shifted by one voxel in x,
         # extract, then muBruteMatcher::enhancedMatch on the device-resident descriptors; the score GEMM is the one MFMA
@@ -333,16 +405,17 @@ def main():
         ex2.KpSiftAlgorithm()
         (da, xa, na), (db, xb, nb) = ex.device_results(), ex2.device_results()
         mt = capi.muBruteMatcher(device=local)
-        secs, secs_e = [], []
+        secs, secs_e, wall, wall_e, exact = [], [], [], [], []
         for _ in range(3):
             mt.injectMatch(da, xa, db, xb, 0.85, on_device=True, n=na, m=nb)   # one full N x M pass: exact flop count
-            secs.append(mt.totalTime)
+            secs.append(mt.totalTime); wall.append(mt.wallTime); exact.append(mt.exact_rows)
             r = mt.enhancedMatch(da, xa, db, xb, 0.85, on_device=True, n=na, m=nb)
-            secs_e.append(mt.totalTime)
+            secs_e.append(mt.totalTime); wall_e.append(mt.wallTime)
         tm = min(secs)
         flop = 2.0 * na * nb * 768
         out["matcher"] = {"workload": f"injectMatch (one full pass) of {na} x {nb} descriptors (two {n}^3 volumes, second shifted 1 voxel)",
-                          "seconds": tm, "enhancedMatch_seconds": min(secs_e), "matched_pairs": int(len(r["pairs"])),
+                          "seconds": tm, "wall_seconds": min(wall), "enhancedMatch_seconds": min(secs_e), "enhancedMatch_wall_seconds": min(wall_e),
+                          "rows_rescored_exactly": int(exact[-1]), "matched_pairs": int(len(r["pairs"])),
                           "roofline": {"bound": "mfma", "kernel": "k_scores_top4 (A.B^T on v_mfma_f32_32x32x2_f32, fused top-4) + k_merge_top4 + k_rescore",
                                        "achieved": flop / tm / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                        "frac": flop / tm / 1e12 / MFMA_F32_PEAK_TF, "traffic": None}}
@@ -366,10 +439,12 @@ def main():
     if args.allpairs and world > 1:
         # BASELINE configs[4] matching leg (not part of `value`): all-gather the device-resident descriptors
         # over RCCL, then every rank runs enhancedMatch on its share of the ordered volume pairs
-        d_desc, d_xyz, nk = ex.device_results()
-        kp_all, desc_all = ex.GetKeypoints()
-        desc_t = torch.from_numpy(desc_all).to(dev)
-        xyz_t = torch.from_numpy(np.stack([kp_all["rx"], kp_all["ry"], kp_all["rz"]], 1).astype(np.float32)).to(dev)
+        # the rank's contribution to the all-gather: D2D export of the device-resident results into buffers the communication
+        # layer owns (sift3d_export_device) -- no host hop
+        _, _, nk = ex.device_results()
+        desc_t = torch.empty((nk, 768), dtype=torch.float32, device=dev)
+        xyz_t = torch.empty((nk, 3), dtype=torch.float32, device=dev)
+        ex.export_device(desc_t.data_ptr(), xyz_t.data_ptr())
         torch.cuda.synchronize()
         mt = capi.muBruteMatcher(device=local)
         acc = {"pairs": 0, "tm": 0.0}

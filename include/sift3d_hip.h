@@ -118,6 +118,10 @@ int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, const float
                  const float *tar_xyz, int m, double thresHold, int mode, int on_device, int device,
                  int *gIdx, int *sIdx, float *gDist, float *sDist, float *pairs6, int *npairs,
                  double *seconds /* device time of the call, may be NULL */);
+/* times of the calling thread's last sift3d_match: device_seconds = HIP events around the device work on the matcher's stream
+ * (what *seconds returned), wall_seconds = host clock around the whole call (scratch reuse, H2D of host inputs, the O(N) host
+ * bookkeeping of Src/cMatcher.cc:81-144 and the D2H of the results included) */
+int sift3d_match_times(double *device_seconds, double *wall_seconds);
 
 int sift3d_device_count(int *n);
 
@@ -195,6 +199,38 @@ int sift3d_run_describe(sift3d_handle h);
  * layer that only addresses its own allocations all-reduce the partitioned descriptor rows and hand them back */
 int sift3d_export_device(sift3d_handle h, float *d_desc_dst, float *d_xyz_dst);
 int sift3d_import_descriptors_device(sift3d_handle h, const float *d_desc_src);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Test hooks (no reference counterpart).  The product has branches that ordinary inputs rarely reach (list
+ * overflow -> regrow -> rerun, the second descriptor pass with the exact fixed-point unit, the register-staged
+ * matcher of >= 4 GB matrices, ...).  A hook forces such a branch so that the parity tests execute it; results must
+ * not change.  Process-wide, read by the next create / run / match; returns the previous value (-1: unknown hook).
+ * The library never reads the environment.
+ * ------------------------------------------------------------------------------------------------------------ */
+enum {
+	SIFT3D_HOOK_DOG_EAGER = 0,      /* 1: write every DoG level (default: first / last level of an octave formed on request) */
+	SIFT3D_HOOK_GLAST_EAGER = 1,    /* 1: build the last Gaussian level of every octave (default: evaluated at parked candidates) */
+	SIFT3D_HOOK_DET_SERIAL = 2,     /* 1: extremum masks of all octaves on one stream with one scratch */
+	SIFT3D_HOOK_SEPARABLE = 3,      /* 1: every Gaussian level by the generic three-pass kernels */
+	SIFT3D_HOOK_DESC_NOCACHE = 4,   /* 1: k_describe recomputes the column chords (the path of windows > 255 planes) */
+	SIFT3D_HOOK_MATCH_NODMA = 5,    /* 1: matcher tiles staged through registers (the path of matrices >= 4 GB) */
+	SIFT3D_HOOK_ONE_STREAM = 6,     /* 1: all octaves on the handle's stream (isolated kernel durations in a trace) */
+	SIFT3D_HOOK_DESC_MASS_SHIFT = 7,/* s: k_describe's first gradient-mass estimate is divided by 2^s -> the exact-unit second pass runs */
+	SIFT3D_HOOK_LIST_CAP = 8,       /* n > 0: initial capacity of the extrema / keypoint lists -> overflow, regrow, rerun */
+	SIFT3D_HOOK_COUNT = 9
+};
+int sift3d_test_hook(int which, int value);
+/* how often the rare paths ran: c[0] list regrows of the last run, c[1] keypoints whose descriptor took the second pass in
+ * the last run, c[2] rows the last sift3d_match re-scored exactly (near-tie guard; process-wide), c[3] reserved */
+int sift3d_debug_counters(sift3d_handle h, int c[4]);
+/* Check_intersect_faces + cart2bary (Src/cSIFT3D.cc:1542-1573, 1592-1637) of k_describe on n gradient vectors (host, n*3):
+ * face index (-1: none) and the three barycentric weights as the kernel forms them, through both of its routes:
+ * route 0 = predicted face verified with the margin (falls back to route 1 when the margin fails), route 1 = the literal
+ * ordered 20-face scan.  Unit-level parity against golden g7. */
+/* GB/s (read + write, best of `iters`) of a float4 device-to-device copy of `bytes` bytes on `device`: the measured copy ceiling
+ * reported beside the 8 TB/s spec peak */
+int sift3d_debug_copy_bandwidth(size_t bytes, int iters, int device, double *gbs);
+int sift3d_debug_face_lookup(const float *grad3, int n, int route, int *face, float *bary3, int device);
 
 const char *sift3d_error_string(int code);
 const char *sift3d_last_error(void); /* thread-local detail of the last failure */

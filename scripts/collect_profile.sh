@@ -9,15 +9,25 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
+# PMC passes FIRST (separate --pmc runs, no trace options): bench.py reports roofline.traffic / descriptor.roofline only from files
+# stamped with the kernel sources it runs on, so they are installed under profiles/ before the bench lines are taken
+python3 $REPO/scripts/measure_traffic.py 512 > $OUT/${TAG}_pyramid_traffic_512.json
+cp $OUT/${TAG}_pyramid_traffic_512.json $REPO/profiles/pyramid_traffic_512.json
+python3 $REPO/scripts/pmc_kernel.py k_describe 512 5 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES > $OUT/${TAG}_pmc_k_describe.json
+python3 - $OUT/${TAG}_pmc_k_describe.json $REPO/profiles/pmc_k_describe_512.json <<'PY'
+import json, sys
+j = json.load(open(sys.argv[1]))
+k = [v for n, v in j.items() if n.startswith("k_describe")][0]
+k["kernel_source_sha"] = j["kernel_source_sha"]
+json.dump(k, open(sys.argv[2], "w"), indent=1)
+PY
+cp $REPO/profiles/pmc_k_describe_512.json $OUT/${TAG}_pmc_k_describe_512.json
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python3 $REPO/bench.py --steps 5 --warmup 2 --cpu-sample 0 > $OUT/${TAG}_bench_under_rocprof.json 2> /tmp/prof_$TAG.err || true
 f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$f" $OUT/${TAG}_rocprofv3_kernel_stats.csv
 python3 $REPO/bench.py > $OUT/${TAG}_bench.json 2> /dev/null
-python3 $REPO/scripts/measure_traffic.py 512 > $OUT/${TAG}_pyramid_traffic_512.json
 head -12 $OUT/${TAG}_rocprofv3_kernel_stats.csv
-# SQ counters of the two dominant kernels (separate --pmc passes, no trace options)
-python3 $REPO/scripts/pmc_kernel.py k_describe 512 5 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES > $OUT/${TAG}_pmc_k_describe.json
-S3D_ONE_STREAM=1 python3 $REPO/scripts/pmc_kernel.py k_march_level 512 1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES > $OUT/${TAG}_pmc_k_march_level.json
+S3D_HOOKS=one_stream=1 python3 $REPO/scripts/pmc_kernel.py k_march_level 512 1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES > $OUT/${TAG}_pmc_k_march_level.json
 # z-slab workload on one GPU: the plain single-GPU run and the simulated 2- and 8-rank runs
 cd $REPO
 ( python3 bench.py --workload slab --steps 3 --warmup 1 2>/dev/null; python3 bench.py --workload slab --sim-ranks 2 --steps 3 --warmup 1 2>/dev/null; python3 bench.py --workload slab --sim-ranks 8 --steps 3 --warmup 1 2>/dev/null ) > $OUT/${TAG}_slab_sim.json

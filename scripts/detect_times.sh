@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/p_kt2; rocprofv3 --kernel-trace -d /tmp/p_kt2 --output-format csv -- python3 /root/repo/scripts/prof_pyramid.py 512 2 5 > /dev/null 2>&1
+rm -rf /tmp/p_kt2; rocprofv3 --kernel-trace -d /tmp/p_kt2 --output-format csv -- python3 ${GRAFT_REPO_ROOT:-/root/repo}/scripts/prof_pyramid.py 512 2 5 > /dev/null 2>&1
 f=$(find /tmp/p_kt2 -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel average durations of one full KpSiftAlgorithm on a 512^3 blob volume (GPU box; rocprofv3 kernel trace)
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/p_kt; rocprofv3 --kernel-trace --stats -d /tmp/p_kt --output-format csv -- python3 /root/repo/scripts/prof_pyramid.py ${1:-512} 3 5 > /dev/null 2>&1
+rm -rf /tmp/p_kt; rocprofv3 --kernel-trace --stats -d /tmp/p_kt --output-format csv -- python3 ${GRAFT_REPO_ROOT:-/root/repo}/scripts/prof_pyramid.py ${1:-512} 3 5 > /dev/null 2>&1
 f=$(find /tmp/p_kt -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys

@@ -2,9 +2,9 @@
 # isolated duration of every pyramid launch of one 512^3 run (all octaves on one stream): GPU box, rocprofv3 kernel trace
 # usage: scripts/level_times.sh [N=512] [lib.so]
 cd /tmp && export TMPDIR=/tmp
-export S3D_ONE_STREAM=1
-[ -n "$2" ] && export S3D_LIB=$(realpath /root/repo/$2)
-rm -rf /tmp/p_lt; rocprofv3 --kernel-trace -d /tmp/p_lt --output-format csv -- python3 /root/repo/scripts/prof_pyramid.py ${1:-512} 3 1 > /dev/null 2>&1
+export S3D_HOOKS=one_stream=1
+[ -n "$2" ] && export S3D_LIB=$(realpath ${GRAFT_REPO_ROOT:-/root/repo}/$2)
+rm -rf /tmp/p_lt; rocprofv3 --kernel-trace -d /tmp/p_lt --output-format csv -- python3 ${GRAFT_REPO_ROOT:-/root/repo}/scripts/prof_pyramid.py ${1:-512} 3 1 > /dev/null 2>&1
 f=$(find /tmp/p_lt -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys,collections

@@ -34,4 +34,8 @@ for i in range(0, len(counters), 8):
                 seen[name].add(r.get("Dispatch_Id", r.get("Correlation_Id", "")))
         for k, v in seen.items():
             out[k]["launches"] = len(v)
-print(json.dumps({k: dict(v) for k, v in out.items()}, indent=1))
+import importlib
+sys.path.insert(0, ROOT)
+res = {k: dict(v) for k, v in out.items()}
+res["kernel_source_sha"] = importlib.import_module("3dsift_amd.capi").kernel_source_sha()  # ties the counters to the kernel sources
+print(json.dumps(res, indent=1))

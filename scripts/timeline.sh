@@ -1,8 +1,8 @@
 #!/bin/bash
 # start/end (us, relative to the first launch) of every pyramid kernel of the last run, octaves on their own streams
 cd /tmp && export TMPDIR=/tmp
-[ -n "$2" ] && export S3D_LIB=$(realpath /root/repo/$2)
-rm -rf /tmp/p_tl; rocprofv3 --kernel-trace -d /tmp/p_tl --output-format csv -- python3 /root/repo/scripts/prof_pyramid.py ${1:-512} 3 1 > /dev/null 2>&1
+[ -n "$2" ] && export S3D_LIB=$(realpath ${GRAFT_REPO_ROOT:-/root/repo}/$2)
+rm -rf /tmp/p_tl; rocprofv3 --kernel-trace -d /tmp/p_tl --output-format csv -- python3 ${GRAFT_REPO_ROOT:-/root/repo}/scripts/prof_pyramid.py ${1:-512} 3 1 > /dev/null 2>&1
 f=$(find /tmp/p_tl -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys

@@ -23,21 +23,36 @@ def extrema_table(e):
     return np.stack([e["octave"], e["level"], e["x"].astype(np.int32), e["y"].astype(np.int32), e["z"].astype(np.int32)], 1)
 
 
-def compare_keypoints(kp, desc, okp, odesc, rms_tol=1e-4):
+def descriptor_errors(desc, odesc):
+    """(global RMS, worst per-keypoint RMS, worst absolute element error) of two [n, 768] descriptor sets"""
+    if len(desc) == 0:
+        return 0.0, 0.0, 0.0
+    d = desc.astype(np.float64) - odesc.astype(np.float64)
+    per_kp = np.sqrt(np.mean(d * d, axis=1))
+    return float(np.sqrt(np.mean(d * d))), float(per_kp.max()), float(np.abs(d).max())
+
+
+def compare_keypoints(kp, desc, okp, odesc, rms_tol=1e-4, max_abs_tol=5e-4):
     """Same count, same (octave, level, x, y, z, scale, rx, ry, rz) in the same order; orientation
-    frames and descriptors within fp32 reduction-order tolerance.  Returns the descriptor RMS."""
+    frames bit-identical; descriptors within the tolerance of their fixed-point histograms.  The descriptor bar (BASELINE.json: 1e-4 RMS) is applied
+    PER KEYPOINT -- one bad keypoint cannot hide in the average -- plus an absolute bound of 5e-4 on every element (1.5 % of the
+    0.0333 clamp).  Returns the global descriptor RMS."""
     assert len(kp) == len(okp), (len(kp), len(okp))
     for f in ("x", "y", "z", "octave", "level", "scale", "rx", "ry", "rz"):
         assert np.array_equal(kp[f], okp[f]), f
     if len(kp) == 0:
         return 0.0
-    # structure tensor / mean gradient: fp32 sums in a different order
-    scale = np.abs(okp["str_tensor"]).max(1, keepdims=True)
-    assert (np.abs(kp["str_tensor"] - okp["str_tensor"]) <= 2e-5 * scale).all()
-    assert np.allclose(kp["win"], okp["win"], rtol=0, atol=2e-5 * np.abs(okp["win"]).max())
-    assert np.allclose(kp["eigvalue"], okp["eigvalue"], rtol=2e-5, atol=1e-7)
-    assert np.abs(kp["Rotation"] - okp["Rotation"]).max() <= 2e-4
-    rms = float(np.sqrt(np.mean((desc.astype(np.float64) - odesc.astype(np.float64)) ** 2)))
+    # r03: the window sums of every accepted keypoint are added in the reference's order (k_orient<true>): structure tensor, mean
+    # gradient, eigenvalues, eigenvectors and the rotation matrix are bit-identical
+    for f in ("str_tensor", "win", "eigvalue", "Rotation"):
+        assert np.array_equal(bits(kp[f]), bits(okp[f])), (f, int((bits(kp[f]) != bits(okp[f])).any(axis=1).sum()), len(kp))
+    # the stored eigenvectors carry the solver's sign (Eigen in the reference, Jacobi here; the golden tests of the oracle skip the
+    # field for the same reason): each of the three vectors equals the reference's or its negation, bit for bit
+    ev, oev = kp["eigvector"].reshape(-1, 3, 3), okp["eigvector"].reshape(-1, 3, 3)
+    same = (bits(ev) == bits(oev)).all(axis=2) | (bits(ev) == bits(-oev)).all(axis=2)
+    assert same.all(), ("eigvector", int((~same).any(axis=1).sum()), len(kp))
+    rms, worst_kp, worst_abs = descriptor_errors(desc, odesc)
     assert rms <= rms_tol, rms
-    assert np.abs(desc - odesc).max() <= 50 * rms_tol
+    assert worst_kp <= rms_tol, ("worst per-keypoint RMS", worst_kp)
+    assert worst_abs <= max_abs_tol, ("worst element", worst_abs)
     return rms

@@ -1,0 +1,66 @@
+"""-m gpu: BASELINE.json configs[4] on the HIP path -- 8 volumes, the descriptors of all of them gathered, all 56 ordered
+(ref, tar) pairs through muBruteMatcher::enhancedMatch (Src/cMatcher.cc:146-228) = sift3d_match on DEVICE-RESIDENT inputs, dealt to
+8 ranks by 3dsift_amd/dist.py exactly as `bench.py --allpairs` does on 8 GPUs (there the gather is an RCCL all-gather; here the
+eight "ranks" run one after the other on the one GPU of the test box).  Every one of the 56 results is compared bit for bit with
+the oracle's matcher on the same descriptors.  Volumes: 256^3, seeds 1234 .. 1237, each once as generated and once shifted by one
+voxel in x (SURVEY 8d's "target" construction), so 8 of the ordered pairs are true correspondences and 48 are unrelated."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+capi = importlib.import_module("3dsift_amd.capi")
+dist = importlib.import_module("3dsift_amd.dist")
+synth = importlib.import_module("3dsift_amd.synth")
+
+N = 256
+WORLD = 8
+
+
+def test_config4_all_56_ordered_pairs_vs_oracle(orc):
+    import os
+    import torch
+
+    dev = torch.device("cuda", 0)
+    descs, xyzs, host = [], [], []
+    for k in range(WORLD):
+        vol = synth.blobs_torch((N, N, N), dev, seed=1234 + k // 2, shift=(float(k % 2), 0.0, 0.0))
+        torch.cuda.synchronize()
+        ex = capi.CSIFT3D(None, device_ptr=vol.data_ptr(), shape=(N, N, N)).KpSiftAlgorithm()
+        kp, ds = ex.GetKeypoints()
+        n = len(kp)
+        assert n > 500
+        # what a rank contributes to the all-gather: its device-resident descriptors and coordinates, exported into buffers the
+        # communication layer owns (sift3d_export_device) -- no host hop
+        d_t = torch.empty((n, 768), dtype=torch.float32, device=dev)
+        x_t = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        ex.export_device(d_t.data_ptr(), x_t.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_t.cpu().numpy(), ds)
+        descs.append(d_t); xyzs.append(x_t)
+        host.append((ds, np.stack([kp["rx"], kp["ry"], kp["rz"]], 1)))
+        ex.close()
+        del vol
+    mt = capi.muBruteMatcher()
+
+    def match_fn(da, xa, db, xb):
+        return mt.enhancedMatch(da.data_ptr(), xa.data_ptr(), db.data_ptr(), xb.data_ptr(), 0.85, on_device=True, n=da.shape[0], m=db.shape[0])
+
+    got = {}
+    for rank in range(WORLD):
+        mine = dist.match_pairs(descs, xyzs, match_fn, rank, WORLD)
+        assert len(mine) == 7
+        got.update(mine)
+    assert sorted(got) == sorted(dist.ordered_pairs(WORLD)) and len(got) == 56
+    orc.set_threads(max(1, min(64, (os.cpu_count() or 2) // 2)))
+    related = 0
+    for (i, j), res in sorted(got.items()):
+        want = orc.match(host[i][0], host[i][1], host[j][0], host[j][1], 0.85, 3)
+        for key in want:
+            assert np.array_equal(res[key], want[key]), (i, j, key)
+        if i // 2 == j // 2:
+            related += 1
+            assert len(want["pairs"]) > 100, (i, j, len(want["pairs"]))   # the shifted copy: most keypoints correspond
+    assert related == 8
