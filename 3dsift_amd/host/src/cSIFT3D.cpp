@@ -39,7 +39,23 @@ struct CSIFT3D::Impl {
 	int levels = 3;
 	int stage = 0;
 	bool fetched = false;
+	unsigned long long desc_hash = 0;  // of the host descriptor block as fetched (OwnerOf: has the caller edited it since?)
 };
+
+// order-sensitive hash of the host descriptor block (four independent multiply-add lanes: ~2 ms per 35 MB): Keypoint::desc is a
+// mutable float*, like the reference's, and a caller may edit descriptors in place (re-normalise, RootSIFT, zero rows) before
+// matching -- the device-resident copy is only a valid stand-in for a block that still hashes to what was fetched
+static unsigned long long hash_block(const float *p, size_t nfloats) {
+	const unsigned long long *w = reinterpret_cast<const unsigned long long *>(p);
+	const size_t n = nfloats / 2;
+	unsigned long long h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+	size_t i = 0;
+	for (; i + 4 <= n; i += 4)
+		for (int k = 0; k < 4; k++) h[k] = h[k] * 0x100000001B3ull + w[i + k];
+	for (; i < n; i++) h[0] = h[0] * 0x100000001B3ull + w[i];
+	if (nfloats & 1) { unsigned v; memcpy(&v, p + nfloats - 1, 4); h[1] = h[1] * 0x100000001B3ull + v; }
+	return (h[0] ^ (h[1] * 3)) + (h[2] ^ (h[3] * 5));
+}
 
 static void complain(const char *where, int rc) {
 	if (rc != SIFT3D_OK) fprintf(stderr, "[3dsift_amd] %s: %s (%s)\n", where, sift3d_error_string(rc), sift3d_last_error());
@@ -75,29 +91,29 @@ CSIFT3D::CSIFT3D(float *volume, int x_dim, int y_dim, int z_dim, int num_kp_leve
 }
 
 CSIFT3D::~CSIFT3D() {
+	// out of the registry first (under the lock OwnerOf holds while it reads filter / impl / the block), then tear down
+	if (global_descriptor) { std::lock_guard<std::mutex> lk(g_reg_mu); g_reg.erase(global_descriptor); }
 	if (impl) {
 		if (impl->h) sift3d_destroy(impl->h);
 		delete impl;
 	}
-	if (global_descriptor) {
-		{ std::lock_guard<std::mutex> lk(g_reg_mu); g_reg.erase(global_descriptor); }
-		free(global_descriptor);
-	}
+	if (global_descriptor) free(global_descriptor);
 }
 
 CSIFT3D *CSIFT3D::OwnerOf(const std::vector<Keypoint> &kp) {
 	if (kp.empty() || !kp[0].desc) return nullptr;
-	CSIFT3D *o = nullptr;
-	{
-		std::lock_guard<std::mutex> lk(g_reg_mu);
-		auto it = g_reg.find(kp[0].desc);
-		if (it != g_reg.end()) o = it->second;
-	}
-	if (!o || o->filter.size() != kp.size() || !o->impl || o->impl->stage < 5) return nullptr;
+	// the registry lock is held for the whole check: ~CSIFT3D and fetch_results take it before they touch the block or the registry
+	std::lock_guard<std::mutex> lk(g_reg_mu);
+	auto it = g_reg.find(kp[0].desc);
+	CSIFT3D *o = it != g_reg.end() ? it->second : nullptr;
+	if (!o || o->filter.size() != kp.size() || !o->impl || o->impl->stage < 5 || !o->impl->fetched || !o->global_descriptor) return nullptr;
 	for (size_t i = 0; i < kp.size(); i++) {
 		const Keypoint &a = kp[i], &b = o->filter[i];
 		if (a.desc != b.desc || a.rx != b.rx || a.ry != b.ry || a.rz != b.rz) return nullptr;
 	}
+	// same rows in the same order -- and the CONTENTS are still what the extractor produced (the reference matcher reads
+	// kp[i].desc, so in-place edits of the descriptors must reach the match: they take the gather path)
+	if (hash_block(o->global_descriptor, kp.size() * (size_t)DESC_NUMEL) != o->impl->desc_hash) return nullptr;
 	return o;
 }
 
@@ -132,7 +148,11 @@ void CSIFT3D::fetch_results() {
 		memcpy(k.str_tensor, s.str_tensor, sizeof(k.str_tensor));
 		k.desc = global_descriptor + (size_t)i * DESC_NUMEL;
 	}
-	if (with_desc) { std::lock_guard<std::mutex> lk(g_reg_mu); g_reg[global_descriptor] = this; }
+	if (with_desc) {
+		impl->desc_hash = hash_block(global_descriptor, (size_t)n * DESC_NUMEL);
+		std::lock_guard<std::mutex> lk(g_reg_mu);
+		g_reg[global_descriptor] = this;
+	}
 }
 
 static void run_to(CSIFT3D *self, sift3d_handle h, int upto, int &stage, bool &fetched, SIFT_TimerPara &tm) {

@@ -61,8 +61,10 @@ float *readNiiFile(const char *filename, int &nx, int &ny, int &nz) {
 		datatype = bswap(datatype); bitpix = bswap(bitpix); vox_offset = bswap(vox_offset);
 	}
 	if (memcmp(hdr + 344, "n+1", 3) != 0) { gzclose(f); fprintf(stderr, "readNiiFile: only single-file NIfTI-1 (n+1) is supported\n"); return nullptr; }
-	// the header is untrusted input: dimensions must be positive, the element size must agree with the datatype code, and the
-	// payload of a single-file image cannot start inside the header (348 bytes + 4 extension bytes)
+	// the header is untrusted input: dimensions must be positive and the element size must agree with the datatype code.  A payload
+	// offset below the header size is read as 348, like the reference's reader does for single-file images (nifti2_io.cpp:5187-5189
+	// "set ioff from vox_offset (but at least sizeof(header))"): lax writers leave vox_offset at 0 or 348; NaN and absurd values are
+	// rejected
 	size_t esize = 0;
 	switch (datatype) {
 	case 2: case 256: esize = 1; break;
@@ -73,7 +75,7 @@ float *readNiiFile(const char *filename, int &nx, int &ny, int &nz) {
 	}
 	const int ndim = dim[0];
 	if (ndim < 1 || ndim > 7 || dim[1] <= 0 || (ndim >= 2 && dim[2] <= 0) || (ndim >= 3 && dim[3] <= 0) || esize == 0 ||
-	    bitpix != (int16_t)(8 * esize) || !(vox_offset >= 352.0f) || vox_offset > 1.0e9f) {
+	    bitpix != (int16_t)(8 * esize) || !(vox_offset == vox_offset) || vox_offset > 1.0e9f || vox_offset < -1.0e9f) {
 		gzclose(f);
 		fprintf(stderr, "readNiiFile: bad or unsupported header (dim %d: %d %d %d, datatype %d, bitpix %d, vox_offset %g)\n", ndim,
 		        (int)dim[1], (int)dim[2], (int)dim[3], (int)datatype, (int)bitpix, (double)vox_offset);
@@ -82,17 +84,30 @@ float *readNiiFile(const char *filename, int &nx, int &ny, int &nz) {
 	}
 	nx = dim[1]; ny = ndim >= 2 ? dim[2] : 1; nz = ndim >= 3 ? dim[3] : 1;
 	const size_t n = (size_t)nx * ny * nz, bytes = n * esize;
+	if (vox_offset < 348.0f) vox_offset = 348.0f;
 	long skip = (long)vox_offset - 348;
-	std::vector<unsigned char> junk((size_t)(skip > 0 ? skip : 0));
-	if (skip > 0 && gzread(f, junk.data(), (unsigned)skip) != skip) { gzclose(f); return nullptr; }
-	std::vector<unsigned char> raw;
-	try { raw.resize(bytes); } catch (...) { gzclose(f); fprintf(stderr, "readNiiFile: out of memory\n"); nx = ny = nz = 0; return nullptr; }
-	size_t got = 0;
-	while (got < bytes) {
-		int r = gzread(f, raw.data() + got, (unsigned)std::min<size_t>(bytes - got, 1u << 30));
-		if (r <= 0) break;
-		got += (size_t)r;
+	for (unsigned char junk[4096]; skip > 0;) {  // header extensions between the header and the payload
+		const int want = (int)std::min<long>(skip, (long)sizeof(junk));
+		if (gzread(f, junk, (unsigned)want) != want) { gzclose(f); fprintf(stderr, "readNiiFile: truncated before the payload\n"); nx = ny = nz = 0; return nullptr; }
+		skip -= want;
 	}
+	// the payload is read in bounded pieces into a buffer that grows with the data that actually arrives: a header that claims
+	// terabytes on a short file ends as "truncated payload", not as an allocation of the claimed size
+	std::vector<unsigned char> raw;
+	size_t got = 0;
+	try {
+		while (got < bytes) {
+			const size_t piece = std::min<size_t>(bytes - got, (size_t)64 << 20);
+			raw.resize(got + piece);
+			int r = gzread(f, raw.data() + got, (unsigned)piece);
+			if (r <= 0) break;
+			got += (size_t)r;
+			if ((size_t)r < piece) {  // short read: EOF unless more follows
+				raw.resize(got);
+				continue;
+			}
+		}
+	} catch (...) { gzclose(f); fprintf(stderr, "readNiiFile: out of memory\n"); nx = ny = nz = 0; return nullptr; }
 	gzclose(f);
 	if (got != bytes) { fprintf(stderr, "readNiiFile: truncated payload\n"); return nullptr; }
 	float *out = new (std::nothrow) float[n];

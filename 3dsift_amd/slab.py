@@ -428,10 +428,14 @@ class SlabExtractor:
                             else:
                                 w.stages[s].ctx.decimate(w.seed_mine.data_ptr(), wait=False)
                     comm.wait(h_urgent)
+                    if not comm.stream_ordered:
+                        comm.sync()   # a backend whose transfers are not ordered on the stream (gloo): host-side wait per level
                 # DoG maxima -> global (threshold of Detect_KeyPoints, Src/cSIFT3D.cc:379-384): MAX all-reduce of a device tensor
                 for w, st in zip(ws, sts):
                     st.ctx.export_dogmax(w.dogmax[s].data_ptr())
                 comm.allreduce_max_([w.dogmax[s] for w in ws])
+                if not comm.stream_ordered:
+                    comm.sync()
                 for w, st in zip(ws, sts):
                     st.ctx.import_dogmax(w.dogmax[s].data_ptr())
             for h in deferred:
@@ -476,19 +480,23 @@ class SlabExtractor:
         if self.noct > self.S:
             th = threading.Thread(target=tail_body, daemon=True)
             th.start()
-        cur.synchronize()
-        self.times["pyramid"] = time.perf_counter() - t0
-        t1 = time.perf_counter()
-        for s in range(self.S):
-            for w in ws:
-                w.stages[s].ctx.detect()
-            for w in ws:
-                w.stages[s].ctx.describe()
-        self.times["keypoints_sharded"] = time.perf_counter() - t1
-        if th is not None:
-            th.join()
-            if err:
-                raise err[0]
+        # whatever happens on this thread (a list-capacity error on one rank, say), the tail thread is joined before the method is
+        # left: it issues a collective and calls into contexts that close() would otherwise destroy under it
+        try:
+            cur.synchronize()
+            self.times["pyramid"] = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            for s in range(self.S):
+                for w in ws:
+                    w.stages[s].ctx.detect()
+                for w in ws:
+                    w.stages[s].ctx.describe()
+            self.times["keypoints_sharded"] = time.perf_counter() - t1
+        finally:
+            if th is not None:
+                th.join()
+        if err:
+            raise err[0]
         self.times["tail"] = time.perf_counter() - t2
         self.times["total"] = time.perf_counter() - t0
         return self

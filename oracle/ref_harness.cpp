@@ -285,4 +285,23 @@ int ref_match(const float *ref_desc, const float *ref_xyz, int n, const float *t
 	return (int)ra.size();
 }
 
+/* key-point coordinate lists: the reference's own writer / reader (Src/cUtil.cc:938-954, 1002-1016), for golden g10.
+ * Not part of oracle_api.h: the C restatement has no file IO; these pin 3dsift_amd/host/src/io.cpp. */
+void ref_write_sift_kp(const float *xyz, int n, const char *path) {
+	std::vector<Cvec> v;
+	for (int i = 0; i < n; i++) v.push_back(Cvec(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+	Mute m;
+	write_sift_kp(v, path);
+}
+
+int ref_read_sift_kp(const char *path, float *xyz, int cap) {
+	std::vector<Cvec> v;
+	{
+		Mute m;
+		read_sift_kp(path, v);
+	}
+	for (int i = 0; i < (int)v.size() && i < cap; i++) { xyz[3 * i] = v[i].x; xyz[3 * i + 1] = v[i].y; xyz[3 * i + 2] = v[i].z; }
+	return (int)v.size();
+}
+
 } /* extern "C" */

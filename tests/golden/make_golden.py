@@ -27,7 +27,9 @@ Fixture inventory (the reference has no golden vec
   g9_nifti.npz      small NIfTI-1 files (bytes) of several datatypes / byte orders / gzip, with non-unit scl_slope, and the
                     float arrays the reference's readNiiFile (oracle/_ref/librefnii.so) returns for them
 
-    python tests/golden/make_golden.py g1 g9     # only these
+  g10_sift_kp.npz   a key-point coordinate list written by the reference's write_sift_kp and read back by its read_sift_kp (8f-4)
+
+    python tests/golden/make_golden.py g1 g9 g10     # only these
 """
 import hashlib
 import importlib
@@ -61,8 +63,9 @@ def interior_mask_hash(level, shell):
     return sha(level[1:-1, 1:-1, 1:-1]) if shell else sha(level)
 
 
-def nifti1_bytes(vol, dtype, code, big_endian=False, slope=2.0, inter=5.0):
-    """a single-file NIfTI-1 image (348-byte header + 4 extension bytes + payload), written by hand"""
+def nifti1_bytes(vol, dtype, code, big_endian=False, slope=2.0, inter=5.0, vox_offset=352.0, hdr_bytes=352):
+    """a single-file NIfTI-1 image (348-byte header + 4 extension bytes + payload), written by hand; vox_offset / hdr_bytes let a
+    fixture imitate lax writers (offset 0 or 348 with the payload straight behind the 348-byte header)"""
     import struct
     nz, ny, nx = vol.shape
     e = ">" if big_endian else "<"
@@ -72,11 +75,11 @@ def nifti1_bytes(vol, dtype, code, big_endian=False, slope=2.0, inter=5.0):
     struct.pack_into(e + "h", h, 70, code)
     struct.pack_into(e + "h", h, 72, np.dtype(dtype).itemsize * 8)
     struct.pack_into(e + "8f", h, 76, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0)  # pixdim
-    struct.pack_into(e + "f", h, 108, 352.0)
+    struct.pack_into(e + "f", h, 108, vox_offset)
     struct.pack_into(e + "f", h, 112, slope)
     struct.pack_into(e + "f", h, 116, inter)
     h[344:348] = b"n+1\0"
-    return bytes(h) + vol.astype(np.dtype(dtype).newbyteorder(e)).tobytes()
+    return bytes(h[:hdr_bytes]) + vol.astype(np.dtype(dtype).newbyteorder(e)).tobytes()
 
 
 def make_g1(ref):
@@ -109,13 +112,17 @@ def make_g9():
     cases = [("f4_le", "f4", 16, False, False), ("f4_be", "f4", 16, True, False), ("f4_gz", "f4", 16, False, True),
              ("i2_le", "i2", 4, False, False), ("i2_be", "i2", 4, True, False), ("u1_le", "u1", 2, False, False),
              ("f8_le", "f8", 64, False, False), ("f8_be", "f8", 64, True, False), ("u2_le", "u2", 512, False, False),
-             ("i4_le", "i4", 8, False, False), ("i1_le", "i1", 256, False, False), ("u4_gz", "u4", 768, False, True)]
+             ("i4_le", "i4", 8, False, False), ("i1_le", "i1", 256, False, False), ("u4_gz", "u4", 768, False, True),
+             # lax writers: vox_offset below the header size is read as 348 by the reference (nifti2_io.cpp:5187-5189)
+             ("f4_off0_tight", "f4", 16, False, False), ("i2_off348_tight", "i2", 4, False, False), ("i2_off100", "i2", 4, False, False)]
+    lax = {"f4_off0_tight": dict(vox_offset=0.0, hdr_bytes=348), "i2_off348_tight": dict(vox_offset=348.0, hdr_bytes=348),
+           "i2_off100": dict(vox_offset=100.0)}
     g9 = {"names": np.array([c[0] for c in cases])}
     with tempfile.TemporaryDirectory() as t:
         for name, dt, code, be, gz in cases:
             info = np.iinfo(dt) if np.dtype(dt).kind in "iu" else None
             vol = np.clip(base, info.min, info.max).astype(dt) if info else base.astype(dt)
-            blob = nifti1_bytes(vol, dt, code, big_endian=be)
+            blob = nifti1_bytes(vol, dt, code, big_endian=be, **lax.get(name, {}))
             if gz:
                 blob = gzip.compress(blob, mtime=0)
             p = os.path.join(t, name + (".nii.gz" if gz else ".nii"))
@@ -132,6 +139,31 @@ def make_g9():
         print(name, "reference == plain cast:", bool(np.array_equal(g9[name + "_data"], g9[name + "_plain"])))
 
 
+def make_g10():
+    """G10: a key-point list written by the REFERENCE's write_sift_kp and read back by its read_sift_kp
+    (Src/cUtil.cc:938-954, 1002-1016; through oracle/_ref): pins write_sift_kp / read_sift_kp of 3dsift_amd/host/src/io.cpp."""
+    import ctypes as C
+    import tempfile
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref3dsift.so"))
+    lib.ref_write_sift_kp.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_char_p]
+    lib.ref_read_sift_kp.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.c_int]
+    rng = np.random.Generator(np.random.PCG64(10))
+    xyz = np.concatenate([
+        rng.uniform(0, 512, (40, 3)),                                   # what toCvec emits: rx, ry, rz of matched key points
+        np.array([[0, 0, 0], [-1.5, 2.25, -3.0], [10.123456, 0.000004, -0.000005], [1e6, 1e-6, 123456.789],
+                  [0.000005, 0.999995, 2.5000049], [511.0, 1.0, 65536.5], [3.4e38, -3.4e38, 1.17549435e-38]]),
+    ]).astype(np.float32)
+    with tempfile.TemporaryDirectory() as t:
+        p = os.path.join(t, "kp.csv")
+        lib.ref_write_sift_kp(xyz.ctypes.data_as(C.POINTER(C.c_float)), len(xyz), p.encode())
+        blob = open(p, "rb").read()
+        back = np.zeros((len(xyz) + 8, 3), np.float32)
+        n = lib.ref_read_sift_kp(p.encode(), back.ctypes.data_as(C.POINTER(C.c_float)), len(back))
+    assert n == len(xyz), n
+    np.savez_compressed(os.path.join(HERE, "g10_sift_kp.npz"), xyz=xyz, csv=np.frombuffer(blob, np.uint8), read_back=back[:n])
+    print("g10:", len(xyz), "points,", len(blob), "bytes; first lines:", blob.decode().splitlines()[:2], "last:", blob.decode().splitlines()[-1])
+
+
 def main():
     only = set(sys.argv[1:])
     ref = ol.load("ref")
@@ -140,7 +172,9 @@ def main():
         make_g1(ref)
     if not only or "g9" in only:
         make_g9()
-    if only and not (only - {"g1", "g9"}):
+    if not only or "g10" in only:
+        make_g10()
+    if only and not (only - {"g1", "g9", "g10"}):
         return
     out = {}
 

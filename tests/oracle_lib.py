@@ -208,7 +208,10 @@ _cache = {}
 
 
 def lib_path(prefix):
-    return os.path.join(ROOT, "oracle", "liboracle3dsift.so") if prefix == "orc" else os.path.join(ROOT, "oracle", "_ref", "libref3dsift.so")
+    if prefix == "orc":
+        # S3D_ORACLE_LIB: the ASan + UBSan build of the restatement (`make -C oracle asan`; tests/test_sanitizers_cpu.py)
+        return os.environ.get("S3D_ORACLE_LIB") or os.path.join(ROOT, "oracle", "liboracle3dsift.so")
+    return os.path.join(ROOT, "oracle", "_ref", "libref3dsift.so")
 
 
 def available(prefix):

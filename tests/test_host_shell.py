@@ -98,7 +98,8 @@ def test_read_nii_rejects_malformed_headers(shell):
     bad = {}
     b = bytearray(good); struct.pack_into("<h", b, 42, -7); bad["negative dim"] = b
     b = bytearray(good); struct.pack_into("<h", b, 72, 32); bad["bitpix != datatype size"] = b
-    b = bytearray(good); struct.pack_into("<f", b, 108, 100.0); bad["vox_offset inside the header"] = b
+    b = bytearray(good); struct.pack_into("<f", b, 108, float("nan")); bad["vox_offset NaN"] = b
+    b = bytearray(good); struct.pack_into("<f", b, 108, 3.0e9); bad["vox_offset absurd"] = b
     b = bytearray(good); struct.pack_into("<h", b, 70, 1536); bad["unsupported datatype"] = b
     bad["truncated payload"] = good[:-10]
     with tempfile.TemporaryDirectory() as t:
@@ -172,6 +173,18 @@ def test_cpp_matcher_uses_device_resident_results(shell, synth):
         for (size_t i = 0; same && i < r1.size(); i++)
             same = r1[i].x == r2[i].x && r1[i].y == r2[i].y && r1[i].z == r2[i].z && t1[i].x == t2[i].x && t1[i].y == t2[i].y && t1[i].z == t2[i].z;
         printf("kp %zu %zu pairs %zu device %d host %d same %d\n", ka.size(), kb.size(), r1.size(), (int)m1.usedDeviceResults, (int)m2.usedDeviceResults, (int)same);
+        // ADVICE r02: Keypoint::desc is a mutable float* -- a caller edits descriptors IN PLACE (here: one reference row zeroed, as a
+        // row-masking caller would); the matcher must see the edit, i.e. leave the device fast path, and agree with deep copies
+        // carrying the same edit
+        size_t victim = 0;
+        for (size_t i = 0; i < ka.size(); i++) if (m1.getGlodenIdx()[i] >= 0) { victim = i; break; }
+        memset(ka[victim].desc, 0, 768 * 4); memset(&da[victim * 768], 0, 768 * 4);
+        muBruteMatcher m3, m4;
+        std::vector<Cvec> r3, t3, r4, t4;
+        m3.enhancedMatch(r3, t3, ka, kb, 0.85);
+        m4.enhancedMatch(r4, t4, ca, cb, 0.85);
+        bool same2 = r3.size() == r4.size() && m3.getGlodenIdx() == m4.getGlodenIdx() && m3.getGlodenDistSquare() == m4.getGlodenDistSquare();
+        printf("edited device %d same %d changed %d\n", (int)m3.usedDeviceResults, (int)same2, (int)(m3.getGlodenIdx() != m1.getGlodenIdx()));
         delete A; delete B;
         return 0;
     }"""
@@ -185,9 +198,10 @@ def test_cpp_matcher_uses_device_resident_results(shell, synth):
         subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(PKG, "host"), "-o", os.path.join(t, "m"), os.path.join(t, "m.cpp"),
                                "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-Wl,-rpath," + PKG])
         out = subprocess.check_output([os.path.join(t, "m"), os.path.join(t, "a.bin"), os.path.join(t, "b.bin")], stderr=subprocess.STDOUT).decode()
-    last = out.strip().splitlines()[-1].split()
+    last = out.strip().splitlines()[-2].split()
     assert int(last[1]) > 20 and int(last[4]) > 5, out
     assert last[5:] == ["device", "1", "host", "0", "same", "1"], out
+    assert out.strip().splitlines()[-1].split() == ["edited", "device", "0", "same", "1", "changed", "1"], out
 
 
 @pytest.mark.gpu
@@ -232,3 +246,38 @@ def test_sift_kp_csv_roundtrip(shell):
         out = subprocess.check_output([os.path.join(t, "m"), os.path.join(t, "kp.csv")]).decode()
         assert open(os.path.join(t, "kp.csv")).read().splitlines() == ["1.50000,2.25000,3.00000", "10.12346,0.00000,-4.50000"]
         assert out.split() == ["10.12346", "0.00000", "-4.50000"]
+
+
+def test_sift_kp_csv_matches_reference_writer_and_reader(shell):
+    """g10: the file the REFERENCE's write_sift_kp produced for a coordinate list (through oracle/_ref, see
+    tests/golden/make_golden.py) byte for byte, and what its read_sift_kp read back from it, bit for bit."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g10_sift_kp.npz"))
+    src = r"""
+    #include "Include/cUtil.h"
+    #include <cstdio>
+    #include <cstdlib>
+    int main(int, char** a) {
+        std::vector<CPUSIFT::Cvec> v, w;
+        FILE* f = fopen(a[1], "rb");
+        float p[3];
+        while (fread(p, 4, 3, f) == 3) v.push_back(CPUSIFT::Cvec(p[0], p[1], p[2]));
+        fclose(f);
+        CPUSIFT::write_sift_kp(v, a[2]);       // our writer on the reference's input
+        CPUSIFT::read_sift_kp(a[3], w);        // our reader on the REFERENCE's file
+        f = fopen(a[4], "wb");
+        for (auto& c : w) { float q[3] = {c.x, c.y, c.z}; fwrite(q, 4, 3, f); }
+        fclose(f);
+        return 0;
+    }"""
+    with tempfile.TemporaryDirectory() as t:
+        open(os.path.join(t, "m.cpp"), "w").write(src)
+        subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(PKG, "host"), "-o", os.path.join(t, "m"), os.path.join(t, "m.cpp"),
+                               "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-Wl,-rpath," + PKG])
+        open(os.path.join(t, "in.bin"), "wb").write(g["xyz"].tobytes())
+        open(os.path.join(t, "ref.csv"), "wb").write(g["csv"].tobytes())
+        subprocess.check_call([os.path.join(t, "m"), os.path.join(t, "in.bin"), os.path.join(t, "ours.csv"), os.path.join(t, "ref.csv"),
+                               os.path.join(t, "back.bin")], stdout=subprocess.DEVNULL)
+        assert open(os.path.join(t, "ours.csv"), "rb").read() == g["csv"].tobytes()
+        back = np.frombuffer(open(os.path.join(t, "back.bin"), "rb").read(), np.float32).reshape(-1, 3)
+    assert back.shape == g["read_back"].shape
+    assert np.array_equal(back.view(np.uint32), g["read_back"].view(np.uint32))
