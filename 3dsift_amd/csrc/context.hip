@@ -119,29 +119,42 @@ static void build_faces(FaceConst *F) {
 	}
 }
 
-// prediction table (see FacePredict): group the 20 face centres by |centre| and sign pattern
-static void build_predict(const FaceConst *F, FacePredict *P) {
-	int nk = 0;
-	for (int f = 0; f < kFaces; f++) {
-		float a[3], n = sqrtf(dot3(F[f].centre, F[f].centre));
-		for (int c = 0; c < 3; c++) a[c] = fabsf(F[f].centre[c]) / n;
-		bool seen = false;
-		for (int k = 0; k < nk; k++)
-			if (fabsf(P->n[k][0] - a[0]) + fabsf(P->n[k][1] - a[1]) + fabsf(P->n[k][2] - a[2]) < 1e-3f) seen = true;
-		if (!seen && nk < 4) { for (int c = 0; c < 3; c++) P->n[nk][c] = a[c]; nk++; }
-	}
-	for (int k = 0; k < 4; k++)
+// symmetry table of the face lookup (see FaceSym): for every (type, sign bits) find the mesh face whose three vertices are the
+// sign-flipped canonical ones, and which of its vertices plays which role
+static bool build_facesym(const FaceConst *F, FaceSym *S) {
+	const double gr = 1.6180339887, nrm = sqrt(1.0 + gr * gr);
+	for (int type = 0; type < 4; type++)
 		for (int bits = 0; bits < 8; bits++) {
-			const float d[3] = {(bits & 1) ? -P->n[k][0] : P->n[k][0], (bits & 2) ? -P->n[k][1] : P->n[k][1],
-			                    (bits & 4) ? -P->n[k][2] : P->n[k][2]};
-			int best = 0;
-			float bs = -1e30f;
-			for (int f = 0; f < kFaces; f++) {
-				const float sc = dot3(d, F[f].centre);
-				if (sc > bs) { bs = sc; best = f; }
+			const double sx = (bits & 1) ? -1.0 : 1.0, sy = (bits & 2) ? -1.0 : 1.0, sz = (bits & 4) ? -1.0 : 1.0;
+			const double A[3] = {0, sy, sz * gr}, B[3] = {sx, sy * gr, 0}, C[3] = {sx * gr, 0, sz};
+			const double Am[3] = {0, -sy, sz * gr}, Bm[3] = {-sx, sy * gr, 0}, Cm[3] = {sx * gr, 0, -sz};  // mirrored across the straddled axis
+			const double *role[3];
+			switch (type) {
+			case 0: role[0] = A; role[1] = B; role[2] = C; break;       // octant face
+			case 1: role[0] = C; role[1] = Cm; role[2] = B; break;      // lambda_A < 0: across edge BC, the face that straddles z
+			case 2: role[0] = A; role[1] = Am; role[2] = C; break;      // lambda_B < 0: across edge AC, straddles y
+			default: role[0] = B; role[1] = Bm; role[2] = A; break;     // lambda_C < 0: across edge AB, straddles x
 			}
-			P->face[k * 8 + bits] = best;
+			int found = -1, slot[3] = {-1, -1, -1};
+			for (int f = 0; f < kFaces && found < 0; f++) {
+				// geometric vertices of the face as the intersection test sees them (after the winding fix): v0 = -t, v1 = v0 + e1, v2 = v0 + e2
+				double v[3][3];
+				for (int c = 0; c < 3; c++) { v[0][c] = -(double)F[f].t[c]; v[1][c] = v[0][c] + (double)F[f].e1[c]; v[2][c] = v[0][c] + (double)F[f].e2[c]; }
+				int sl[3] = {-1, -1, -1}, hit = 0;
+				for (int r = 0; r < 3; r++)
+					for (int j = 0; j < 3; j++) {
+						double d = 0;
+						for (int c = 0; c < 3; c++) d += fabs(v[j][c] - role[r][c] / nrm);
+						if (d < 1e-4) { sl[r] = j; hit++; }
+					}
+				if (hit == 3 && sl[0] != sl[1] && sl[1] != sl[2] && sl[0] != sl[2]) { found = f; for (int r = 0; r < 3; r++) slot[r] = sl[r]; }
+			}
+			if (found < 0) return false;
+			const int key = type * 8 + bits;
+			S->face[key] = found;
+			for (int r = 0; r < 3; r++) { S->slot[key][r] = slot[r]; S->vert[key][r] = F[found].idx[slot[r]]; }
 		}
+	return true;
 }
 
 }  // namespace s3d
@@ -582,9 +595,9 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	if (rc) { sift3d_destroy(c); return rc; }
 	FaceConst faces[kFaces];
 	build_faces(faces);
-	FacePredict pred;
-	build_predict(faces, &pred);
-	CHECKED(upload_faces(faces, &pred));
+	FaceSym sym;
+	if (!build_facesym(faces, &sym)) { set_last_error("icosahedron symmetry table: no matching face"); sift3d_destroy(c); return SIFT3D_ERR_STATE; }
+	CHECKED(upload_faces(faces, &sym));
 
 	// keypoint lists: synthetic blob volumes give ~6e-4*V extrema; leave 8x headroom, regrow on overflow
 	const size_t V0 = (size_t)cfg.nx * cfg.ny * scan_planes;
@@ -1016,9 +1029,9 @@ extern "C" int sift3d_debug_face_lookup(const float *grad3, int n, int route, in
 	if (n == 0) return SIFT3D_OK;
 	FaceConst faces[kFaces];
 	build_faces(faces);
-	FacePredict pred;
-	build_predict(faces, &pred);
-	S3D_HIP(upload_faces(faces, &pred));
+	FaceSym sym;
+	if (!build_facesym(faces, &sym)) { set_last_error("icosahedron symmetry table: no matching face"); return SIFT3D_ERR_STATE; }
+	S3D_HIP(upload_faces(faces, &sym));
 	float *d = nullptr;
 	S3D_HIP(hipMalloc(&d, sizeof(float) * (size_t)n * 7));
 	int *d_face = reinterpret_cast<int *>(d + (size_t)n * 6);

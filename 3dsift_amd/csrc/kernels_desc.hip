@@ -21,10 +21,10 @@
 //   * lane compaction: chords are ragged and many voxels are inactive, so each wave pushes its ACTIVE voxels
 //     (bin coordinates + weighted gradient) into a small LDS queue by ballot rank and runs the heavy part (rotation, face
 //     test, trilinear weights, 24 atomics) only on full 64-lane batches; all loops are wave-uniform
-//   * face lookup: the face is PREDICTED from |g| (4 dot products + sign bits -> table), verified with
-//     the reference's exact Moller-Trumbore arithmetic for that face and accepted only when all three
-//     barycentrics clear a 1e-4 margin (then no other face can pass the reference's -1.19e-6 test, so
-//     "first passing face in mesh order" is this face); otherwise the literal 20-face ordered scan runs
+//   * face lookup by the symmetry of the icosahedron (face_lookup below): |g| falls into the canonical octant face or one of its
+//     three neighbours, the sign bits pick the mesh face; accepted when all three barycentrics clear a 2e-5 margin (then no other
+//     face can pass the reference's -1.19e-6 test, so "first passing face in mesh order" is this face); otherwise the literal
+//     20-face ordered scan runs
 //   * the 24 products of a voxel go to an LDS histogram kept in 32-BIT FIXED POINT and are added with ds_add_u32: on gfx950
 //     an LDS float atomic (ds_add_f32) costs ~190 cycles per wave instruction, ds_add_u32 4.3 + 3.8 per extra lane on the same
 //     address, ds_add_u64 6.4 + 7.5 (scripts/microbench/lds_atomics.hip), and integer sums are order independent, so descriptors
@@ -46,12 +46,12 @@
 namespace s3d {
 
 __constant__ FaceConst c_faces[kFaces];
-__constant__ FacePredict c_pred;
+__constant__ FaceSym c_sym;
 
 // __constant__ symbols live per device: called by every create on its own device (set by the caller)
-hipError_t upload_faces(const FaceConst *faces, const FacePredict *pred) {
+hipError_t upload_faces(const FaceConst *faces, const FaceSym *sym) {
 	hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_faces), faces, sizeof(FaceConst) * kFaces);
-	if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_pred), pred, sizeof(FacePredict));
+	if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_sym), sym, sizeof(FaceSym));
 	return e;
 }
 
@@ -65,8 +65,7 @@ __device__ __forceinline__ void win_bounds_d(float c, float rad, float u, int n,
 constexpr float kBaryEps = (float)(FLT_EPSILON * 1E1);  // Src/cSIFT3D.cc:23
 
 // Histogram bins are 32-bit two's-complement fixed point in units of 1 / WinLut::fix_scale (see the header).
-constexpr float kFastMargin = 1.0e-4f;
-constexpr int kFaceStride = 16;  // floats per face in the LDS table
+constexpr float kFastMargin = 2.0e-5f;  // >> the ~1e-6 rounding of either barycentric evaluation and the reference's 1.19e-6 tolerance
 #ifndef S3D_DESC_REP
 #define S3D_DESC_REP 4
 #endif
@@ -96,27 +95,6 @@ __device__ __forceinline__ int bin_index(int j) {  // descriptor element j = (ix
 	return (c & 3) * kSX + ((c >> 2) & 3) * kSY + (c >> 4) * kSZ + v * kSV;
 }
 
-// reference Moller-Trumbore for ONE face whose constants sit at F[0..15]:
-// e1(0..2) e2(3..5) t(6..8) q(9..11) qe2(12); returns pass/fail exactly like Check_intersect_faces' body
-#define FC(i) Fb[(i) * kFaceT]
-constexpr int kFaceT = 20;  // faces per constant row of the transposed table
-__device__ __forceinline__ bool face_test(const float *Fb, float gx, float gy, float gz, float &b0, float &b1, float &b2) {
-	const float F[13] = {FC(0), FC(1), FC(2), FC(3), FC(4), FC(5), FC(6), FC(7), FC(8), FC(9), FC(10), FC(11), FC(12)};
-	const float px = gy * F[5] - gz * F[4];
-	const float py = gz * F[3] - gx * F[5];
-	const float pz = gx * F[4] - gy * F[3];
-	const float det = F[0] * px + F[1] * py + F[2] * pz;
-	if (fabsf(det) < kBaryEps) return false;
-	// reference: (float)(1.0 / (double)det).  A correctly rounded fp32 division gives the same value: double
-	// rounding is innocuous for division when the wide format has >= 2p+2 = 50 bits (binary64 has 53)
-	const float det_inv = __fdiv_rn(1.0f, det);
-	b1 = det_inv * (px * F[6] + py * F[7] + pz * F[8]);
-	b2 = det_inv * (gx * F[9] + gy * F[10] + gz * F[11]);
-	b0 = 1.0f - b1 - b2;
-	const float k = det_inv * F[12];
-	return !(b0 < -kBaryEps || b1 < -kBaryEps || b2 < -kBaryEps || k < 0.0f);
-}
-
 // literal Check_intersect_faces: first face in mesh order that passes (wave-uniform loop, constant memory)
 __device__ __forceinline__ int intersect_scan(float gx, float gy, float gz, float &b0, float &b1, float &b2) {
 	int found = -1;
@@ -139,48 +117,65 @@ __device__ __forceinline__ int intersect_scan(float gx, float gy, float gz, floa
 	return found;
 }
 
-// face constants -> LDS (per-lane face index => LDS gather instead of a 20-way constant waterfall); 256 threads, caller syncs
-__device__ __forceinline__ void stage_face_tables(int tid, float *s_face, int *s_fidx, float *s_predn, int *s_predf) {
-	for (int i = tid; i < kFaces * kFaceStride; i += 256) {
-		const int f = i / kFaceStride, j = i - f * kFaceStride;
-		const FaceConst &F = c_faces[f];
-		float v = 0.f;
-		if (j < 3) v = F.e1[j];
-		else if (j < 6) v = F.e2[j - 3];
-		else if (j < 9) v = F.t[j - 6];
-		else if (j < 12) v = F.q[j - 9];
-		else if (j == 12) v = F.qe2;
-		s_face[j * kFaceT + f] = v;  // j < 16 rows of 20 faces: same 320 floats
-	}
-	for (int i = tid; i < kFaces * 4; i += 256) s_fidx[i] = (i & 3) < 3 ? c_faces[i >> 2].idx[i & 3] * kSV : 0;  // vertex -> its first bin
-	if (tid < 12) s_predn[tid] = c_pred.n[tid / 3][tid % 3];
-	if (tid < 32) s_predf[tid] = c_pred.face[tid];
+// lookup tables -> LDS; 256 threads, caller syncs.  s_fidx[f * 4 + j]: BYTE offset (inside a replica-interleaved histogram) of the first
+// bin of vertex idx[j] of face f (slow path); s_sym[key]: the same for the three roles of the symmetric lookup, plus
+// face | slot0 << 8 | slot1 << 10 | slot2 << 12 (see FaceSym)
+__device__ __forceinline__ void stage_face_tables(int tid, int *s_fidx, int4 *s_sym) {
+	constexpr int kVB = kSV * kRep * (int)sizeof(bin_t);  // bytes between the first bins of consecutive vertices
+	for (int i = tid; i < kFaces * 4; i += 256) s_fidx[i] = (i & 3) < 3 ? c_faces[i >> 2].idx[i & 3] * kVB : 0;
+	if (tid < 32)
+		s_sym[tid] = make_int4(c_sym.vert[tid][0] * kVB, c_sym.vert[tid][1] * kVB, c_sym.vert[tid][2] * kVB,
+		                       c_sym.face[tid] | c_sym.slot[tid][0] << 8 | c_sym.slot[tid][1] << 10 | c_sym.slot[tid][2] << 12);
 }
 
-// Check_intersect_faces for one gradient (Src/cSIFT3D.cc:1542-1573): the face is PREDICTED (best of the 4 face normals of the
-// positive octant, then the sign bits), verified with the reference's exact arithmetic for that face and accepted when all three
-// barycentrics clear kFastMargin; otherwise the literal ordered 20-face scan decides.  Wave-uniform control flow.
-__device__ __forceinline__ int face_lookup(bool valid, float rx, float ry, float rz, const float *s_face, const float *s_predn,
-                                           const int *s_predf, float &b0, float &b1, float &b2, bool scan_only = false) {
-	int f = -1;
+// Check_intersect_faces + cart2bary for one gradient (Src/cSIFT3D.cc:1542-1573, 1592-1637) by the symmetry of the mesh (r03; before:
+// four dot products to predict a face, then the reference's Moller-Trumbore arithmetic for that face from a 13-constant LDS gather).
+// With a = |g| componentwise the ray hits the canonical octant face A = (0,1,phi), B = (1,phi,0), C = (phi,0,1) or, across one of
+// its edges, the half of a neighbouring face that reaches into the octant; the signs of g then select the mesh face (s_sym).
+//   octant face:   a = lA A + lB B + lC C  with  lA = az + ay/phi^2 - ax/phi  (and cyclically): inside iff all three >= 0
+//   lX < 0 (the smallest): the neighbour across the edge opposite X.  After the cyclic permutation (u, v, w) of a that maps it onto
+//   {A, A' = (0,-1,phi), C}:  weights  t + v,  t - v,  2 u / phi  with  t = w / phi - u / phi^2  (v >= 0: the larger one belongs to the
+//   vertex on g's side of the straddled axis)
+// The barycentrics are the weights over their sum: the same quantities the reference's b = (1 - y - z, y, z) expresses, to rounding
+// (|difference| <~ 5e-7).  They are accepted when all three clear kFastMargin: no other face can then pass the reference's
+// >= -1.19e-6 test, so "first passing face in mesh order" is this face; otherwise (direction within the margin of an edge or a
+// vertex: ~1 % of the waves) the literal ordered 20-face scan decides.  Wave-uniform control flow.
+// Out: f, the three weights and the BYTE offsets of the first bins of their vertices; *packed = f | slot_r << (8 + 2 r): position of
+// weight r in the reference's bary[] (debug entry).
+constexpr float kInvPhi = 0.6180339888f, kInvPhi2 = 0.3819660113f;
+__device__ __forceinline__ int face_lookup(bool valid, float rx, float ry, float rz, const int *s_fidx, const int4 *s_sym, float &b0,
+                                           float &b1, float &b2, int &o0, int &o1, int &o2, int *packed = nullptr, bool scan_only = false) {
+	int f = -1, pk = 0;
 	bool slow = false;
+	o0 = o1 = o2 = 0;
 	if (valid) {
 		const float ax = fabsf(rx), ay = fabsf(ry), az = fabsf(rz);
-		float best = ax * s_predn[0] + ay * s_predn[1] + az * s_predn[2];
-		int kb = 0;
-#pragma unroll
-		for (int t = 1; t < 4; t++) {
-			const float sc = ax * s_predn[3 * t] + ay * s_predn[3 * t + 1] + az * s_predn[3 * t + 2];
-			if (sc > best) { best = sc; kb = t; }
-		}
+		const float lA = __fmaf_rn(-kInvPhi, ax, __fmaf_rn(kInvPhi2, ay, az));
+		const float lB = __fmaf_rn(-kInvPhi, az, __fmaf_rn(kInvPhi2, ax, ay));
+		const float lC = __fmaf_rn(-kInvPhi, ay, __fmaf_rn(kInvPhi2, az, ax));
+		const float mn = fminf(fminf(lA, lB), lC);
+		const bool oct = !(mn < 0.0f);
+		const bool isA = lA == mn, isB = !isA && lB == mn;
+		const float u = isA ? ay : (isB ? ax : az), v = isA ? az : (isB ? ay : ax), w = isA ? ax : (isB ? az : ay);
+		const float t = __fmaf_rn(kInvPhi, w, -kInvPhi2 * u);
+		const float l0 = oct ? lA : t + v, l1 = oct ? lB : t - v, l2 = oct ? lC : (2.0f * kInvPhi) * u;
+		const float inv = __builtin_amdgcn_rcpf(l0 + l1 + l2);  // 1 ulp
+		b0 = l0 * inv; b1 = l1 * inv; b2 = l2 * inv;
+		const int type = oct ? 0 : (isA ? 1 : (isB ? 2 : 3));
 		const int bits = (rx < 0.f ? 1 : 0) | (ry < 0.f ? 2 : 0) | (rz < 0.f ? 4 : 0);
-		f = s_predf[kb * 8 + bits];
-		const bool ok = face_test(&s_face[f], rx, ry, rz, b0, b1, b2);
-		slow = scan_only || !(ok && b0 >= kFastMargin && b1 >= kFastMargin && b2 >= kFastMargin);
+		const int4 e = s_sym[type * 8 + bits];
+		o0 = e.x; o1 = e.y; o2 = e.z; pk = e.w; f = e.w & 31;
+		slow = scan_only || !(fminf(fminf(b0, b1), b2) >= kFastMargin);
 	}
 	if (__any(slow)) {
-		if (slow) f = intersect_scan(rx, ry, rz, b0, b1, b2);
+		if (slow) {
+			f = intersect_scan(rx, ry, rz, b0, b1, b2);
+			const int ff = f < 0 ? 0 : f;
+			o0 = s_fidx[ff * 4]; o1 = s_fidx[ff * 4 + 1]; o2 = s_fidx[ff * 4 + 2];
+			pk = ff | 0 << 8 | 1 << 10 | 2 << 12;
+		}
 	}
+	if (packed) *packed = pk;
 	return f;
 }
 
@@ -198,18 +193,24 @@ __device__ __forceinline__ int cvt_rpi(float x) {
 // (Src/cSIFT3D.cc:1323-1325, 1468) run here, on the compacted voxels only.
 __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by, float bz, float gx, float gy, float gz,
                                                  float R0, float R1, float R2, float R3, float R4, float R5, float R6, float R7, float R8,
-                                                 float fix_scale, const float *s_face, const int *s_fidx, const float *s_predn,
-                                                 const int *s_predf, bin_t *hist_rep, int spread /* lane constant: bits 0..2 = r */) {
+                                                 float fix_scale, const int *s_fidx, const int4 *s_sym, bin_t *hist_rep,
+                                                 int spread /* lane constant: bits 0..2 = r */) {
 #if defined(S3D_DDIAG) && (S3D_DDIAG & 2)  // timing only: march and queue without the heavy part
 	return 0.0f;
 #endif
+	// The rotated gradient is formed exactly like the reference's (separate multiplies and adds, left to right): the face lookup
+	// below is a DISCONTINUOUS function of its direction -- Initialize_geometry swaps the coordinates of the first two vertices of
+	// a face whose normal points inwards but not their bin indices (Src/cUtil.cc:164-171), so across an edge between such a face
+	// and a regular one the weights of two bins trade places -- and a last-bit difference (fused multiply-adds were tried) moved
+	// single strong voxels across: one descriptor element off by 1e-3 in a handful of the 11 292 keypoints of the 512^3 volume
 	const float rx = R0 * gx + R1 * gy + R2 * gz;
 	const float ry = R3 * gx + R4 * gy + R5 * gz;
 	const float rz = R6 * gx + R7 * gy + R8 * gz;
 	const float g2 = rx * rx + ry * ry + rz * rz;
 	valid = valid && !(g2 < kBaryEps);
 	float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-	const int f = face_lookup(valid, rx, ry, rz, s_face, s_predn, s_predf, b0, b1, b2);
+	int o0, o1, o2;
+	const int f = face_lookup(valid, rx, ry, rz, s_fidx, s_sym, b0, b1, b2, o0, o1, o2);
 	if (!valid || f < 0) return 0.0f;
 	const float mag = __fsqrt_rn(g2);
 	const float fx = bx - floorf(bx), fy = by - floorf(by), fz = bz - floorf(bz);
@@ -229,9 +230,8 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 	// (24-bit multiplies: full rate; v_mul_lo_u32 issues at a quarter of it)
 	const int base = __mul24(ix + (qx ? 1 : 0), kSX * kRep) + __mul24(iy + (qy ? 1 : 0), kSY * kRep) + __mul24(iz + (qz ? 1 : 0), kSZ * kRep);
 	const float pxy[4] = {ax[0] * ay[0], ax[0] * ay[1], ax[1] * ay[0], ax[1] * ay[1]};  // index ddx*2 + ddy
-	bin_t *h0 = hist_rep + base + s_fidx[f * 4] * kRep;
-	bin_t *h1 = hist_rep + base + s_fidx[f * 4 + 1] * kRep;
-	bin_t *h2 = hist_rep + base + s_fidx[f * 4 + 2] * kRep;
+	char *hb = reinterpret_cast<char *>(hist_rep + base);
+	bin_t *h0 = reinterpret_cast<bin_t *>(hb + o0), *h1 = reinterpret_cast<bin_t *>(hb + o1), *h2 = reinterpret_cast<bin_t *>(hb + o2);
 #pragma unroll
 	for (int d = 0; d < 8; d++) {
 		const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;
@@ -321,9 +321,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	__shared__ bin_t hist[kBins * kRep];  // [bin][replica], two's-complement fixed point, units of 1 / lut.fix_scale
 	__shared__ float s_lut[LUT_LDS ? kMaxDescLut : 1];
 	__shared__ float s_q[4][6][kQCap];                 // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
-	__shared__ float s_predn[12];
-	__shared__ int s_predf[32];
-	__shared__ __attribute__((aligned(16))) float s_face[kFaces * kFaceStride];
+	__shared__ int4 s_sym[32];
 	__shared__ int s_fidx[kFaces * 4];
 	__shared__ float red[4];
 	__shared__ unsigned short s_units[kPairCap];  // the non-empty column pairs of the chunk, longest z range first
@@ -333,7 +331,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	const unsigned count = min(d_count[0], cap);
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
-	stage_face_tables(tid, s_face, s_fidx, s_predn, s_predf);
+	stage_face_tables(tid, s_fidx, s_sym);
 	int cur_lut = -1;
 #if defined(S3D_EXP) && S3D_EXP == 21
 	unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
@@ -660,7 +658,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 					if (qcount >= 64) {
 						const int pos = (qhead + lane) & (kQCap - 1);
 						msum += accumulate_voxel(true, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale,
-						                 s_face, s_fidx, s_predn, s_predf, hist_rep, spread);
+						                 s_fidx, s_sym, hist_rep, spread);
 						qhead = (qhead + 64) & (kQCap - 1);
 						qcount -= 64;
 #if defined(S3D_EXP) && S3D_EXP == 21
@@ -676,7 +674,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			const int pos = (qhead + lane) & (kQCap - 1);
 			const bool valid = lane < qcount;
 			msum += accumulate_voxel(valid, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale,
-			                 s_face, s_fidx, s_predn, s_predf, hist_rep, spread);
+			                 s_fidx, s_sym, hist_rep, spread);
 		}
 		S3D_DSTAMP(6)  // drain
 		// gradient mass of the window (block sum; fp32 sums of non-negative terms, 1e-4 relative at worst: covered by the margins)
@@ -748,21 +746,25 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 
 // sift3d_debug_face_lookup: the face lookup of k_describe on caller-provided gradients (unit parity against golden g7)
 __global__ void __launch_bounds__(256) k_face_lookup(const float *__restrict__ g3, int n, int route, int *__restrict__ face, float *__restrict__ bary3) {
-	__shared__ float s_predn[12];
-	__shared__ int s_predf[32];
-	__shared__ __attribute__((aligned(16))) float s_face[kFaces * kFaceStride];
+	__shared__ int4 s_sym[32];
 	__shared__ int s_fidx[kFaces * 4];
-	stage_face_tables(threadIdx.x, s_face, s_fidx, s_predn, s_predf);
+	stage_face_tables(threadIdx.x, s_fidx, s_sym);
 	__syncthreads();
 	for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {  // wave-uniform trip count (face_lookup votes)
 		const int i = base + threadIdx.x;
 		const bool valid = i < n;
 		const float gx = valid ? g3[3 * i] : 1.f, gy = valid ? g3[3 * i + 1] : 0.f, gz = valid ? g3[3 * i + 2] : 0.f;
-		float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+		float b[3] = {0.f, 0.f, 0.f};
+		int o0, o1, o2, pk = 0;
 		// |g|^2 < eps rejects first, like Check_intersect_faces (Src/cSIFT3D.cc:1546) and accumulate_voxel
 		const float g2 = gx * gx + gy * gy + gz * gz;
-		const int f = face_lookup(valid && !(g2 < kBaryEps), gx, gy, gz, s_face, s_predn, s_predf, b0, b1, b2, route != 0);
-		if (valid) { face[i] = f; bary3[3 * i] = b0; bary3[3 * i + 1] = b1; bary3[3 * i + 2] = b2; }
+		const int f = face_lookup(valid && !(g2 < kBaryEps), gx, gy, gz, s_fidx, s_sym, b[0], b[1], b[2], o0, o1, o2, &pk, route != 0);
+		if (valid) {
+			face[i] = f;
+			// weights back into the reference's order bary[0..2] (= v0, v1, v2 of the face after the winding fix)
+#pragma unroll
+			for (int r = 0; r < 3; r++) bary3[3 * i + ((pk >> (8 + 2 * r)) & 3)] = f < 0 ? 0.0f : b[r];
+		}
 	}
 }
 void launch_face_lookup(const float *d_g3, int n, int route, int *d_face, float *d_bary3, hipStream_t st) {

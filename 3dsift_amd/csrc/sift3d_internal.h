@@ -105,12 +105,17 @@ struct WinLut {
 };
 constexpr int kMaxDescLut = 1536;  // descriptor window table entries staged in LDS (default params: 1293)
 
-// Face PREDICTION table for the descriptor kernel (speed only, never correctness: the predicted face
-// is verified with the exact reference test and a margin, otherwise the ordered 20-face scan runs).
-// n[k] = the 4 distinct |face centre| directions of the icosahedron; face[k*8 + signbits] = mesh index.
-struct FacePredict {
-	float n[4][3];
+// Face lookup of the descriptor kernel by the SYMMETRY of the icosahedron (r03; see face_lookup in kernels_desc.hip).  The mesh
+// (0, +-1, +-phi), (+-1, +-phi, 0), (+-phi, 0, +-1) is invariant under sign flips of the coordinates, so the direction |g| (componentwise)
+// lies in the canonical octant face (0,1,phi) (1,phi,0) (phi,0,1) or in the half of one of its three neighbours that reaches into
+// the positive octant; key = type * 8 + sign bits of g, type 0 = octant face, 1 + m = the neighbour across the edge opposite
+// vertex m.  Per key: the mesh face, and for each of the three ROLES of the canonical solution (see face_lookup) the vertex whose
+// histogram bins receive that weight (Tri::idx of the reference, Src/cUtil.cc:36-55, winding quirk included) and the position j of
+// that weight in the reference's bary[0..2].
+struct FaceSym {
 	int face[32];
+	int vert[32][3];
+	int slot[32][3];
 };
 
 // ---- kernels_pyramid.hip -------------------------------------------------------------------
@@ -198,7 +203,7 @@ void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigne
                   hipStream_t st);
 
 // ---- kernels_desc.hip ----------------------------------------------------------------------
-hipError_t upload_faces(const FaceConst *faces, const FacePredict *pred);  // into the current device's __constant__ memory
+hipError_t upload_faces(const FaceConst *faces, const FaceSym *sym);  // into the current device's __constant__ memory
 // part_rank / part_world: only keypoints with slot % part_world == part_rank are described (multi-GPU split of
 // replicated octaves); 0 / 1 = all
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels,
