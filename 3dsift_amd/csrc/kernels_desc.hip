@@ -69,12 +69,16 @@ constexpr float kFastMargin = 2.0e-5f;  // >> the ~1e-6 rounding of either baryc
 #ifndef S3D_DESC_REP
 #define S3D_DESC_REP 4
 #endif
-// (no waves-per-SIMD hint in __launch_bounds__: any value >= 2 makes hipcc schedule for occupancy and the kernel 10 % slower)
+// Four waves per SIMD (r03): with the face tables gone the kernel fits 128 registers without spilling, and a fourth workgroup per
+// CU (4 x 38 KB of LDS) hides more of the march's load latency: 3.68 -> 3.32 ms at 512^3.  (r02: the same limit forced spills, 5.5 ms.)
+#ifndef S3D_DESC_WPE
+#define S3D_DESC_WPE 4
+#endif
 #ifndef S3D_DESC_CLIPM
 #define S3D_DESC_CLIPM 0.25f /* widening of the cube clip of a column's z range, voxels */
 #endif
 #ifndef S3D_DESC_ATTR
-#define S3D_DESC_ATTR
+#define S3D_DESC_ATTR __attribute__((amdgpu_waves_per_eu(S3D_DESC_WPE, S3D_DESC_WPE)))
 #endif
 typedef unsigned bin_t;
 typedef int sbin_t;
@@ -89,11 +93,32 @@ constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = 
 // vertex-major: idx = 72 v + ix + 18 iy + 4 iz.  The cell strides have the residues 1, 2, 4 modulo 8 (and ix + 4 iz < 16 <= 18), the
 // vertex stride is 0 modulo 8: the bank of an add depends on the cell and the replica only, not on the face of the voxel
 // (864 bins = 13.8 KB with 4 replicas; the cell-major layout 17 ix + 74 iy + 300 iz + v: 1200 bins, 19.2 KB, 24 % more conflict cycles).
+#ifndef S3D_DESC_PARITY
+#define S3D_DESC_PARITY 0
+#endif
+#if S3D_DESC_PARITY
+// Parity layout (r03, measured and NOT the default): idx = 64 v + 32 (iz >> 1) + 16 (iy >> 1) + 8 (ix >> 1) + 4 (iz & 1) + 2 (iy & 1) + (ix & 1).
+// The eight cells a voxel adds to have eight different parities, and lane l visits them in the order d ^ r ^ p (r = l & 7 as before,
+// p = the parity of the voxel's own base cell), i.e. at step d it is on parity d ^ r: the eight lanes of a group (one replica) are on
+// eight different banks WHATEVER their cells and faces are (after the compaction through the queue a group mixes voxels of several
+// units; with the data-independent order their banks collide by chance).  Counters at 512^3: bank-conflict cycles 453 M -> 87 M
+// (share 0.43 -> 0.12), LDS-active cycles 1 064 M -> 698 M -- but the data-dependent order costs 52 VALU instructions per batch
+// (2 255 M -> 2 524 M) and the kernel is bound by VALU issue: 3.32 -> 3.55 ms.
+constexpr int kSV = 64, kBins = 12 * kSV;
+__device__ __forceinline__ int cell_index(int ix, int iy, int iz) {
+	return 32 * (iz >> 1) + 16 * (iy >> 1) + 8 * (ix >> 1) + 4 * (iz & 1) + 2 * (iy & 1) + (ix & 1);
+}
+__device__ __forceinline__ int bin_index(int j) {  // descriptor element j = (ix + 4 iy + 16 iz) * 12 + v  ->  histogram index
+	const int c = j / 12, v = j - c * 12;
+	return cell_index(c & 3, (c >> 2) & 3, c >> 4) + v * kSV;
+}
+#else
 constexpr int kSX = 1, kSY = 18, kSZ = 4, kSV = 72, kBins = 12 * kSV;
 __device__ __forceinline__ int bin_index(int j) {  // descriptor element j = (ix + 4 iy + 16 iz) * 12 + v  ->  histogram index
 	const int c = j / 12, v = j - c * 12;
 	return (c & 3) * kSX + ((c >> 2) & 3) * kSY + (c >> 4) * kSZ + v * kSV;
 }
+#endif
 
 // literal Check_intersect_faces: first face in mesh order that passes (wave-uniform loop, constant memory)
 __device__ __forceinline__ int intersect_scan(float gx, float gy, float gz, float &b0, float &b1, float &b2) {
@@ -222,6 +247,18 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 	const float m0 = ms * b0, m1 = ms * b1, m2 = ms * b2;
 	// cells ix+ddx etc. are >= 0 by construction; only the upper bound can fail (skip cells outside [0,3])
 	const bool okx = ix < 3, oky = iy < 3, okz = iz < 3;
+#if S3D_DESC_PARITY
+	// step d of this lane is the cell offset d ^ q, q = r ^ parity of the base cell: weights and address steps swap roles per axis where
+	// the bit of q is set.  Per axis the index term of coordinate c is (c >> 1) * B + (c & 1) * P (B = 8 / 16 / 32, P = 1 / 2 / 4): going
+	// from c to c + 1 adds P from an even c and B - P from an odd one.
+	const int pxb = ix & 1, pyb = iy & 1, pzb = iz & 1;
+	const bool qx = ((spread ^ pxb) & 1) != 0, qy = (((spread >> 1) ^ pyb) & 1) != 0, qz = (((spread >> 2) ^ pzb) & 1) != 0;
+	const float ax[2] = {qx ? fx : wx0, qx ? wx0 : fx}, ay[2] = {qy ? fy : wy0, qy ? wy0 : fy}, az[2] = {qz ? fz : wz0, qz ? wz0 : fz};
+	const bool badx[2] = {qx && !okx, !qx && !okx}, bady[2] = {qy && !oky, !qy && !oky}, badz[2] = {qz && !okz, !qz && !okz};
+	const int dxs = (pxb ? 8 - 1 : 1) * kRep, dys = (pyb ? 16 - 2 : 2) * kRep, dzs = (pzb ? 32 - 4 : 4) * kRep;   // c -> c + 1, elements
+	const int stx = qx ? -dxs : dxs, sty = qy ? -dys : dys, stz = qz ? -dzs : dzs;
+	const int base = cell_index(ix, iy, iz) * kRep + (qx ? dxs : 0) + (qy ? dys : 0) + (qz ? dzs : 0);
+#else
 	// step d of this lane is the cell offset d ^ r: weights and cell strides swap roles per axis where the bit of r is set
 	const bool qx = spread & 1, qy = spread & 2, qz = spread & 4;
 	const float ax[2] = {qx ? fx : wx0, qx ? wx0 : fx}, ay[2] = {qy ? fy : wy0, qy ? wy0 : fy}, az[2] = {qz ? fz : wz0, qz ? wz0 : fz};
@@ -229,6 +266,7 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 	const int stx = qx ? -kSX * kRep : kSX * kRep, sty = qy ? -kSY * kRep : kSY * kRep, stz = qz ? -kSZ * kRep : kSZ * kRep;
 	// (24-bit multiplies: full rate; v_mul_lo_u32 issues at a quarter of it)
 	const int base = __mul24(ix + (qx ? 1 : 0), kSX * kRep) + __mul24(iy + (qy ? 1 : 0), kSY * kRep) + __mul24(iz + (qz ? 1 : 0), kSZ * kRep);
+#endif
 	const float pxy[4] = {ax[0] * ay[0], ax[0] * ay[1], ax[1] * ay[0], ax[1] * ay[1]};  // index ddx*2 + ddy
 	char *hb = reinterpret_cast<char *>(hist_rep + base);
 	bin_t *h0 = reinterpret_cast<bin_t *>(hb + o0), *h1 = reinterpret_cast<bin_t *>(hb + o1), *h2 = reinterpret_cast<bin_t *>(hb + o2);
