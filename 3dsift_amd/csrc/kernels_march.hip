@@ -1,12 +1,25 @@
-// kernels_march.hip -- the pyramid hot kernel for tile-aligned levels (nx, ny multiples of 32): ONE pass over HBM per level,
+// kernels_march.hip -- the pyramid hot kernel (levels of at least 32 x 32 voxels per plane): ONE pass over HBM per level,
 // one workgroup barrier per plane, no register ring.
 //
 //   G[i] = gauss_z(gauss_y(gauss_x(G[i-1])))   and   DoG[i-1] = (G[i] - G[i-1]) * (-1)   and   max|DoG[i-1]|
 //
 // replaces, per level, GaussianSmooth_3D + Im_permute + Sub + im_max_abs (Src/cSIFT3D.cc:535-882, Src/cUtil.cc:587-605) exactly
-// like kernels_fused.hip (which stays the path for every other shape); the arithmetic contract is the same: every output is the
+// (r01's kernels_fused.hip did the same with a register ring and is gone since r03); the arithmetic contract: every output is the
 // literal chain acc = acc + tap[d+hw]*term for d = -hw..+hw with separate IEEE multiply and add (-ffp-contract=off), boundary terms
-// through the extended line E[] of kernels_fused.hip's header (E[-k] = src[k]; E[dim_end+k] = (1-f_k) src[dim_end-k-1] + f_k src[dim_end-k]).
+// through the extended line E[] (E[-k] = src[k]; E[dim_end+k] = (1-f_k) src[dim_end-k-1] + f_k src[dim_end-k], see "Boundaries" below).
+//
+// Boundaries (Src/cSIFT3D.cc:722-788).  Along an axis of length n (dim_end = n - 1) output p in [hw, n-2-hw] is the plain tap chain; the
+// others take, for every tap, the coordinate c = p - d mirrored at 0 (c < 0 -> -c) or mapped by c' = 2 dim_end - c - 0.1f (c >= dim_end)
+// and the term (1 - frac) src[lo] + frac src[lo + 1], lo = (int)c', frac = c' - lo.  For c = dim_end + k (k = 0..hw) that is
+// lo = dim_end - k - 1 and ONE fp32 fraction f_k per k (computed on the host like the reference does): the taps of every output read
+// an EXTENDED line E[] whose entries beyond the ends are those lerps / mirrored values -- so edge tiles run the interior code on a
+// patched window, and the z ends become a feed order (below).
+//
+// Shapes (r03).  Tiles are 32 x 32; a level whose width or height is not a multiple of 32 gets ONE shifted tile column / row: the last
+// tile starts at nx - 32 (ny - 32) and overlaps its neighbour, which stores only the pieces in front of it (columns < nx - 32 rounded
+// up to a whole 16-byte piece: the two or three columns both write carry identical values -- same taps, same operands, interior
+// rule on both sides).  Every tile is a full tile: no masked lanes, no partial-tile code.  A shifted tile's global addresses are
+// only dword aligned; LDS-DMA and 16-byte stores take that (scripts/microbench/glds_unaligned.hip).
 //
 // What is different (r02; the old kernel issued 230 lane-instructions per voxel at hw 8 against 102 of blur arithmetic, had 41-52 %
 // LDS bank-conflict cycles and two barriers per plane):
@@ -148,7 +161,11 @@ __global__ void __launch_bounds__(256, ((S3D_MARCH_VGPR_OCC > 0 && !CR) ? S3D_MA
 		lb = xcd * per + min(xcd, rem) + idx;
 	}
 	const int tile_x = lb % ntx, tile_y = (lb / ntx) % nty, chunk = lb / (ntx * nty);
-	const int x0 = tile_x * C::TX, y0 = tile_y * C::TY;
+	// the last tile column / row is shifted back to end on the level's edge (see "Shapes" in the header); the tile in front of it keeps
+	// the pieces / rows below that start
+	const int x0 = min(tile_x * C::TX, nx - C::TX), y0 = min(tile_y * C::TY, ny - C::TY);
+	const int xlim = tile_x + 1 < ntx ? min((tile_x + 1) * C::TX, (nx - C::TX + 3) & ~3) : nx;
+	const int ylim = tile_y + 1 < nty ? min((tile_y + 1) * C::TY, ny - C::TY) : ny;
 	const int nz = zr.nz, zoff = zr.zoff, dim_end = zr.nzg - 1;
 	const int zc0 = zr.zo0 + chunk * cz, zc1 = min(zr.zo1, zc0 + cz);
 	const int sy = nx, sz = nx * ny;
@@ -211,6 +228,7 @@ __global__ void __launch_bounds__(256, ((S3D_MARCH_VGPR_OCC > 0 && !CR) ? S3D_MA
 	const int xq = tid & 7, ty = tid >> 3;
 	const int ycol = ty * C::XP + 4 * xq;
 	const unsigned out_voff = (unsigned)((y0 + ty) * sy + x0 + 4 * xq) * 4u;
+	const bool own = x0 + 4 * xq < xlim && y0 + ty < ylim;  // this thread's piece belongs to this tile (always, unless the next tile is shifted)
 	const int park_off = ((ty + HW) * C::W4 + ((C::HX / 4 + xq) ^ ((ty + HW) & 1))) * 4;  // raw centre piece in the tile
 
 	float A[2 * HW][4];
@@ -247,7 +265,7 @@ __global__ void __launch_bounds__(256, ((S3D_MARCH_VGPR_OCC > 0 && !CR) ? S3D_MA
 		// DoG centre values of the output this step completes, without a centre ring: requested before anything else of the step
 		const int e_out = e_start - (j - 1);            // feed consumed by the y/z stage of this step
 		const int p_loc = e_out + HW - zoff;            // output plane it completes (local)
-		const bool emit = j >= 1 && p_loc >= zc0 && p_loc < zc1;
+		const bool emit = j >= 1 && p_loc >= zc0 && p_loc < zc1 && own;
 		mf4 cen = {0.f, 0.f, 0.f, 0.f};
 		if (DOG && !CR) {
 			if (j >= 1) cen = cenb[(j & 1) * C::NT + tid];  // landed before the previous step's barrier (own wave's DMA, own lanes)
@@ -379,16 +397,17 @@ __global__ void __launch_bounds__(256, ((S3D_MARCH_VGPR_OCC > 0 && !CR) ? S3D_MA
 #if S3D_MARCH_SCHEDB
 			__builtin_amdgcn_sched_barrier(0);  // keep the accumulator updates in front of the stores and of the wait for the DMA
 #endif
+			// stores this WAVE issues in this step (the counted wait below): a store instruction is issued when any lane of the wave
+			// owns its piece -- in the tile in front of a shifted one some lanes, or whole waves (rows), do not
+			nst = __any(emit && !((S3D_MDIAG & 2) && out[0] != 12345.678f)) ? (DOG ? 2 : 1) : 0;
 			if (emit && !((S3D_MDIAG & 2) && out[0] != 12345.678f)) {
 				float *gb = dst + (size_t)sz * (size_t)p_loc;
 				m_store16(gb, out_voff, mf4{out[0], out[1], out[2], out[3]});
-				nst = 1;
 				if (DOG) {
 					float dg[4];
 					dg[0] = (out[0] - cen.x) * (-1.0f); dg[1] = (out[1] - cen.y) * (-1.0f);
 					dg[2] = (out[2] - cen.z) * (-1.0f); dg[3] = (out[3] - cen.w) * (-1.0f);
 					m_store16(dog + (size_t)sz * (size_t)p_loc, out_voff, mf4{dg[0], dg[1], dg[2], dg[3]});
-					nst = 2;
 #pragma unroll
 					for (int c = 0; c < 4; c++) mx = m_absmax(mx, dg[c]);
 				}
@@ -434,7 +453,7 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	for (int i = 0; i < 2 * kMarchMaxHW + 1; i++) t.w[i] = i < 2 * HW + 1 ? tg.w[i] : 0.0f;
 	const int nzo = zr.zo1 - zr.zo0;
 	if (nzo <= 0) return;
-	const int ntx = nx / C::TX, nty = ny / C::TY, ntiles = ntx * nty;
+	const int ntx = (nx + C::TX - 1) / C::TX, nty = (ny + C::TY - 1) / C::TY, ntiles = ntx * nty;
 	// z chunking.  A CU retires workgroup-planes at about the same rate with three or four resident workgroups (measured: the fourth
 	// buys nothing at 512^3), so a residency round of R workgroups costs (planes marched) x max(1, R / 768); what the fourth slot does
 	// buy is ONE round instead of two when a level has more tiles than 768 (1024^2 levels: 1024 tiles -- the z-slabs of configs[3]).
@@ -476,13 +495,15 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio);
 }
 
-// false => not applicable (shape not tile aligned, level too small for the extended-line boundary form, half width without an
-// instantiation): the caller falls through to kernels_fused.hip / kernels_pyramid.hip
+// false => not applicable (a plane smaller than one tile, a shifted last tile that would reach into the mirrored left / top zone, a level
+// too thin for the extended-line boundary form, a half width without an instantiation): the caller takes the generic separable
+// kernels of kernels_pyramid.hip
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
                         hipStream_t st, int plan_slots, int prio) {
 	static const bool off = dev_tune_i("S3D_MARCH", 1) == 0;
 	if (off) return false;
-	if ((nx % 32) || (ny % 32) || nx < 2 * t.hw + 2 || ny < 2 * t.hw + 2 || zr.nzg < 2 * t.hw + 2) return false;
+	auto fits = [&](int n) { return n == 32 || n >= 32 + t.hw; };  // the shifted tile starts at n - 32: 0 or beyond the mirror zone [0, hw)
+	if (!fits(nx) || !fits(ny) || zr.nzg < 2 * t.hw + 2) return false;
 	switch (t.hw) {
 	case 2: launch_march_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
 	case 3: launch_march_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
