@@ -44,6 +44,9 @@ SYMBOLS = [
     "sift3d_export_orientation_device", "sift3d_import_orientation_device", "sift3d_run_describe",
     "sift3d_set_stream", "sift3d_slab_export_dogmax_device", "sift3d_slab_import_dogmax_device", "sift3d_slab_decimate_async",
     # test hooks / debug accessors / matcher timing
+    # native driver of the z-slab sharding
+    "sift3d_sharded_create", "sift3d_sharded_run", "sift3d_sharded_num_keypoints", "sift3d_sharded_get_keypoints", "sift3d_sharded_info",
+    "sift3d_sharded_error", "sift3d_sharded_destroy",
     "sift3d_test_hook", "sift3d_debug_counters", "sift3d_debug_face_lookup", "sift3d_match_times", "sift3d_debug_copy_bandwidth",
 ]
 HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "desc_nocache": 4, "match_nodma": 5, "one_stream": 6,
@@ -134,6 +137,14 @@ def lib():
         L.sift3d_import_orientation_device.argtypes = [C.c_void_p, C.c_void_p]
         L.sift3d_run_describe.argtypes = [C.c_void_p]
         L.sift3d_import_descriptors_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_sharded_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Params), _ip, C.c_int, C.c_int, C.c_int]
+        L.sift3d_sharded_run.argtypes = [C.c_void_p]
+        L.sift3d_sharded_num_keypoints.argtypes = [C.c_void_p, _ip]
+        L.sift3d_sharded_get_keypoints.argtypes = [C.c_void_p, C.c_void_p, _fp]
+        L.sift3d_sharded_info.argtypes = [C.c_void_p, _ip, _ip, _ip, C.POINTER(C.c_double)]
+        L.sift3d_sharded_error.argtypes = [C.c_void_p]
+        L.sift3d_sharded_error.restype = C.c_char_p
+        L.sift3d_sharded_destroy.argtypes = [C.c_void_p]
         L.sift3d_test_hook.argtypes = [C.c_int, C.c_int]
         L.sift3d_debug_counters.argtypes = [C.c_void_p, _ip]
         L.sift3d_debug_face_lookup.argtypes = [_fp, C.c_int, C.c_int, _ip, _fp, C.c_int]
@@ -476,6 +487,50 @@ class SlabCSIFT3D(CSIFT3D):
 
     def import_dogmax(self, src_ptr):
         _check(lib().sift3d_slab_import_dogmax_device(self._h, C.c_void_p(int(src_ptr))))
+
+
+class ShardedCSIFT3D:
+    """One host volume [z, y, x] sharded as z-slabs by the library's native driver (csrc/sharded.hip): `devices` = one rank per GPU
+    over RCCL, or sim_ranks = n ranks simulated on devices[0]."""
+
+    def __init__(self, volume, devices=(0,), sim_ranks=0, sharded_octaves=0, **kw):
+        vol = np.ascontiguousarray(volume, dtype=np.float32)
+        nz, ny, nx = vol.shape
+        self._h = C.c_void_p()
+        p = _params(kw)
+        devs = (C.c_int * len(devices))(*devices)
+        _check(lib().sift3d_sharded_create(C.byref(self._h), vol.ctypes.data_as(C.c_void_p), nx, ny, nz, C.byref(p), devs, len(devices),
+                                           int(sim_ranks), int(sharded_octaves)))
+
+    def KpSiftAlgorithm(self):
+        rc = lib().sift3d_sharded_run(self._h)
+        if rc:
+            raise Sift3dError(f"{lib().sift3d_error_string(rc).decode()}: {lib().sift3d_sharded_error(self._h).decode()}")
+        return self
+
+    def GetKeypoints(self):
+        n = C.c_int(0)
+        _check(lib().sift3d_sharded_num_keypoints(self._h, C.byref(n)))
+        kp = np.zeros(n.value, KP_DTYPE); desc = np.zeros((n.value, DESC), np.float32)
+        if n.value:
+            _check(lib().sift3d_sharded_get_keypoints(self._h, kp.ctypes.data, _f(desc)))
+        return kp, desc
+
+    def info(self):
+        w = C.c_int(0); s = C.c_int(0); h = C.c_int(0); t = (C.c_double * 2)()
+        _check(lib().sift3d_sharded_info(self._h, C.byref(w), C.byref(s), C.byref(h), t))
+        return {"world": w.value, "sharded_octaves": s.value, "halo": h.value, "seconds": t[0], "seconds_incl_merge": t[1]}
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().sift3d_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def CreateCSIFT3D(volume, **kw):

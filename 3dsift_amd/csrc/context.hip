@@ -659,10 +659,10 @@ static void smooth_level(sift3d_ctx *c, int o, const float *src, const Level &ds
 	static const int prio_mode = dev_tune_i("S3D_PRIO", 2);
 	const int prio = (prio_mode && c->noct > 1) ? (o >= 2 ? 2 : (o == 1 && prio_mode == 1 ? 1 : 0)) : 0;
 	const int plan_slots = c->noct > 1 ? (o == 0 ? (level > c->p.num_kp_levels ? tail_slots : 0) : bg_slots) : 0;
-	// hot path: one fused pass (x, y, z blur + DoG + abs-max); prev == src for every DoG-producing level
+	// hot path: one fused pass (x, y, z blur + DoG + abs-max; kernels_march.hip); prev == src for every DoG-producing level
 	static const int fused_min = dev_tune_i("S3D_FUSED_MIN", S3D_FUSED_MIN_DEFAULT);
 	if (c->use_fused && (prev == nullptr || prev == src) && std::min(dst.nx, std::min(dst.ny, dst.nz)) >= fused_min &&
-	    launch_fused_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.zr_all(), t, st, plan_slots, prio))
+	    launch_march_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.zr_all(), t, st, plan_slots, prio))
 		return;
 	launch_conv_axis(0, src, c->tmpA[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
 	launch_conv_axis(1, c->tmpA[o], c->tmpB[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
@@ -692,13 +692,23 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		// fork: every octave stream starts after the main stream reached this point; octave o is seeded by
 		// G[o-1][num_kp_levels] (DownSample_3D), everything else of octave o-1 overlaps with octave o
 		S3D_HIP(hipEventRecord(c->ev_fork, st));
-		for (int o = 0; o < c->noct; o++) {
+		// Enqueue order: head(0), head(1), tail(0), head(2), tail(1), ... -- head(o) = the levels of octave o up to its seed level
+		// G[o][num_kp_levels], tail(o) = the levels behind it.  The critical path of the stage is the chain of heads (every octave
+		// waits for the seed level of the one above); the tail of octave 0 (its widest Gaussian) is machine-filling work that is off
+		// that path and starts together with head(1).  Measured and rejected (r03, S3D_DEFER_TAIL=1): tail(0) waiting for the seed of
+		// octave 1, so that head(1) -- 351 us alone, 604 us beside tail(0) in the rocprofv3 timeline -- runs undisturbed and tail(0)
+		// fills the machine under the launch-latency chain of the small octaves instead: 2.36 -> 2.51 ms at 512^3 for every slot
+		// planning tried (the tail is longer than that chain).
+		static const int defer_tail = dev_tune_i("S3D_DEFER_TAIL", 0);
+		auto enqueue = [&](int o, bool head) -> int {
 			hipStream_t so = c->ostream[o];
-			if (o > 0) {
+			if (head && o > 0) {
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_fork, 0));
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[o - 1], 0));
 			}
-			for (int i = 0; i < c->ng; i++) {
+			if (!head && o == 0 && defer_tail && c->noct > 1) S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[1], 0));
+			const int i0 = head ? 0 : c->p.num_kp_levels + 1, i1 = head ? c->p.num_kp_levels + 1 : c->ng;
+			for (int i = i0; i < i1; i++) {
 				const Level &L = c->gss[(size_t)o * c->ng + i];
 				if (o == 0 && i == 0) {
 					if (!c->seeded) smooth_level(c, o, c->in.d, L, c->base_taps, nullptr, nullptr, nullptr);
@@ -715,7 +725,12 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 				}
 				if (i == c->p.num_kp_levels) S3D_HIP(hipEventRecord(c->ev_seed[o], so));
 			}
-			if (o > 0) S3D_HIP(hipEventRecord(c->ev_done[o], so));
+			if (!head && o > 0) S3D_HIP(hipEventRecord(c->ev_done[o], so));
+			return SIFT3D_OK;
+		};
+		for (int o = 0; o <= c->noct; o++) {
+			if (o < c->noct && (rc = enqueue(o, true)) != SIFT3D_OK) return rc;
+			if (o >= 1 && (rc = enqueue(o - 1, false)) != SIFT3D_OK) return rc;
 		}
 		for (int o = 1; o < c->noct; o++) S3D_HIP(hipStreamWaitEvent(st, c->ev_done[o], 0));  // join
 		S3D_HIP(hipEventRecord(c->ev[1], st));
@@ -882,7 +897,7 @@ extern "C" int sift3d_copy_level(sift3d_handle c, int is_dog, int idx, float *ou
 		const int i = is_dog ? idx % c->nd : idx % c->ng;
 		if (((is_dog && i == c->nd - 1) || (!is_dog && i == c->ng - 1)) && (c->g_last_built.empty() || !c->g_last_built[0])) {
 			const Level &G = c->gss[c->ng - 1];
-			if (!launch_fused_level(c->gss[c->ng - 2].d, G.d, nullptr, nullptr, G.nx, G.ny, G.zr(c->own0 - G.zoff, c->own1 - G.zoff), c->taps[c->ng - 1],
+			if (!launch_march_level(c->gss[c->ng - 2].d, G.d, nullptr, nullptr, G.nx, G.ny, G.zr(c->own0 - G.zoff, c->own1 - G.zoff), c->taps[c->ng - 1],
 			                        c->stream)) return SIFT3D_ERR_STATE;
 			S3D_HIP(hipStreamSynchronize(c->stream));
 			c->g_last_built.assign(1, 1);
@@ -1218,13 +1233,14 @@ extern "C" int sift3d_slab_create(sift3d_handle *out, const sift3d_slab_desc *d,
 	if (rc) return rc;
 	sift3d_ctx *c = *out;
 	if (c->noct < 1) { sift3d_destroy(c); *out = nullptr; set_last_error("volume too small for one octave"); return SIFT3D_ERR_ARG; }
-	// the fused level kernel is the only slab-aware Gaussian: default half widths and n >= 2*hw+2 along x and y
+	// the march kernel is the only slab-aware Gaussian: default half widths, planes of at least 32 x 32 voxels (and not 33 .. 31 + hw)
 	for (int i = c->seeded ? 1 : 0; i < c->ng; i++) {
 		const int hw = i == 0 ? c->base_taps.hw : c->taps[i].hw;
 		const bool inst = hw == 2 || hw == 3 || hw == 4 || hw == 5 || hw == 6 || hw == 8;
-		if (!inst || c->nx < 2 * hw + 2 || c->ny < 2 * hw + 2 || hw + 1 > c->halo) {
+		auto fits = [&](int n) { return n == 32 || n >= 32 + hw; };
+		if (!inst || !fits(c->nx) || !fits(c->ny) || hw + 1 > c->halo) {
 			sift3d_destroy(c); *out = nullptr;
-			set_last_error("slab mode needs the fused level kernel (default sigma schedule, nx,ny >= 18) and halo > hw");
+			set_last_error("slab mode needs the fused level kernel (default sigma schedule, nx, ny >= 40) and halo > hw");
 			return SIFT3D_ERR_ARG;
 		}
 	}
@@ -1345,7 +1361,7 @@ extern "C" int sift3d_slab_level(sift3d_handle c, int i) {
 		c->g_last_built.assign(1, 0);
 		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(c->nd + 4), c->stream));
 		// octave > 0: level 0 is the decimated G[octave-1][num_kp_levels], written by the caller
-		ok = c->seeded ? true : launch_fused_level(c->in.d, L.d, nullptr, nullptr, L.nx, L.ny, zr, c->base_taps, c->stream);
+		ok = c->seeded ? true : launch_march_level(c->in.d, L.d, nullptr, nullptr, L.nx, L.ny, zr, c->base_taps, c->stream);
 	} else {
 		// like the single-volume path, the first and last DoG level of the octave are not materialised (read only as the centre-voxel
 		// neighbour of extremum candidates: no halo, no abs-max)
@@ -1356,7 +1372,7 @@ extern "C" int sift3d_slab_level(sift3d_handle c, int i) {
 		c->g_last_elide = c->dog_elide && !glast_eager && 2 * (2 * c->taps[c->ng - 1].hw + 1) <= kLazySlots;
 		if (c->g_last_elide && i == c->ng - 1) { c->stage = std::max(c->stage, 1); return SIFT3D_OK; }
 		const bool elided = c->dog_elide && (i - 1 == 0 || i - 1 == c->nd - 1);
-		ok = launch_fused_level(c->gss[i - 1].d, L.d, elided ? nullptr : c->dog[i - 1].d, elided ? nullptr : c->d_dogmax + (i - 1), L.nx, L.ny,
+		ok = launch_march_level(c->gss[i - 1].d, L.d, elided ? nullptr : c->dog[i - 1].d, elided ? nullptr : c->d_dogmax + (i - 1), L.nx, L.ny,
 		                        zr, c->taps[i], c->stream);
 	}
 	if (!ok) { set_last_error("no fused kernel for this level"); return SIFT3D_ERR_STATE; }

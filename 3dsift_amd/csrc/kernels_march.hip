@@ -116,8 +116,15 @@ __device__ __forceinline__ float m_absmax(float m, float v) {
 #ifndef S3D_MARCH_CR_MAXHW
 #define S3D_MARCH_CR_MAXHW 5  /* DoG centre ring in LDS up to this half width (three workgroups per CU still fit); wider levels re-read the centre plane */
 #endif
-#ifndef S3D_MOCC_LO
-#define S3D_MOCC_LO 3
+// workgroups per CU a launch is planned for (residency rounds) and the register budget that goes with it
+#ifndef S3D_MOCC_2
+#define S3D_MOCC_2 3
+#endif
+#ifndef S3D_MOCC_3
+#define S3D_MOCC_3 3
+#endif
+#ifndef S3D_MOCC_4
+#define S3D_MOCC_4 3
 #endif
 #ifndef S3D_MOCC_5
 #define S3D_MOCC_5 3
@@ -129,10 +136,14 @@ __device__ __forceinline__ float m_absmax(float m, float v) {
 #define S3D_MOCC_8 3
 #endif
 template <int HW, bool CR>
-constexpr int march_occ() { return CR ? 3 : (HW <= 4 ? S3D_MOCC_LO : (HW == 5 ? S3D_MOCC_5 : (HW == 6 ? S3D_MOCC_6 : S3D_MOCC_8))); }
+constexpr int march_occ() { return CR ? 3 : (HW == 2 ? S3D_MOCC_2 : (HW == 3 ? S3D_MOCC_3 : (HW == 4 ? S3D_MOCC_4 : (HW == 5 ? S3D_MOCC_5 : (HW == 6 ? S3D_MOCC_6 : S3D_MOCC_8))))); }
+template <int HW, bool CR>
+constexpr int march_lb() {  // __launch_bounds__ second argument: at least the planned workgroups per CU, the fourth slot for kernels without the ring
+	return (S3D_MARCH_VGPR_OCC > march_occ<HW, CR>() && !CR) ? S3D_MARCH_VGPR_OCC : march_occ<HW, CR>();
+}
 
 template <int HW, bool DOG, bool CR>
-__global__ void __launch_bounds__(256, ((S3D_MARCH_VGPR_OCC > 0 && !CR) ? S3D_MARCH_VGPR_OCC : march_occ<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
+__global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                         unsigned *__restrict__ dogmax, int nx, int ny, ZRange zr, MTaps t, MEdge ef, int ntx,
                                                         int nty, int cz, int prio) {
 	using C = MCfg<HW>;
@@ -435,7 +446,7 @@ __global__ void __launch_bounds__(256, ((S3D_MARCH_VGPR_OCC > 0 && !CR) ? S3D_MA
 	}
 }
 
-static void march_edge_fractions(int n, int hw, float *f) {  // Src/cSIFT3D.cc:751-760, see kernels_fused.hip
+static void march_edge_fractions(int n, int hw, float *f) {  // Src/cSIFT3D.cc:751-760, see "Boundaries" in the header
 	const int dim_end = n - 1;
 	for (int k = 0; k <= hw; k++) {
 		const float c = (float)(dim_end + k);
@@ -460,6 +471,7 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	// Kernels with the DoG centre ring in LDS fit three per CU; where a fourth slot saves a round the ring-less instantiation runs.
 	constexpr bool kHasCR = HW <= S3D_MARCH_CR_MAXHW;
 	const int ramp = 2 * HW + 1;
+	const int sat = (dog && kHasCR) ? 3 : march_occ<HW, false>();  // workgroups per CU at which a CU's plane rate saturates
 	auto plan = [&](int cap, int &cz_out) {
 		if (plan_slots > 0) cap = std::min(cap, plan_slots);
 		double best = 1e300;
@@ -470,16 +482,18 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 			double cost = 0.0;
 			while (left > 0) {
 				const long r = std::min<long>(left, cap);
-				cost += (double)(czn + ramp) * std::max(1.0, (double)r / 768.0);
+				cost += (double)(czn + ramp) * std::max(1.0, (double)r / (256.0 * sat));
 				left -= r;
 			}
 			if (cost < best - 1e-9) { best = cost; cz_out = czn; }
 		}
 		return best;
 	};
+	// (kernels without the ring: planned for march_occ workgroups per CU; one more slot may be used where it saves a round)
+	constexpr int kOcc = march_occ<HW, false>();
 	int cz3 = nzo, cz4 = nzo;
-	const double cost3 = plan(768, cz3), cost4 = plan(1024, cz4);
-	// dog + ring: three per CU unless four without the ring are clearly ahead; everything else may use the fourth slot
+	const double cost3 = plan(256 * (dog && kHasCR ? 3 : kOcc), cz3), cost4 = plan(256 * (dog && kHasCR ? 4 : kOcc + 1), cz4);
+	// dog + ring: three per CU unless four without the ring are clearly ahead; everything else may use the extra slot
 	const bool use_cr = dog && kHasCR && !(cost4 * 1.12 < cost3);
 	const int cz = (dog && kHasCR) ? (use_cr ? cz3 : cz4) : (cost4 < cost3 ? cz4 : cz3);
 	const int nchunks = (nzo + cz - 1) / cz;
@@ -500,8 +514,6 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 // kernels of kernels_pyramid.hip
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
                         hipStream_t st, int plan_slots, int prio) {
-	static const bool off = dev_tune_i("S3D_MARCH", 1) == 0;
-	if (off) return false;
 	auto fits = [&](int n) { return n == 32 || n >= 32 + t.hw; };  // the shifted tile starts at n - 32: 0 or beyond the mirror zone [0, hw)
 	if (!fits(nx) || !fits(ny) || zr.nzg < 2 * t.hw + 2) return false;
 	switch (t.hw) {

@@ -31,7 +31,7 @@ struct Taps {
 	float w[kMaxTaps];
 };
 
-// fp32 lerp fractions of the right-boundary rule per axis (x, y, z), see kernels_fused.hip
+// fp32 lerp fractions of the right-boundary rule per axis (x, y, z), see kernels_march.hip
 struct EdgeFrac {
 	float f[3][kMaxHW + 1];
 };
@@ -126,10 +126,8 @@ void launch_dog_from_gss(const float *hi, const float *lo, float *dog, size_t n,
 // dog = -(dst - prev) and accumulates max|dog| (bits) into d_dogmax.
 void launch_conv_axis(int axis, const float *src, float *dst, int nx, int ny, int nz, const Taps &t,
                       const float *prev, float *dog, unsigned *d_dogmax, hipStream_t st);
-// fused single-pass level kernel (kernels_fused.hip); false => no instantiation for this half width
-bool launch_fused_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr,
-                        const Taps &t, hipStream_t st, int plan_slots = 0, int prio = 0);
-// tile-aligned levels (kernels_march.hip): descending z-march with scatter accumulators; false => not applicable, use the above
+// fused single-pass level kernel (kernels_march.hip): descending z-march with scatter accumulators; false => not applicable (half
+// width without an instantiation, planes smaller than a tile): the caller takes the separable kernels above
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
                         hipStream_t st, int plan_slots = 0, int prio = 0 /* wave priority class: 0 normal, 1, 2 */);
 void launch_copy16(const float *src, float *dst, size_t nfloats, hipStream_t st);  // float4 copy (bandwidth ceiling probe)

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "../../../include/sift3d_hip.h"
 #include "../Include/Util/matrixIO3D.h"
@@ -33,8 +34,32 @@ int GetDevice() {
 static std::mutex g_reg_mu;
 static std::map<const float *, CSIFT3D *> g_reg;
 
+// SIFT3D_DEVICES = "0,1,2,3" or "0-7": GPUs one extractor shards a volume over (z-slabs, halo exchange over RCCL; csrc/sharded.hip);
+// SIFT3D_SIM_RANKS = n: that many ranks simulated on the one selected device (how a 1-GPU box tests the sharded driver)
+static std::vector<int> shard_devices() {
+	std::vector<int> d;
+	const char *e = getenv("SIFT3D_DEVICES");
+	if (!e) return d;
+	for (const char *p = e; *p;) {
+		char *q = nullptr;
+		long a = strtol(p, &q, 10);
+		if (q == p) break;
+		long b = a;
+		if (*q == '-') { const char *r = q + 1; b = strtol(r, &q, 10); if (q == r) break; }
+		for (long v = a; v <= b && d.size() < 64; v++) d.push_back((int)v);
+		p = (*q == ',') ? q + 1 : q;
+		if (*q && *q != ',') break;
+	}
+	return d;
+}
+static int sim_ranks() {
+	const char *e = getenv("SIFT3D_SIM_RANKS");
+	return e ? atoi(e) : 0;
+}
+
 struct CSIFT3D::Impl {
 	sift3d_handle h = nullptr;
+	sift3d_sharded_handle sh = nullptr;  // set instead of h when the volume is sharded over several GPUs
 	int device = 0;
 	int levels = 3;
 	int stage = 0;
@@ -87,6 +112,15 @@ CSIFT3D::CSIFT3D(float *volume, int x_dim, int y_dim, int z_dim, int num_kp_leve
 	p.corner_thresh = corner_thresh_;
 	impl->levels = num_kp_levels_;
 	impl->device = GetDevice();
+	const std::vector<int> devs = shard_devices();
+	const int sim = sim_ranks();
+	if (devs.size() > 1 || sim > 1) {
+		const int one = impl->device;
+		const int rc = sift3d_sharded_create(&impl->sh, volume, x_dim, y_dim, z_dim, &p, sim > 1 ? &one : devs.data(), sim > 1 ? 1 : (int)devs.size(),
+		                                     sim > 1 ? sim : 0, 0);
+		complain("CSIFT3D (sharded upload + normalise)", rc);
+		return;
+	}
 	complain("CSIFT3D (upload + normalise)", sift3d_create(&impl->h, volume, x_dim, y_dim, z_dim, &p, impl->device, 0));
 }
 
@@ -95,6 +129,7 @@ CSIFT3D::~CSIFT3D() {
 	if (global_descriptor) { std::lock_guard<std::mutex> lk(g_reg_mu); g_reg.erase(global_descriptor); }
 	if (impl) {
 		if (impl->h) sift3d_destroy(impl->h);
+		if (impl->sh) sift3d_sharded_destroy(impl->sh);
 		delete impl;
 	}
 	if (global_descriptor) free(global_descriptor);
@@ -125,14 +160,16 @@ void CSIFT3D::fetch_results() {
 		global_descriptor = nullptr;
 	}
 	impl->fetched = true;
-	if (!impl->h || impl->stage < 4) return;
+	if ((!impl->h && !impl->sh) || impl->stage < 4) return;
 	int n = 0;
-	sift3d_num_keypoints(impl->h, &n);
+	if (impl->sh) sift3d_sharded_num_keypoints(impl->sh, &n);
+	else sift3d_num_keypoints(impl->h, &n);
 	if (n <= 0) return;
 	std::vector<sift3d_keypoint> pod((size_t)n);
 	const bool with_desc = impl->stage >= 5;
 	global_descriptor = (float *)calloc((size_t)n * DESC_NUMEL, sizeof(float));
-	int rc = sift3d_get_keypoints(impl->h, pod.data(), with_desc ? global_descriptor : nullptr);
+	int rc = impl->sh ? sift3d_sharded_get_keypoints(impl->sh, pod.data(), with_desc ? global_descriptor : nullptr)
+	                  : sift3d_get_keypoints(impl->h, pod.data(), with_desc ? global_descriptor : nullptr);
 	complain("GetKeypoints", rc);
 	if (rc != SIFT3D_OK) return;
 	filter.resize((size_t)n);
@@ -148,7 +185,7 @@ void CSIFT3D::fetch_results() {
 		memcpy(k.str_tensor, s.str_tensor, sizeof(k.str_tensor));
 		k.desc = global_descriptor + (size_t)i * DESC_NUMEL;
 	}
-	if (with_desc) {
+	if (with_desc && !impl->sh) {  // (sharded results live on several devices: the matcher takes the host path)
 		impl->desc_hash = hash_block(global_descriptor, (size_t)n * DESC_NUMEL);
 		std::lock_guard<std::mutex> lk(g_reg_mu);
 		g_reg[global_descriptor] = this;
@@ -170,7 +207,20 @@ static void run_to(CSIFT3D *self, sift3d_handle h, int upto, int &stage, bool &f
 	(void)self;
 }
 
-void CSIFT3D::KpSiftAlgorithm() { run_to(this, impl->h, 5, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::KpSiftAlgorithm() {
+	if (impl->sh) {  // sharded over several GPUs: the whole pipeline in one call (the stage-by-stage methods need a single-GPU extractor)
+		const int rc = sift3d_sharded_run(impl->sh);
+		complain("KpSiftAlgorithm (sharded)", rc);
+		if (rc != SIFT3D_OK) return;
+		impl->stage = 5;
+		impl->fetched = false;
+		double sec[2] = {0, 0};
+		sift3d_sharded_info(impl->sh, nullptr, nullptr, nullptr, sec);
+		m_timer.d_TotalTime = sec[0];
+		return;
+	}
+	run_to(this, impl->h, 5, impl->stage, impl->fetched, m_timer);
+}
 void CSIFT3D::Initialize() {}
 void CSIFT3D::Build_Gaussian_Scale_Space() { run_to(this, impl->h, 1, impl->stage, impl->fetched, m_timer); }
 void CSIFT3D::Build_DOG_Scale_Space() { run_to(this, impl->h, 2, impl->stage, impl->fetched, m_timer); }

@@ -298,9 +298,9 @@ class SlabWorker:
         self.levels = params.get("num_kp_levels", 3)
         self.halo = int(halo) if halo is not None else capi.slab_min_halo(**params)
         self.noct = octaves_total(nx, ny, nz)
-        # octaves sharded as slabs: at most all but none below the fused kernel's minimum extent (18 voxels in x, y)
+        # octaves sharded as slabs: at most all but none below the fused kernel's minimum extent (40 voxels in x, y: one 32 x 32 tile + the widest half width)
         S = max(1, min(sharded_octaves, self.noct))
-        while S > 1 and (min(nx, ny) >> (S - 1) < 18 or (nz >> S) < world):
+        while S > 1 and (min(nx, ny) >> (S - 1) < 40 or (nz >> S) < world):
             S -= 1
         self.S = S
         self.stages = []

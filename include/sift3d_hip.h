@@ -201,6 +201,27 @@ int sift3d_export_device(sift3d_handle h, float *d_desc_dst, float *d_xyz_dst);
 int sift3d_import_descriptors_device(sift3d_handle h, const float *d_desc_src);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Native driver of the z-slab sharding (3dsift_amd/csrc/sharded.hip): ONE host volume over the GPUs of a node, with the call
+ * shape of the single-GPU path -- create (copy + normalise, Src/cSIFT3D.cc:146-163), run (KpSiftAlgorithm, :165-235), read
+ * back (GetKeypoints, :1686-1688; reference order).  devices[ndev]: one rank per listed GPU, halo exchange over RCCL (ncclSend /
+ * ncclRecv between z-neighbours over xGMI, one host thread per GPU; librccl is opened at run time).  sim_ranks > 0 (ndev == 1):
+ * that many ranks simulated on the one device -- device copies instead of sends -- which is how 1-GPU boxes test the driver.
+ * sharded_octaves: octaves split into slabs (0 = default 2); the remaining octaves run replicated from an all-gathered seed level.
+ * Results equal the single-GPU results: pyramid / extrema / orientation bit for bit, descriptors bit for bit as well (integer
+ * histograms).  The C++ shell reaches it through CreateCSIFT3D when SIFT3D_DEVICES lists several GPUs.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct sift3d_sharded *sift3d_sharded_handle;
+int sift3d_sharded_create(sift3d_sharded_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
+                          const int *devices, int ndev, int sim_ranks, int sharded_octaves);
+int sift3d_sharded_run(sift3d_sharded_handle h);
+int sift3d_sharded_num_keypoints(sift3d_sharded_handle h, int *n);
+int sift3d_sharded_get_keypoints(sift3d_sharded_handle h, sift3d_keypoint *out, float *desc /* n*768, may be NULL */);
+/* ranks, sharded octaves, halo planes; seconds[0] = wall time of the last run up to the results on the host, [1] = incl. the merge */
+int sift3d_sharded_info(sift3d_sharded_handle h, int *world, int *sharded_octaves, int *halo, double seconds[2]);
+const char *sift3d_sharded_error(sift3d_sharded_handle h);
+int sift3d_sharded_destroy(sift3d_sharded_handle h);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Test hooks (no reference counterpart).  The product has branches that ordinary inputs rarely reach (list
  * overflow -> regrow -> rerun, the second descriptor pass with the exact fixed-point unit, the register-staged
  * matcher of >= 4 GB matrices, ...).  A hook forces such a branch so that the parity tests execute it; results must

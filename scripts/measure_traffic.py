@@ -7,7 +7,7 @@ Two separate --pmc passes (FETCH_SIZE uses 3 of the 4 TCC slots, WRITE_SIZE 2: t
 kernel-trace style options are NOT combined with them.  Units and gfx950 corrections follow
 /opt/skills/guides/MI355X_MICROARCH.md section HBM: the counters are in KiB; FETCH_SIZE reports exactly half of the
 bytes of a wide coalesced streaming read on gfx950 (so it is doubled), WRITE_SIZE is exact for streaming stores.
-The sum covers every pyramid kernel of ONE KpSiftAlgorithm stage-1 run (k_fused_level, k_downsample, k_conv_axis).
+The sum covers every pyramid kernel of ONE KpSiftAlgorithm stage-1 run (k_march_level, k_downsample, k_conv_axis).
 """
 import collections
 import csv
@@ -21,7 +21,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 n = sys.argv[1] if len(sys.argv) > 1 else "512"
-KERNELS = ("k_march_level", "k_fused_level", "k_downsample", "k_conv_axis")
+KERNELS = ("k_march_level", "k_downsample", "k_conv_axis")
 
 
 def one_pass(counter):

@@ -1,0 +1,88 @@
+"""-m gpu: the NATIVE (C++) driver of the z-slab sharding (3dsift_amd/csrc/sharded.hip; SURVEY 8e, BASELINE.json configs[3]) through
+the C-ABI sift3d_sharded_* and through the C++ shell (CSIFT3DFactory::CreateCSIFT3D with SIFT3D_SIM_RANKS / SIFT3D_DEVICES).
+
+A 1-GPU box cannot run several RCCL ranks (one rank per device), so the driver is checked in two ways:
+  * simulated ranks (device copies instead of ncclSend / ncclRecv, same plan, same slab contexts, same merge): 2, 3 (uneven), 4 and
+    8 ranks, one and two sharded octaves -- keypoints AND descriptors bit-identical to the single-volume extractor;
+  * the RCCL transport itself with a world of ONE rank on the one GPU: librccl is opened, three communicators are created, the
+    MAX all-reduce of the DoG maxima, the broadcast group of the seed level and the integer SUM all-reduce of the tail's
+    orientation rows really run through RCCL on the device (the point-to-point halo sends need a second GPU)."""
+import importlib
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+capi = importlib.import_module("3dsift_amd.capi")
+synth = importlib.import_module("3dsift_amd.synth")
+PKG = os.path.dirname(capi.__file__)
+
+
+@pytest.fixture(scope="module")
+def vol_and_single():
+    vol = synth.blobs((160, 96, 128), seed=77, noise=0.01)   # nz 160: 8 ranks x 20 planes (5 after two halvings); ny 96, nx 128
+    ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+    kp, ds = ex.GetKeypoints()
+    assert len(kp) > 100 and ex.num_octaves >= 3
+    return vol, kp, ds
+
+
+@pytest.mark.parametrize("ranks,octs", [(2, 1), (2, 2), (3, 2), (4, 2), (8, 2), (5, 1)])
+def test_simulated_ranks_equal_the_single_volume(vol_and_single, ranks, octs):
+    vol, kp, ds = vol_and_single
+    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs)
+    info = sh.info()
+    assert info["world"] == ranks and 1 <= info["sharded_octaves"] <= octs
+    for _ in range(2):   # a second run on the same contexts gives the same result
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        assert np.array_equal(k2, kp), (ranks, octs)
+        assert np.array_equal(d2, ds), (ranks, octs)
+    sh.close()
+
+
+def test_rccl_transport_world_of_one(vol_and_single):
+    vol, kp, ds = vol_and_single
+    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=0, sharded_octaves=2)   # one real rank: every collective goes through librccl
+    assert sh.info()["world"] == 1
+    k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+    sh.close()
+    assert np.array_equal(k2, kp) and np.array_equal(d2, ds)
+
+
+def test_cpp_shell_shards_for_the_unchanged_user():
+    """The reference's user code (CreateCSIFT3D / KpSiftAlgorithm / GetKeypoints, Example.cpp:21-44) unchanged: with SIFT3D_SIM_RANKS=4
+    the shell shards the volume with the native driver; the keypoint list equals the single-GPU one bit for bit."""
+    src = r"""
+    #include "Include/cSIFT3D.h"
+    #include <cstdio>
+    using namespace CPUSIFT;
+    int main(int, char** a) {
+        CSIFT3D *A = CSIFT3DFactory::CreateCSIFT3D(std::string(a[1]));
+        A->KpSiftAlgorithm();
+        std::vector<Keypoint> k = A->GetKeypoints();
+        FILE* f = fopen(a[2], "wb");
+        for (auto& p : k) { fwrite(&p.x, 4, 3, f); fwrite(&p.octave, 4, 2, f); fwrite(p.Rotation, 4, 9, f); fwrite(p.desc, 4, 768, f); }
+        fclose(f);
+        printf("keypoints %zu total %.6f\n", k.size(), A->m_timer.d_TotalTime);
+        delete A;
+        return 0;
+    }"""
+    vol = synth.blobs((96, 80, 112), seed=5, noise=0.01)
+    with tempfile.TemporaryDirectory() as t:
+        with open(os.path.join(t, "v.bin"), "wb") as f:
+            f.write(struct.pack("<3i", 112, 80, 96) + vol.tobytes())
+        open(os.path.join(t, "m.cpp"), "w").write(src)
+        subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(PKG, "host"), "-o", os.path.join(t, "m"), os.path.join(t, "m.cpp"),
+                               "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-Wl,-rpath," + PKG])
+        outs = []
+        for env in ({}, {"SIFT3D_SIM_RANKS": "4"}, {"SIFT3D_DEVICES": "0"}):
+            e = dict(os.environ, **env)
+            o = subprocess.check_output([os.path.join(t, "m"), os.path.join(t, "v.bin"), os.path.join(t, "k.bin")], env=e, stderr=subprocess.STDOUT).decode()
+            outs.append((o.strip().splitlines()[-1].split()[1], open(os.path.join(t, "k.bin"), "rb").read()))
+    assert int(outs[0][0]) > 30
+    assert outs[1] == outs[0] and outs[2] == outs[0]
