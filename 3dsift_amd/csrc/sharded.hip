@@ -420,26 +420,38 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	return SIFT3D_OK;
 }
 
-void destroy_worker(Worker &w) {
+// phase 0: everything that may still enqueue on or wait for a stream; phase 1: the streams (simulated ranks SHARE rank 0's stream: it
+// must outlive the contexts of every rank -- destroying it with rank 0 made the other ranks synchronise a dead stream, which hung
+// about one run in ten)
+void destroy_worker(Worker &w, int phase) {
 	(void)hipSetDevice(w.device);
-	if (w.stream) (void)hipStreamSynchronize(w.stream);
-	if (w.dstream) (void)hipStreamSynchronize(w.dstream);
-	if (w.tail) sift3d_destroy(w.tail);
-	for (Stage &s : w.stages) {
-		if (s.ctx) { (void)sift3d_set_stream(s.ctx, nullptr); sift3d_destroy(s.ctx); }
-		if (s.arena) (void)hipFree(s.arena);
+	if (phase == 0) {
+		if (w.stream) (void)hipStreamSynchronize(w.stream);
+		if (w.dstream) (void)hipStreamSynchronize(w.dstream);
+		if (w.tail) sift3d_destroy(w.tail);
+		w.tail = nullptr;
+		for (Stage &s : w.stages) {
+			if (s.ctx) { (void)sift3d_set_stream(s.ctx, nullptr); sift3d_destroy(s.ctx); s.ctx = nullptr; }
+			if (s.arena) (void)hipFree(s.arena);
+			s.arena = nullptr;
+		}
+		for (float *&d : w.dogmax) { if (d) (void)hipFree(d); d = nullptr; }
+		if (w.seed) (void)hipFree(w.seed);
+		if (w.seed_mine) (void)hipFree(w.seed_mine);
+		w.seed = w.seed_mine = nullptr;
+		if (w.ev_level) (void)hipEventDestroy(w.ev_level);
+		if (w.ev_def) (void)hipEventDestroy(w.ev_def);
+		if (w.ev_seed) (void)hipEventDestroy(w.ev_seed);
+		w.ev_level = w.ev_def = w.ev_seed = nullptr;
+		if (w.c_urgent) (void)g_rccl.CommDestroy(w.c_urgent);
+		if (w.c_deferred) (void)g_rccl.CommDestroy(w.c_deferred);
+		if (w.c_tail) (void)g_rccl.CommDestroy(w.c_tail);
+		w.c_urgent = w.c_deferred = w.c_tail = nullptr;
+	} else {
+		if (w.dstream) (void)hipStreamDestroy(w.dstream);
+		if (w.own_stream && w.stream) (void)hipStreamDestroy(w.stream);
+		w.dstream = w.stream = nullptr;
 	}
-	for (float *d : w.dogmax) if (d) (void)hipFree(d);
-	if (w.seed) (void)hipFree(w.seed);
-	if (w.seed_mine) (void)hipFree(w.seed_mine);
-	if (w.ev_level) (void)hipEventDestroy(w.ev_level);
-	if (w.ev_def) (void)hipEventDestroy(w.ev_def);
-	if (w.ev_seed) (void)hipEventDestroy(w.ev_seed);
-	if (w.c_urgent) (void)g_rccl.CommDestroy(w.c_urgent);
-	if (w.c_deferred) (void)g_rccl.CommDestroy(w.c_deferred);
-	if (w.c_tail) (void)g_rccl.CommDestroy(w.c_tail);
-	if (w.dstream) (void)hipStreamDestroy(w.dstream);
-	if (w.own_stream && w.stream) (void)hipStreamDestroy(w.stream);
 }
 
 // rows (keypoint slots, reference order) whose descriptor a partitioned handle computes: the library deals the accepted keypoints in
@@ -458,7 +470,8 @@ std::vector<int> described_rows(const std::vector<sift3d_keypoint> &kp, int rank
 
 extern "C" int sift3d_sharded_destroy(sift3d_sharded_handle H) {
 	if (!H) return SIFT3D_OK;
-	for (Worker &w : H->workers) destroy_worker(w);
+	for (int phase = 0; phase < 2; phase++)
+		for (Worker &w : H->workers) destroy_worker(w, phase);
 	delete H;
 	return SIFT3D_OK;
 }
