@@ -1308,7 +1308,12 @@ extern "C" int sift3d_slab_halo_planes(sift3d_handle c, int i, int *planes) {
 	// input reach of the next Gaussian level: its z-march loads planes p-hw-1 .. p+hw (the extra low plane feeds the
 	// right-boundary lerp of the last planes of the volume, Src/cSIFT3D.cc:751-760)
 	if (i + 1 < c->ng) need = c->taps[i + 1].hw + 1;
-	if (i >= 1 && i <= c->p.num_kp_levels) need = c->halo;       // orientation / descriptor windows on G[1..levels]
+	if (i >= 1 && i <= c->p.num_kp_levels) {
+		// orientation / descriptor windows of the keypoints of level i live on G[i]: the z reach of ITS descriptor window (r03; before:
+		// the reach of the widest level for all of them: 3 x 38 planes per side instead of 24 + 30 + 38 with the default parameters)
+		const float radius = 2.0f * (c->dog[(size_t)i].scale * 7.071067812f);
+		need = std::max(need, (int)ceilf(__builtin_fabsf(radius) / c->dog[(size_t)i].unit) + 2);
+	}
 	*planes = std::min(need, c->halo);
 	return SIFT3D_OK;
 }

@@ -502,7 +502,8 @@ extern "C" int sift3d_sharded_create(sift3d_sharded_handle *out, const float *vo
 	if (H->noct < 1) return fail(SIFT3D_ERR_ARG, "volume too small for one octave");
 	// sharded octaves: as asked, but none whose planes are smaller than the level kernel's tile (+ widest half width) or thinner than the ranks
 	int S = std::max(1, std::min(sharded_octaves > 0 ? sharded_octaves : 2, H->noct));
-	while (S > 1 && ((std::min(nx, ny) >> (S - 1)) < 40 || (nz >> S) < H->world)) S--;
+	auto fits = [](int n) { return n == 32 || n >= 40; };  // one 32 x 32 tile, or room for a shifted last tile behind the widest mirror zone
+	while (S > 1 && (!fits(nx >> (S - 1)) || !fits(ny >> (S - 1)) || (nz >> S) < H->world)) S--;
 	H->S = S;
 	Bounds b;
 	if (!slab_bounds(nz, H->world, 1 << S, b)) return fail(SIFT3D_ERR_ARG, "too few planes for this many slabs");

@@ -300,7 +300,8 @@ class SlabWorker:
         self.noct = octaves_total(nx, ny, nz)
         # octaves sharded as slabs: at most all but none below the fused kernel's minimum extent (40 voxels in x, y: one 32 x 32 tile + the widest half width)
         S = max(1, min(sharded_octaves, self.noct))
-        while S > 1 and (min(nx, ny) >> (S - 1) < 40 or (nz >> S) < world):
+        fits = lambda n: n == 32 or n >= 40   # planes the level kernel tiles: one 32 x 32 tile, or room for a shifted last tile behind the widest mirror zone
+        while S > 1 and (not fits(nx >> (S - 1)) or not fits(ny >> (S - 1)) or (nz >> S) < world):
             S -= 1
         self.S = S
         self.stages = []
