@@ -45,19 +45,17 @@ __device__ __forceinline__ void block_max_to_global(float m, unsigned *dst) {
 
 // ---------------------------------------------------------------------------------------------
 // measured device-copy ceiling beside the spec peak (sift3d_debug_copy_bandwidth): the float4 copy the MI355X guide
-// quotes 6.29 TB/s for -- one 16-byte load and store per lane and iteration, grid-stride, read + write counted
+// quotes 6.29 TB/s for -- one 16-byte load and store per lane, read + write counted
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_copy16(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n4) {
-	const size_t stride = (size_t)gridDim.x * blockDim.x;
-	size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-	for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
-		const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-		dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-	}
-	for (; i < n4; i += stride) dst[i] = src[i];
+	// ONE 16-byte piece per lane, as many workgroups as pieces: the workgroups in flight cover a contiguous, moving window of the
+	// buffers (scripts/microbench/copy_bw.hip: 6.29 TB/s this way, 4.5-5.0 TB/s as a grid-stride loop of 4096 workgroups)
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n4) dst[i] = src[i];
 }
 void launch_copy16(const float *src, float *dst, size_t nfloats, hipStream_t st) {
-	hipLaunchKernelGGL(k_copy16, dim3(256 * 16), dim3(256), 0, st, reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), nfloats / 4);
+	const size_t n4 = nfloats / 4;
+	hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), n4);
 }
 
 // ---------------------------------------------------------------------------------------------
