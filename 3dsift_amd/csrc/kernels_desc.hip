@@ -22,7 +22,7 @@
 //     (bin coordinates + weighted gradient) into a small LDS queue by ballot rank and runs the heavy part (rotation, face
 //     test, trilinear weights, 24 atomics) only on full 64-lane batches; all loops are wave-uniform
 //   * face lookup by the symmetry of the icosahedron (face_lookup below): |g| falls into the canonical octant face or one of its
-//     three neighbours, the sign bits pick the mesh face; accepted when all three barycentrics clear a 2e-5 margin (then no other
+//     three neighbours, the sign bits pick the mesh face; accepted when all three barycentrics clear a 6e-6 margin (then no other
 //     face can pass the reference's -1.19e-6 test, so "first passing face in mesh order" is this face); otherwise the literal
 //     20-face ordered scan runs
 //   * the 24 products of a voxel go to an LDS histogram kept in 32-BIT FIXED POINT and are added with ds_add_u32: on gfx950
@@ -65,7 +65,11 @@ __device__ __forceinline__ void win_bounds_d(float c, float rad, float u, int n,
 constexpr float kBaryEps = (float)(FLT_EPSILON * 1E1);  // Src/cSIFT3D.cc:23
 
 // Histogram bins are 32-bit two's-complement fixed point in units of 1 / WinLut::fix_scale (see the header).
-constexpr float kFastMargin = 2.0e-5f;  // >> the ~1e-6 rounding of either barycentric evaluation and the reference's 1.19e-6 tolerance
+// The neighbour across an edge is the mirror image of the face (every edge of the icosahedron lies in a symmetry plane), so a weight of
+// +m on this side is -m on the other: no other face can pass the reference's >= -1.19e-6 test when m exceeds 1.19e-6 plus the rounding
+// of both evaluations (measured: the two routes differ by <= 3e-7).  6e-6 leaves a factor of three; the ordered scan behind it costs
+// ~900 instructions per wave that has one such lane (2e-5: 0.17 ms of 3.4 at 512^3; tests/test_gpu_parity.py samples the zone densely).
+constexpr float kFastMargin = 6.0e-6f;
 #ifndef S3D_DESC_REP
 #define S3D_DESC_REP 4
 #endif
@@ -164,7 +168,7 @@ __device__ __forceinline__ void stage_face_tables(int tid, int *s_fidx, int4 *s_
 // The barycentrics are the weights over their sum: the same quantities the reference's b = (1 - y - z, y, z) expresses, to rounding
 // (|difference| <~ 5e-7).  They are accepted when all three clear kFastMargin: no other face can then pass the reference's
 // >= -1.19e-6 test, so "first passing face in mesh order" is this face; otherwise (direction within the margin of an edge or a
-// vertex: ~1 % of the waves) the literal ordered 20-face scan decides.  Wave-uniform control flow.
+// vertex) the literal ordered 20-face scan decides.  Wave-uniform control flow.
 // Out: f, the three weights and the BYTE offsets of the first bins of their vertices; *packed = f | slot_r << (8 + 2 r): position of
 // weight r in the reference's bary[] (debug entry).
 constexpr float kInvPhi = 0.6180339888f, kInvPhi2 = 0.3819660113f;
@@ -191,6 +195,9 @@ __device__ __forceinline__ int face_lookup(bool valid, float rx, float ry, float
 		const int4 e = s_sym[type * 8 + bits];
 		o0 = e.x; o1 = e.y; o2 = e.z; pk = e.w; f = e.w & 31;
 		slow = scan_only || !(fminf(fminf(b0, b1), b2) >= kFastMargin);
+#if defined(S3D_DDIAG) && (S3D_DDIAG & 128)  // timing only: never the ordered scan
+		slow = scan_only;
+#endif
 	}
 	if (__any(slow)) {
 		if (slow) {

@@ -452,7 +452,7 @@ def test_g7_face_lookup_on_device(capi):
     """Check_intersect_faces + cart2bary (Src/cSIFT3D.cc:1542-1637) as k_describe evaluates them, against golden g7 (1000 random
     directions, some below the |g|^2 rejection, + the mesh's vertices, edge midpoints and face centres, where the eps-tolerant
     first-hit rule matters).  Route 1 = the literal ordered scan: face and barycentrics bit for bit.  Route 0 = what the kernel
-    takes for ~99 % of the voxels, the lookup by the symmetry of the mesh (falls back to the scan within 2e-5 of an edge): the same
+    takes for ~99 % of the voxels, the lookup by the symmetry of the mesh (falls back to the scan within 6e-6 of an edge): the same
     face for every direction, the barycentrics to rounding (they are the same rational functions of g evaluated by other formulas)."""
     g = golden("g7_mesh.npz")
     f1, b1 = capi.face_lookup(g["dirs"], route=1)
@@ -464,11 +464,11 @@ def test_g7_face_lookup_on_device(capi):
     assert np.abs(b0[hit] - g["bary"][hit]).max() <= 2e-6
     # many more directions, dense around the edges of the mesh: route 0 must agree with the scan on the FACE everywhere
     rng = np.random.Generator(np.random.PCG64(8))
-    d = rng.normal(size=(200000, 3)).astype(np.float32)
+    d = rng.normal(size=(100000, 3)).astype(np.float32)
     v = g["verts"].reshape(-1, 3, 3)
     e = rng.integers(0, 20, 50000)
     t = rng.random((50000, 1)).astype(np.float32)
-    near = (v[e, 0] * t + v[e, 1] * (1 - t) + rng.normal(scale=3e-5, size=(50000, 3))).astype(np.float32)   # within ~1e-4 of an edge
+    near = (v[e, 0] * t + v[e, 1] * (1 - t) + rng.normal(scale=1e-5, size=(50000, 3))).astype(np.float32)   # within ~3e-5 of an edge
     d = np.concatenate([d, near, near * np.float32(7.5), -near])
     fa, ba = capi.face_lookup(d, route=0)
     fb, bb = capi.face_lookup(d, route=1)
