@@ -82,16 +82,33 @@ __device__ __forceinline__ void m_barrier() {
 template <int N>
 __device__ __forceinline__ void m_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// cache-policy bits of the output stores and of the tile DMA loads (measurement builds: S3D_MARCH_ST_POL / S3D_MARCH_LD_POL = 0 default,
+// 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt)
+#ifndef S3D_MARCH_ST_POL
+#define S3D_MARCH_ST_POL 1  /* nt: the outputs are streamed, they should not displace the tile rows neighbouring workgroups re-read from the L2 (2.35 -> 2.32 ms; nt LOADS: 3.48 ms -- the L2 does absorb most of the halo re-reads) */
+#endif
+#ifndef S3D_MARCH_LD_POL
+#define S3D_MARCH_LD_POL 0
+#endif
+#define S3D_POL_STR_0 ""
+#define S3D_POL_STR_1 " nt"
+#define S3D_POL_STR_2 " sc1"
+#define S3D_POL_STR_3 " sc0 sc1"
+#define S3D_POL_STR_4 " sc0 sc1 nt"
+#define S3D_POL_CAT(a, b) a##b
+#define S3D_POL_STR(n) S3D_POL_CAT(S3D_POL_STR_, n)
+#define S3D_MARCH_ST_POLICY S3D_POL_STR(S3D_MARCH_ST_POL)
+#define S3D_MARCH_LD_POLICY S3D_POL_STR(S3D_MARCH_LD_POL)
 // LDS-DMA: lane l's 16 bytes at base + voff land at lds_dst + 16*l.  M0 carries the wave-uniform LDS byte address (restored).
 __device__ __forceinline__ void m_dma16(const float *base, unsigned voff, unsigned lds_dst) {
 	unsigned keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" S3D_MARCH_LD_POLICY "\n\ts_mov_b32 m0, %0"
 	             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 // untracked store (hipcc would make later loads that re-use the data registers wait for the store to COMPLETE); nothing reads
 // dst / dog back in this kernel.  The wait states cover the hardware's read of the four data registers.
 __device__ __forceinline__ void m_store16(float *base, unsigned voff, mf4 d) {
-	asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 2" ::"v"(voff), "v"(d), "s"(base));
+	asm volatile("global_store_dwordx4 %0, %1, %2" S3D_MARCH_ST_POLICY "\n\ts_nop 2" ::"v"(voff), "v"(d), "s"(base));
 }
 
 __device__ __forceinline__ float m_absmax(float m, float v) {

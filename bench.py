@@ -521,14 +521,27 @@ def main():
         if slab_err is None:
             # the same volume through the NATIVE driver: rank 0's process drives all the node's GPUs (one host thread each, RCCL), the
             # other ranks idle at a barrier.  Its failure is reported, not fatal: this transport has never met a second GPU in development.
-            nat_err = None
+            # The other ranks wait on the rendezvous STORE (host side): a NCCL barrier would park a spinning kernel on their GPUs
+            # while rank 0's threads use them.
+            store = None
+            try:
+                store = dist.distributed_c10d._get_default_store()
+            except Exception:
+                store = None
             if rank == 0:
                 torch.cuda.empty_cache()
                 nres, nat_err = guarded(lambda: run_slab_native(parse_dims(args.slab_dims), list(range(world)), 3, 1), 180)
                 out["slab_native"] = nres if nat_err is None else {"error": nat_err}
-            if nat_err is None:
+                if store is not None:
+                    try:
+                        store.set("s3d_native_done", "1")
+                    except Exception:
+                        pass
+            elif store is not None:
+                torch.cuda.empty_cache()
                 try:
-                    dist.barrier()
+                    import datetime
+                    store.wait(["s3d_native_done"], datetime.timedelta(seconds=200))
                 except Exception:
                     pass
     if rank == 0:
