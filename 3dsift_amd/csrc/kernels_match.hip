@@ -265,68 +265,269 @@ __global__ void __launch_bounds__(256, 2) k_scores_top4(const float *__restrict_
 	}  // next row block of this workgroup's share
 }
 
-// merge the per-split partial lists of a row into its global top-4 (score desc, column asc)
+// ---- r03: the score kernel, second form (S3D_MATCH_V2; the DMA form above stays for A/B builds, the register-staged one for >= 4 GB) ----
+// What is different:
+//   * A never touches the LDS.  A wave's 32 rows are read by nobody else: lane (li, lh) loads the 16 floats k0 + 16 lh .. + 15 of
+//     its row straight into registers, one chunk ahead (two lanes use one 128-byte line completely).  Only the B chunks travel by
+//     LDS-DMA: 32 KB instead of 73 KB of LDS per workgroup -> THREE workgroups per CU (three waves per SIMD hide the barrier and
+//     fragment-read stalls of each other), half the LDS-DMA traffic.
+//   * the selection does not run the insert in lock step.  Each lane compares its 32 scores of a half band with its list's last
+//     entry and keeps a bit mask; only the marked scores are re-read and inserted (bubble), so a wave iterates max-over-lanes
+//     popcount times instead of once per column in which ANY lane has a candidate (three out of four before).
+//   * the score band of a wave is dumped in two halves of 64 columns (33 KB per workgroup, aliasing the B buffers).
+// Lists are per (row, lane half): lane (li, lh) scans the columns 32 lh .. 32 lh + 31 of each 64-column half band, in ascending
+// column order over the tiles, with the reference's strict '>' rule; the halves are merged at the end (order independent).
+#ifndef S3D_MATCH_V2
+#define S3D_MATCH_V2 1
+#endif
+#ifndef S3D_MATCH_V2_OCC
+#define S3D_MATCH_V2_OCC 3
+#endif
+constexpr int SP2 = 65;  // pitch of a half band (row per lane: conflict-free scans)
+// development diagnostics, timing only (wrong results by construction; never set in the product build): 1 no selection, 2 no B DMA,
+// 4 no A refresh loads, 8 no barriers inside the chunk loop
+#ifndef S3D_XDIAG
+#define S3D_XDIAG 0
+#endif
+__global__ void __launch_bounds__(256, S3D_MATCH_V2_OCC) k_scores_topk2(const float *__restrict__ A, const int *__restrict__ row_ids, int nrows,
+                                                                      const float *__restrict__ B, int m, int slots,
+                                                                      Cand *__restrict__ part /*[nrows][slots][TOPK]*/) {
+	constexpr int kStage = BN * BK;  // floats per B stage
+	constexpr int kSm = 2 * kStage > 4 * 32 * SP2 ? 2 * kStage : 4 * 32 * SP2;
+	__shared__ __attribute__((aligned(1024))) float smem[kSm];
+	const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int li = lane & 31, lh = lane >> 5;
+	const int ntiles = (m + BN - 1) / BN;
+	const long long total = (long long)((nrows + BM - 1) / BM) * ntiles;
+	const long long L0 = (long long)blockIdx.x * total / gridDim.x, L1 = (long long)(blockIdx.x + 1) * total / gridDim.x;
+	const int srow = tid >> 3;
+	const unsigned swz = (unsigned)((tid & 7) ^ ((srow >> 1) & 7)) * 16u;
+	const unsigned lds_b = (unsigned)(unsigned long long)&smem[0];
+	const unsigned slab = (unsigned)wid * (8u * 32u * 4u);
+	const unsigned fswz = (unsigned)((li >> 1) & 7);
+	for (long long L = L0; L < L1;) {
+		const int rbi = (int)(L / ntiles);
+		const int tile_lo = (int)(L - (long long)rbi * ntiles), tile_hi = (int)min((long long)ntiles, tile_lo + (L1 - L));
+		L += tile_hi - tile_lo;
+		const long long X = (long long)rbi * ntiles;
+		const int wfirst = (int)(((X + 1) * gridDim.x + total - 1) / total) - 1;
+		const int slot = (int)blockIdx.x - wfirst;
+		const int row0 = rbi * BM;
+		const int my_row = row0 + wid * 32 + li;
+		const bool my_row_ok = my_row < nrows;
+		const int arow_id = my_row_ok ? (row_ids ? row_ids[my_row] : my_row) : (row_ids ? row_ids[0] : 0);
+		const float *arow = A + (size_t)arow_id * KD + 16 * lh;
+		const unsigned arow_off = (unsigned)arow_id * (unsigned)(KD * 4) + (unsigned)(64 * lh);  // byte offset (both matrices < 4 GB)
+		float bs[TOPK];
+		int bj[TOPK];
+#pragma unroll
+		for (int t = 0; t < TOPK; t++) { bs[t] = -FLT_MAX; bj[t] = -1; }
+
+		for (int tile = tile_lo; tile < tile_hi; tile++) {
+			const int col0 = tile * BN;
+			unsigned boff[4];
+#pragma unroll
+			for (int p = 0; p < 4; p++) {
+				const int c = col0 + srow + 32 * p;
+				boff[p] = (unsigned)(c < m ? c : 0) * (unsigned)(KD * 4) + swz;
+			}
+			auto dma = [&](int buf, int k0) {
+#pragma unroll
+				for (int p = 0; p < 4; p++)
+					if (!(S3D_XDIAG & 2)) x_dma16(B, boff[p] + (unsigned)(k0 * 4), lds_b + (unsigned)(buf * kStage * 4) + (unsigned)(p * 32 * 32 * 4) + slab);
+			};
+			f32x16 acc[4];
+#pragma unroll
+			for (int nb = 0; nb < 4; nb++)
+#pragma unroll
+				for (int r = 0; r < 16; r++) acc[nb][r] = 0.0f;
+			// A fragments: a[q] = floats k0 + 16 lh + 4 q .. + 3 of this lane's row.  Piece q of the NEXT chunk is requested into the
+			// same registers right behind the sixteen MFMAs that consumed it (an untracked load: the compiler would wait for it -- and for
+			// the DMA issued before it -- at the top of the next iteration; the wait is the counted one in front of the barrier)
+			f32x4 a[4];
+			constexpr int NCH = KD / BK;
+			__syncthreads();  // every wave is done with the score band of the previous tile (it aliases the B stages)
+			dma(0, 0);
+#pragma unroll
+			for (int q = 0; q < 4; q++) a[q] = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
+			asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
+			__syncthreads();
+#pragma unroll 1
+			for (int ch = 0; ch < NCH; ch++) {
+				const int buf = ch & 1;
+				const bool more = ch + 1 < NCH;
+				if (more) dma(buf ^ 1, (ch + 1) * BK);
+				const float *br = smem + buf * kStage + li * 32;
+				const unsigned anext = arow_off + (more ? (unsigned)((ch + 1) * BK * 4) : 0u);  // (the last chunk re-requests chunk 0: no branch; waited for below)
+				f32x4 bq[2][4];
+#pragma unroll
+				for (int nb = 0; nb < 4; nb++) bq[0][nb] = *reinterpret_cast<const f32x4 *>(br + nb * 32 * 32 + (int)((((unsigned)lh << 2) ^ fswz) * 4u));
+#pragma unroll
+				for (int q = 0; q < 4; q++) {
+					if (q < 3) {  // the fragments of the next group are in flight during this group's MFMAs
+						const int po = (int)((((unsigned)lh << 2 | (unsigned)(q + 1)) ^ fswz) * 4u);
+#pragma unroll
+						for (int nb = 0; nb < 4; nb++) bq[(q + 1) & 1][nb] = *reinterpret_cast<const f32x4 *>(br + nb * 32 * 32 + po);
+						__builtin_amdgcn_sched_barrier(0);  // (hipcc sinks these reads behind the 15th MFMA of the group otherwise)
+					}
+#pragma unroll
+					for (int e = 0; e < 4; e++)
+#pragma unroll
+						for (int nb = 0; nb < 4; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], bq[q & 1][nb][e], acc[nb], 0, 0, 0);
+					if (!(S3D_XDIAG & 4)) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(a[q]) : "v"(anext + (unsigned)(q * 16)), "s"(A) : "memory");
+				}
+				asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
+				if (!(S3D_XDIAG & 8) || !more) __syncthreads();  // (after the last chunk: all waves finished reading the B stages, the score band may overwrite them)
+			}
+			float *S = smem + wid * 32 * SP2;
+			if (S3D_XDIAG & 1) {  // keep the accumulators alive
+				float sum = 0.f;
+#pragma unroll
+				for (int nb = 0; nb < 4; nb++)
+#pragma unroll
+					for (int r = 0; r < 16; r++) sum += acc[nb][r];
+				if (sum == 12345.678f) bs[0] = sum;
+			}
+#pragma unroll
+			for (int h = 0; h < ((S3D_XDIAG & 1) ? 0 : 2); h++) {
+#pragma unroll
+				for (int nn = 0; nn < 2; nn++)
+#pragma unroll
+					for (int r = 0; r < 16; r++) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * SP2 + nn * 32 + li] = acc[2 * h + nn][r];
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				const float *sp = S + li * SP2 + 32 * lh;
+				const int cbase = col0 + 64 * h + 32 * lh;
+				const int ncol = my_row_ok ? max(0, min(32, m - cbase)) : 0;
+				const float thr = bs[TOPK - 1];  // -FLT_MAX while the list is short: every finite score passes
+				unsigned mask = 0;
+#pragma unroll
+				for (int jj = 0; jj < 32; jj++) mask |= (sp[jj] > thr ? 1u : 0u) << jj;
+				if (ncol < 32) mask &= (1u << ncol) - 1u;
+				while (__any(mask != 0)) {
+					if (mask) {
+						const int jj = __builtin_ctz(mask);
+						mask &= mask - 1;
+						const float sv = sp[jj];
+						if (sv > bs[TOPK - 1] || bj[TOPK - 1] < 0) topk_bubble(bs, bj, sv, cbase + jj);
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();  // the band is rewritten by the next half
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			}
+		}
+#pragma unroll
+		for (int t = 0; t < TOPK; t++) {
+			const float os = __shfl(bs[t], li + 32, 64);
+			const int oj = __shfl(bj[t], li + 32, 64);
+			if (lane < 32 && oj >= 0) top4_insert(bs, bj, os, oj);
+		}
+		if (lane < 32 && my_row_ok && slot < slots) {
+			Cand *o = part + ((size_t)my_row * slots + slot) * TOPK;
+#pragma unroll
+			for (int t = 0; t < TOPK; t++) o[t] = Cand{bs[t], bj[t]};
+		}
+	}  // next row block of this workgroup's share
+}
+
+// merge the per-split partial lists of a row into its global top-K (score desc, column asc).  Eight lanes per row: lane s takes the
+// slots s and s + 8, then three butterfly rounds join the eight lists (r03: one thread per row walked up to 16 x K entries one
+// after the other, 50-70 us per pass).  The order (score desc, column asc) does not depend on the order of the inserts.
 __global__ void __launch_bounds__(256) k_merge_top4(const Cand *__restrict__ part, int nrows, int splits, int *__restrict__ cand,
-                                                    float *__restrict__ s4 /* 4th fp32 score of the row, -FLT_MAX if the list is short */) {
-	const int r = blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= nrows) return;
+                                                    float *__restrict__ s4 /* K-th fp32 score of the row, -FLT_MAX if the list is short */) {
+	const int gid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+	const int r = gid >> 3, sub = gid & 7;
+	const bool ok = r < nrows;
 	float bs[TOPK];
 	int bj[TOPK];
 #pragma unroll
 	for (int t = 0; t < TOPK; t++) { bs[t] = -FLT_MAX; bj[t] = -1; }
-	for (int s = 0; s < splits; s++)
-		for (int t = 0; t < TOPK; t++) {
-			const Cand c = part[((size_t)r * splits + s) * TOPK + t];
-			if (c.j >= 0) top4_insert(bs, bj, c.s, c.j);
-		}
+	if (ok)
+		for (int s = sub; s < splits; s += 8)
 #pragma unroll
-	for (int t = 0; t < TOPK; t++) cand[(size_t)r * TOPK + t] = bj[t];
-	s4[r] = bj[TOPK - 1] >= 0 ? bs[TOPK - 1] : -FLT_MAX;
-}
-
-// squared norms of the rows of X (one wave per row), and their maximum (bits of a non-negative float)
-__global__ void __launch_bounds__(256) k_row_norm2(const float *__restrict__ X, int nrows, float *__restrict__ n2, unsigned *__restrict__ n2max) {
-	const int lane = threadIdx.x & 63;
-	const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	if (r >= nrows) return;
-	const float *x = X + (size_t)r * KD;
-	float a = 0.f;
-	for (int k = lane; k < KD; k += 64) a = a + x[k] * x[k];
+			for (int t = 0; t < TOPK; t++) {
+				const Cand c = part[((size_t)r * splits + s) * TOPK + t];
+				if (c.j >= 0) top4_insert(bs, bj, c.s, c.j);
+			}
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) a = a + __shfl_xor(a, o, 64);
-	if (lane == 0) {
-		a = a * 1.0001f;  // fp32 summation error of 768 non-negative terms
-		if (n2) n2[r] = a;
-		if (n2max) atomicMax(n2max, __float_as_uint(a));
+	for (int o = 4; o > 0; o >>= 1) {
+		float os[TOPK];
+		int oj[TOPK];
+#pragma unroll
+		for (int t = 0; t < TOPK; t++) { os[t] = __shfl(bs[t], lane ^ o, 64); oj[t] = __shfl(bj[t], lane ^ o, 64); }
+#pragma unroll
+		for (int t = 0; t < TOPK; t++)
+			if (oj[t] >= 0) top4_insert(bs, bj, os[t], oj[t]);
+	}
+	if (ok && sub == 0) {
+#pragma unroll
+		for (int t = 0; t < TOPK; t++) cand[(size_t)r * TOPK + t] = bj[t];
+		s4[r] = bj[TOPK - 1] >= 0 ? bs[TOPK - 1] : -FLT_MAX;
 	}
 }
 
-// exact re-score + replay of the reference update rule (Src/cMatcher.cc:52-77)
+// squared norms of the rows of X (one wave per row, four rows per wave), and their maximum (bits of a non-negative float): ONE
+// atomic per workgroup (r03: one per row -- 11 000 atomics on one address were 0.13 ms of a pass)
+__global__ void __launch_bounds__(256) k_row_norm2(const float *__restrict__ X, int nrows, float *__restrict__ n2, unsigned *__restrict__ n2max) {
+	__shared__ float s_m[4];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	float mx = 0.f;
+	for (int i = 0; i < 4; i++) {
+		const int r = (blockIdx.x * 4 + wv) * 4 + i;
+		if (r >= nrows) break;  // wave-uniform
+		const float *x = X + (size_t)r * KD;
+		float a = 0.f;
+		for (int k = lane; k < KD; k += 64) a = a + x[k] * x[k];
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) a = a + __shfl_xor(a, o, 64);
+		a = a * 1.0001f;  // fp32 summation error of 768 non-negative terms
+		if (lane == 0 && n2) n2[r] = a;
+		mx = fmaxf(mx, a);
+	}
+	if (lane == 0) s_m[wv] = mx;
+	__syncthreads();
+	if (threadIdx.x == 0 && n2max) {
+		const float m4 = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+		if (m4 > 0.f) atomicMax(n2max, __float_as_uint(m4));
+	}
+}
+
+// exact re-score + replay of the reference update rule (Src/cMatcher.cc:52-77).  A lane re-scores ONE candidate of one row exactly
+// like the reference (fp32 product, fp64 accumulate, k ascending); a wave holds 64 / K rows (r03: one row per wave left 58 lanes idle
+// and the pass took 0.16 ms), the first lane of a row gathers its K (column, score) pairs and replays them in ascending column order.
+constexpr int kRowsPerWave = 64 / TOPK;
 __global__ void __launch_bounds__(256) k_rescore(const float *__restrict__ A, const int *__restrict__ row_ids, int nrows,
                                                  const float *__restrict__ B, const int *__restrict__ cand, float *__restrict__ gd,
                                                  float *__restrict__ sd, int *__restrict__ gi, int *__restrict__ si,
                                                  const float *__restrict__ s4, const float *__restrict__ a_n2,
                                                  const unsigned *__restrict__ b_n2max, int *__restrict__ redo /* [0] count, then r */) {
-	// one wave per row: lanes 0..3 each re-score one candidate sequentially (k ascending)
 	const int lane = threadIdx.x & 63;
-	const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	if (r >= nrows) return;
-	const int row = row_ids ? row_ids[r] : r;
+	const int rr = lane / TOPK, t0 = lane - rr * TOPK;
+	const int r = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kRowsPerWave + rr;
+	const bool ok = rr < kRowsPerWave && r < nrows;
+	const int row = ok ? (row_ids ? row_ids[r] : r) : 0;
 	int j = -1;
 	double s = 0.0;
-	if (lane < TOPK) {
-		j = cand[(size_t)r * TOPK + lane];
+	if (ok) {
+		j = cand[(size_t)r * TOPK + t0];
 		if (j >= 0) {
-			const float *a = A + (size_t)row * KD, *b = B + (size_t)j * KD;
-			for (int k = 0; k < KD; k++) s += (double)(a[k] * b[k]);
+			const f32x4 *a = reinterpret_cast<const f32x4 *>(A + (size_t)row * KD), *b = reinterpret_cast<const f32x4 *>(B + (size_t)j * KD);
+#pragma unroll 4
+			for (int k = 0; k < KD / 4; k++) {
+				const f32x4 av = a[k], bv = b[k];
+				s += (double)(av.x * bv.x); s += (double)(av.y * bv.y); s += (double)(av.z * bv.z); s += (double)(av.w * bv.w);
+			}
 		}
 	}
-	// gather the 4 (j, s) pairs on lane 0 and replay in ascending j
+	// gather the K (j, s) pairs of a row on its first lane and replay in ascending j
 	int js[TOPK];
 	double ss[TOPK];
+	const int base = lane - t0;
 #pragma unroll
-	for (int t = 0; t < TOPK; t++) { js[t] = __shfl(j, t, 64); ss[t] = __shfl(s, t, 64); }
-	if (lane == 0) {
+	for (int t = 0; t < TOPK; t++) { js[t] = __shfl(j, (base + t) & 63, 64); ss[t] = __shfl(s, (base + t) & 63, 64); }
+	if (ok && t0 == 0) {
 #pragma unroll
 		for (int a = 1; a < TOPK; a++)
 #pragma unroll
@@ -407,19 +608,23 @@ int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const f
 	// at most kMaxSplits - 1 workgroups per row block (plus the one that straddles its start)
 	const int rb = (nrows + BM - 1) / BM, ntiles = (m + BN - 1) / BN;
 	const long long total = (long long)rb * ntiles;
-	const int nwg = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(2 * 256, total), (long long)(kMaxSplits - 1) * rb));
+	const bool v2 = S3D_MATCH_V2 && g.small_offsets;
+	const int per_cu = v2 ? S3D_MATCH_V2_OCC : 2;
+	const int nwg = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(per_cu * 256, total), (long long)(kMaxSplits - 1) * rb));
 	// workgroups that can touch one row block: those starting inside it plus the one running into it
 	const int slots = std::min(kMaxSplits, (int)(((long long)ntiles * nwg + total - 1) / total) + 1);
 	(void)hipMemsetAsync(d_part, 0xFF, sizeof(Cand) * (size_t)TOPK * slots * nrows, st);  // j = -1: empty
 	// (the DMA form addresses A and B with 32-bit byte offsets; row_ids index the caller's whole A, whose size is not known here:
 	// the caller says whether both matrices stay below 4 GB)
-	if (g.small_offsets)
+	if (v2)
+		hipLaunchKernelGGL(k_scores_topk2, dim3(nwg), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, slots, (Cand *)d_part);
+	else if (g.small_offsets)
 		hipLaunchKernelGGL(k_scores_top4<true>, dim3(nwg), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, slots, (Cand *)d_part);
 	else
 		hipLaunchKernelGGL(k_scores_top4<false>, dim3(nwg), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, slots, (Cand *)d_part);
-	hipLaunchKernelGGL(k_merge_top4, dim3((nrows + 255) / 256), dim3(256), 0, st, (const Cand *)d_part, nrows, slots, d_cand, g.s4);
+	hipLaunchKernelGGL(k_merge_top4, dim3((nrows + 31) / 32), dim3(256), 0, st, (const Cand *)d_part, nrows, slots, d_cand, g.s4);
 	(void)hipMemsetAsync(g.redo, 0, sizeof(int), st);
-	hipLaunchKernelGGL(k_rescore, dim3((nrows + 3) / 4), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, d_cand, d_gd, d_sd, d_gi, d_si,
+	hipLaunchKernelGGL(k_rescore, dim3((nrows + 4 * kRowsPerWave - 1) / (4 * kRowsPerWave)), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, d_cand, d_gd, d_sd, d_gi, d_si,
 	                   g.s4, g.a_n2, g.b_n2max, g.redo);
 	hipLaunchKernelGGL(k_exact_rows, dim3(std::min(nrows, 1024)), dim3(256), 0, st, d_a, d_row_ids, d_b, m, g.redo, d_gd, d_sd, d_gi, d_si);
 	return SIFT3D_OK;
@@ -573,8 +778,8 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 
 		MCHK(hipEventRecord(S.e0, st));
 		MCHK(hipMemsetAsync(d_nmax, 0, 2 * sizeof(unsigned), st));
-		if (n) hipLaunchKernelGGL(k_row_norm2, dim3((n + 3) / 4), dim3(256), 0, st, d_a, n, d_an2, d_nmax);
-		if (m) hipLaunchKernelGGL(k_row_norm2, dim3((m + 3) / 4), dim3(256), 0, st, d_b, m, d_bn2, d_nmax + 1);
+		if (n) hipLaunchKernelGGL(k_row_norm2, dim3((n + 15) / 16), dim3(256), 0, st, d_a, n, d_an2, d_nmax);
+		if (m) hipLaunchKernelGGL(k_row_norm2, dim3((m + 15) / 16), dim3(256), 0, st, d_b, m, d_bn2, d_nmax + 1);
 		// matrices of 4 GB and more take the register-staged form (SIFT3D_HOOK_MATCH_NODMA forces it on any size, for the tests)
 		const bool small = !hook(SIFT3D_HOOK_MATCH_NODMA) && (size_t)std::max(n, m) * KD * sizeof(float) < ((size_t)1 << 32);
 		const MatchGuard g_fwd{d_s4, d_an2, d_nmax + 1, d_redo, small}, g_rev{d_s4, d_bn2, d_nmax, d_redo, small};
