@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "sift3d_internal.h"
 
@@ -268,143 +269,155 @@ __global__ void __launch_bounds__(256, 2) k_scores_top4(const float *__restrict_
 // ---- r03: the score kernel, second form (S3D_MATCH_V2; the DMA form above stays for A/B builds, the register-staged one for >= 4 GB) ----
 // What is different:
 //   * A never touches the LDS.  A wave's 32 rows are read by nobody else: lane (li, lh) loads the 16 floats k0 + 16 lh .. + 15 of
-//     its row straight into registers, one chunk ahead (two lanes use one 128-byte line completely).  Only the B chunks travel by
-//     LDS-DMA: 32 KB instead of 73 KB of LDS per workgroup -> THREE workgroups per CU (three waves per SIMD hide the barrier and
-//     fragment-read stalls of each other), half the LDS-DMA traffic.
-//   * the selection does not run the insert in lock step.  Each lane compares its 32 scores of a half band with its list's last
+//     its row straight into registers (two lanes use one 128-byte line completely).  Piece q of the NEXT chunk is requested into
+//     the same four registers right behind the sixteen MFMAs that consumed it, by an untracked load; each MFMA group waits for its
+//     piece with a COUNTED s_waitcnt (vmcnt retires in order; the eight younger operations -- three A pieces, the four DMA
+//     instructions of the chunk, one refreshed piece -- stay in flight).  Only the B chunks travel by LDS-DMA: 33 KB instead of
+//     73 KB of LDS per workgroup -> THREE workgroups per CU, half the LDS-DMA traffic.
+//   * every chunk issues exactly four DMA instructions: the last chunk of a tile requests the first chunk of the NEXT tile into the
+//     free stage, so it lands during the selection and a tile costs one barrier more than its 24 chunks.
+//   * the selection does not run the insert in lock step.  Each lane compares its 16 scores of a quarter band with its list's last
 //     entry and keeps a bit mask; only the marked scores are re-read and inserted (bubble), so a wave iterates max-over-lanes
-//     popcount times instead of once per column in which ANY lane has a candidate (three out of four before).
-//   * the score band of a wave is dumped in two halves of 64 columns (33 KB per workgroup, aliasing the B buffers).
-// Lists are per (row, lane half): lane (li, lh) scans the columns 32 lh .. 32 lh + 31 of each 64-column half band, in ascending
-// column order over the tiles, with the reference's strict '>' rule; the halves are merged at the end (order independent).
+//     popcount times instead of once per column in which ANY lane has a candidate (three out of four before).  The score band of a
+//     wave is dumped one 32-column block at a time into the stage the prefetch does not use.
+//   * the work is dealt in HALF tiles (128 rows x 64 columns): 7 921 tiles over 768 resident workgroups are 10.3 each and the
+//     launch lasts 11 (+ 6.7 %); 15 842 halves are 20.6 each (21: + 1.8 %).  A share's first / last tile may be an upper / lower
+//     half: the same code with two of the four accumulators.
+// Lists are per (row, lane half): lane (li, lh) scans the columns 16 lh .. 16 lh + 15 of each 32-column block, in ascending column
+// order over the tiles, with the reference's strict '>' rule; the halves are merged at the end (order independent).
 #ifndef S3D_MATCH_V2
 #define S3D_MATCH_V2 1
 #endif
 #ifndef S3D_MATCH_V2_OCC
 #define S3D_MATCH_V2_OCC 3
 #endif
-constexpr int SP2 = 65;  // pitch of a half band (row per lane: conflict-free scans)
+constexpr int SP2 = 33;  // pitch of a 32-column score block
 // development diagnostics, timing only (wrong results by construction; never set in the product build): 1 no selection, 2 no B DMA,
 // 4 no A refresh loads, 8 no barriers inside the chunk loop
 #ifndef S3D_XDIAG
 #define S3D_XDIAG 0
 #endif
+template <int N>
+__device__ __forceinline__ void x_wait_piece(f32x4 &piece) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(piece) : "n"(N) : "memory"); }
+
 __global__ void __launch_bounds__(256, S3D_MATCH_V2_OCC) k_scores_topk2(const float *__restrict__ A, const int *__restrict__ row_ids, int nrows,
                                                                       const float *__restrict__ B, int m, int slots,
                                                                       Cand *__restrict__ part /*[nrows][slots][TOPK]*/) {
-	constexpr int kStage = BN * BK;  // floats per B stage
-	constexpr int kSm = 2 * kStage > 4 * 32 * SP2 ? 2 * kStage : 4 * 32 * SP2;
-	__shared__ __attribute__((aligned(1024))) float smem[kSm];
+	constexpr int kStage = BN * BK;  // floats per B stage; stage 1 is followed by the tail of the score blocks (4 waves x 32 x 33 floats)
+	__shared__ __attribute__((aligned(1024))) float smem[kStage + 4 * 32 * SP2];
 	const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int li = lane & 31, lh = lane >> 5;
-	const int ntiles = (m + BN - 1) / BN;
-	const long long total = (long long)((nrows + BM - 1) / BM) * ntiles;
+	const int ntiles = (m + BN - 1) / BN, nunits = 2 * ntiles;  // units: half tiles
+	const long long total = (long long)((nrows + BM - 1) / BM) * nunits;
 	const long long L0 = (long long)blockIdx.x * total / gridDim.x, L1 = (long long)(blockIdx.x + 1) * total / gridDim.x;
 	const int srow = tid >> 3;
 	const unsigned swz = (unsigned)((tid & 7) ^ ((srow >> 1) & 7)) * 16u;
 	const unsigned lds_b = (unsigned)(unsigned long long)&smem[0];
 	const unsigned slab = (unsigned)wid * (8u * 32u * 4u);
 	const unsigned fswz = (unsigned)((li >> 1) & 7);
+	constexpr int NCH = KD / BK;
 	for (long long L = L0; L < L1;) {
-		const int rbi = (int)(L / ntiles);
-		const int tile_lo = (int)(L - (long long)rbi * ntiles), tile_hi = (int)min((long long)ntiles, tile_lo + (L1 - L));
-		L += tile_hi - tile_lo;
-		const long long X = (long long)rbi * ntiles;
+		const int rbi = (int)(L / nunits);
+		const int u_lo = (int)(L - (long long)rbi * nunits), u_hi = (int)min((long long)nunits, u_lo + (L1 - L));
+		L += u_hi - u_lo;
+		const int tile_lo = u_lo >> 1, tile_hi = (u_hi + 1) >> 1;
+		// index of this workgroup among those that cover row block rbi: the first one is the largest w with L0(w) <= rbi * nunits
+		const long long X = (long long)rbi * nunits;
 		const int wfirst = (int)(((X + 1) * gridDim.x + total - 1) / total) - 1;
 		const int slot = (int)blockIdx.x - wfirst;
 		const int row0 = rbi * BM;
 		const int my_row = row0 + wid * 32 + li;
 		const bool my_row_ok = my_row < nrows;
 		const int arow_id = my_row_ok ? (row_ids ? row_ids[my_row] : my_row) : (row_ids ? row_ids[0] : 0);
-		const float *arow = A + (size_t)arow_id * KD + 16 * lh;
 		const unsigned arow_off = (unsigned)arow_id * (unsigned)(KD * 4) + (unsigned)(64 * lh);  // byte offset (both matrices < 4 GB)
 		float bs[TOPK];
 		int bj[TOPK];
 #pragma unroll
 		for (int t = 0; t < TOPK; t++) { bs[t] = -FLT_MAX; bj[t] = -1; }
 
-		for (int tile = tile_lo; tile < tile_hi; tile++) {
-			const int col0 = tile * BN;
-			unsigned boff[4];
+		auto dma = [&](int buf, int col0, int k0) {  // chunk k0 .. k0 + 31 of the 128 B rows from col0 on -> stage buf (always four instructions)
 #pragma unroll
 			for (int p = 0; p < 4; p++) {
 				const int c = col0 + srow + 32 * p;
-				boff[p] = (unsigned)(c < m ? c : 0) * (unsigned)(KD * 4) + swz;
+				const unsigned off = (unsigned)(c < m ? c : 0) * (unsigned)(KD * 4) + swz + (unsigned)(k0 * 4);
+				if (!(S3D_XDIAG & 2)) x_dma16(B, off, lds_b + (unsigned)(buf * kStage * 4) + (unsigned)(p * 32 * 32 * 4) + slab);
 			}
-			auto dma = [&](int buf, int k0) {
+		};
+		f32x4 a[4];
+		__syncthreads();  // every wave is done with the score blocks of the previous share (they alias stage 1)
+		dma(0, tile_lo * BN, 0);
 #pragma unroll
-				for (int p = 0; p < 4; p++)
-					if (!(S3D_XDIAG & 2)) x_dma16(B, boff[p] + (unsigned)(k0 * 4), lds_b + (unsigned)(buf * kStage * 4) + (unsigned)(p * 32 * 32 * 4) + slab);
-			};
+		for (int q = 0; q < 4; q++) a[q] = *reinterpret_cast<const f32x4 *>(A + (size_t)arow_id * KD + 16 * lh + 4 * q);
+		asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
+
+		// one tile: NB0 .. NB1 - 1 are the 32-column blocks this share owns of it
+		auto tile_body = [&](int tile, auto nb0_c, auto nb1_c) {
+			constexpr int NB0 = decltype(nb0_c)::value, NB1 = decltype(nb1_c)::value;
+			const int col0 = tile * BN;
 			f32x16 acc[4];
 #pragma unroll
-			for (int nb = 0; nb < 4; nb++)
+			for (int nb = NB0; nb < NB1; nb++)
 #pragma unroll
 				for (int r = 0; r < 16; r++) acc[nb][r] = 0.0f;
-			// A fragments: a[q] = floats k0 + 16 lh + 4 q .. + 3 of this lane's row.  Piece q of the NEXT chunk is requested into the
-			// same registers right behind the sixteen MFMAs that consumed it (an untracked load: the compiler would wait for it -- and for
-			// the DMA issued before it -- at the top of the next iteration; the wait is the counted one in front of the barrier)
-			f32x4 a[4];
-			constexpr int NCH = KD / BK;
-			__syncthreads();  // every wave is done with the score band of the previous tile (it aliases the B stages)
-			dma(0, 0);
-#pragma unroll
-			for (int q = 0; q < 4; q++) a[q] = *reinterpret_cast<const f32x4 *>(arow + 4 * q);
-			asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
-			__syncthreads();
+			__syncthreads();  // chunk 0 has landed in stage 0 (every wave waited for its DMA); the score blocks are free
 #pragma unroll 1
 			for (int ch = 0; ch < NCH; ch++) {
 				const int buf = ch & 1;
 				const bool more = ch + 1 < NCH;
-				if (more) dma(buf ^ 1, (ch + 1) * BK);
+				// next chunk of this tile, or the first chunk of the next tile (the last tile of the share: its own, never read)
+				dma(buf ^ 1, more ? col0 : (tile + 1 < tile_hi ? col0 + BN : col0), more ? (ch + 1) * BK : 0);
 				const float *br = smem + buf * kStage + li * 32;
-				const unsigned anext = arow_off + (more ? (unsigned)((ch + 1) * BK * 4) : 0u);  // (the last chunk re-requests chunk 0: no branch; waited for below)
+				const unsigned anext = arow_off + (more ? (unsigned)((ch + 1) * BK * 4) : 0u);  // (the last chunk re-requests chunk 0: the next tile's)
 				f32x4 bq[2][4];
 #pragma unroll
-				for (int nb = 0; nb < 4; nb++) bq[0][nb] = *reinterpret_cast<const f32x4 *>(br + nb * 32 * 32 + (int)((((unsigned)lh << 2) ^ fswz) * 4u));
+				for (int nb = NB0; nb < NB1; nb++) bq[0][nb] = *reinterpret_cast<const f32x4 *>(br + nb * 32 * 32 + (int)((((unsigned)lh << 2) ^ fswz) * 4u));
 #pragma unroll
 				for (int q = 0; q < 4; q++) {
 					if (q < 3) {  // the fragments of the next group are in flight during this group's MFMAs
 						const int po = (int)((((unsigned)lh << 2 | (unsigned)(q + 1)) ^ fswz) * 4u);
 #pragma unroll
-						for (int nb = 0; nb < 4; nb++) bq[(q + 1) & 1][nb] = *reinterpret_cast<const f32x4 *>(br + nb * 32 * 32 + po);
-						__builtin_amdgcn_sched_barrier(0);  // (hipcc sinks these reads behind the 15th MFMA of the group otherwise)
+						for (int nb = NB0; nb < NB1; nb++) bq[(q + 1) & 1][nb] = *reinterpret_cast<const f32x4 *>(br + nb * 32 * 32 + po);
+						__builtin_amdgcn_sched_barrier(0);  // (hipcc sinks these reads behind the last MFMAs of the group otherwise)
+					}
+					// in flight behind piece q: the other three pieces (or their refreshes) and the four DMA instructions of this chunk
+					if (!(S3D_XDIAG & 4)) {
+						if (q == 0) x_wait_piece<7>(a[0]);
+						else x_wait_piece<7>(a[q]);
 					}
 #pragma unroll
 					for (int e = 0; e < 4; e++)
 #pragma unroll
-						for (int nb = 0; nb < 4; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], bq[q & 1][nb][e], acc[nb], 0, 0, 0);
+						for (int nb = NB0; nb < NB1; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], bq[q & 1][nb][e], acc[nb], 0, 0, 0);
 					if (!(S3D_XDIAG & 4)) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(a[q]) : "v"(anext + (unsigned)(q * 16)), "s"(A) : "memory");
 				}
-				asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
-				if (!(S3D_XDIAG & 8) || !more) __syncthreads();  // (after the last chunk: all waves finished reading the B stages, the score band may overwrite them)
+				// the four DMA instructions are the oldest of the eight operations in flight
+				asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+				if (!(S3D_XDIAG & 8) || !more) __syncthreads();  // (after the last chunk: stage 1 is free for the score blocks)
 			}
-			float *S = smem + wid * 32 * SP2;
 			if (S3D_XDIAG & 1) {  // keep the accumulators alive
 				float sum = 0.f;
 #pragma unroll
-				for (int nb = 0; nb < 4; nb++)
+				for (int nb = NB0; nb < NB1; nb++)
 #pragma unroll
 					for (int r = 0; r < 16; r++) sum += acc[nb][r];
 				if (sum == 12345.678f) bs[0] = sum;
 			}
+			float *S = smem + kStage + wid * 32 * SP2;
 #pragma unroll
-			for (int h = 0; h < ((S3D_XDIAG & 1) ? 0 : 2); h++) {
+			for (int nb = (S3D_XDIAG & 1) ? NB1 : NB0; nb < NB1; nb++) {
 #pragma unroll
-				for (int nn = 0; nn < 2; nn++)
-#pragma unroll
-					for (int r = 0; r < 16; r++) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * SP2 + nn * 32 + li] = acc[2 * h + nn][r];
+				for (int r = 0; r < 16; r++) S[((r & 3) + 8 * (r >> 2) + 4 * lh) * SP2 + li] = acc[nb][r];
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-				const float *sp = S + li * SP2 + 32 * lh;
-				const int cbase = col0 + 64 * h + 32 * lh;
-				const int ncol = my_row_ok ? max(0, min(32, m - cbase)) : 0;
+				const float *sp = S + li * SP2 + 16 * lh;
+				const int cbase = col0 + 32 * nb + 16 * lh;
+				const int ncol = my_row_ok ? max(0, min(16, m - cbase)) : 0;
 				const float thr = bs[TOPK - 1];  // -FLT_MAX while the list is short: every finite score passes
 				unsigned mask = 0;
 #pragma unroll
-				for (int jj = 0; jj < 32; jj++) mask |= (sp[jj] > thr ? 1u : 0u) << jj;
-				if (ncol < 32) mask &= (1u << ncol) - 1u;
+				for (int jj = 0; jj < 16; jj++) mask |= (sp[jj] > thr ? 1u : 0u) << jj;
+				mask &= (1u << ncol) - 1u;
 				while (__any(mask != 0)) {
 					if (mask) {
 						const int jj = __builtin_ctz(mask);
@@ -414,10 +427,18 @@ __global__ void __launch_bounds__(256, S3D_MATCH_V2_OCC) k_scores_topk2(const fl
 					}
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();  // the band is rewritten by the next half
+				__builtin_amdgcn_wave_barrier();  // the block is rewritten by the next one
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			}
+		};
+		using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+		for (int tile = tile_lo; tile < tile_hi; tile++) {
+			const bool from_half = 2 * tile < u_lo, to_half = 2 * tile + 2 > u_hi;  // (never both: a share of one half tile has u_hi = u_lo + 1)
+			if (from_half) tile_body(tile, I2{}, I4{});
+			else if (to_half) tile_body(tile, I0{}, I2{});
+			else tile_body(tile, I0{}, I4{});
 		}
+		asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");  // the last refreshes and the idle prefetch
 #pragma unroll
 		for (int t = 0; t < TOPK; t++) {
 			const float os = __shfl(bs[t], li + 32, 64);
@@ -436,16 +457,26 @@ __global__ void __launch_bounds__(256, S3D_MATCH_V2_OCC) k_scores_topk2(const fl
 // slots s and s + 8, then three butterfly rounds join the eight lists (r03: one thread per row walked up to 16 x K entries one
 // after the other, 50-70 us per pass).  The order (score desc, column asc) does not depend on the order of the inserts.
 __global__ void __launch_bounds__(256) k_merge_top4(const Cand *__restrict__ part, int nrows, int splits, int *__restrict__ cand,
-                                                    float *__restrict__ s4 /* K-th fp32 score of the row, -FLT_MAX if the list is short */) {
+                                                    float *__restrict__ s4 /* K-th fp32 score of the row, -FLT_MAX if the list is short */,
+                                                    int nunits, int nwg, int *__restrict__ redo_count) {
 	const int gid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+	if (gid == 0) *redo_count = 0;  // (k_rescore, the next launch, counts the rows that fail the guard)
 	const int r = gid >> 3, sub = gid & 7;
 	const bool ok = r < nrows;
+	// slots the score kernel wrote for this row's block: one per workgroup whose share [L0, L1) of the nunits units per row block
+	// meets the block (the same arithmetic as in the score kernels), so the partial lists need no initialisation
+	int used = 0;
+	if (ok) {
+		const long long total = (long long)((nrows + BM - 1) / BM) * nunits, X = (long long)(r / BM) * nunits, Y = X + nunits;
+		const int wfirst = (int)(((X + 1) * nwg + total - 1) / total) - 1, wlast = (int)((Y * nwg + total - 1) / total) - 1;
+		used = min(splits, wlast - wfirst + 1);
+	}
 	float bs[TOPK];
 	int bj[TOPK];
 #pragma unroll
 	for (int t = 0; t < TOPK; t++) { bs[t] = -FLT_MAX; bj[t] = -1; }
 	if (ok)
-		for (int s = sub; s < splits; s += 8)
+		for (int s = sub; s < used; s += 8)
 #pragma unroll
 			for (int t = 0; t < TOPK; t++) {
 				const Cand c = part[((size_t)r * splits + s) * TOPK + t];
@@ -468,59 +499,92 @@ __global__ void __launch_bounds__(256) k_merge_top4(const Cand *__restrict__ par
 	}
 }
 
-// squared norms of the rows of X (one wave per row, four rows per wave), and their maximum (bits of a non-negative float): ONE
-// atomic per workgroup (r03: one per row -- 11 000 atomics on one address were 0.13 ms of a pass)
-__global__ void __launch_bounds__(256) k_row_norm2(const float *__restrict__ X, int nrows, float *__restrict__ n2, unsigned *__restrict__ n2max) {
+// squared norms of the rows of both matrices in ONE launch (one wave per row, four rows per wave, 16-byte loads), and their maxima
+// (bits of a non-negative float): one atomic per workgroup (r03: one per row -- 11 000 atomics on one address were 0.13 ms of a pass)
+__global__ void __launch_bounds__(256) k_row_norm2(const float *__restrict__ X0, int n0, float *__restrict__ o0, const float *__restrict__ X1,
+                                                   int n1, float *__restrict__ o1, unsigned *__restrict__ n2max /* [2] */) {
 	__shared__ float s_m[4];
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int nb0 = (n0 + 15) / 16;
+	const bool second = (int)blockIdx.x >= nb0;
+	const float *X = second ? X1 : X0;
+	float *out = second ? o1 : o0;
+	const int nrows = second ? n1 : n0, blk = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
 	float mx = 0.f;
 	for (int i = 0; i < 4; i++) {
-		const int r = (blockIdx.x * 4 + wv) * 4 + i;
+		const int r = (blk * 4 + wv) * 4 + i;
 		if (r >= nrows) break;  // wave-uniform
-		const float *x = X + (size_t)r * KD;
+		const f32x4 *x = reinterpret_cast<const f32x4 *>(X + (size_t)r * KD);
 		float a = 0.f;
-		for (int k = lane; k < KD; k += 64) a = a + x[k] * x[k];
+#pragma unroll
+		for (int k = 0; k < KD / 256; k++) {
+			const f32x4 v = x[k * 64 + lane];
+			a = a + v.x * v.x; a = a + v.y * v.y; a = a + v.z * v.z; a = a + v.w * v.w;
+		}
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) a = a + __shfl_xor(a, o, 64);
 		a = a * 1.0001f;  // fp32 summation error of 768 non-negative terms
-		if (lane == 0 && n2) n2[r] = a;
+		if (lane == 0) out[r] = a;
 		mx = fmaxf(mx, a);
 	}
 	if (lane == 0) s_m[wv] = mx;
 	__syncthreads();
-	if (threadIdx.x == 0 && n2max) {
+	if (threadIdx.x == 0) {
 		const float m4 = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
-		if (m4 > 0.f) atomicMax(n2max, __float_as_uint(m4));
+		if (m4 > 0.f) atomicMax(n2max + (second ? 1 : 0), __float_as_uint(m4));
 	}
 }
 
-// exact re-score + replay of the reference update rule (Src/cMatcher.cc:52-77).  A lane re-scores ONE candidate of one row exactly
-// like the reference (fp32 product, fp64 accumulate, k ascending); a wave holds 64 / K rows (r03: one row per wave left 58 lanes idle
-// and the pass took 0.16 ms), the first lane of a row gathers its K (column, score) pairs and replays them in ascending column order.
-constexpr int kRowsPerWave = 64 / TOPK;
-__global__ void __launch_bounds__(256) k_rescore(const float *__restrict__ A, const int *__restrict__ row_ids, int nrows,
+// exact re-score + replay of the reference update rule (Src/cMatcher.cc:52-77).  A candidate's exact score is the reference's chain
+// s += (double)(a[k] * b[k]), k ascending.  A wave holds 64 / K rows (K candidates each: 60 chains for K = 6) and walks the 768
+// products in pieces of 64: the PRODUCTS are formed cooperatively (sixteen lanes per chain, 16-byte loads along the rows -- a lane
+// per chain reading its own two rows touched 60 cache lines per load instruction and the pass took 0.07 ms, one row per wave as in
+// r02 0.16 ms), parked in the wave's LDS block, and lane c then adds the 128 products of chain c in order.  The first lane of a row
+// gathers its K (column, score) pairs and replays them in ascending column order.
+constexpr int kRowsPerWave = 64 / TOPK, kChains = kRowsPerWave * TOPK, kRsPiece = 64, kRsPitch = kRsPiece + 4, kRsWaves = 2;
+static_assert(kChains % 4 == 0, "k_rescore forms the products of four chains per step");
+__global__ void __launch_bounds__(64 * kRsWaves) k_rescore(const float *__restrict__ A, const int *__restrict__ row_ids, int nrows,
                                                  const float *__restrict__ B, const int *__restrict__ cand, float *__restrict__ gd,
                                                  float *__restrict__ sd, int *__restrict__ gi, int *__restrict__ si,
                                                  const float *__restrict__ s4, const float *__restrict__ a_n2,
                                                  const unsigned *__restrict__ b_n2max, int *__restrict__ redo /* [0] count, then r */) {
-	const int lane = threadIdx.x & 63;
+	__shared__ __attribute__((aligned(16))) float s_prod[kRsWaves][kChains * kRsPitch];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const int rr = lane / TOPK, t0 = lane - rr * TOPK;
-	const int r = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kRowsPerWave + rr;
+	const int r = (blockIdx.x * kRsWaves + wv) * kRowsPerWave + rr;
 	const bool ok = rr < kRowsPerWave && r < nrows;
 	const int row = ok ? (row_ids ? row_ids[r] : r) : 0;
-	int j = -1;
+	const int j = ok ? cand[(size_t)r * TOPK + t0] : -1;
+	float *P = s_prod[wv];
+	const int quarter = lane >> 4, l4 = lane & 15;
 	double s = 0.0;
-	if (ok) {
-		j = cand[(size_t)r * TOPK + t0];
-		if (j >= 0) {
-			const f32x4 *a = reinterpret_cast<const f32x4 *>(A + (size_t)row * KD), *b = reinterpret_cast<const f32x4 *>(B + (size_t)j * KD);
-#pragma unroll 4
-			for (int k = 0; k < KD / 4; k++) {
-				const f32x4 av = a[k], bv = b[k];
-				s += (double)(av.x * bv.x); s += (double)(av.y * bv.y); s += (double)(av.z * bv.z); s += (double)(av.w * bv.w);
+#pragma unroll 1
+	for (int k0 = 0; k0 < KD; k0 += kRsPiece) {
+		// products of chains 4 i + quarter, piece k0 .. k0 + 63: lane l4 takes the four floats 4 l4 .. 4 l4 + 3
+#pragma unroll 5
+		for (int i = 0; i < kChains / 4; i++) {
+			const int c = 4 * i + quarter;
+			const int crow = __shfl(row, c, 64), cj = __shfl(j, c, 64);
+			const f32x4 av = *reinterpret_cast<const f32x4 *>(A + (size_t)crow * KD + k0 + 4 * l4);
+			const f32x4 bv = *reinterpret_cast<const f32x4 *>(B + (size_t)(cj >= 0 ? cj : 0) * KD + k0 + 4 * l4);
+			*reinterpret_cast<f32x4 *>(P + c * kRsPitch + 4 * l4) = f32x4{av.x * bv.x, av.y * bv.y, av.z * bv.z, av.w * bv.w};
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (lane < kChains) {
+			const f32x4 *pc = reinterpret_cast<const f32x4 *>(P + lane * kRsPitch);
+#pragma unroll 8
+			for (int q = 0; q < kRsPiece / 4; q++) {
+				const f32x4 v = pc[q];
+				s += (double)v.x; s += (double)v.y; s += (double)v.z; s += (double)v.w;
 			}
 		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();  // the block is rewritten by the next piece
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	}
+	if (j < 0) s = 0.0;
 	// gather the K (j, s) pairs of a row on its first lane and replay in ascending j
 	int js[TOPK];
 	double ss[TOPK];
@@ -607,13 +671,13 @@ int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const f
 	// as many workgroups as fit ONE residency round (two per CU), each with an equal share of the (row block, column tile) pairs;
 	// at most kMaxSplits - 1 workgroups per row block (plus the one that straddles its start)
 	const int rb = (nrows + BM - 1) / BM, ntiles = (m + BN - 1) / BN;
-	const long long total = (long long)rb * ntiles;
 	const bool v2 = S3D_MATCH_V2 && g.small_offsets;
 	const int per_cu = v2 ? S3D_MATCH_V2_OCC : 2;
+	const int nunits = v2 ? 2 * ntiles : ntiles;  // the second form deals half tiles
+	const long long total = (long long)rb * nunits;
 	const int nwg = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(per_cu * 256, total), (long long)(kMaxSplits - 1) * rb));
 	// workgroups that can touch one row block: those starting inside it plus the one running into it
-	const int slots = std::min(kMaxSplits, (int)(((long long)ntiles * nwg + total - 1) / total) + 1);
-	(void)hipMemsetAsync(d_part, 0xFF, sizeof(Cand) * (size_t)TOPK * slots * nrows, st);  // j = -1: empty
+	const int slots = std::min(kMaxSplits, (int)(((long long)nunits * nwg + total - 1) / total) + 1);
 	// (the DMA form addresses A and B with 32-bit byte offsets; row_ids index the caller's whole A, whose size is not known here:
 	// the caller says whether both matrices stay below 4 GB)
 	if (v2)
@@ -622,9 +686,8 @@ int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const f
 		hipLaunchKernelGGL(k_scores_top4<true>, dim3(nwg), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, slots, (Cand *)d_part);
 	else
 		hipLaunchKernelGGL(k_scores_top4<false>, dim3(nwg), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, m, slots, (Cand *)d_part);
-	hipLaunchKernelGGL(k_merge_top4, dim3((nrows + 31) / 32), dim3(256), 0, st, (const Cand *)d_part, nrows, slots, d_cand, g.s4);
-	(void)hipMemsetAsync(g.redo, 0, sizeof(int), st);
-	hipLaunchKernelGGL(k_rescore, dim3((nrows + 4 * kRowsPerWave - 1) / (4 * kRowsPerWave)), dim3(256), 0, st, d_a, d_row_ids, nrows, d_b, d_cand, d_gd, d_sd, d_gi, d_si,
+	hipLaunchKernelGGL(k_merge_top4, dim3((nrows + 31) / 32), dim3(256), 0, st, (const Cand *)d_part, nrows, slots, d_cand, g.s4, nunits, nwg, g.redo);
+	hipLaunchKernelGGL(k_rescore, dim3((nrows + kRsWaves * kRowsPerWave - 1) / (kRsWaves * kRowsPerWave)), dim3(64 * kRsWaves), 0, st, d_a, d_row_ids, nrows, d_b, d_cand, d_gd, d_sd, d_gi, d_si,
 	                   g.s4, g.a_n2, g.b_n2max, g.redo);
 	hipLaunchKernelGGL(k_exact_rows, dim3(std::min(nrows, 1024)), dim3(256), 0, st, d_a, d_row_ids, d_b, m, g.redo, d_gd, d_sd, d_gi, d_si);
 	return SIFT3D_OK;
@@ -778,8 +841,7 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 
 		MCHK(hipEventRecord(S.e0, st));
 		MCHK(hipMemsetAsync(d_nmax, 0, 2 * sizeof(unsigned), st));
-		if (n) hipLaunchKernelGGL(k_row_norm2, dim3((n + 15) / 16), dim3(256), 0, st, d_a, n, d_an2, d_nmax);
-		if (m) hipLaunchKernelGGL(k_row_norm2, dim3((m + 15) / 16), dim3(256), 0, st, d_b, m, d_bn2, d_nmax + 1);
+		if (n + m > 0) hipLaunchKernelGGL(k_row_norm2, dim3((n + 15) / 16 + (m + 15) / 16), dim3(256), 0, st, d_a, n, d_an2, d_b, m, d_bn2, d_nmax);
 		// matrices of 4 GB and more take the register-staged form (SIFT3D_HOOK_MATCH_NODMA forces it on any size, for the tests)
 		const bool small = !hook(SIFT3D_HOOK_MATCH_NODMA) && (size_t)std::max(n, m) * KD * sizeof(float) < ((size_t)1 << 32);
 		const MatchGuard g_fwd{d_s4, d_an2, d_nmax + 1, d_redo, small}, g_rev{d_s4, d_bn2, d_nmax, d_redo, small};
@@ -789,11 +851,13 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 			match_rows_device(d_a, nullptr, n, d_b, m, d_cand, d_part, d_gd, d_sd, d_gi, d_si, g_fwd, st);
 			MCHK(hipMemcpyAsync(h_gd, d_gd, 4 * 4 * big, hipMemcpyDeviceToHost, st));
 			MCHK(hipMemcpyAsync(h_redo, d_redo, sizeof(int), hipMemcpyDeviceToHost, st));
+			MCHK(hipEventRecord(S.e1, st));  // device time ends with the last device operation of the call (recorded again behind a reverse pass)
 			MCHK(hipStreamSynchronize(st));
 			memcpy(gd.data(), h_gd, sizeof(float) * n); memcpy(sd.data(), h_sd, sizeof(float) * n);
 			memcpy(gi.data(), h_gi, sizeof(int) * n); memcpy(si.data(), h_si, sizeof(int) * n);
 			redo_rows += h_redo[0];
 		} else {
+			MCHK(hipEventRecord(S.e1, st));
 			MCHK(hipStreamSynchronize(st));
 			// no targets: every dot loop is empty -> d = 2 - 2*FLT_MIN, idx -1
 			for (int i = 0; i < n; i++) { gd[i] = sd[i] = (float)(2 - 2 * (double)FLT_MIN); }
@@ -812,6 +876,7 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 				match_rows_device(d_b, d_rows, (int)rows.size(), d_a, n, d_cand, d_part, d_gd, d_sd, d_gi, d_si, g_rev, st);
 				MCHK(hipMemcpyAsync(h_gd, d_gd, 4 * 4 * big, hipMemcpyDeviceToHost, st));
 				MCHK(hipMemcpyAsync(h_redo, d_redo, sizeof(int), hipMemcpyDeviceToHost, st));
+				MCHK(hipEventRecord(S.e1, st));
 				MCHK(hipStreamSynchronize(st));
 				for (int j : rows) { gd2[j] = h_gd[j]; sd2[j] = h_sd[j]; gi2[j] = h_gi[j]; si2[j] = h_si[j]; }
 				redo_rows += h_redo[0];
@@ -823,7 +888,6 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 				if (gi2[j] != i) gi[i] *= -1;
 			}
 		}
-		MCHK(hipEventRecord(S.e1, st));
 		MCHK(hipEventSynchronize(S.e1));
 		float ms = 0;
 		hipEventElapsedTime(&ms, S.e0, S.e1);

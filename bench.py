@@ -461,7 +461,7 @@ def main():
         out["matcher"] = {"workload": f"injectMatch (one full pass) of {na} x {nb} descriptors (two {n}^3 volumes, second shifted 1 voxel)",
                           "seconds": tm, "wall_seconds": min(wall), "enhancedMatch_seconds": min(secs_e), "enhancedMatch_wall_seconds": min(wall_e),
                           "rows_rescored_exactly": int(exact[-1]), "matched_pairs": int(len(r["pairs"])),
-                          "roofline": {"bound": "mfma", "kernel": "k_scores_top4 (A.B^T on v_mfma_f32_32x32x2_f32, fused top-4) + k_merge_top4 + k_rescore",
+                          "roofline": {"bound": "mfma", "kernel": "k_scores_topk2 (A.B^T on v_mfma_f32_32x32x2_f32, fused top-K) + k_row_norm2 + k_merge_top4 + k_rescore + k_exact_rows: device time of the whole pass",
                                        "achieved": flop / tm / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                        "frac": flop / tm / 1e12 / MFMA_F32_PEAK_TF, "traffic": None}}
         if not args.no_cpu:

@@ -19,9 +19,12 @@ for shift in ((0, 0, 0), (1.0, 0, 0)):
 (da, xa, na), (db, xb, nb) = exs[0].device_results(), exs[1].device_results()
 m = capi.muBruteMatcher()
 for mode in ("injectMatch", "enhancedMatch"):
-    for _ in range(3):
+    reps = []
+    for _ in range(5):
         t0 = time.perf_counter()
         r = getattr(m, mode)(da, xa, db, xb, 0.85, on_device=True, n=na, m=nb)
         wall = time.perf_counter() - t0
+        reps.append(round(m.totalTime * 1e3, 2))
+    print(mode, "device ms of every repetition", reps)
     fl = 2.0 * na * nb * 768 * (2 if mode == "enhancedMatch" else 1)
     print(f"{mode}: {na} x {nb} descriptors, device {m.totalTime*1e3:.2f} ms, wall {wall*1e3:.2f} ms, {fl/m.totalTime/1e12:.1f} TFLOP/s fp32, {len(r['pairs'])} pairs")

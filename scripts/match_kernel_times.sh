@@ -15,4 +15,10 @@ for r in csv.DictReader(open(sys.argv[1])):
     if any(k in n for k in ('k_scores','k_merge','k_rescore','k_exact','k_row_norm')):
         print("  %-60s calls %4s  avg %9.1f us  min %9.1f  max %9.1f"%(n.split('(')[0][-60:], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3, float(r['MaxNs'])/1e3))
 PY
+  t=$(find /tmp/p_mk -name "*kernel_trace.csv" | head -1)
+  python3 - "$t" <<'PY'
+import csv,sys
+d=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in csv.DictReader(open(sys.argv[1])) if 'k_scores' in r['Kernel_Name']]
+print("  k_scores launches (us):", " ".join("%.0f"%x for x in d))
+PY
 done
