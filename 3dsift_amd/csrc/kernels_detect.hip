@@ -32,6 +32,16 @@ namespace s3d {
 #ifndef S3D_DET_QUEUE
 #define S3D_DET_QUEUE 640  /* 640: the queue is drained after a batch of 8 ballot words; 128: after every word (1.06 vs 0.99 ms detection) */
 #endif
+// development diagnostics, timing only (wrong results; never set in the product build): 1 no neighbour gathers, 2 nothing is queued
+#ifndef S3D_DETDIAG
+#define S3D_DETDIAG 0
+#endif
+#ifndef S3D_DET_LEAN
+#define S3D_DET_LEAN 1
+#endif
+#ifndef S3D_DET_XPRE
+#define S3D_DET_XPRE 0  /* generic row loop, 1: the two x neighbours are read with the centre values (two more coalesced loads per word) and tested before a voxel is queued -- no gain on the blob volumes (noise makes two voxels out of three x extrema) */
+#endif
 constexpr int kRows = S3D_DET_ROWS;   // rows per block
 constexpr int kThreads = 256;
 
@@ -48,8 +58,7 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
                                                    unsigned *__restrict__ prov, unsigned *__restrict__ prov_count, unsigned prov_cap,
                                                    unsigned *__restrict__ total) {
 	__shared__ unsigned s_cnt[kThreads / 64];
-	__shared__ float s_qv[kThreads / 64][kQueue];
-	__shared__ unsigned short s_qi[kThreads / 64][kQueue];
+	__shared__ uint2 s_q[kThreads / 64][kQueue];  // (value bits, (row within the wave) << 12 | word << 6 | lane bit): one 8-byte LDS write per candidate
 	// [wave][row of the wave][word of the segment]: dynamic, sized by the launcher for min(wpr, 64) words per row -- with the queue it
 	// is what limits the workgroups per CU, and the kernel is bound by memory latency x waves in flight
 	extern __shared__ unsigned long long s_mask_dyn[];
@@ -74,30 +83,46 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	const int nrows = min(kRows, ny - y0);
 	const int swid = __builtin_amdgcn_readfirstlane(wid);
 	const int r_lo = swid * (kRows / 4), r_hi = min(nrows, (swid + 1) * (kRows / 4));
-	float *qv = s_qv[swid];
-	unsigned short *qi = s_qi[swid];
+	uint2 *q = s_q[swid];
 	unsigned long long *mloc = s_mask_dyn + (size_t)swid * (kRows / 4) * segw;
 	for (int i = lane; i < (kRows / 4) * segw; i += 64) mloc[i] = 0ull;
 	const unsigned long long lt = (1ull << lane) - 1ull;
 	const size_t plane0 = sz * (size_t)z + sy * (size_t)y0;
 	int qn = 0;  // wave-uniform
+	const bool lean = S3D_DET_LEAN && (nx & 63) == 0;  // rows of whole ballot words take the lean row loop (below)
 	// evaluate `n` queued candidates starting at entry `first` (n <= 64)
 	auto evaluate = [&](int first, int n, int seg0) {
-		const bool act = lane < n;
-		const int e = first + (act ? lane : 0);
-		const float v = qv[e];
-		const unsigned id = qi[e];                       // (row within the wave) << 12 | word << 6 | lane bit
-		const int rr = (int)(id >> 12), xw = (int)((id >> 6) & 63), bit = (int)(id & 63);
-		const size_t i = plane0 + sy * (size_t)(r_lo + rr) + (size_t)((seg0 + xw) * 64 + bit);
+		if (S3D_DETDIAG & 1) {  // no gathers: the queue entry alone decides (keeps the queue traffic alive)
+			const uint2 qd = q[first + min(lane, n - 1)];
+			if (lane < n && __uint_as_float(qd.x) == 12345.678f) atomicOr(&mloc[0], 1ull);
+			return;
+		}
+		const bool in_q = lane < n;
+		const int e = first + (in_q ? lane : 0);
+		const uint2 qe = q[e];
+		const float v = __uint_as_float(qe.x);
+		const unsigned id = qe.y;                        // (row within the wave) << 12 | word << 6 | lane bit
+		const int rr = (int)((id >> 12) & 15), xw = (int)((id >> 6) & 63), bit = (int)(id & 63);
+		static_assert(kRows / 4 <= 16, "four bits for the row of a wave");
+		// (the lean row loop queues by the peak threshold alone: the first and the last voxel of a row are dropped here)
+		const int xq = (seg0 + xw) * 64 + bit;
+		const bool act = in_q && xq >= 1 && xq <= nx - 2;
+		const size_t i = plane0 + sy * (size_t)(r_lo + rr) + (size_t)xq;
 		// idle lanes read voxel (1, 1) of the plane: candidates only exist on interior planes of volumes with ny, nx >= 3, so all
 		// eight neighbour addresses of that voxel are inside the level
 		const size_t ic = act ? i : sz * (size_t)z + sy + 1;
 		// elided first / last DoG level: formed from the two Gaussian levels like Sub does (block-uniform choice)
 		const float n0 = lazy_prev ? (L.prev0_hi[ic] - L.prev0_lo[ic]) * (-1.0f) : prev[ic];
-		const float n1 = cur[ic - 1], n2 = cur[ic + 1], n3 = cur[ic + sy], n4 = cur[ic - sy], n5 = cur[ic + sz], n6 = cur[ic - sz];
+		// lean row loop: the four in-plane neighbours were tested in registers (bit 16 of the entry: the voxel is a strict MAXIMUM among
+		// them, else a strict minimum); only the neighbours in z and in scale are gathered
+		const bool pre = lean;  // kernel-uniform
+		const bool dmax = (id >> 16) & 1u;
+		float n1 = 0.f, n2 = 0.f, n3 = 0.f, n4 = 0.f;
+		if (!pre) { n1 = cur[ic - 1]; n2 = cur[ic + 1]; n3 = cur[ic + sy]; n4 = cur[ic - sy]; }
+		const float n5 = cur[ic + sz], n6 = cur[ic - sz];
 		if (lazy_g) {  // block-uniform
-			const bool mn7 = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6;
-			const bool mx7 = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6;
+			const bool mn7 = pre ? (!dmax && v < n0 && v < n5 && v < n6) : (v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6);
+			const bool mx7 = pre ? (dmax && v > n0 && v > n5 && v > n6) : (v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6);
 			// one counter increment per wave (a single word takes ~90 atomics per microsecond: one per candidate cost 0.45 ms)
 			const bool park = act && (mn7 || mx7);
 			const unsigned long long pm = __ballot(park);
@@ -114,36 +139,105 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 			return;
 		}
 		const float n7 = lazy_next ? (L.nextl_hi[ic] - L.nextl_lo[ic]) * (-1.0f) : next[ic];
-		const bool mn = v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 && v < n7;
-		const bool mx = v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 && v > n7;
+		const bool mn = pre ? (!dmax && v < n0 && v < n5 && v < n6 && v < n7) : (v < n0 && v < n1 && v < n2 && v < n3 && v < n4 && v < n5 && v < n6 && v < n7);
+		const bool mx = pre ? (dmax && v > n0 && v > n5 && v > n6 && v > n7) : (v > n0 && v > n1 && v > n2 && v > n3 && v > n4 && v > n5 && v > n6 && v > n7);
 		if (act && (mn || mx)) atomicOr(&mloc[rr * segw + xw], 1ull << bit);
 	};
 	unsigned cnt = 0;
 	// rows wider than 64 ballot words (nx > 4096) are handled in segments of 64 words: the local mask copy holds one segment
 	for (int seg0 = 0; seg0 < wpr; seg0 += 64) {
 		const int seg1 = min(wpr, seg0 + 64);
-		for (int ry = r_lo; ry < r_hi; ry++) {
+		// r03 -- the lean row loop (rows of whole ballot words).  Timing-only builds showed the kernel bound by INSTRUCTION ISSUE, not by
+		// memory: with nothing queued and no gather it still took 0.48 of its 0.52 ms at 512^3, ~25 vector + ~26 scalar instructions per
+		// 64 voxels (per-lane border predicates, clamped 64-bit addresses, two threshold compares, queue bookkeeping).  Here a word
+		// costs three loads (uniform row pointer + lane offset + immediate: the row below, and the row itself shifted by one voxel
+		// either way -- L1 hits), seven vector instructions for the tests, the push (two mbcnt, one address, one 8-byte LDS write) and a
+		// few scalar ones; border rows / planes are skipped as a whole, the x borders are dropped by evaluate().
+		// The FOUR IN-PLANE NEIGHBOURS are tested here, in registers: a wave walks its rows top down and keeps the rows above and
+		// below (8 + 2 rows read for 8).  With the threshold alone 10 % of the voxels of the blob volumes were queued and their eight
+		// gathers (64 different cache lines per instruction) cost 0.19 of the remaining 0.48 ms; now two candidates out of five
+		// survive (noise: a voxel is an extremum of five with probability 2/5) and four neighbours are left to gather.
+		if (lean && z_in) {
+			// rows of this wave with 1 <= y <= ny-2 (a contiguous range; the rows above and below it exist)
+			const int ry_a = max(r_lo, 1 - y0), ry_b = min(r_hi, ny - 1 - y0);
+			const int nws = seg1 - seg0;
+			const float *__restrict__ pl = cur + sz * (size_t)z + (size_t)seg0 * 64;
+			// one word: v against the peak threshold and against its four in-plane neighbours (up / down rows, left / right voxels)
+			auto word = [&](float v, float u, float d, float xl, float xr, int wseg, unsigned idrow) {
+				const float hi = fmaxf(fmaxf(u, d), fmaxf(xl, xr)), lo = fminf(fminf(u, d), fminf(xl, xr));
+				const bool gmax = v > hi;
+				const bool c = fabsf(v) > thr && (gmax || v < lo) && !((S3D_DETDIAG & 2) && v != 12345.678f);  // |v| > thr == (v > thr || v < -thr)
+				const unsigned long long m = __ballot(c);
+				if (c) {
+					const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)qn));
+					q[pos] = make_uint2(__float_as_uint(v), idrow | (gmax ? 0x10000u : 0u) | (unsigned)(wseg << 6) | (unsigned)lane);
+				}
+				qn += (int)__popcll(m);
+			};
+			int w0 = 0;
+			for (; w0 + kBatch <= nws && ry_a < ry_b; w0 += kBatch) {
+				float up[kBatch], mid[kBatch];
+				{
+					const float *ra = pl + sy * (size_t)(y0 + ry_a - 1), *rb = ra + sy;
+#pragma unroll
+					for (int bb = 0; bb < kBatch; bb++) { up[bb] = ra[(unsigned)((w0 + bb) * 64 + lane)]; mid[bb] = rb[(unsigned)((w0 + bb) * 64 + lane)]; }
+				}
+				for (int ry = ry_a; ry < ry_b; ry++) {
+					const float *rm = pl + sy * (size_t)(y0 + ry), *rd = rm + sy;
+					float dn[kBatch], xl[kBatch], xr[kBatch];
+#pragma unroll
+					for (int bb = 0; bb < kBatch; bb++) {
+						const unsigned o = (unsigned)((w0 + bb) * 64 + lane);
+						dn[bb] = rd[o];
+						// (x - 1 of the row's first voxel / x + 1 of its last: the neighbouring rows' ends, in bounds, and evaluate() drops both voxels)
+						xl[bb] = (rm - 1)[o]; xr[bb] = (rm + 1)[o];
+					}
+					const unsigned idrow = (unsigned)((ry - r_lo) << 12);
+#pragma unroll
+					for (int bb = 0; bb < kBatch; bb++) word(mid[bb], up[bb], dn[bb], xl[bb], xr[bb], w0 + bb, idrow);
+					while (qn >= 64) {  // entries are consumed from the END so the front stays in place
+						qn -= 64;
+						evaluate(qn, 64, seg0);
+					}
+#pragma unroll
+					for (int bb = 0; bb < kBatch; bb++) { up[bb] = mid[bb]; mid[bb] = dn[bb]; }
+				}
+			}
+			for (; w0 < nws; w0++)  // rows whose word count is not a multiple of the batch
+				for (int ry = ry_a; ry < ry_b; ry++) {
+					const float *rm = pl + sy * (size_t)(y0 + ry);
+					const unsigned o = (unsigned)(w0 * 64 + lane);
+					word(rm[o], (rm - sy)[o], (rm + sy)[o], (rm - 1)[o], (rm + 1)[o], w0, (unsigned)((ry - r_lo) << 12));
+					if (qn >= 64) { qn -= 64; evaluate(qn, 64, seg0); }
+				}
+		}
+		for (int ry = r_lo; !lean && ry < r_hi; ry++) {
 			const int y = y0 + ry;
 			const bool y_in = z_in && y >= 1 && y <= ny - 2;
 			const size_t rowbase = sy * (size_t)y + sz * (size_t)z;
 			for (int xw0 = seg0; xw0 < seg1; xw0 += kBatch) {
-				float val[kBatch];
+				float val[kBatch], vxm[kBatch], vxp[kBatch];
 				bool in[kBatch];
 #pragma unroll
 				for (int bb = 0; bb < kBatch; bb++) {
 					const int x = (xw0 + bb) * 64 + lane;
 					in[bb] = y_in && xw0 + bb < seg1 && x >= 1 && x <= nx - 2;
-					val[bb] = cur[in[bb] ? rowbase + (size_t)x : sz * (size_t)z];  // unconditional load, clamped address
+					const float *a = cur + (in[bb] ? rowbase + (size_t)x : sz * (size_t)z + 1);  // unconditional loads, clamped address
+					val[bb] = a[0];
+					if (S3D_DET_XPRE) { vxm[bb] = a[-1]; vxp[bb] = a[1]; }
 				}
 #pragma unroll
 				for (int bb = 0; bb < kBatch; bb++) {
 					const float v = val[bb];
-					const bool c = in[bb] && (v > thr || v < -thr);
+					// r03: the gathers of the queued voxels (8 x 64 different cache lines per 64 candidates, 10 % of the voxels of the blob
+					// volumes pass the peak threshold) kept the texture addresser busy for the whole kernel (TA_BUSY = kernel time, 438 M cache
+					// accesses per 512^3); a voxel that is not a strict extremum among its two x neighbours cannot pass the full test
+					const bool xext = !S3D_DET_XPRE || (((int)(v > vxm[bb]) & (int)(v > vxp[bb])) | ((int)(v < vxm[bb]) & (int)(v < vxp[bb]))) != 0;
+					const bool c = in[bb] && (v > thr || v < -thr) && xext && !((S3D_DETDIAG & 2) && v != 12345.678f);
 					const unsigned long long m = __ballot(c);
 					if (c) {
 						const int pos = qn + (int)__popcll(m & lt);
-						qv[pos] = v;
-						qi[pos] = (unsigned short)(((ry - r_lo) << 12) | ((xw0 + bb - seg0) << 6) | lane);
+						q[pos] = make_uint2(__float_as_uint(v), (unsigned)(((ry - r_lo) << 12) | ((xw0 + bb - seg0) << 6) | lane));
 					}
 					qn += (int)__popcll(m);
 					if (kQueue < 63 + kBatch * 64 && qn >= 64) {  // small queue: drain after every word

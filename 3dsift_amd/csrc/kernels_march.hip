@@ -130,6 +130,9 @@ __device__ __forceinline__ float m_absmax(float m, float v) {
 #ifndef S3D_MARCH_YG
 #define S3D_MARCH_YG 4  /* y-blur rows requested per group (6 spills at hw 8 under the 128-register budget) */
 #endif
+#ifndef S3D_MARCH_YPRE
+#define S3D_MARCH_YPRE 1  /* 1: the first group of y-blur rows is requested in front of the x-blur (their latency hides behind its arithmetic) */
+#endif
 #ifndef S3D_MARCH_CR_MAXHW
 #define S3D_MARCH_CR_MAXHW 5  /* DoG centre ring in LDS up to this half width (three workgroups per CU still fit); wider levels re-read the centre plane */
 #endif
@@ -302,6 +305,15 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 		}
 		if (j + 1 < nsteps) issue_dma(j + 1);
 
+		constexpr int KG = S3D_MARCH_YG, NTAP = 2 * HW + 1;
+		constexpr bool YPRE = S3D_MARCH_YPRE && HW <= 6;
+		mf4 ypre[KG];
+		if (YPRE) {  // (step 0 reads rows nobody has written: never used)
+			const float *yc0 = xb + (buf ^ 1) * C::XB_F + ycol;
+#pragma unroll
+			for (int i = 0; i < KG; i++) ypre[i] = *reinterpret_cast<const mf4 *>(yc0 + (i < NTAP ? 2 * HW - i : 0) * C::XP);
+			__builtin_amdgcn_sched_barrier(0);
+		}
 		// ---------------- x-blur of feed j: tile[buf] -> xb[buf] ----------------
 		if (j < nsteps) {
 			const int role = S3D_MARCH_ROT ? ((wid + j) & 3) : wid;  // wave-uniform
@@ -381,10 +393,9 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 			{
 				// step s = d + HW reads row ty + 2*HW - s; rows are requested a group ahead of their use (hipcc keeps only two reads
 				// in flight on its own and exposes the LDS latency nine times per plane)
-				constexpr int KG = S3D_MARCH_YG, NTAP = 2 * HW + 1;
 				mf4 cur[KG], nxt[KG];
 #pragma unroll
-				for (int i = 0; i < KG; i++) cur[i] = *reinterpret_cast<const mf4 *>(yc + (i < NTAP ? 2 * HW - i : 0) * C::XP);
+				for (int i = 0; i < KG; i++) cur[i] = YPRE ? ypre[i] : *reinterpret_cast<const mf4 *>(yc + (i < NTAP ? 2 * HW - i : 0) * C::XP);
 #pragma unroll
 				for (int g0 = 0; g0 < NTAP; g0 += KG) {
 #pragma unroll

@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256, S3D_MATCH_V2_OCC) k_scores_topk2(const fl
 					for (int e = 0; e < 4; e++)
 #pragma unroll
 						for (int nb = NB0; nb < NB1; nb++) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], bq[q & 1][nb][e], acc[nb], 0, 0, 0);
-					if (!(S3D_XDIAG & 4)) asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(a[q]) : "v"(anext + (unsigned)(q * 16)), "s"(A) : "memory");
+					if (!(S3D_XDIAG & 4)) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(a[q]) : "v"(anext + (unsigned)(q * 16)), "s"(A) : "memory");  // ("+v": the same registers in every chunk, no copy at the back-edge while the load is in flight)
 				}
 				// the four DMA instructions are the oldest of the eight operations in flight
 				asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
