@@ -33,7 +33,7 @@ SYMBOLS = [
     "sift3d_default_params", "sift3d_create", "sift3d_destroy", "sift3d_run", "sift3d_run_stages",
     "sift3d_stage_times", "sift3d_num_keypoints", "sift3d_get_keypoints", "sift3d_device_results",
     "sift3d_num_octaves", "sift3d_level_info", "sift3d_copy_level", "sift3d_copy_input", "sift3d_num_extrema",
-    "sift3d_get_extrema", "sift3d_get_orientation_codes", "sift3d_gaussian_smooth", "sift3d_match",
+    "sift3d_get_extrema", "sift3d_get_orientation_codes", "sift3d_gaussian_smooth", "sift3d_downsample", "sift3d_dog_sub", "sift3d_match",
     "sift3d_device_count", "sift3d_error_string", "sift3d_last_error",
     # multi-GPU sharding (z-slabs of octave 0 + seeded replicated tail)
     "sift3d_slab_min_halo", "sift3d_slab_arena_floats", "sift3d_slab_create", "sift3d_slab_buffer", "sift3d_slab_upload",
@@ -104,6 +104,8 @@ def lib():
         L.sift3d_get_extrema.argtypes = [C.c_void_p, C.c_void_p]
         L.sift3d_get_orientation_codes.argtypes = [C.c_void_p, _ip]
         L.sift3d_gaussian_smooth.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, C.c_int]
+        L.sift3d_downsample.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.sift3d_dog_sub.argtypes = [_fp, _fp, C.c_size_t, _fp, C.c_int]
         L.sift3d_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                    C.c_int, C.c_int, _ip, _ip, _fp, _fp, _fp, _ip, C.POINTER(C.c_double)]
         L.sift3d_device_count.argtypes = [_ip]
@@ -543,6 +545,25 @@ def gaussian_smooth(vol, sigma, device=0):
     nz, ny, nx = vol.shape
     out = np.empty_like(vol)
     _check(lib().sift3d_gaussian_smooth(_f(vol), nx, ny, nz, float(sigma), _f(out), device))
+    return out
+
+
+def downsample(vol, out_shape=None, device=0):
+    """DownSample_3D (Include/cSIFT3D.h:210): out(k, m, n) = vol(2k, 2m, 2n); out_shape defaults to the halves (rounded down)."""
+    vol = np.ascontiguousarray(vol, dtype=np.float32)
+    snz, sny, snx = vol.shape
+    nz, ny, nx = out_shape if out_shape is not None else (snz // 2, sny // 2, snx // 2)
+    out = np.empty((nz, ny, nx), np.float32)
+    _check(lib().sift3d_downsample(_f(vol), snx, sny, snz, _f(out), nx, ny, nz, device))
+    return out
+
+
+def dog_sub(prev, cur, device=0):
+    """Sub (Include/cSIFT3D.h:218): (cur - prev) * (-1)."""
+    prev = np.ascontiguousarray(prev, dtype=np.float32); cur = np.ascontiguousarray(cur, dtype=np.float32)
+    assert prev.shape == cur.shape
+    out = np.empty_like(prev)
+    _check(lib().sift3d_dog_sub(_f(prev), _f(cur), prev.size, _f(out), device))
     return out
 
 

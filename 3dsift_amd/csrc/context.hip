@@ -997,6 +997,44 @@ extern "C" int sift3d_gaussian_smooth(const float *src, int nx, int ny, int nz, 
 }
 
 
+extern "C" int sift3d_downsample(const float *src, int snx, int sny, int snz, float *dst, int nx, int ny, int nz, int device) {
+	if (!src || !dst || nx <= 0 || ny <= 0 || nz <= 0 || snx <= 0 || sny <= 0 || snz <= 0 || 2 * (nx - 1) >= snx || 2 * (ny - 1) >= sny ||
+	    2 * (nz - 1) >= snz)
+		return SIFT3D_ERR_ARG;
+	int rc = set_device(device);
+	if (rc) return rc;
+	const size_t ns = (size_t)snx * sny * snz, nd = (size_t)nx * ny * nz;
+	float *d = nullptr;
+	S3D_HIP(hipMalloc(&d, sizeof(float) * (ns + nd)));
+	hipError_t e = hipMemcpy(d, src, sizeof(float) * ns, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		launch_downsample(d, snx, sny, d + ns, nx, ny, nz, nullptr);
+		e = hipDeviceSynchronize();
+	}
+	if (e == hipSuccess) e = hipMemcpy(dst, d + ns, sizeof(float) * nd, hipMemcpyDeviceToHost);
+	hipFree(d);
+	if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return SIFT3D_ERR_HIP; }
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_dog_sub(const float *prev, const float *cur, size_t n, float *dog, int device) {
+	if (!prev || !cur || !dog || n == 0) return SIFT3D_ERR_ARG;
+	int rc = set_device(device);
+	if (rc) return rc;
+	float *d = nullptr;
+	S3D_HIP(hipMalloc(&d, sizeof(float) * n * 3));
+	hipError_t e = hipMemcpy(d, prev, sizeof(float) * n, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(d + n, cur, sizeof(float) * n, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		launch_dog_from_gss(d + n, d, d + 2 * n, n, nullptr);  // (cur - prev) * (-1)
+		e = hipDeviceSynchronize();
+	}
+	if (e == hipSuccess) e = hipMemcpy(dog, d + 2 * n, sizeof(float) * n, hipMemcpyDeviceToHost);
+	hipFree(d);
+	if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return SIFT3D_ERR_HIP; }
+	return SIFT3D_OK;
+}
+
 // best-of-iters bandwidth (GB/s, read + write) of a float4 device-to-device copy of `bytes` bytes: the achievable HBM ceiling
 // bench.py reports beside the 8 TB/s spec peak
 extern "C" int sift3d_debug_copy_bandwidth(size_t bytes, int iters, int device, double *gbs) {

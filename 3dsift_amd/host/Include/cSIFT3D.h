@@ -114,6 +114,15 @@ public:
 	                              float max_eigo_thres = EIG_THRES, float corner_thresh = CORNER_THRESH);
 };
 
+// The volume-level free functions of the reference's header (Include/cSIFT3D.h:208-218), on host TexImages: each call moves its
+// operands to the GPU, runs the pipeline's own kernel and copies the result back.  dst / dog are (re)sized like the reference's
+// callers size them: GaussianSmooth_3D and Sub give dst the dimensions, units and scale of src / prev; DownSample_3D fills the
+// caller-sized dst (dst(n, m, k) = src(2n, 2m, 2k)).  The per-voxel helpers of that header (IsExtrema_neighbor, cart2bary, ...)
+// have no host-side counterpart here: they live inside the device kernels.
+SIFT_LIBRARY_API void DownSample_3D(TexImage *src, TexImage *dst);
+SIFT_LIBRARY_API void GaussianSmooth_3D(TexImage *src, TexImage *dst, float sigma);
+SIFT_LIBRARY_API void Sub(TexImage *prev, TexImage *cur, TexImage *dog);
+
 // device selection for subsequently created extractors / matchers (default 0, or env SIFT3D_DEVICE)
 SIFT_LIBRARY_API void SetDevice(int device);
 SIFT_LIBRARY_API int GetDevice();

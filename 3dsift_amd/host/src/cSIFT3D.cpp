@@ -21,6 +21,41 @@ int sift_thread_num = 1;
 
 static int g_device = -1;
 void SetDevice(int device) { g_device = device; }
+
+// ---- free functions of the reference's header (Include/cSIFT3D.h:208-218) ----
+static bool contiguous(TexImage *t) {
+	return t && t->_Data && t->GetXstride() == 1 && t->GetYstride() == (size_t)t->GetDimX() &&
+	       t->GetZstride() == (size_t)t->GetDimX() * (size_t)t->GetDimY();
+}
+static void shape_like(TexImage *dst, TexImage *src) {
+	if (dst->GetDimX() != src->GetDimX() || dst->GetDimY() != src->GetDimY() || dst->GetDimZ() != src->GetDimZ() || !dst->_Data) {
+		dst->SetImageSize(src->GetDimX(), src->GetDimY(), src->GetDimZ());
+		dst->MallocArrayMemory();
+	}
+	dst->SetImageUnit(src->GetUnitX(), src->GetUnitY(), src->GetUnitZ());
+}
+void GaussianSmooth_3D(TexImage *src, TexImage *dst, float sigma) {  // Src/cSIFT3D.cc:535-622
+	if (!contiguous(src) || !dst) { std::cerr << "GaussianSmooth_3D: bad image" << std::endl; return; }
+	shape_like(dst, src);
+	const int rc = sift3d_gaussian_smooth(src->_Data, src->GetDimX(), src->GetDimY(), src->GetDimZ(), sigma, dst->_Data, GetDevice());
+	if (rc) std::cerr << "GaussianSmooth_3D: " << sift3d_last_error() << std::endl;
+}
+void DownSample_3D(TexImage *src, TexImage *dst) {  // Src/cSIFT3D.cc:506-533
+	if (!contiguous(src) || !contiguous(dst)) { std::cerr << "DownSample_3D: bad image" << std::endl; return; }
+	const int rc = sift3d_downsample(src->_Data, src->GetDimX(), src->GetDimY(), src->GetDimZ(), dst->_Data, dst->GetDimX(), dst->GetDimY(),
+	                                 dst->GetDimZ(), GetDevice());
+	if (rc) std::cerr << "DownSample_3D: " << (rc == SIFT3D_ERR_ARG ? "dst does not fit src / 2" : sift3d_last_error()) << std::endl;
+}
+void Sub(TexImage *prev, TexImage *cur, TexImage *dog) {  // Src/cSIFT3D.cc:849-882
+	if (!contiguous(prev) || !contiguous(cur) || !dog || prev->GetDimX() != cur->GetDimX() || prev->GetDimY() != cur->GetDimY() ||
+	    prev->GetDimZ() != cur->GetDimZ()) {
+		std::cout << "Wrong in Sub function" << std::endl;  // the reference's message (cc:855)
+		return;
+	}
+	shape_like(dog, prev);
+	const int rc = sift3d_dog_sub(prev->_Data, cur->_Data, (size_t)prev->GetDimX() * prev->GetDimY() * prev->GetDimZ(), dog->_Data, GetDevice());
+	if (rc) std::cerr << "Sub: " << sift3d_last_error() << std::endl;
+}
 int GetDevice() {
 	if (g_device < 0) {
 		const char *e = getenv("SIFT3D_DEVICE");

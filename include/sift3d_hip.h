@@ -107,6 +107,11 @@ int sift3d_get_orientation_codes(sift3d_handle h, int *codes);
 /* Replaces the free function GaussianSmooth_3D (Include/cSIFT3D.h:212; Src/cSIFT3D.cc:535-622) on a
  * host volume (unit-level parity tests). */
 int sift3d_gaussian_smooth(const float *src, int nx, int ny, int nz, float sigma, float *dst, int device);
+/* Replaces the free function DownSample_3D (Include/cSIFT3D.h:210; Src/cSIFT3D.cc:506-533): dst(n, m, k) = src(2n, 2m, 2k) for every
+ * voxel of the caller-sized dst (2 (nx - 1) < snx etc.), host volumes. */
+int sift3d_downsample(const float *src, int snx, int sny, int snz, float *dst, int nx, int ny, int nz, int device);
+/* Replaces the free function Sub (Include/cSIFT3D.h:218; Src/cSIFT3D.cc:849-882): dog = (cur - prev) * (-1), n voxels, host volumes. */
+int sift3d_dog_sub(const float *prev, const float *cur, size_t n, float *dog, int device);
 
 /* Replaces muBruteMatcher::injectMatch / bijectMatch / enhancedMatch (Src/cMatcher.cc:146-228).
  * mode 1 inject, 2 biject, 3 enhanced.  desc: n*768 / m*768, xyz: n*3 / m*3 (rx,ry,rz).

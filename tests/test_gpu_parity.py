@@ -474,3 +474,26 @@ def test_g7_face_lookup_on_device(capi):
     fb, bb = capi.face_lookup(d, route=1)
     assert np.array_equal(fa, fb)
     assert np.abs(ba - bb).max() <= 2e-6 and (fa >= 0).all()
+
+
+@pytest.mark.gpu
+def test_free_functions_downsample_and_sub(capi, orc):
+    """DownSample_3D / Sub of the reference's header (Include/cSIFT3D.h:210, 218; Src/cSIFT3D.cc:506-533, 849-882) through the
+    C-ABI: every second voxel, and (cur - prev) * (-1) in fp32 -- bit for bit; against the oracle's pyramid where it has the same
+    operation (octave 1 level 0 is the decimated level 3 of octave 0; DoG[i] = Sub(G[i], G[i + 1]))."""
+    rng = np.random.default_rng(5)
+    for shape in ((20, 33, 47), (64, 64, 64), (9, 10, 11)):
+        v = rng.random(shape, dtype=np.float32)
+        half = tuple(s // 2 for s in shape)
+        assert np.array_equal(capi.downsample(v), v[::2, ::2, ::2][:half[0], :half[1], :half[2]])
+        up = tuple((s + 1) // 2 for s in shape)   # the largest dst that fits
+        assert np.array_equal(capi.downsample(v, up), v[::2, ::2, ::2])
+        w = rng.random(shape, dtype=np.float32)
+        assert np.array_equal(capi.dog_sub(v, w), (w - v) * np.float32(-1.0))
+    with pytest.raises(Exception):
+        capi.downsample(np.zeros((8, 8, 8), np.float32), (5, 4, 4))   # 2 * (5 - 1) >= 8: does not fit
+    vol = np.random.default_rng(6).random((40, 48, 56), dtype=np.float32)
+    o = orc.extractor(vol); o.run(2)
+    g3, g10 = o.gss(0, 3), o.gss(1, 0)
+    assert np.array_equal(capi.downsample(g3, g10.shape), g10)
+    assert np.array_equal(capi.dog_sub(o.gss(0, 1), o.gss(0, 2)), o.dog(0, 1))

@@ -281,3 +281,58 @@ def test_sift_kp_csv_matches_reference_writer_and_reader(shell):
         back = np.frombuffer(open(os.path.join(t, "back.bin"), "rb").read(), np.float32).reshape(-1, 3)
     assert back.shape == g["read_back"].shape
     assert np.array_equal(back.view(np.uint32), g["read_back"].view(np.uint32))
+
+
+FREE_FN_SRC = r"""
+#include "Include/cSIFT3D.h"
+#include <cstdio>
+#include <cstdlib>
+using namespace CPUSIFT;
+int main() {
+	TexImage a(16, 12, 10), b(16, 12, 10), g, d, h(8, 6, 5);
+	a.MallocArrayMemory(); b.MallocArrayMemory(); h.MallocArrayMemory();
+	for (int z = 0; z < 10; z++) for (int y = 0; y < 12; y++) for (int x = 0; x < 16; x++) {
+		a.SetImageDataWithIdx((float)((x * 7 + y * 3 + z * 11) % 13) / 13.0f, x, y, z);
+		b.SetImageDataWithIdx((float)((x * 5 + y * 2 + z) % 7) / 7.0f, x, y, z);
+	}
+	a.SetImageUnit(2.f, 2.f, 2.f);
+	GaussianSmooth_3D(&a, &g, 1.1f);
+	Sub(&a, &b, &d);
+	DownSample_3D(&a, &h);
+	int bad = 0;
+	for (int z = 0; z < 10; z++) for (int y = 0; y < 12; y++) for (int x = 0; x < 16; x++)
+		if (d.GetImageDataWithIdx(x, y, z) != (b.GetImageDataWithIdx(x, y, z) - a.GetImageDataWithIdx(x, y, z)) * (-1)) bad++;
+	for (int z = 0; z < 5; z++) for (int y = 0; y < 6; y++) for (int x = 0; x < 8; x++)
+		if (h.GetImageDataWithIdx(x, y, z) != a.GetImageDataWithIdx(2 * x, 2 * y, 2 * z)) bad++;
+	double s = 0; for (int z = 0; z < 10; z++) for (int y = 0; y < 12; y++) for (int x = 0; x < 16; x++) s += g.GetImageDataWithIdx(x, y, z);
+	printf("bad %d dims %d %d %d unit %g sum %.6f\n", bad, g.GetDimX(), g.GetDimY(), g.GetDimZ(), g.GetUnitX(), s);
+	return bad;
+}
+"""
+
+
+def _build_free_fn_program(t):
+    os.makedirs(os.path.join(t, "Include"), exist_ok=True)
+    src = os.path.join(t, "free_fn.cpp")
+    open(src, "w").write(FREE_FN_SRC)
+    subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(PKG, "host"), "-o", os.path.join(t, "free_fn"), src,
+                           "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-Wl,-rpath," + PKG])
+    return os.path.join(t, "free_fn")
+
+
+def test_free_functions_of_the_public_header_link(shell):
+    """DownSample_3D / GaussianSmooth_3D / Sub (Include/cSIFT3D.h:210-218) are exported by the C++ shell: a user program compiles and links."""
+    with tempfile.TemporaryDirectory() as t:
+        _build_free_fn_program(t)
+
+
+@pytest.mark.gpu
+def test_free_functions_of_the_public_header_run(shell, orc):
+    with tempfile.TemporaryDirectory() as t:
+        out = subprocess.check_output([_build_free_fn_program(t)], text=True)
+    assert out.startswith("bad 0 dims 16 12 10 unit 2 "), out
+    # the smoothed volume against the oracle's GaussianSmooth_3D on the same input
+    z, y, x = np.meshgrid(np.arange(10), np.arange(12), np.arange(16), indexing="ij")
+    a = (((x * 7 + y * 3 + z * 11) % 13).astype(np.float32) / np.float32(13.0)).astype(np.float32)
+    want = orc.gaussian_smooth(a, 1.1).astype(np.float64).sum()
+    assert abs(float(out.split("sum")[1]) - want) < 1e-4 * max(1.0, abs(want))
