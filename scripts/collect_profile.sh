@@ -34,4 +34,9 @@ cd $REPO
 bash $REPO/scripts/kernel_times.sh > $OUT/${TAG}_kernel_times.txt 2>&1
 bash $REPO/scripts/level_times.sh 512 > $OUT/${TAG}_levels_isolated.txt 2>&1
 bash $REPO/scripts/timeline.sh 512 > $OUT/${TAG}_timeline.txt 2>&1
+bash $REPO/scripts/timeline_full.sh 512 > $OUT/${TAG}_timeline_full.txt 2>&1
+bash $REPO/scripts/match_kernel_times.sh > $OUT/${TAG}_match_kernels.txt 2>&1
+cd /tmp
+python3 $REPO/scripts/pmc_kernel.py k_mark 512 3 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TA_BUSY_avr > $OUT/${TAG}_pmc_k_mark.json
+python3 $REPO/scripts/small_volume_times.py > $OUT/${TAG}_small_volumes.txt 2>/dev/null
 cat $OUT/${TAG}_bench.json

@@ -8,6 +8,8 @@ sys.path.insert(0, ROOT)
 tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 names = ["rocprofv3_kernel_stats.csv", "bench_under_rocprof.json", "bench.json", "pyramid_traffic_512.json", "pmc_k_describe.json", "pmc_k_describe_512.json",
          "pmc_k_march_level.json", "slab_sim.json", "kernel_times.txt", "levels_isolated.txt", "timeline.txt"]
+for n in ["timeline_full.txt", "match_kernels.txt", "pmc_k_mark.json", "small_volumes.txt"]:   # since r03b
+    if os.path.exists(os.path.join(ROOT, "gpurun_out", f"{tag}_{n}")): names.append(n)
 for n in names:
     shutil.copy(os.path.join(ROOT, "gpurun_out", f"{tag}_{n}"), os.path.join(ROOT, "profiles", f"{tag}_{n}"))
 shutil.copy(os.path.join(ROOT, "gpurun_out", f"{tag}_pyramid_traffic_512.json"), os.path.join(ROOT, "profiles", "pyramid_traffic_512.json"))
