@@ -510,7 +510,16 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	const bool one_stream = hook(SIFT3D_HOOK_ONE_STREAM) != 0;
 	for (size_t o = 0; o < c->ostream.size(); o++) {
 		if (o > 0 && one_stream) c->ostream[o] = c->stream;
-		else if (o > 0) CHECKED(hipStreamCreateWithFlags(&c->ostream[o], hipStreamNonBlocking));
+		else if (o > 0) {
+#ifndef S3D_STREAM_PRIO
+#define S3D_STREAM_PRIO 0  /* first octave whose stream is created with the highest queue priority (0: none) */
+#endif
+			int pr_lo = 0, pr_hi = 0;
+			if (S3D_STREAM_PRIO > 0 && (int)o >= S3D_STREAM_PRIO && hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi) == hipSuccess && pr_hi != pr_lo)
+				CHECKED(hipStreamCreateWithPriority(&c->ostream[o], hipStreamNonBlocking, pr_hi));
+			else
+				CHECKED(hipStreamCreateWithFlags(&c->ostream[o], hipStreamNonBlocking));
+		}
 		CHECKED(hipEventCreateWithFlags(&c->ev_seed[o], hipEventDisableTiming));
 		CHECKED(hipEventCreateWithFlags(&c->ev_done[o], hipEventDisableTiming));
 	}
@@ -732,19 +741,25 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 			if (o < c->noct && (rc = enqueue(o, true)) != SIFT3D_OK) return rc;
 			if (o >= 1 && (rc = enqueue(o - 1, false)) != SIFT3D_OK) return rc;
 		}
-		for (int o = 1; o < c->noct; o++) S3D_HIP(hipStreamWaitEvent(st, c->ev_done[o], 0));  // join
-		S3D_HIP(hipEventRecord(c->ev[1], st));
-		S3D_HIP(hipEventRecord(c->ev[2], st));  // DoG is fused: zero-length stage
-		// ---- Detect_KeyPoints (Src/cSIFT3D.cc:362-425) ----
-		if (upto >= 3) {
-			const bool two = c->det_o.size() > 1;  // masks of octaves >= 1 on a second stream beside octave 0's
-			hipStream_t sb = two ? c->ostream[1] : st;
-			if (two) { S3D_HIP(hipEventRecord(c->ev_det_fork, st)); S3D_HIP(hipStreamWaitEvent(sb, c->ev_det_fork, 0)); }
-			std::vector<DetectLevels> DLs((size_t)c->noct);
+		// r03, an option that is OFF (S3D_DET_EARLY_DEFAULT) -- octave 0's extremum masks start right behind its last level, BESIDE the chains of the small octaves: after octave 0's
+		// widest level the stage used to end with ~0.3 ms of launch-latency-bound chain (octaves 2..6: 60 launches of a few
+		// microseconds, each octave waiting for the seed level of the one above) on a nearly idle machine, while k_mark of octave 0
+		// -- 0.38 ms, memory bound -- waited behind the join.  The pyramid stage still ends when EVERY octave's pyramid has
+		// (ev[1] is recorded on the second detection stream after it has waited for all of them), so the stage times stay honest:
+		// the pyramid's is its wall time, the detection's is what is left of it behind the pyramid.
+		const bool two = upto >= 3 && c->det_o.size() > 1;  // masks of octaves >= 1 on a second stream beside octave 0's
+#ifndef S3D_DET_EARLY_DEFAULT
+#define S3D_DET_EARLY_DEFAULT 0  /* measured (r03, 512^3): detection 0.87 -> 0.73 ms but the pyramid stage 2.31 -> 2.40 ms -- the launches of the small octaves' chain wait for slots behind k_mark's 24 576 workgroups: 7.64 -> 7.60 ms per step, and the pyramid's roofline fraction would pay for it; queue priorities for the chain's streams (S3D_STREAM_PRIO) make every cross-stream wait slower (pyramid 3.8-4.3 ms) */
+#endif
+		static const int det_early_mode = dev_tune_i("S3D_DET_EARLY", S3D_DET_EARLY_DEFAULT);
+		const bool early = two && det_early_mode != 0 && c->noct > 1 && c->ostream.size() > 1 && c->ostream[1] != st;
+		std::vector<DetectLevels> DLs((size_t)c->noct);
+		const int nl = c->nd - 2;  // DoG levels 1 .. nd-2 (Src/cSIFT3D.cc:376)
+		const Taps *lt = c->g_last_elide ? &c->taps[c->ng - 1] : nullptr;
+		if (upto >= 3)
 			for (int o = 0; o < c->noct; o++) {
 				DetectLevels &DL = DLs[(size_t)o];
 				memset(&DL, 0, sizeof(DL));
-				const int nl = c->nd - 2;  // DoG levels 1 .. nd-2 (Src/cSIFT3D.cc:376)
 				for (int i = 1; i <= nl; i++) {
 					DL.cur[i - 1] = c->dog[(size_t)o * c->nd + i].d;
 					DL.prev[i - 1] = c->dog[(size_t)o * c->nd + i - 1].d;
@@ -760,8 +775,23 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 					if (c->g_last_elide) { DL.nextl_hi = nullptr; DL.lazy_src = DL.nextl_lo; }
 				}
 			}
-			const int nl = c->nd - 2;
-			const Taps *lt = c->g_last_elide ? &c->taps[c->ng - 1] : nullptr;
+		hipStream_t sb = two ? c->ostream[1] : st;
+		if (early) {
+			const Level &C0 = c->dog[(size_t)0 * c->nd + 1];
+			S3D_HIP(hipEventRecord(c->ev_det_fork, st));  // octave 0's pyramid is complete (the main stream is its stream)
+			launch_detect_mark(DLs[0], nl, C0.nx, C0.ny, C0.zr_all(), c->p.peak_thresh, 0 + c->octave_base, c->det, st, lt);
+			S3D_HIP(hipStreamWaitEvent(sb, c->ev_det_fork, 0));
+			for (int o = 2; o < c->noct; o++) S3D_HIP(hipStreamWaitEvent(sb, c->ev_done[o], 0));  // (octave 1's own work is in sb's order)
+			S3D_HIP(hipEventRecord(c->ev[1], sb));  // every octave's pyramid is complete
+			S3D_HIP(hipEventRecord(c->ev[2], sb));  // DoG is fused: zero-length stage
+		} else {
+			for (int o = 1; o < c->noct; o++) S3D_HIP(hipStreamWaitEvent(st, c->ev_done[o], 0));  // join
+			S3D_HIP(hipEventRecord(c->ev[1], st));
+			S3D_HIP(hipEventRecord(c->ev[2], st));  // DoG is fused: zero-length stage
+		}
+		// ---- Detect_KeyPoints (Src/cSIFT3D.cc:362-425) ----
+		if (upto >= 3) {
+			if (two && !early) { S3D_HIP(hipEventRecord(c->ev_det_fork, st)); S3D_HIP(hipStreamWaitEvent(sb, c->ev_det_fork, 0)); }
 			if (two) {
 				for (int o = 1; o < c->noct; o++) {
 					const Level &C = c->dog[(size_t)o * c->nd + 1];
@@ -772,7 +802,7 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 			for (int o = 0; o < c->noct; o++) {
 				const Level &C = c->dog[(size_t)o * c->nd + 1];
 				const DetectBufs &b = (two && o > 0) ? c->det_o[(size_t)o] : c->det;
-				if (!(two && o > 0)) launch_detect_mark(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, b, st, lt);
+				if (!(two && o > 0) && !(early && o == 0)) launch_detect_mark(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, b, st, lt);
 				if (two && o == 1) S3D_HIP(hipStreamWaitEvent(st, c->ev_det_join, 0));
 				launch_detect_emit(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), o + c->octave_base, b, c->d_ext, c->ext_cap, st);
 			}
