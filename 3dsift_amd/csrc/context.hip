@@ -648,14 +648,19 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 #ifndef S3D_FUSED_MIN_DEFAULT
 #define S3D_FUSED_MIN_DEFAULT 33  /* levels with a dimension <= 32 (octaves 4+ of a 512^3 volume) take the generic separable kernels: 3.88 vs 4.02 ms */
 #endif
+#ifndef S3D_FUSED_HALF
+#define S3D_FUSED_HALF 1  /* the seed level's march kernel also writes level 0 of the next octave (no decimation launch on the octave -> octave chain) */
+#endif
 #ifndef S3D_O0_TAIL_SLOTS_DEFAULT
 #define S3D_O0_TAIL_SLOTS_DEFAULT 512  /* r02 (march kernel): 2.92 vs 3.05 ms with bg 256 */
 #endif
 #ifndef S3D_BG_SLOTS_DEFAULT
 #define S3D_BG_SLOTS_DEFAULT 256
 #endif
-static void smooth_level(sift3d_ctx *c, int o, const float *src, const Level &dst, const Taps &t, const float *prev, float *dog,
-                         unsigned *dogmax, int level = 0) {
+// half_out (optional): level 0 of the next octave; returns true when the march kernel wrote it together with dst (the caller then
+// skips the decimation launch)
+static bool smooth_level(sift3d_ctx *c, int o, const float *src, const Level &dst, const Taps &t, const float *prev, float *dog,
+                         unsigned *dogmax, int level = 0, const Level *half_out = nullptr) {
 	hipStream_t st = c->ostream[o];
 	// Slot planning across the octave streams (single-round launches keep every slot they take until they end): the levels of
 	// octave 0 behind the seed level G[0][num_kp_levels] leave a third of the machine to the chains of the smaller octaves, which
@@ -670,12 +675,17 @@ static void smooth_level(sift3d_ctx *c, int o, const float *src, const Level &ds
 	const int plan_slots = c->noct > 1 ? (o == 0 ? (level > c->p.num_kp_levels ? tail_slots : 0) : bg_slots) : 0;
 	// hot path: one fused pass (x, y, z blur + DoG + abs-max; kernels_march.hip); prev == src for every DoG-producing level
 	static const int fused_min = dev_tune_i("S3D_FUSED_MIN", S3D_FUSED_MIN_DEFAULT);
-	if (c->use_fused && (prev == nullptr || prev == src) && std::min(dst.nx, std::min(dst.ny, dst.nz)) >= fused_min &&
-	    launch_march_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.zr_all(), t, st, plan_slots, prio))
-		return;
+	if (c->use_fused && (prev == nullptr || prev == src) && std::min(dst.nx, std::min(dst.ny, dst.nz)) >= fused_min) {
+		MarchHalf hf;
+		const bool want_half = S3D_FUSED_HALF && half_out != nullptr && march_half_ok(dst.nx, dst.ny, dst.zr_all());
+		if (want_half) { hf.d = half_out->d; hf.nx = half_out->nx; hf.ny = half_out->ny; hf.nz = half_out->nz; }
+		if (launch_march_level(src, dst.d, dog, dogmax, dst.nx, dst.ny, dst.zr_all(), t, st, plan_slots, prio, want_half ? &hf : nullptr))
+			return want_half;
+	}
 	launch_conv_axis(0, src, c->tmpA[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
 	launch_conv_axis(1, c->tmpA[o], c->tmpB[o], dst.nx, dst.ny, dst.nz, t, nullptr, nullptr, nullptr, st);
 	launch_conv_axis(2, c->tmpB[o], dst.d, dst.nx, dst.ny, dst.nz, t, prev, dog, dogmax, st);
+	return false;
 }
 
 static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
@@ -709,6 +719,7 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		// fills the machine under the launch-latency chain of the small octaves instead: 2.36 -> 2.51 ms at 512^3 for every slot
 		// planning tried (the tail is longer than that chain).
 		static const int defer_tail = dev_tune_i("S3D_DEFER_TAIL", 0);
+		std::vector<char> half_written((size_t)c->noct + 1, 0);  // level 0 of octave o was written by the seed level's kernel of octave o - 1
 		auto enqueue = [&](int o, bool head) -> int {
 			hipStream_t so = c->ostream[o];
 			if (head && o > 0) {
@@ -724,13 +735,17 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 					// seeded: G[octave_base][0] was written by sift3d_seed_upload
 				} else if (i == 0) {
 					const Level &P = c->gss[(size_t)(o - 1) * c->ng + c->p.num_kp_levels];
-					launch_downsample(P.d, P.nx, P.ny, L.d, L.nx, L.ny, L.nz, so);
+					if (!half_written[(size_t)o]) launch_downsample(P.d, P.nx, P.ny, L.d, L.nx, L.ny, L.nz, so);
 				} else {
 					const Level &P = c->gss[(size_t)o * c->ng + i - 1];
 					const Level &D = c->dog[(size_t)o * c->nd + i - 1];
 					if (c->g_last_elide && i == c->ng - 1) continue;  // never built (k_lazy_next / sift3d_copy_level form what is asked for)
-					if (c->dog_elide && (i - 1 == 0 || i - 1 == c->nd - 1)) smooth_level(c, o, P.d, L, c->taps[i], nullptr, nullptr, nullptr, i);
-					else smooth_level(c, o, P.d, L, c->taps[i], P.d, D.d, c->d_dogmax + (size_t)o * c->nd + i - 1, i);
+					// the seed level also leaves decimated, as level 0 of the next octave (whole volumes, not seeded / partitioned contexts' inputs)
+					const Level *half = (i == c->p.num_kp_levels && o + 1 < c->noct) ? &c->gss[(size_t)(o + 1) * c->ng] : nullptr;
+					bool hw_ = false;
+					if (c->dog_elide && (i - 1 == 0 || i - 1 == c->nd - 1)) hw_ = smooth_level(c, o, P.d, L, c->taps[i], nullptr, nullptr, nullptr, i, half);
+					else hw_ = smooth_level(c, o, P.d, L, c->taps[i], P.d, D.d, c->d_dogmax + (size_t)o * c->nd + i - 1, i, half);
+					if (half) half_written[(size_t)o + 1] = hw_ ? 1 : 0;
 				}
 				if (i == c->p.num_kp_levels) S3D_HIP(hipEventRecord(c->ev_seed[o], so));
 			}

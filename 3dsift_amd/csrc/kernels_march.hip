@@ -51,6 +51,7 @@ constexpr int kMarchMaxHW = 8;
 struct MTaps { float w[2 * kMarchMaxHW + 1]; };
 struct MEdge { float f[3][kMarchMaxHW + 1]; };  // x, y, z fractions of the right-boundary rule
 typedef float mf4 __attribute__((ext_vector_type(4)));
+typedef float mf2 __attribute__((ext_vector_type(2)));
 
 template <int HW>
 struct MCfg {
@@ -165,7 +166,7 @@ constexpr int march_lb() {  // __launch_bounds__ second argument: at least the p
 template <int HW, bool DOG, bool CR>
 __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                         unsigned *__restrict__ dogmax, int nx, int ny, ZRange zr, MTaps t, MEdge ef, int ntx,
-                                                        int nty, int cz, int prio) {
+                                                        int nty, int cz, int prio, float *__restrict__ half, int hnx, int hny, int hnz) {
 	using C = MCfg<HW>;
 	__shared__ __attribute__((aligned(1024))) float tile[2 * C::TILE_F];
 	__shared__ __attribute__((aligned(16))) float xb[2 * C::XB_F];
@@ -439,6 +440,21 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 			// stores this WAVE issues in this step (the counted wait below): a store instruction is issued when any lane of the wave
 			// owns its piece -- in the tile in front of a shifted one some lanes, or whole waves (rows), do not
 			nst = __any(emit && !((S3D_MDIAG & 2) && out[0] != 12345.678f)) ? (DOG ? 2 : 1) : 0;
+			// r03: the seed level of the next octave -- DownSample_3D (Src/cSIFT3D.cc:506-533): every second voxel of every second row of
+			// every second plane -- leaves with the level's own store (`half` = level 0 of the next octave, whole volumes with nx % 4 ==
+			// 0 only): the decimation launch sat on the stage's critical chain octave -> octave and read the level again
+			if (half != nullptr && (p_loc & 1) == 0) {  // wave-uniform
+				const int hy = (y0 + ty) >> 1, hx = (x0 + 4 * xq) >> 1, hz = p_loc >> 1;
+				const bool hs = emit && ((y0 + ty) & 1) == 0 && hy < hny && hx < hnx && hz < hnz;
+				if (__any(hs)) {
+					nst += 1;
+					if (hs) {
+						const unsigned hoff = (unsigned)((hz * hny + hy) * hnx + hx) * 4u;
+						if (hx + 1 < hnx) asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(hoff), "v"(mf2{out[0], out[2]}), "s"(half));
+						else asm volatile("global_store_dword %0, %1, %2\n\ts_nop 1" ::"v"(hoff), "v"(out[0]), "s"(half));
+					}
+				}
+			}
 			if (emit && !((S3D_MDIAG & 2) && out[0] != 12345.678f)) {
 				float *gb = dst + (size_t)sz * (size_t)p_loc;
 				m_store16(gb, out_voff, mf4{out[0], out[1], out[2], out[3]});
@@ -456,6 +472,7 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 
 		// the DMA of the next tile was issued before this step's stores (vmcnt retires in order)
 		if (S3D_MDIAG & 4) {}
+		else if (nst == 3) m_wait_vmcnt<3>();
 		else if (nst == 2) m_wait_vmcnt<2>();
 		else if (nst == 1) m_wait_vmcnt<1>();
 		else m_wait_vmcnt<0>();
@@ -486,7 +503,7 @@ static void march_edge_fractions(int n, int hw, float *f) {  // Src/cSIFT3D.cc:7
 
 template <int HW>
 static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &tg,
-                            hipStream_t st, int plan_slots, int prio) {
+                            hipStream_t st, int plan_slots, int prio, const MarchHalf &hf) {
 	using C = MCfg<HW>;
 	MTaps t;
 	for (int i = 0; i < 2 * kMarchMaxHW + 1; i++) t.w[i] = i < 2 * HW + 1 ? tg.w[i] : 0.0f;
@@ -532,25 +549,30 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	march_edge_fractions(zr.nzg, HW, ef.f[2]);
 	const dim3 grid((unsigned)(ntiles * nchunks)), block(C::NT);
 	// DoG centre ring in LDS where three workgroups per CU still fit (hw <= 5); otherwise the centre piece travels by LDS-DMA
-	if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio);
-	else if (dog) hipLaunchKernelGGL((k_march_level<HW, true, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio);
-	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio);
+	if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
+	else if (dog) hipLaunchKernelGGL((k_march_level<HW, true, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
+	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 }
 
 // false => not applicable (a plane smaller than one tile, a shifted last tile that would reach into the mirrored left / top zone, a level
 // too thin for the extended-line boundary form, a half width without an instantiation): the caller takes the generic separable
 // kernels of kernels_pyramid.hip
+bool march_half_ok(int nx, int ny, const ZRange &zr) { return (nx & 3) == 0 && zr.zoff == 0 && zr.nz == zr.nzg; }  // whole volumes, pieces on even x
+
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
-                        hipStream_t st, int plan_slots, int prio) {
+                        hipStream_t st, int plan_slots, int prio, const MarchHalf *half) {
+	MarchHalf hf;
+	if (half && half->d && march_half_ok(nx, ny, zr)) hf = *half;
+	else if (half && half->d) return false;  // (the caller asks first: march_half_ok)
 	auto fits = [&](int n) { return n == 32 || n >= 32 + t.hw; };  // the shifted tile starts at n - 32: 0 or beyond the mirror zone [0, hw)
 	if (!fits(nx) || !fits(ny) || zr.nzg < 2 * t.hw + 2) return false;
 	switch (t.hw) {
-	case 2: launch_march_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
-	case 3: launch_march_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
-	case 4: launch_march_hw<4>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
-	case 5: launch_march_hw<5>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
-	case 6: launch_march_hw<6>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
-	case 8: launch_march_hw<8>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio); return true;
+	case 2: launch_march_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
+	case 3: launch_march_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
+	case 4: launch_march_hw<4>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
+	case 5: launch_march_hw<5>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
+	case 6: launch_march_hw<6>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
+	case 8: launch_march_hw<8>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
 	default: return false;
 	}
 }

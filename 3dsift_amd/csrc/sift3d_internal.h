@@ -128,8 +128,11 @@ void launch_conv_axis(int axis, const float *src, float *dst, int nx, int ny, in
                       const float *prev, float *dog, unsigned *d_dogmax, hipStream_t st);
 // fused single-pass level kernel (kernels_march.hip): descending z-march with scatter accumulators; false => not applicable (half
 // width without an instantiation, planes smaller than a tile): the caller takes the separable kernels above
+// level 0 of the next octave, written by the march kernel together with the seed level (DownSample_3D fused into the producer)
+struct MarchHalf { float *d = nullptr; int nx = 0, ny = 0, nz = 0; };
+bool march_half_ok(int nx, int ny, const ZRange &zr);
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
-                        hipStream_t st, int plan_slots = 0, int prio = 0 /* wave priority class: 0 normal, 1, 2 */);
+                        hipStream_t st, int plan_slots = 0, int prio = 0, const MarchHalf *half = nullptr);
 void launch_copy16(const float *src, float *dst, size_t nfloats, hipStream_t st);  // float4 copy (bandwidth ceiling probe)
 void launch_downsample(const float *src, int snx, int sny, float *dst, int nx, int ny, int nz, hipStream_t st);
 
