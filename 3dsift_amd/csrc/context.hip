@@ -814,13 +814,16 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 				}
 				S3D_HIP(hipEventRecord(c->ev_det_join, sb));
 			}
+			std::vector<DetectEmitItem> rest;  // two streams: the octaves behind the first one are emitted by one scan + one emit launch
 			for (int o = 0; o < c->noct; o++) {
 				const Level &C = c->dog[(size_t)o * c->nd + 1];
 				const DetectBufs &b = (two && o > 0) ? c->det_o[(size_t)o] : c->det;
 				if (!(two && o > 0) && !(early && o == 0)) launch_detect_mark(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, b, st, lt);
 				if (two && o == 1) S3D_HIP(hipStreamWaitEvent(st, c->ev_det_join, 0));
-				launch_detect_emit(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), o + c->octave_base, b, c->d_ext, c->ext_cap, st);
+				if (two && o > 0 && c->noct - 1 <= 8) rest.push_back(DetectEmitItem{&DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), o + c->octave_base, &b});
+				else launch_detect_emit(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), o + c->octave_base, b, c->d_ext, c->ext_cap, st);
 			}
+			if (!rest.empty()) launch_detect_emit_multi(rest.data(), (int)rest.size(), c->d_ext, c->ext_cap, c->d_total, st);
 		}
 		S3D_HIP(hipEventRecord(c->ev[3], st));
 		// ---- Assign_Orientation (Src/cSIFT3D.cc:427-482) ----

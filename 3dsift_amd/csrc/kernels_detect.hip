@@ -18,6 +18,7 @@
 // k_mark + k_lazy_next of octaves >= 1 may run on a second stream with their own scratch (launch_detect_mark); k_scan + k_emit
 // (launch_detect_emit) run in octave order on one stream.  No host synchronisation anywhere; the running total stays on the device.
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -467,14 +468,28 @@ __global__ void __launch_bounds__(256) k_lazy_next(DetectLevels L, Taps t, int n
 
 // exclusive scan of block_counts[0..nblocks) by ONE workgroup; offsets start at the running total
 // total[0], which is then advanced.
-__global__ void __launch_bounds__(1024) k_scan(const unsigned *__restrict__ block_counts, unsigned *__restrict__ block_offsets,
-                                               unsigned nblocks, unsigned *__restrict__ total) {
-	__shared__ unsigned s_wave[16];
+// exclusive scan of the block counts of one octave on top of `base` (one 1024-thread workgroup); returns base + the octave's total
+__device__ __forceinline__ unsigned scan_octave(const unsigned *__restrict__ block_counts, unsigned *__restrict__ block_offsets, unsigned nblocks,
+                                                unsigned base, unsigned *s_wave) {
 	const unsigned t = threadIdx.x;
-	const unsigned chunk = (nblocks + 1023u) / 1024u;
+	// a thread owns `chunk` consecutive counts (a multiple of four: 16-byte loads and stores where the arrays' alignment allows --
+	// r03: 24 dependent 4-byte loads per thread at a stride of 96 bytes across the lanes made this launch 33 us at 512^3)
+	const unsigned chunk = (((nblocks + 1023u) / 1024u) + 3u) & ~3u;
 	const unsigned lo = min(t * chunk, nblocks), hi = min(lo + chunk, nblocks);
+	const bool vec = (((size_t)block_counts | (size_t)block_offsets) & 15) == 0 && hi - lo == chunk && chunk <= 32;
+	unsigned cnt[32];
 	unsigned sum = 0;
-	for (unsigned i = lo; i < hi; i++) sum += block_counts[i];
+	if (vec) {
+#pragma unroll
+		for (unsigned q = 0; q < 8; q++)
+			if (q * 4 < chunk) {
+				const uint4 c4 = *reinterpret_cast<const uint4 *>(block_counts + lo + 4 * q);
+				cnt[4 * q] = c4.x; cnt[4 * q + 1] = c4.y; cnt[4 * q + 2] = c4.z; cnt[4 * q + 3] = c4.w;
+				sum += c4.x + c4.y + c4.z + c4.w;
+			}
+	} else {
+		for (unsigned i = lo; i < hi; i++) sum += block_counts[i];
+	}
 	unsigned v = sum;
 	const int lane = t & 63, wid = t >> 6;
 #pragma unroll
@@ -490,20 +505,58 @@ __global__ void __launch_bounds__(1024) k_scan(const unsigned *__restrict__ bloc
 	}
 	__syncthreads();
 	const unsigned incl = v + s_wave[wid];
-	const unsigned base = total[0];
 	unsigned run = base + (incl - sum);
-	for (unsigned i = lo; i < hi; i++) { block_offsets[i] = run; run += block_counts[i]; }
+	if (vec) {
+#pragma unroll
+		for (unsigned q = 0; q < 8; q++)
+			if (q * 4 < chunk) {
+				uint4 o4;
+				o4.x = run; run += cnt[4 * q]; o4.y = run; run += cnt[4 * q + 1]; o4.z = run; run += cnt[4 * q + 2]; o4.w = run; run += cnt[4 * q + 3];
+				*reinterpret_cast<uint4 *>(block_offsets + lo + 4 * q) = o4;
+			}
+	} else {
+		for (unsigned i = lo; i < hi; i++) { block_offsets[i] = run; run += block_counts[i]; }
+	}
+	__syncthreads();  // every thread has read its slot of s_wave
+	if (t == 1023) s_wave[0] = base + incl;
 	__syncthreads();
-	if (t == 1023) total[0] = base + incl;
+	const unsigned nbase = s_wave[0];
+	__syncthreads();
+	return nbase;
+}
+
+__global__ void __launch_bounds__(1024) k_scan(const unsigned *__restrict__ block_counts, unsigned *__restrict__ block_offsets,
+                                               unsigned nblocks, unsigned *__restrict__ total) {
+	__shared__ unsigned s_wave[16];
+	const unsigned nb = scan_octave(block_counts, block_offsets, nblocks, total[0], s_wave);
+	if (threadIdx.x == 0) total[0] = nb;
+}
+
+// r03: the octaves behind the first one in ONE scan launch and ONE emit launch (their 2 x 6 launches of ~5 us each sat, one after
+// the other, between the extremum masks and the orientation stage)
+struct EmitOct {
+	const unsigned long long *masks;
+	const unsigned *counts;
+	unsigned *offsets;
+	int nx, ny, nyb, octave;
+	ZRange zr;
+	unsigned nblocks, block0;
+	int level_id[kMaxKpLevels];
+	float scale[kMaxKpLevels];
+};
+struct EmitMulti { EmitOct o[8]; int n; };
+__global__ void __launch_bounds__(1024) k_scan_multi(EmitMulti M, unsigned *__restrict__ total) {
+	__shared__ unsigned s_wave[16];
+	unsigned base = total[0];
+	__syncthreads();
+	for (int k = 0; k < M.n; k++) base = scan_octave(M.o[k].counts, M.o[k].offsets, M.o[k].nblocks, base, s_wave);
+	if (threadIdx.x == 0) total[0] = base;
 }
 
 // one thread per ballot word of a block (16 rows x wpr words, same block decomposition as k_mark)
-__global__ void __launch_bounds__(kThreads) k_emit(const unsigned long long *__restrict__ masks,
-                                                   const unsigned *__restrict__ block_offsets, int nx, int ny, ZRange zr, int nyb,
-                                                   int octave, DetectLevels L, DevKp *__restrict__ out, unsigned cap,
-                                                   unsigned *__restrict__ total) {
-	__shared__ unsigned s_wave[kThreads / 64];
-	const int b = blockIdx.x;
+__device__ __forceinline__ void emit_block(int b, const unsigned long long *__restrict__ masks, const unsigned *__restrict__ block_offsets, int nx,
+                                           int ny, const ZRange &zr, int nyb, int octave, const int *level_id, const float *scale,
+                                           DevKp *__restrict__ out, unsigned cap, unsigned *__restrict__ total, unsigned *s_wave) {
 	const int nz = zr.zo1 - zr.zo0;
 	const int yb = b % nyb, zi = (b / nyb) % nz, lvl = b / (nyb * nz);
 	const int z = zr.zo0 + zi + zr.zoff;  // GLOBAL plane: keypoint coordinates are global
@@ -544,7 +597,7 @@ __global__ void __launch_bounds__(kThreads) k_emit(const unsigned long long *__r
 			if (pos < cap) {
 				DevKp k;
 				k.x = xw * 64 + bit; k.y = y; k.z = z;
-				k.octave = octave; k.level = L.level_id[lvl]; k.scale = L.scale[lvl]; k.code = 0; k.slot = -1;
+				k.octave = octave; k.level = level_id[lvl]; k.scale = scale[lvl]; k.code = 0; k.slot = -1;
 #pragma unroll
 				for (int j = 0; j < 3; j++) { k.win[j] = 0.f; k.eigvalue[j] = 0.f; }
 #pragma unroll
@@ -557,6 +610,22 @@ __global__ void __launch_bounds__(kThreads) k_emit(const unsigned long long *__r
 		}
 		running += all;
 	}
+}
+
+__global__ void __launch_bounds__(kThreads) k_emit(const unsigned long long *__restrict__ masks,
+                                                   const unsigned *__restrict__ block_offsets, int nx, int ny, ZRange zr, int nyb,
+                                                   int octave, DetectLevels L, DevKp *__restrict__ out, unsigned cap,
+                                                   unsigned *__restrict__ total) {
+	__shared__ unsigned s_wave[kThreads / 64];
+	emit_block((int)blockIdx.x, masks, block_offsets, nx, ny, zr, nyb, octave, L.level_id, L.scale, out, cap, total, s_wave);
+}
+
+__global__ void __launch_bounds__(kThreads) k_emit_multi(EmitMulti M, DevKp *__restrict__ out, unsigned cap, unsigned *__restrict__ total) {
+	__shared__ unsigned s_wave[kThreads / 64];
+	int k = 0;
+	while (k + 1 < M.n && blockIdx.x >= M.o[k + 1].block0) k++;  // block-uniform
+	const EmitOct &E = M.o[k];
+	emit_block((int)(blockIdx.x - E.block0), E.masks, E.offsets, E.nx, E.ny, E.zr, E.nyb, E.octave, E.level_id, E.scale, out, cap, total, s_wave);
 }
 
 // first half of an octave's detection: the ballot masks of the strict extrema (k_mark) and the parked candidates of the lazy level
@@ -596,6 +665,28 @@ void launch_detect_emit(const DetectLevels &L, int nlevels, int nx, int ny, cons
 	hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, b.block_counts, b.block_offsets, nblocks, b.total);
 	hipLaunchKernelGGL(k_emit, dim3(nblocks), dim3(kThreads), 0, st, b.masks, b.block_offsets, nx, ny, zr, nyb, octave, L, out, cap,
 	                   b.total);
+}
+
+// second half for several octaves at once (in the order given = octave order): one scan launch, one emit launch
+void launch_detect_emit_multi(const DetectEmitItem *items, int n, DevKp *out, unsigned cap, unsigned *total, hipStream_t st) {
+	EmitMulti M;
+	memset(&M, 0, sizeof(M));
+	unsigned blocks = 0;
+	for (int k = 0; k < n && M.n < 8; k++) {
+		const DetectEmitItem &it = items[k];
+		const int nyb = (it.ny + kRows - 1) / kRows, nzl = it.zr.zo1 - it.zr.zo0;
+		if (nzl <= 0) continue;
+		const unsigned nblocks = (unsigned)(it.nlevels * nzl * nyb);
+		if (nblocks == 0) continue;
+		EmitOct &E = M.o[M.n++];
+		E.masks = it.b->masks; E.counts = it.b->block_counts; E.offsets = it.b->block_offsets;
+		E.nx = it.nx; E.ny = it.ny; E.nyb = nyb; E.octave = it.octave; E.zr = it.zr; E.nblocks = nblocks; E.block0 = blocks;
+		for (int l = 0; l < kMaxKpLevels; l++) { E.level_id[l] = it.L->level_id[l]; E.scale[l] = it.L->scale[l]; }
+		blocks += nblocks;
+	}
+	if (M.n == 0) return;
+	hipLaunchKernelGGL(k_scan_multi, dim3(1), dim3(1024), 0, st, M, total);
+	hipLaunchKernelGGL(k_emit_multi, dim3(blocks), dim3(kThreads), 0, st, M, out, cap, total);
 }
 
 void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, float peak_thresh, int octave,

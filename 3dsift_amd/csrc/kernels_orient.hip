@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const i
 #pragma unroll
 	for (int l = 0; l <= kL; l++) tot[l] = 0;
 	// codes[] carries (level << 4) | 1 for accepted extrema, the reject code (< 0) or 0 otherwise: one dense array to read
-	constexpr int kU = 4;  // rows of 64 requested together (the loop is a chain of dependent loads otherwise)
+	constexpr int kU = 8;  // rows of 64 requested together (the loop is a chain of dependent loads otherwise)
 	for (unsigned i0 = lo; i0 < hi; i0 += 64 * kU) {
 		int c[kU];
 #pragma unroll

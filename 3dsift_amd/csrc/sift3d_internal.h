@@ -173,6 +173,8 @@ void launch_detect_mark(const DetectLevels &L, int nlevels, int nx, int ny, cons
                         const DetectBufs &b, hipStream_t st, const Taps *lazy_taps);
 void launch_detect_emit(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, int octave, const DetectBufs &b, DevKp *out,
                         unsigned cap, hipStream_t st);
+struct DetectEmitItem { const DetectLevels *L; int nlevels, nx, ny; ZRange zr; int octave; const DetectBufs *b; };
+void launch_detect_emit_multi(const DetectEmitItem *items, int n, DevKp *out, unsigned cap, unsigned *total, hipStream_t st);
 void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, float peak_thresh, int octave,
                           const DetectBufs &b, DevKp *out, unsigned cap, hipStream_t st, const Taps *lazy_taps = nullptr);
 
