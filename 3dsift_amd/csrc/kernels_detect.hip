@@ -292,7 +292,13 @@ __device__ __forceinline__ void lazy_tap_src(int p, int d, int n, int &lo, int &
 constexpr int kLT = kLazySlots / 2 - 1;   // taps at most (17)
 constexpr int kLR = kLT + 1;              // real samples an axis reads: one contiguous range of at most 2 hw + 2 indices
 constexpr int kLP = kLR + 1;              // x pitch of the staged block (odd: lanes = rows read conflict-free)
-__global__ void __launch_bounds__(256) k_lazy_next(DetectLevels L, Taps t, int nx, int ny, ZRange zr, int nyb,
+#ifndef S3D_LAZY_BATCHES
+#define S3D_LAZY_BATCHES 1  /* the 17^3 block of a candidate is requested in this many batches (1: 20 loads per thread in flight, 201 registers, two workgroups per CU) */
+#endif
+#ifndef S3D_LAZY_OCC
+#define S3D_LAZY_OCC 2
+#endif
+__global__ void __launch_bounds__(256, S3D_LAZY_OCC) k_lazy_next(DetectLevels L, Taps t, int nx, int ny, ZRange zr, int nyb,
                                                    const unsigned *__restrict__ prov, const unsigned *__restrict__ prov_count,
                                                    unsigned prov_cap, unsigned long long *__restrict__ masks,
                                                    unsigned *__restrict__ block_counts) {
@@ -329,20 +335,23 @@ __global__ void __launch_bounds__(256) k_lazy_next(DetectLevels L, Taps t, int n
 			const float *base = src + ic - (size_t)H * sz - (size_t)H * sy - (size_t)H;
 			{
 				// all loads of a thread first, then the LDS writes: a load -> store loop serialises on the memory latency (20 round trips)
-				constexpr int NS = (N * N * N + 255) / 256;
-				float v[NS];
+				constexpr int NS = (N * N * N + 255) / 256, NB = S3D_LAZY_BATCHES, NSB = (NS + NB - 1) / NB;
 #pragma unroll
-				for (int q = 0; q < NS; q++) {
-					const int i = min(tid + 256 * q, N * N * N - 1);
-					const int xi = i % N, r = i / N, yi = r % N, zi2 = r / N;
-					v[q] = base[sz * (size_t)zi2 + sy * (size_t)yi + (size_t)xi];
-				}
+				for (int bq = 0; bq < NB; bq++) {
+					float v[NSB];
 #pragma unroll
-				for (int q = 0; q < NS; q++) {
-					const int i = tid + 256 * q;
-					if (i < N * N * N) {
+					for (int q = 0; q < NSB; q++) {
+						const int i = min(tid + 256 * (bq * NSB + q), N * N * N - 1);
 						const int xi = i % N, r = i / N, yi = r % N, zi2 = r / N;
-						s_blk[(zi2 * kLR + yi) * kLP + xi] = v[q];
+						v[q] = base[sz * (size_t)zi2 + sy * (size_t)yi + (size_t)xi];
+					}
+#pragma unroll
+					for (int q = 0; q < NSB; q++) {
+						const int i = tid + 256 * (bq * NSB + q);
+						if (i < N * N * N) {
+							const int xi = i % N, r = i / N, yi = r % N, zi2 = r / N;
+							s_blk[(zi2 * kLR + yi) * kLP + xi] = v[q];
+						}
 					}
 				}
 			}
@@ -642,7 +651,7 @@ void launch_detect_mark(const DetectLevels &L, int nlevels, int nx, int ny, cons
 	const size_t mask_lds = sizeof(unsigned long long) * (kThreads / 64) * (kRows / 4) * (size_t)std::min((nx + 63) >> 6, 64);
 	hipLaunchKernelGGL(k_mark, dim3(nblocks), dim3(kThreads), mask_lds, st, L, nx, ny, zr, nyb, peak_thresh, b.masks, b.block_counts, b.prov,
 	                   b.prov_count, b.prov_cap, b.total);
-	static const int lazy_grid = dev_tune_i("S3D_LAZY_GRID", 256 * 2);  // = the resident workgroups (201 VGPRs: two per CU); 512 / 1280 / 5120: detection 0.95 / 0.99 / 1.02 ms
+	static const int lazy_grid = dev_tune_i("S3D_LAZY_GRID", 256 * S3D_LAZY_OCC);  // = the resident workgroups (201 VGPRs: two per CU); 512 / 1280 / 5120: detection 0.95 / 0.99 / 1.02 ms
 	if (lazy) hipLaunchKernelGGL(k_lazy_next, dim3(lazy_grid), dim3(256), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
 	                             b.masks, b.block_counts);
 	static const bool dbg = dev_tune_i("S3D_LAZY_DEBUG", 0) != 0;
