@@ -26,4 +26,31 @@ for r in last:
     tot[n]+=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3; cnt[n]+=1
 print("one step: wall %.2f ms, GPU busy (union of kernel intervals) %.2f ms, sum of kernel durations %.2f ms, %d launches"%((t1-t0)/1e6,busy/1e6,sum(tot.values())/1e3,len(last)))
 for n,v in sorted(tot.items(),key=lambda x:-x[1])[:24]: print("  %-34s %5d launches %9.1f us"%(n,cnt[n],v))
+# per queue (the sharded stages run on the ranks' shared stream, the replicated tails on the tail contexts' streams)
+perq=collections.defaultdict(lambda: collections.defaultdict(float))
+for r in last:
+    n=r['Kernel_Name'].split('(')[0].replace('void ','').replace('s3d::','')
+    perq[r.get('Queue_Id','?')][n]+=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
+for q,d in sorted(perq.items(), key=lambda x:-sum(x[1].values())):
+    top=sorted(d.items(), key=lambda x:-x[1])[:6]
+    print("queue %s: %.1f ms  "%(q, sum(d.values())/1e3)+", ".join("%s %.2f"%(a.split('<')[0]+('<'+a.split('<')[1] if '<' in a else ''),b/1e3) for a,b in top))
+PY
+python3 - "$f" <<'PY'
+# idle gaps of the busiest queue (the sharded stages' stream): what the GPU waits for between its kernels
+import csv,sys,collections
+rows=[r for r in csv.DictReader(open(sys.argv[1])) if 's3d::' in r['Kernel_Name']]
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+l0=[i for i,r in enumerate(rows) if 'k_march_level<2' in r['Kernel_Name']]
+last=rows[l0[len(l0)-len(l0)//3]:]
+cnt=collections.Counter(r.get('Queue_Id','?') for r in last)
+q=cnt.most_common(1)[0][0]
+qs=[r for r in last if r.get('Queue_Id','?')==q]
+gaps=[]
+for a,b in zip(qs,qs[1:]):
+    g=(int(b['Start_Timestamp'])-int(a['End_Timestamp']))/1e3
+    if g>40: gaps.append((g,a['Kernel_Name'].split('(')[0].replace('void s3d::','').replace('s3d::',''),b['Kernel_Name'].split('(')[0].replace('void s3d::','').replace('s3d::','')))
+print("queue %s: %d gaps > 40 us, %.2f ms in sum"%(q,len(gaps),sum(g for g,_,_ in gaps)/1e3))
+agg=collections.defaultdict(lambda:[0,0.0])
+for g,a,b in gaps: agg[(a,b)][0]+=1; agg[(a,b)][1]+=g
+for (a,b),(n,t) in sorted(agg.items(), key=lambda x:-x[1][1])[:12]: print("  %-28s -> %-28s %3d gaps %8.1f us"%(a,b,n,t))
 PY
