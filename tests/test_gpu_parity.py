@@ -76,6 +76,8 @@ def test_g4_g6_golden_keypoints(capi, synth, tag):
     ((96, 64, 32), 6, 0.01),        # nx = 32: ONE tile column (left and right edge in the same tile), two tile rows; edge fast path
     ((40, 32, 64), 8, 0.0),         # ny = 32: one tile row (top and bottom edge in the same tile), two tile columns
     ((33, 96, 96), 10, 0.01),       # 3 x 3 tiles: every edge class and an interior tile, odd depth
+    ((48, 40, 128), 31, 0.02),      # nx = 128: rows of whole ballot words -> k_mark's lean row loop, two words per row (r03)
+    ((20, 70, 192), 32, 0.3),       # nx = 192: three words per row (the loop behind the batches of eight), dense: candidates on every border
 ])
 def test_full_pipeline_vs_oracle(capi, orc, synth, shape, seed, noise):
     vol = synth.blobs(shape, seed=seed, noise=noise)
@@ -497,3 +499,30 @@ def test_free_functions_downsample_and_sub(capi, orc):
     g3, g10 = o.gss(0, 3), o.gss(1, 0)
     assert np.array_equal(capi.downsample(g3, g10.shape), g10)
     assert np.array_equal(capi.dog_sub(o.gss(0, 1), o.gss(0, 2)), o.dog(0, 1))
+
+
+@pytest.mark.gpu
+def test_matcher_awkward_sizes(capi, orc):
+    """The score kernel deals HALF tiles (128 rows x 64 columns) to a fixed number of workgroups and the merge kernel recomputes which
+    slots were written (r03): sizes around the tile edges -- one row, one column, 63 / 65 / 127 / 129 columns, more row blocks than
+    column tiles and the other way round, a set large enough that a workgroup's share crosses row blocks -- all outputs against the
+    oracle's matcher (Src/cMatcher.cc:146-228)."""
+    rng = np.random.Generator(np.random.PCG64(23))
+
+    def descs(n):
+        d = np.clip(rng.normal(0.02, 0.03, size=(n, 768)), 0, None).astype(np.float32)
+        d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-12)
+        return d.astype(np.float32)
+
+    mt = capi.muBruteMatcher()
+    for n, m in ((1, 1), (1, 200), (200, 1), (63, 65), (127, 129), (129, 127), (300, 64), (64, 300), (1500, 40), (40, 1500), (2100, 2300)):
+        a, b = descs(n), descs(m)
+        k = min(n, m) // 2
+        if k:
+            b[:k] = a[:k] + rng.normal(0, 0.004, size=(k, 768)).astype(np.float32)
+        ax = rng.uniform(0, 100, (n, 3)).astype(np.float32); bx = rng.uniform(0, 100, (m, 3)).astype(np.float32)
+        for mode in (1, 3):
+            got = mt._match(a, ax, b, bx, 0.85, mode)
+            want = orc.match(a, ax, b, bx, 0.85, mode)
+            for key in want:
+                assert np.array_equal(got[key], want[key]), (n, m, mode, key)
