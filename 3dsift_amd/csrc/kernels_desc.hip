@@ -635,6 +635,11 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			f2g edC = f2g{0.f, 0.f};
 			if (top || bot) edC = *reinterpret_cast<g2p>(c + e_off);  // the strip's outer row of plane z
 			int z = zA;
+#if S3D_DDIAG_V & 256
+			float bx0[2], by0[2], bz0[2];
+#pragma unroll
+			for (int k = 0; k < 2; k++) { bx0[k] = (px[k] + desc_hw) * bin_fctr - 0.5f; by0[k] = (py[k] + desc_hw) * bin_fctr - 0.5f; bz0[k] = (pz[k] + desc_hw) * bin_fctr - 0.5f; }
+#endif
 			for (int step = 0; step < maxlen; step++) {
 				// software pipeline: the row piece of plane z+2 and the y rows of plane z+1 are requested now; clamped addresses stay
 				// inside the planes zA-1 .. zB+1 of the window
@@ -656,6 +661,9 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 #if defined(S3D_EXP) && S3D_EXP == 21
 				st_acc[8]++;
 #endif
+#if S3D_DDIAG_V & 256
+				const float qxk = R2 * bin_fctr, qyk = R5 * bin_fctr, qzk = R8 * bin_fctr;
+#endif
 				const int dz = z - czi;
 				const int dz2 = __mul24(dz, dz);  // |dz| < 2^11 (full-rate 24-bit multiply; v_mul_lo_u32 issues at quarter rate)
 				const float vzd = (float)dz * u;
@@ -664,9 +672,13 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
 					const bool in = ((int)(step < zlen) & (int)((unsigned)(z - za[k]) <= (unsigned)(zb[k] - za[k]))) != 0;  // empty column: za = 2^28, zb = -2^28
+#if S3D_DDIAG_V & 256  // timing only: the cell coordinates as one fused multiply-add per axis from per-column constants
+					float bx = __fmaf_rn(vzd, qxk, bx0[k]), by = __fmaf_rn(vzd, qyk, by0[k]), bz = __fmaf_rn(vzd, qzk, bz0[k]);
+#else
 					float bx = px[k] + R2 * vzd, by = py[k] + R5 * vzd, bz = pz[k] + R8 * vzd;
 					bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
 					bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
+#endif
 					// inside the 4x4x4 cube: the reference's !(b <= -0.5 || b >= 3.5) per axis (Src/cSIFT3D.cc:1299-1303)
 					// (bitwise &: straight-line compares; && makes hipcc wrap each operand in an exec-mask branch)
 					const bool act = ((int)in & (int)(fminf(fminf(bx, by), bz) > -0.5f) & (int)(fmaxf(fmaxf(bx, by), bz) < 3.5f)) != 0;
