@@ -314,6 +314,9 @@ __device__ unsigned long long g_dstamp[64][4][10];
 // tiling of the circular footprint leaves 35-45 % of the lane-steps idle: rim tiles march their longest chord with most lanes
 // outside the sphere.  Measured at 512^3, k_describe: tiles 4.92 ms, sorted single pairs 4.71, 1x4 units 4.39, 2x4 units 4.26,
 // 2x2 / 4x2 4.32, 4x4 4.46, 1x8 4.50.)
+#ifndef S3D_DESC_WIDE_BELOW
+#define S3D_DESC_WIDE_BELOW 1400  /* runs with fewer keypoints than this take eight waves per keypoint (0: never); measured crossover between 1100 (0.49 vs 0.60 ms) and 1850 keypoints (0.75 vs 0.71) */
+#endif
 #ifndef S3D_DESC_UCAP
 #define S3D_DESC_UCAP 1024
 #endif
@@ -354,21 +357,34 @@ constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <=
 
 // LUT_LDS: the window's weight table is staged in LDS (default parameters: 1293 entries).  Larger windows (sigma_default well
 // above 1.6) read the table from global memory instead (L2-resident, a few KB): slower, but no size limit.
-template <bool LUT_LDS>
-__global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
+// NT threads per workgroup (= per keypoint): 256, or 512 for runs with few keypoints (r03: a keypoint's window is marched by ONE
+// workgroup, 0.1-0.4 ms for the large windows -- with fewer keypoints than a few per resident workgroup that latency is the
+// kernel's time: 0.53 ms for the 286 keypoints of a 128^3 volume, 0.45 ms for the 80 a rank gets of a sharded run's replicated tail;
+// eight waves halve it).  Both variants are launched; the one whose range [nkp_min, nkp_max) does not hold the keypoint count
+// returns at once (the count is only known on the device).  Results are bit-identical: the histograms are integer sums, and the
+// final normalisation always runs on the first 256 threads in the same order.
+template <bool LUT_LDS, int NT>
+__global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
                                                   const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap,
                                                   int part_rank, int part_world, const int *__restrict__ order,
-                                                  const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work, int dev_flags) {
+                                                  const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work, int dev_flags, unsigned nkp_min,
+                                                  unsigned nkp_max) {
+	constexpr int NW = NT / 64;
+	static_assert(NT == 256 || NT == 512, "k_describe: 4 or 8 waves per keypoint");
+	{
+		const unsigned n_all = min(d_nkp[0], kp_cap);
+		if (n_all < nkp_min || n_all >= nkp_max) return;  // the other variant's run
+	}
 	// d_work[0] = the work counter, d_work[1] = keypoints that took the second pass (sift3d_debug_counters)
 	// dev_flags (test hooks): bit 0 = recompute the chords (SIFT3D_HOOK_DESC_NOCACHE), bits 8.. = s of SIFT3D_HOOK_DESC_MASS_SHIFT
 	__shared__ unsigned s_item, s_tile;
 	__shared__ bin_t hist[kBins * kRep];  // [bin][replica], two's-complement fixed point, units of 1 / lut.fix_scale
 	__shared__ float s_lut[LUT_LDS ? kMaxDescLut : 1];
-	__shared__ float s_q[4][6][kQCap];                 // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
+	__shared__ float s_q[NW][6][kQCap];                 // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
 	__shared__ int4 s_sym[32];
 	__shared__ int s_fidx[kFaces * 4];
-	__shared__ float red[4];
+	__shared__ float red[NW];
 	__shared__ unsigned short s_units[kPairCap];  // the non-empty column pairs of the chunk, longest z range first
 	__shared__ unsigned s_chord[kPairCap];        // z ranges of a pair's two columns: (za0, zb0, za1, zb1) - z0, one byte each
 	__shared__ unsigned s_cnt[kLenBins];          // counting sort: pairs per length, then the running start of each length
@@ -397,7 +413,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		for (unsigned pos = blockIdx.x; pos < nkp; pos += gridDim.x)
 			if (pos % pw != pr) {
 				const size_t row = (size_t)kps[order[pos]].slot;
-				for (int i = tid; i < kDesc; i += 256) d_desc[row * kDesc + i] = 0.0f;
+				for (int i = tid; i < kDesc; i += NT) d_desc[row * kDesc + i] = 0.0f;
 			}
 	const unsigned nown = nkp > pr ? (nkp - pr + pw - 1) / pw : 0u;
 	for (;;) {
@@ -455,10 +471,10 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		for (int attempt = 0;; attempt++) {  // block-uniform; a second pass only when the first unit was too fine
 		float msum = 0.0f;  // this lane's share of the gradient mass
 		__syncthreads();  // previous keypoint / pass finished with hist / s_lut
-		for (int i = tid; i < kBins * kRep; i += 256) hist[i] = 0;
+		for (int i = tid; i < kBins * kRep; i += NT) hist[i] = 0;
 		if (tid == 0) s_tile = 0u;
 		if (LUT_LDS && cur_lut != li) {
-			for (int i = tid; i < lut.len && i < kMaxDescLut; i += 256) s_lut[i] = lutpool[lut.off + i];
+			for (int i = tid; i < lut.len && i < kMaxDescLut; i += NT) s_lut[i] = lutpool[lut.off + i];
 			cur_lut = li;
 		}
 		const gfloat_p lut_g = as_global(lutpool) + lut.off;
@@ -522,10 +538,10 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		for (int u0 = 0; u0 < nunits; u0 += kChunkUnits) {  // chunks of units in row-major order
 		const int nch = min(nunits - u0, kChunkUnits);
 		if (u0 > 0) __syncthreads();                         // previous chunk's march is done with s_units / s_tile
-		for (int i = tid; i < kLenBins; i += 256) s_cnt[i] = 0u;
+		for (int i = tid; i < kLenBins; i += NT) s_cnt[i] = 0u;
 		if (tid == 0) s_tile = 0u;
 		__syncthreads();
-		for (int ps = tid; ps < nch * kUL; ps += 256) {  // pair slot = unit * kUL + position in the unit: kUL consecutive lanes per unit
+		for (int ps = tid; ps < nch * kUL; ps += NT) {  // pair slot = unit * kUL + position in the unit: kUL consecutive lanes per unit
 			const int uu = ps / kUL, spos = ps % kUL;
 			const int uyi = (u0 + uu) / nux, uxi = (u0 + uu) - uyi * nux;
 			int rr[2], za[2], zb[2];
@@ -556,7 +572,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			if (lane == 63) s_nnz = incl - cb;  // key 0 comes last: everything before it is non-empty
 		}
 		__syncthreads();
-		for (int uu = tid; uu < nch; uu += 256) {
+		for (int uu = tid; uu < nch; uu += NT) {
 			int len;
 			if (chord_cached) {
 				int lo = 255, hi = 0;
@@ -740,7 +756,9 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 		__syncthreads();
 		if (lane == 0) red[wid] = msum;
 		__syncthreads();
-		const float mass = ((red[0] + red[1]) + (red[2] + red[3])) * 1.001f;
+		float mass_sum = (red[0] + red[1]) + (red[2] + red[3]);
+		if (NW == 8) mass_sum = mass_sum + ((red[4] + red[5]) + (red[6] + red[7]));
+		const float mass = mass_sum * 1.001f;
 		// every bin (and replica) sum is <= mass * fix_scale + half a unit per contribution (< 2^20 contributions)
 		// ... and a first guess far ABOVE the mass (a sharp structure inside the orientation window, a flat descriptor window: the
 		// zero background of CT / MR volumes) leaves a unit that much coarser than necessary: below 1/64 of the range the keypoint is
@@ -761,15 +779,29 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 
 		// normalise -> clamp -> normalise (Src/cSIFT3D.cc:1350-1358, 1639-1656)
 		const float trunc_thresh = (float)(0.2 * 128 / kDesc);
-		long long a0 = 0, a1 = 0, a2 = 0;
+		float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+		if (NT == 256) {
+			long long a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
-		for (int r = 0; r < kRep; r++) {
-			const int rr2 = (r + tid) % kRep;  // stagger the replica order across lanes
-			a0 += (long long)(sbin_t)hist[bin_index(tid) * kRep + rr2];
-			a1 += (long long)(sbin_t)hist[bin_index(tid + 256) * kRep + rr2];
-			a2 += (long long)(sbin_t)hist[bin_index(tid + 512) * kRep + rr2];
+			for (int r = 0; r < kRep; r++) {
+				const int rr2 = (r + tid) % kRep;  // stagger the replica order across lanes
+				a0 += (long long)(sbin_t)hist[bin_index(tid) * kRep + rr2];
+				a1 += (long long)(sbin_t)hist[bin_index(tid + 256) * kRep + rr2];
+				a2 += (long long)(sbin_t)hist[bin_index(tid + 512) * kRep + rr2];
+			}
+			v0 = (float)((double)a0 * fix_inv); v1 = (float)((double)a1 * fix_inv); v2 = (float)((double)a2 * fix_inv);
+		} else {
+			// every thread converts its bins (exact integer sums), the first 256 threads then normalise exactly like the 256-thread variant
+			float *vbuf = &s_q[0][0][0];  // (the queues are idle: every wave has drained)
+			for (int e = tid; e < kDesc; e += NT) {
+				long long a = 0;
+#pragma unroll
+				for (int r = 0; r < kRep; r++) a += (long long)(sbin_t)hist[bin_index(e) * kRep + (r + e) % kRep];
+				vbuf[e] = (float)((double)a * fix_inv);
+			}
+			__syncthreads();
+			if (tid < 256) { v0 = vbuf[tid]; v1 = vbuf[tid + 256]; v2 = vbuf[tid + 512]; }
 		}
-		float v0 = (float)((double)a0 * fix_inv), v1 = (float)((double)a1 * fix_inv), v2 = (float)((double)a2 * fix_inv);
 		for (int pass = 0; pass < 2; pass++) {
 			float s = v0 * v0 + v1 * v1 + v2 * v2;
 #pragma unroll
@@ -777,7 +809,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			__syncthreads();
 			if (lane == 0) red[wid] = s;
 			__syncthreads();
-			float norm = (red[0] + red[1]) + (red[2] + red[3]);
+			float norm = (red[0] + red[1]) + (red[2] + red[3]);  // (waves 0..3 hold the 768 elements in both variants)
 			norm = (float)((double)__fsqrt_rn(norm) + DBL_EPSILON);
 			const float inv = (float)(1.0 / (double)norm);
 			v0 = v0 * inv; v1 = v1 * inv; v2 = v2 * inv;
@@ -788,7 +820,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 			}
 		}
 		float *out = d_desc + (size_t)slot * kDesc;
-		out[tid] = v0; out[tid + 256] = v1; out[tid + 512] = v2;
+		if (tid < 256) { out[tid] = v0; out[tid + 256] = v1; out[tid + 512] = v2; }
 		S3D_DSTAMP(7)  // normalise + store
 #if defined(S3D_EXP) && S3D_EXP == 6
 		__syncthreads();
@@ -797,7 +829,7 @@ __global__ void __launch_bounds__(256) S3D_DESC_ATTR k_describe(const DevKp *__r
 	}
 #if defined(S3D_EXP) && S3D_EXP == 21
 	if (blockIdx.x < 64 && lane == 0)
-		for (int i = 0; i < 10; i++) g_dstamp[blockIdx.x][wid][i] = st_acc[i];
+		for (int i = 0; i < 10; i++) if (wid < 4) g_dstamp[blockIdx.x][wid][i] = st_acc[i];
 #endif
 }
 
@@ -835,12 +867,18 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
 	static const int desc_grid = dev_tune_i("S3D_DESC_GRID", 256 * 8);  // persistent workgroups (work counter)
 	static const unsigned dyn_lds = (unsigned)dev_tune_i("S3D_DESC_DYNLDS", 0);  // unused dynamic LDS per workgroup (occupancy experiments)
 	const int dev_flags = (hook(SIFT3D_HOOK_DESC_NOCACHE) ? 1 : 0) | (hook(SIFT3D_HOOK_DESC_MASS_SHIFT) & 63) << 8;
-	if (lut_in_lds)
-		hipLaunchKernelGGL(k_describe<true>, dim3(desc_grid), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-		                   part_rank, part_world, order, d_nkp, d_work, dev_flags);
-	else
-		hipLaunchKernelGGL(k_describe<false>, dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-		                   part_rank, part_world, order, d_nkp, d_work, dev_flags);
+	// few keypoints: eight waves per keypoint (see k_describe); the count lives on the device, so both variants are launched
+	const unsigned wide_below = (unsigned)S3D_DESC_WIDE_BELOW;
+	if (lut_in_lds) {
+		hipLaunchKernelGGL((k_describe<true, 256>), dim3(desc_grid), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
+		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, wide_below, 0xFFFFFFFFu);
+		if (wide_below > 0)
+			hipLaunchKernelGGL((k_describe<true, 512>), dim3(256 * 2), dim3(512), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
+			                   part_rank, part_world, order, d_nkp, d_work, dev_flags, 0u, wide_below);
+	} else {
+		hipLaunchKernelGGL((k_describe<false, 256>), dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
+		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, 0u, 0xFFFFFFFFu);
+	}
 #if defined(S3D_EXP) && S3D_EXP == 21
 	{
 		hipStreamSynchronize(st);
