@@ -198,6 +198,7 @@ struct sift3d_ctx {
 	std::vector<hipEvent_t> ev_seed, ev_done;
 	hipEvent_t ev_fork = nullptr;
 	unsigned *d_words = nullptr;  // [0] input max bits, [1..] per-DoG-level max bits, then counters
+	unsigned *h_words = nullptr;  // pinned: the five counters a run reads back (a pageable destination makes the copy a staged, synchronous one)
 	unsigned *d_inmax = nullptr, *d_dogmax = nullptr, *d_total = nullptr, *d_nkp = nullptr;
 	DetectBufs det{};
 	size_t det_blocks = 0;
@@ -323,6 +324,7 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	free_lists(c);
 	if (!c->ext_arena) hipFree(c->arena);
 	hipFree(c->d_words);
+	if (c->h_words) (void)hipHostFree(c->h_words);
 	hipFree(c->det.masks); hipFree(c->det.block_counts); hipFree(c->det.block_offsets);
 	hipFree(c->d_masks2); hipFree(c->d_counts2); hipFree(c->d_offsets2);
 	if (c->ev_det_fork) hipEventDestroy(c->ev_det_fork);
@@ -549,6 +551,7 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	const size_t nwords = 1 + (size_t)std::max(1, c->noct * c->nd) + 8;  // ... + total, overflow, nkp, describe work counter, describe redo counter, orientation redo counter
 	CHECKED(hipMalloc(&c->d_words, sizeof(unsigned) * nwords));
 	CHECKED(hipMemset(c->d_words, 0, sizeof(unsigned) * nwords));
+	CHECKED(hipHostMalloc(&c->h_words, sizeof(unsigned) * 8, hipHostMallocDefault));
 	c->d_inmax = c->d_words;
 	c->d_dogmax = c->d_words + 1;
 	c->d_total = c->d_words + 1 + std::max(1, c->noct * c->nd);  // [0] extrema total, [1] overflow flag
@@ -840,7 +843,7 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		}
 		if (upto >= 4) launch_finalize(c->d_ext, c->d_total, c->ext_cap, upto >= 5, c->d_kpout, c->d_xyz, c->kp_cap, st);
 		S3D_HIP(hipEventRecord(c->ev[5], st));
-		unsigned host_words[5] = {0, 0, 0, 0, 0};  // total, overflow, nkp, describe work counter, describe second passes
+		unsigned *host_words = c->h_words;  // total, overflow, nkp, describe work counter, describe second passes
 		S3D_HIP(hipMemcpyAsync(host_words, c->d_total, sizeof(unsigned) * 5, hipMemcpyDeviceToHost, st));
 		S3D_HIP(hipStreamSynchronize(st));
 		S3D_HIP(hipGetLastError());
