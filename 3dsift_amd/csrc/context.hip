@@ -198,6 +198,7 @@ struct sift3d_ctx {
 	std::vector<hipEvent_t> ev_seed, ev_done;
 	hipEvent_t ev_fork = nullptr;
 	unsigned *d_words = nullptr;  // [0] input max bits, [1..] per-DoG-level max bits, then counters
+	unsigned *d_slots_part = nullptr;  // scratch of launch_slots (per-wave totals)
 	unsigned *h_words = nullptr;  // pinned: the five counters a run reads back (a pageable destination makes the copy a staged, synchronous one)
 	unsigned *d_inmax = nullptr, *d_dogmax = nullptr, *d_total = nullptr, *d_nkp = nullptr;
 	DetectBufs det{};
@@ -325,6 +326,7 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	if (!c->ext_arena) hipFree(c->arena);
 	hipFree(c->d_words);
 	if (c->h_words) (void)hipHostFree(c->h_words);
+	hipFree(c->d_slots_part);
 	hipFree(c->det.masks); hipFree(c->det.block_counts); hipFree(c->det.block_offsets);
 	hipFree(c->d_masks2); hipFree(c->d_counts2); hipFree(c->d_offsets2);
 	if (c->ev_det_fork) hipEventDestroy(c->ev_det_fork);
@@ -552,6 +554,7 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	CHECKED(hipMalloc(&c->d_words, sizeof(unsigned) * nwords));
 	CHECKED(hipMemset(c->d_words, 0, sizeof(unsigned) * nwords));
 	CHECKED(hipHostMalloc(&c->h_words, sizeof(unsigned) * 8, hipHostMallocDefault));
+	CHECKED(hipMalloc(&c->d_slots_part, sizeof(unsigned) * slots_scratch_words()));
 	c->d_inmax = c->d_words;
 	c->d_dogmax = c->d_words + 1;
 	c->d_total = c->d_words + 1 + std::max(1, c->noct * c->nd);  // [0] extrema total, [1] overflow flag
@@ -833,7 +836,7 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		if (upto >= 4) {
 			launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
 			              c->p.corner_thresh, part_orient ? c->part_rank : 0, part_orient ? c->part_world : 1, c->d_order, c->d_nkp + 3, st);
-			launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, st);
+			launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, c->d_slots_part, st);
 		}
 		S3D_HIP(hipEventRecord(c->ev[4], st));
 		// ---- Extract_Description (Src/cSIFT3D.cc:484-502) ----
@@ -1264,7 +1267,7 @@ extern "C" int sift3d_run_describe(sift3d_handle c) {
 	if (rc) return rc;
 	hipStream_t st = c->stream;
 	S3D_HIP(hipEventRecord(c->ev[6], st));
-	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, st);
+	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, c->d_slots_part, st);
 	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, c->part_rank,
 	                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st, c->desc_lut_lds);
 	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
@@ -1563,7 +1566,7 @@ extern "C" int sift3d_slab_describe(sift3d_handle c) {
 	hipStream_t st = c->stream;
 	launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
 	              c->p.corner_thresh, 0, 1, c->d_order, c->d_nkp + 3, st);
-	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, st);
+	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, c->d_slots_part, st);
 	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, 0, 1, c->d_order, c->d_nkp,
 	                c->d_nkp + 1, st, c->desc_lut_lds);
 	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);

@@ -527,31 +527,33 @@ void launch_orient_unpack(DevKp *kps, int *codes, const unsigned *d_count, unsig
 	hipLaunchKernelGGL(k_orient_unpack, dim3(1024), dim3(256), 0, st, kps, codes, d_count, cap, src);
 }
 
-// order-preserving compaction index: slot = exclusive scan of (code == 1); one workgroup.
-__global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const int *__restrict__ codes,
-                                                const unsigned *__restrict__ d_count, unsigned cap, unsigned *__restrict__ d_nkp,
-                                                int *__restrict__ order, unsigned kp_cap) {
-	// slot  = exclusive scan of (code == 1) in list order: the keypoint's row in the results (reference order)
-	// order = the accepted extrema sorted by keypoint level DESCENDING (stable): the descriptor window volume grows 4x
-	//         from level 1 to level 3, and handing out the big ones first (longest processing time first) keeps the
-	//         tail of the descriptor kernel short.  Deterministic (ballot ranks, no atomics), so every rank of a
-	//         partitioned run derives the same list.
-	// One workgroup; wave w owns the contiguous range [w*per, (w+1)*per) and walks it 64 entries at a time (coalesced),
-	// ranks inside a row of 64 come from ballots.
-	constexpr int kL = 6;  // levels 0..5 (kMaxKpLevels = 5); key kL = all accepted
-	__shared__ unsigned s_wave[16][kL + 1];
-	__shared__ unsigned s_base[kL];
+// order-preserving compaction index of the accepted extrema, two launches over 256 waves (r03: one 1024-thread workgroup walked the
+// whole list twice, 60 us at 512^3):
+//   slot  = exclusive scan of (code == 1) in list order: the keypoint's row in the results (reference order)
+//   order = the accepted extrema sorted by keypoint level DESCENDING (stable): the descriptor window volume grows 4x
+//           from level 1 to level 3, and handing out the big ones first (longest processing time first) keeps the
+//           tail of the descriptor kernel short.  Deterministic (ballot ranks, no atomics), so every rank of a
+//           partitioned run derives the same list.
+// Wave g of the 256 owns the contiguous range [g * per, (g + 1) * per) and walks it 64 entries at a time (coalesced); k_slots_count
+// leaves its totals per key (levels 0..5, key 6 = all accepted) in part[g][], k_slots_write turns them into the wave's start
+// positions and writes.  codes[] carries (level << 4) | 1 for accepted extrema, the reject code (< 0) or 0 otherwise.
+constexpr int kSlotL = 6;  // levels 0..5 (kMaxKpLevels = 5); key kSlotL = all accepted
+constexpr int kSlotBlocks = 64, kSlotWaves = kSlotBlocks * 4;
+__device__ __forceinline__ void slot_range(unsigned count, unsigned g, unsigned &lo, unsigned &hi) {
+	const unsigned per = ((count + kSlotWaves - 1) / kSlotWaves + 63u) & ~63u;  // per-wave range, multiple of 64
+	lo = min(g * per, count); hi = min(lo + per, count);
+}
+__global__ void __launch_bounds__(256) k_slots_count(const int *__restrict__ codes, const unsigned *__restrict__ d_count, unsigned cap,
+                                                     unsigned *__restrict__ part /* [kSlotWaves][kSlotL + 1] */) {
 	const unsigned count = min(d_count[0], cap);
-	const unsigned t = threadIdx.x;
-	const int lane = t & 63, wid = t >> 6;
-	const unsigned per = ((count + 15u) / 16u + 63u) & ~63u;  // per-wave range, multiple of 64
-	const unsigned lo = min((unsigned)wid * per, count), hi = min(lo + per, count);
-	const unsigned long long lt = (1ull << lane) - 1ull;
-	unsigned tot[kL + 1];
+	const int lane = threadIdx.x & 63;
+	const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6);
+	unsigned lo, hi;
+	slot_range(count, g, lo, hi);
+	unsigned tot[kSlotL + 1];
 #pragma unroll
-	for (int l = 0; l <= kL; l++) tot[l] = 0;
-	// codes[] carries (level << 4) | 1 for accepted extrema, the reject code (< 0) or 0 otherwise: one dense array to read
-	constexpr int kU = 8;  // rows of 64 requested together (the loop is a chain of dependent loads otherwise)
+	for (int l = 0; l <= kSlotL; l++) tot[l] = 0;
+	constexpr int kU = 4;  // rows of 64 requested together
 	for (unsigned i0 = lo; i0 < hi; i0 += 64 * kU) {
 		int c[kU];
 #pragma unroll
@@ -559,32 +561,49 @@ __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const i
 #pragma unroll
 		for (int q = 0; q < kU; q++) {
 			const bool acc = c[q] > 0 && (c[q] & 15) == 1;
-			const int lv = acc ? min(c[q] >> 4, kL - 1) : -1;
+			const int lv = acc ? min(c[q] >> 4, kSlotL - 1) : -1;
 #pragma unroll
-			for (int l = 0; l < kL; l++) tot[l] += (unsigned)__popcll(__ballot(lv == l));
-			tot[kL] += (unsigned)__popcll(__ballot(acc));
+			for (int l = 0; l < kSlotL; l++) tot[l] += (unsigned)__popcll(__ballot(lv == l));
+			tot[kSlotL] += (unsigned)__popcll(__ballot(acc));
 		}
 	}
 	if (lane == 0)
 #pragma unroll
-		for (int l = 0; l <= kL; l++) s_wave[wid][l] = tot[l];
-	__syncthreads();
-	if (t <= kL) {
-		unsigned a = 0;
-		for (int w = 0; w < 16; w++) { unsigned c = s_wave[w][t]; s_wave[w][t] = a; a += c; }
-		if (t < kL) s_base[t] = a;  // total of level t (turned into the start position below)
-		else d_nkp[0] = a;
-	}
-	__syncthreads();
-	if (t == 0) {
-		unsigned a = 0;
-		for (int l = kL - 1; l >= 0; l--) { unsigned c = s_base[l]; s_base[l] = a; a += c; }  // higher levels first
-	}
-	__syncthreads();
-	unsigned run[kL + 1];
+		for (int l = 0; l <= kSlotL; l++) part[g * (kSlotL + 1) + l] = tot[l];
+}
+__global__ void __launch_bounds__(256) k_slots_write(DevKp *__restrict__ kps, const int *__restrict__ codes, const unsigned *__restrict__ d_count,
+                                                     unsigned cap, const unsigned *__restrict__ part, unsigned *__restrict__ d_nkp,
+                                                     int *__restrict__ order, unsigned kp_cap) {
+	const unsigned count = min(d_count[0], cap);
+	const int lane = threadIdx.x & 63;
+	const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6);
+	unsigned lo, hi;
+	slot_range(count, g, lo, hi);
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	// per key: the entries of the waves before this one, and of all waves (every wave sums the 256 x 7 table for itself)
+	unsigned before[kSlotL + 1], all[kSlotL + 1];
 #pragma unroll
-	for (int l = 0; l < kL; l++) run[l] = s_base[l] + s_wave[wid][l];
-	run[kL] = s_wave[wid][kL];
+	for (int l = 0; l <= kSlotL; l++) {
+		unsigned b = 0, a = 0;
+#pragma unroll
+		for (int q = 0; q < kSlotWaves / 64; q++) {
+			const unsigned w = (unsigned)(q * 64 + lane), v = part[w * (kSlotL + 1) + l];
+			a += v;
+			b += w < g ? v : 0u;
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+		before[l] = b; all[l] = a;
+	}
+	if (g == 0 && lane == 0) d_nkp[0] = all[kSlotL];
+	unsigned run[kSlotL + 1];
+	{
+		unsigned start = 0;  // higher levels first
+#pragma unroll
+		for (int l = kSlotL - 1; l >= 0; l--) { run[l] = start + before[l]; start += all[l]; }
+		run[kSlotL] = before[kSlotL];
+	}
+	constexpr int kU = 4;
 	for (unsigned i0 = lo; i0 < hi; i0 += 64 * kU) {
 		int c[kU];
 #pragma unroll
@@ -593,10 +612,10 @@ __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const i
 		for (int q = 0; q < kU; q++) {
 			const unsigned i = i0 + 64 * q + lane;
 			const bool acc = c[q] > 0 && (c[q] & 15) == 1;
-			const int lv = acc ? min(c[q] >> 4, kL - 1) : -1;
+			const int lv = acc ? min(c[q] >> 4, kSlotL - 1) : -1;
 			unsigned pos = 0;
 #pragma unroll
-			for (int l = 0; l < kL; l++) {
+			for (int l = 0; l < kSlotL; l++) {
 				const unsigned long long m = __ballot(lv == l);
 				if (lv == l) pos = run[l] + (unsigned)__popcll(m & lt);
 				run[l] += (unsigned)__popcll(m);
@@ -604,16 +623,18 @@ __global__ void __launch_bounds__(1024) k_slots(DevKp *__restrict__ kps, const i
 			const unsigned long long ma = __ballot(acc);
 			if (acc) {
 				if (pos < kp_cap) order[pos] = (int)i;
-				kps[i].slot = (int)(run[kL] + (unsigned)__popcll(ma & lt));
+				kps[i].slot = (int)(run[kSlotL] + (unsigned)__popcll(ma & lt));
 			} else if (i < hi) kps[i].slot = -1;
-			run[kL] += (unsigned)__popcll(ma);
+			run[kSlotL] += (unsigned)__popcll(ma);
 		}
 	}
 }
 
+size_t slots_scratch_words() { return (size_t)kSlotWaves * (kSlotL + 1); }
 void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigned cap, unsigned *d_nkp, int *order, unsigned kp_cap,
-                  hipStream_t st) {
-	hipLaunchKernelGGL(k_slots, dim3(1), dim3(1024), 0, st, kps, codes, d_count, cap, d_nkp, order, kp_cap);
+                  unsigned *scratch, hipStream_t st) {
+	hipLaunchKernelGGL(k_slots_count, dim3(kSlotBlocks), dim3(256), 0, st, codes, d_count, cap, scratch);
+	hipLaunchKernelGGL(k_slots_write, dim3(kSlotBlocks), dim3(256), 0, st, kps, codes, d_count, cap, scratch, d_nkp, order, kp_cap);
 }
 
 }  // namespace s3d

@@ -202,8 +202,9 @@ constexpr int kOrientWords = 34;  // code + win[3] + eigvalue[3] + eigvector[9] 
 void launch_orient_pack(const DevKp *kps, const unsigned *d_count, unsigned cap, int *dst, int part_rank, int part_world, hipStream_t st);
 void launch_orient_unpack(DevKp *kps, int *codes, const unsigned *d_count, unsigned cap, const int *src, hipStream_t st);
 // slot = order-preserving index among the accepted keypoints; order[slot] = extremum index
+size_t slots_scratch_words();  // unsigned words of per-context scratch launch_slots needs
 void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigned cap, unsigned *d_nkp, int *order, unsigned kp_cap,
-                  hipStream_t st);
+                  unsigned *scratch, hipStream_t st);
 
 // ---- kernels_desc.hip ----------------------------------------------------------------------
 hipError_t upload_faces(const FaceConst *faces, const FaceSym *sym);  // into the current device's __constant__ memory
