@@ -225,13 +225,16 @@ __global__ void __launch_bounds__(256) k_orient(DevKp *__restrict__ kps, int *__
 			vx = vx * inv_u; vy = vy * inv_u; vz = vz * inv_u;
 			if (!EXACT) {
 				if (ok) {
-					t00 = t00 + vx * vx * ww;
-					t01 = t01 + vx * vy * ww;
-					t02 = t02 + vx * vz * ww;
-					t11 = t11 + vy * vy * ww;
-					t12 = t12 + vy * vz * ww;
-					t22 = t22 + vz * vz * ww;
-					g0 = g0 + vx * ww; g1 = g1 + vy * ww; g2 = g2 + vz * ww;
+					// the parallel sums only SCREEN (k_orient_finish flags everything within 100x their error of a threshold and the
+					// flagged extrema are redone in the reference's order and arithmetic): fused multiply-adds on pre-weighted components
+					const float wx = vx * ww, wy = vy * ww, wz = vz * ww;
+					t00 = __fmaf_rn(vx, wx, t00);
+					t01 = __fmaf_rn(vx, wy, t01);
+					t02 = __fmaf_rn(vx, wz, t02);
+					t11 = __fmaf_rn(vy, wy, t11);
+					t12 = __fmaf_rn(vy, wz, t12);
+					t22 = __fmaf_rn(vz, wz, t22);
+					g0 = g0 + wx; g1 = g1 + wy; g2 = g2 + wz;
 				}
 			} else {
 				tb[0 * kTermPitch + lane] = ok ? vx * vx * ww : 0.0f;
