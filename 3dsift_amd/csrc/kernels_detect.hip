@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	const unsigned long long lt = (1ull << lane) - 1ull;
 	const size_t plane0 = sz * (size_t)z + sy * (size_t)y0;
 	int qn = 0;  // wave-uniform
-	const bool lean = S3D_DET_LEAN && (nx & 63) == 0;  // rows of whole ballot words take the lean row loop (below)
+	const bool lean = S3D_DET_LEAN != 0;  // the lean row loop (below); S3D_DET_LEAN=0 builds keep the generic one for A/B runs
 	// evaluate `n` queued candidates starting at entry `first` (n <= 64)
 	auto evaluate = [&](int first, int n, int seg0) {
 		if (S3D_DETDIAG & 1) {  // no gathers: the queue entry alone decides (keeps the queue traffic alive)
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 	// rows wider than 64 ballot words (nx > 4096) are handled in segments of 64 words: the local mask copy holds one segment
 	for (int seg0 = 0; seg0 < wpr; seg0 += 64) {
 		const int seg1 = min(wpr, seg0 + 64);
-		// r03 -- the lean row loop (rows of whole ballot words).  Timing-only builds showed the kernel bound by INSTRUCTION ISSUE, not by
+		// r03 -- the lean row loop.  Timing-only builds showed the kernel bound by INSTRUCTION ISSUE, not by
 		// memory: with nothing queued and no gather it still took 0.48 of its 0.52 ms at 512^3, ~25 vector + ~26 scalar instructions per
 		// 64 voxels (per-lane border predicates, clamped 64-bit addresses, two threshold compares, queue bookkeeping).  Here a word
 		// costs three loads (uniform row pointer + lane offset + immediate: the row below, and the row itself shifted by one voxel
@@ -175,27 +175,32 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 				}
 				qn += (int)__popcll(m);
 			};
-			int w0 = 0;
-			for (; w0 + kBatch <= nws && ry_a < ry_b; w0 += kBatch) {
+			// any row width: the word index of a batch is clamped to the row's last word and the lane offset to its last voxel (the
+			// lanes / words beyond repeat it; words beyond the row are not scanned, lanes beyond it are dropped by evaluate())
+			const unsigned omax = (unsigned)(nx - 1 - seg0 * 64);
+			for (int w0 = 0; w0 < nws && ry_a < ry_b; w0 += kBatch) {
+				unsigned off[kBatch];
+#pragma unroll
+				for (int bb = 0; bb < kBatch; bb++) off[bb] = min((unsigned)(min(w0 + bb, nws - 1) * 64 + lane), omax);
 				float up[kBatch], mid[kBatch];
 				{
 					const float *ra = pl + sy * (size_t)(y0 + ry_a - 1), *rb = ra + sy;
 #pragma unroll
-					for (int bb = 0; bb < kBatch; bb++) { up[bb] = ra[(unsigned)((w0 + bb) * 64 + lane)]; mid[bb] = rb[(unsigned)((w0 + bb) * 64 + lane)]; }
+					for (int bb = 0; bb < kBatch; bb++) { up[bb] = ra[off[bb]]; mid[bb] = rb[off[bb]]; }
 				}
 				for (int ry = ry_a; ry < ry_b; ry++) {
 					const float *rm = pl + sy * (size_t)(y0 + ry), *rd = rm + sy;
 					float dn[kBatch], xl[kBatch], xr[kBatch];
 #pragma unroll
 					for (int bb = 0; bb < kBatch; bb++) {
-						const unsigned o = (unsigned)((w0 + bb) * 64 + lane);
-						dn[bb] = rd[o];
+						dn[bb] = rd[off[bb]];
 						// (x - 1 of the row's first voxel / x + 1 of its last: the neighbouring rows' ends, in bounds, and evaluate() drops both voxels)
-						xl[bb] = (rm - 1)[o]; xr[bb] = (rm + 1)[o];
+						xl[bb] = (rm - 1)[off[bb]]; xr[bb] = (rm + 1)[off[bb]];
 					}
 					const unsigned idrow = (unsigned)((ry - r_lo) << 12);
 #pragma unroll
-					for (int bb = 0; bb < kBatch; bb++) word(mid[bb], up[bb], dn[bb], xl[bb], xr[bb], w0 + bb, idrow);
+					for (int bb = 0; bb < kBatch; bb++)
+						if (w0 + bb < nws) word(mid[bb], up[bb], dn[bb], xl[bb], xr[bb], w0 + bb, idrow);  // wave-uniform
 					while (qn >= 64) {  // entries are consumed from the END so the front stays in place
 						qn -= 64;
 						evaluate(qn, 64, seg0);
@@ -204,13 +209,6 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 					for (int bb = 0; bb < kBatch; bb++) { up[bb] = mid[bb]; mid[bb] = dn[bb]; }
 				}
 			}
-			for (; w0 < nws; w0++)  // rows whose word count is not a multiple of the batch
-				for (int ry = ry_a; ry < ry_b; ry++) {
-					const float *rm = pl + sy * (size_t)(y0 + ry);
-					const unsigned o = (unsigned)(w0 * 64 + lane);
-					word(rm[o], (rm - sy)[o], (rm + sy)[o], (rm - 1)[o], (rm + 1)[o], w0, (unsigned)((ry - r_lo) << 12));
-					if (qn >= 64) { qn -= 64; evaluate(qn, 64, seg0); }
-				}
 		}
 		for (int ry = r_lo; !lean && ry < r_hi; ry++) {
 			const int y = y0 + ry;
