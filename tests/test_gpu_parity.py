@@ -78,6 +78,8 @@ def test_g4_g6_golden_keypoints(capi, synth, tag):
     ((33, 96, 96), 10, 0.01),       # 3 x 3 tiles: every edge class and an interior tile, odd depth
     ((48, 40, 128), 31, 0.02),      # nx = 128: rows of whole ballot words -> k_mark's lean row loop, two words per row (r03)
     ((20, 70, 192), 32, 0.3),       # nx = 192: three words per row (the loop behind the batches of eight), dense: candidates on every border
+    ((45, 51, 64), 33, 0.02),       # nx % 4 == 0 with odd ny and nz: the decimation fused into the seed level's kernel drops the odd last row / plane
+    ((36, 40, 300), 34, 0.1),       # nx = 300: a partial last ballot word in the lean row loop (clamped lane offsets)
 ])
 def test_full_pipeline_vs_oracle(capi, orc, synth, shape, seed, noise):
     vol = synth.blobs(shape, seed=seed, noise=noise)
