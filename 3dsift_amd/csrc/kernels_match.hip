@@ -5,8 +5,10 @@
 // each ref row i the best and second-best DOT PRODUCT over all target rows j (strict '>', ties keep
 // the lower j, both start at FLT_MIN), reported as d = 2 - 2*dot.  The reference accumulates fp32
 // products in fp64; an fp32 MFMA chain cannot reproduce that bit-for-bit, so the work is split:
-//   k_scores_topk : S = A * B^T with v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), fused running
-//                   top-4 per row ordered by (score desc, j asc) -- candidate SELECTION only
+//   k_scores_topk2: S = A * B^T with v_mfma_f32_32x32x2_f32 (exact fp32 fma chain), fused running
+//                   top-K per row ordered by (score desc, j asc) -- candidate SELECTION only.  (r03: the second form of the kernel,
+//                   A straight into registers / B by LDS-DMA / three workgroups per CU; k_scores_top4<DMA> is the r02 form, kept for
+//                   A/B builds -DS3D_MATCH_V2=0, k_scores_top4<false> the register-staged one for matrices of 4 GB and more)
 //   k_rescore     : the 4 candidates of each row are re-scored exactly like the reference
 //                   (fp32 product, fp64 accumulate, k ascending) and the reference's update rule is
 //                   replayed over them in ascending j -- bit-identical d1, d2, i1, i2 as long as the
@@ -380,10 +382,7 @@ __global__ void __launch_bounds__(256, S3D_MATCH_V2_OCC) k_scores_topk2(const fl
 						__builtin_amdgcn_sched_barrier(0);  // (hipcc sinks these reads behind the last MFMAs of the group otherwise)
 					}
 					// in flight behind piece q: the other three pieces (or their refreshes) and the four DMA instructions of this chunk
-					if (!(S3D_XDIAG & 4)) {
-						if (q == 0) x_wait_piece<7>(a[0]);
-						else x_wait_piece<7>(a[q]);
-					}
+					if (!(S3D_XDIAG & 4)) x_wait_piece<7>(a[q]);
 #pragma unroll
 					for (int e = 0; e < 4; e++)
 #pragma unroll
