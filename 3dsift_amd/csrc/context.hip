@@ -1363,8 +1363,9 @@ extern "C" int sift3d_slab_upload(sift3d_handle c, const float *planes, int zg0,
 	int rc = set_device(c->device);
 	if (rc) return rc;
 	const size_t pl = (size_t)c->nx * c->ny;
-	S3D_HIP(hipMemcpyAsync(c->in.d + pl * (size_t)(zg0 - c->in.zoff), planes, sizeof(float) * pl * (size_t)(zg1 - zg0),
-	                       on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+	float *dst = c->in.d + pl * (size_t)(zg0 - c->in.zoff);
+	if (on_device) S3D_HIP(hipMemcpyAsync(dst, planes, sizeof(float) * pl * (size_t)(zg1 - zg0), hipMemcpyDeviceToDevice, c->stream));
+	else if ((rc = staged_h2d(dst, planes, sizeof(float) * pl * (size_t)(zg1 - zg0), c->device, c->stream)) != SIFT3D_OK) return rc;  // pageable host planes: pinned staging (r04)
 	S3D_HIP(hipStreamSynchronize(c->stream));
 	return SIFT3D_OK;
 }

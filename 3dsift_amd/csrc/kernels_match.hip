@@ -732,14 +732,14 @@ struct MatchState {
 constexpr int kMaxDev = 64;
 MatchState g_match[kMaxDev];
 thread_local double t_match_dev = 0.0, t_match_wall = 0.0;
-int g_match_redo_rows = 0;  // rows re-scored exactly by the last call (sift3d_debug_counters)
+thread_local int t_match_redo_rows = 0;  // rows re-scored exactly by the calling thread's last call (sift3d_debug_counters)
 
 int ensure(MatchState &S, size_t d_bytes, size_t ab_floats, size_t h_bytes) {
-	if (!S.ready) {
-		S3D_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-		S3D_HIP(hipEventCreate(&S.e0));
-		S3D_HIP(hipEventCreate(&S.e1));
-		S3D_HIP(hipEventCreateWithFlags(&S.e_in, hipEventDisableTiming));
+	if (!S.ready) {  // (a failed creation leaves the objects made so far in place: the next call goes on from there)
+		if (!S.stream) S3D_HIP(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+		if (!S.e0) S3D_HIP(hipEventCreate(&S.e0));
+		if (!S.e1) S3D_HIP(hipEventCreate(&S.e1));
+		if (!S.e_in) S3D_HIP(hipEventCreateWithFlags(&S.e_in, hipEventDisableTiming));
 		S.ready = true;
 	}
 	auto grow = [](size_t want) { return want + want / 4 + 4096; };  // head room: sets of similar size do not reallocate
@@ -768,7 +768,7 @@ int ensure(MatchState &S, size_t d_bytes, size_t ab_floats, size_t h_bytes) {
 size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 }  // namespace
 
-namespace s3d { int match_redo_rows() { return g_match_redo_rows; } }
+namespace s3d { int match_redo_rows() { return t_match_redo_rows; } }
 
 extern "C" int sift3d_match_times(double *device_seconds, double *wall_seconds) {
 	if (device_seconds) *device_seconds = t_match_dev;
@@ -911,7 +911,7 @@ extern "C" int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, 
 		}
 	}
 #undef MCHK
-	g_match_redo_rows = redo_rows;
+	t_match_redo_rows = redo_rows;
 	t_match_wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
 	return SIFT3D_OK;
 }

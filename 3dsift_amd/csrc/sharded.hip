@@ -19,6 +19,10 @@
 //          issued in the same order on every rank, and the three flows run concurrently), point-to-point ncclSend / ncclRecv between
 //          z-neighbours over xGMI inside ncclGroupStart / End, on the rank's own streams: no host synchronisation between the
 //          levels.  librccl is opened at run time (dlopen), so the library loads on hosts without it.
+//          Failure protocol (r04): the first rank (or tail thread) whose step fails aborts EVERY communicator of the handle
+//          (ncclCommAbort), so that z-neighbours blocked in a receive / reduction kernel return instead of wedging the process; the
+//          handle is then dead -- sift3d_sharded_run returns an error from now on, the caller destroys it and, if it wants to go on,
+//          starts a fresh process (nothing is restarted in place).
 //   SIM    all ranks in this process on ONE GPU and one stream: sends are device copies, reductions go through the host.  This is
 //          how the 1-GPU test boxes check the driver (same code, same plan) against the single-volume result.
 //
@@ -29,9 +33,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <vector>
 
@@ -178,6 +184,11 @@ struct sift3d_sharded {
 	std::vector<float> desc;
 	double times[4] = {0, 0, 0, 0};
 	std::string err;
+	// failure protocol of the RCCL transport: `failed` is set once, by the first rank whose step failed, which then aborts every
+	// communicator.  Ranks hold comm_mu shared while they ISSUE RCCL calls (short, host side) and the aborter takes it exclusively,
+	// so that no thread is inside a call on a communicator while it is torn down.
+	std::atomic<bool> failed{false};
+	std::shared_timed_mutex comm_mu;
 };
 
 namespace {
@@ -185,6 +196,19 @@ namespace {
 #define SH_HIP(w, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (w).err = std::string(#call) + ": " + hipGetErrorString(e_); return SIFT3D_ERR_HIP; } } while (0)
 #define SH_ABI(w, call) do { int r_ = (call); if (r_ != SIFT3D_OK) { (w).err = std::string(#call) + ": " + sift3d_error_string(r_) + " (" + sift3d_last_error() + ")"; return r_; } } while (0)
 #define SH_NCCL(w, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { (w).err = std::string(#call) + ": " + g_rccl.GetErrorString(r_); return SIFT3D_ERR_HIP; } } while (0)
+
+// The first failing rank: mark the handle dead and abort every communicator so that no peer stays blocked in a receive, a
+// reduction or a broadcast whose partner will never arrive.  The exclusive lock is awaited for a bounded time only: a peer stuck
+// INSIDE a call (connection set-up waiting for the rank that failed) holds it shared, and aborting under it is what frees that peer.
+void abort_all(sift3d_sharded *H) {
+	if (H->sim || H->failed.exchange(true)) return;
+	const bool locked = H->comm_mu.try_lock_for(std::chrono::seconds(2));
+	for (Worker &w : H->workers)
+		for (ncclComm_t *c : {&w.c_urgent, &w.c_deferred, &w.c_tail})
+			if (*c) { (void)g_rccl.CommAbort(*c); *c = nullptr; }
+	if (locked) H->comm_mu.unlock();
+}
+#define SH_LIVE(H, w) do { if ((H)->failed.load()) { if ((w).err.empty()) (w).err = "aborted: another rank failed"; return SIFT3D_ERR_STATE; } } while (0)
 
 // posts the transfers this set of local workers takes part in.  SIM: device copies on the shared stream.  RCCL: one group of
 // sends / receives of the one local rank on `comm` / `stream` of the given flow (0 urgent, 1 deferred).
@@ -206,6 +230,9 @@ int exchange(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<Tra
 	bool any = false;
 	for (const Transfer &t : ts) any = any || t.src == w.rank || t.dst == w.rank;
 	if (!any) return SIFT3D_OK;
+	std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
+	SH_LIVE(H, w);
+	comm = flow ? w.c_deferred : w.c_urgent;  // (read under the lock: the aborter nulls it)
 	SH_NCCL(w, g_rccl.GroupStart());
 	for (const Transfer &t : ts) {
 		if (t.src != w.rank && t.dst != w.rank) continue;
@@ -234,6 +261,8 @@ int allreduce_max_dev(sift3d_sharded *H, std::vector<Worker *> &ws, int stage, i
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
+	std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
+	SH_LIVE(H, w);
 	SH_NCCL(w, g_rccl.AllReduce(w.dogmax[(size_t)stage], w.dogmax[(size_t)stage], (size_t)n, ncclFloat, ncclMax, w.c_urgent, w.stream));
 	return SIFT3D_OK;
 }
@@ -253,6 +282,8 @@ int allgather_seed(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
+	std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
+	SH_LIVE(H, w);
 	SH_NCCL(w, g_rccl.GroupStart());
 	size_t off = 0;
 	for (int r = 0; r < H->world; r++) {
@@ -299,9 +330,16 @@ int run_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	} else if (next[0] > 0) {
 		Worker &w = *ws[0];
 		hipStream_t ts = nullptr;  // the tail's collective runs on the null stream of the rank's device, ordered behind the export above
-		ncclResult_t r = g_rccl.AllReduce(rows[0], rows[0], (size_t)next[0] * SIFT3D_ORIENT_WORDS, ncclInt32, ncclSum, w.c_tail, ts);
-		if (r != ncclSuccess) { w.err = std::string("ncclAllReduce (tail): ") + g_rccl.GetErrorString(r); rc = SIFT3D_ERR_HIP; }
-		else if (hipStreamSynchronize(ts) != hipSuccess) rc = SIFT3D_ERR_HIP;
+		ncclResult_t r = ncclSuccess;
+		{
+			std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
+			if (H->failed.load() || !w.c_tail) { w.err = "aborted: another rank failed"; rc = SIFT3D_ERR_STATE; }
+			else r = g_rccl.AllReduce(rows[0], rows[0], (size_t)next[0] * SIFT3D_ORIENT_WORDS, ncclInt32, ncclSum, w.c_tail, ts);
+		}
+		if (rc != SIFT3D_OK) {}
+		else if (r != ncclSuccess) { w.err = std::string("ncclAllReduce (tail): ") + g_rccl.GetErrorString(r); rc = SIFT3D_ERR_HIP; }
+		else if (hipStreamSynchronize(ts) != hipSuccess) { w.err = "tail all-reduce did not complete"; rc = SIFT3D_ERR_HIP; }
+		if (rc == SIFT3D_OK && H->failed.load()) { w.err = "aborted: another rank failed"; rc = SIFT3D_ERR_STATE; }  // an aborted collective leaves garbage rows
 	}
 	for (size_t i = 0; i < ws.size(); i++) {
 		Worker *w = ws[i];
@@ -384,7 +422,7 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	// replicated tail on its own host thread (RCCL), beside the sharded detection and descriptors; inline for simulated ranks
 	int tail_rc = SIFT3D_OK;
 	std::thread tail_thread;
-	if (has_tail && !H->sim) tail_thread = std::thread([&] { tail_rc = run_tail(H, ws); });
+	if (has_tail && !H->sim) tail_thread = std::thread([&] { tail_rc = run_tail(H, ws); if (tail_rc != SIFT3D_OK) abort_all(H); });
 	int rc = SIFT3D_OK;
 	for (int s = 0; s < H->S && rc == SIFT3D_OK; s++) {
 		for (Worker *w : ws) {
@@ -394,7 +432,9 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 			if (rc != SIFT3D_OK) { w->err = std::string("sharded keypoints: ") + sift3d_error_string(rc) + " (" + sift3d_last_error() + ")"; break; }
 		}
 	}
+	if (rc != SIFT3D_OK) abort_all(H);               // (the tail thread may sit in its all-reduce waiting for ranks that will not come)
 	if (tail_thread.joinable()) tail_thread.join();  // joined whatever happened above: it calls into contexts destroy would free
+	if (rc == SIFT3D_OK && H->failed.load()) { w0.err = "aborted: another rank failed"; rc = SIFT3D_ERR_STATE; }  // halos of an aborted exchange are garbage
 	if (has_tail && H->sim && rc == SIFT3D_OK) tail_rc = run_tail(H, ws);
 	if (rc == SIFT3D_OK) rc = tail_rc;
 	if (rc != SIFT3D_OK) return rc;
@@ -578,13 +618,33 @@ extern "C" int sift3d_sharded_create(sift3d_sharded_handle *out, const float *vo
 	const size_t pl = (size_t)nx * ny;
 	float gmax = 0.f;
 	std::vector<float> lmax((size_t)H->world, 0.f);
-	for (Worker &w : H->workers) {
-		CR_HIP(hipSetDevice(w.device));
-		Stage &st = w.stages[0];
-		CR_ABI(sift3d_slab_upload(st.ctx, volume + pl * (size_t)st.z0, st.z0, st.z1, 0));
-		CR_ABI(sift3d_slab_input_absmax(st.ctx, &lmax[(size_t)w.rank]));
-		gmax = std::max(gmax, lmax[(size_t)w.rank]);  // (one process holds every rank: the MAX all-reduce is a host loop)
+	if (H->sim) {
+		for (Worker &w : H->workers) {
+			CR_HIP(hipSetDevice(w.device));
+			Stage &st = w.stages[0];
+			CR_ABI(sift3d_slab_upload(st.ctx, volume + pl * (size_t)st.z0, st.z0, st.z1, 0));
+			CR_ABI(sift3d_slab_input_absmax(st.ctx, &lmax[(size_t)w.rank]));
+		}
+	} else {
+		// one host thread per GPU: every rank stages its own slab through its device's pinned pool (csrc/staging.hip), so the
+		// constructor's H2D scales with the number of GPUs instead of running the slabs one after the other
+		std::vector<std::thread> th;
+		std::vector<int> rcs((size_t)H->world, SIFT3D_OK);
+		std::vector<std::string> errs((size_t)H->world);
+		for (int r = 0; r < H->world; r++)
+			th.emplace_back([&, r] {
+				Worker &w = H->workers[(size_t)r];
+				Stage &st = w.stages[0];
+				int rc = hipSetDevice(w.device) == hipSuccess ? SIFT3D_OK : SIFT3D_ERR_HIP;
+				if (rc == SIFT3D_OK) rc = sift3d_slab_upload(st.ctx, volume + pl * (size_t)st.z0, st.z0, st.z1, 0);
+				if (rc == SIFT3D_OK) rc = sift3d_slab_input_absmax(st.ctx, &lmax[(size_t)r]);
+				if (rc != SIFT3D_OK) errs[(size_t)r] = sift3d_last_error();  // (the error text is thread-local)
+				rcs[(size_t)r] = rc;
+			});
+		for (auto &t : th) t.join();
+		for (int r = 0; r < H->world; r++) if (rcs[(size_t)r]) return fail(rcs[(size_t)r], "slab upload of rank " + std::to_string(r) + ": " + errs[(size_t)r]);
 	}
+	for (float v : lmax) gmax = std::max(gmax, v);  // (one process holds every rank: the MAX all-reduce is a host loop)
 	for (Worker &w : H->workers) { CR_HIP(hipSetDevice(w.device)); CR_ABI(sift3d_slab_input_scale(w.stages[0].ctx, gmax)); }
 	{
 		const std::vector<Transfer> ts = halo_transfers(b, nz, KIND_INPUT, 0, 0, H->hws[0] + 1, 0);
@@ -603,7 +663,8 @@ extern "C" int sift3d_sharded_create(sift3d_sharded_handle *out, const float *vo
 					std::vector<Worker *> ws{&w};
 					(void)hipSetDevice(w.device);
 					rcs[(size_t)r] = exchange(H, ws, ts, 0);
-					if (rcs[(size_t)r] == SIFT3D_OK && hipStreamSynchronize(w.stream) != hipSuccess) rcs[(size_t)r] = SIFT3D_ERR_HIP;
+					if (rcs[(size_t)r] != SIFT3D_OK) abort_all(H);
+					else if (hipStreamSynchronize(w.stream) != hipSuccess) rcs[(size_t)r] = SIFT3D_ERR_HIP;
 				});
 			for (auto &t : th) t.join();
 			for (int v : rcs) if (v) rc = v;
@@ -618,6 +679,11 @@ extern "C" int sift3d_sharded_create(sift3d_sharded_handle *out, const float *vo
 
 extern "C" int sift3d_sharded_run(sift3d_sharded_handle H) {
 	if (!H) return SIFT3D_ERR_ARG;
+	if (H->failed.load()) {  // a rank failed in an earlier run and the communicators were aborted: nothing is restarted in place
+		H->err = "this sharded extractor is dead (an earlier run failed and its communicators were aborted): destroy it";
+		set_last_error(H->err);
+		return SIFT3D_ERR_STATE;
+	}
 	const auto t0 = std::chrono::steady_clock::now();
 	int rc = SIFT3D_OK;
 	if (H->sim) {
@@ -629,9 +695,18 @@ extern "C" int sift3d_sharded_run(sift3d_sharded_handle H) {
 		std::vector<std::thread> th;
 		std::vector<int> rcs((size_t)H->world, SIFT3D_OK);
 		for (int r = 0; r < H->world; r++)
-			th.emplace_back([&, r] { std::vector<Worker *> ws{&H->workers[(size_t)r]}; rcs[(size_t)r] = run_local(H, ws); });
+			th.emplace_back([&, r] {
+				std::vector<Worker *> ws{&H->workers[(size_t)r]};
+				rcs[(size_t)r] = run_local(H, ws);
+				if (rcs[(size_t)r] != SIFT3D_OK) abort_all(H);  // frees the z-neighbours blocked in a receive / reduction with this rank
+			});
 		for (auto &t : th) t.join();
-		for (int r = 0; r < H->world; r++) if (rcs[(size_t)r]) { rc = rcs[(size_t)r]; H->err = "rank " + std::to_string(r) + ": " + H->workers[(size_t)r].err; break; }
+		// the rank that failed FIRST carries the cause; the others report "aborted: another rank failed"
+		for (int pass = 0; pass < 2 && rc == SIFT3D_OK; pass++)
+			for (int r = 0; r < H->world; r++) {
+				const std::string &e = H->workers[(size_t)r].err;
+				if (rcs[(size_t)r] && (pass == 1 || e.compare(0, 8, "aborted:") != 0)) { rc = rcs[(size_t)r]; H->err = "rank " + std::to_string(r) + ": " + e; break; }
+			}
 	}
 	if (rc) { set_last_error(H->err); return rc; }
 	H->times[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

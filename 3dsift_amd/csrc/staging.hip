@@ -18,24 +18,22 @@ namespace s3d {
 namespace {
 constexpr size_t kChunk = (size_t)16 << 20;  // bytes per pinned buffer
 constexpr int kBufs = 2;
+// One pool per device (r04; before: one process-wide pool behind one mutex whose events were re-created whenever the calling device
+// changed -- the rank threads of the sharded driver took turns through it inside the timed region): 2 x 16 MB of pinned memory and
+// two events per device that is ever used, created on first use by a thread whose current device is that device.
 struct Pool {
 	std::mutex mu;
 	char *buf[kBufs] = {nullptr, nullptr};
 	hipEvent_t ev[kBufs] = {nullptr, nullptr};
-	int device = -1;  // events belong to a device
 };
-Pool g_pool;
+constexpr int kMaxDev = 64;
+Pool g_pools[kMaxDev];
+Pool &pool_of(int device) { return g_pools[(device >= 0 && device < kMaxDev) ? device : 0]; }
 
-int pool_ready(Pool &P, int device) {
-	for (int i = 0; i < kBufs; i++)
+int pool_ready(Pool &P) {  // the caller holds P.mu and has made the pool's device current
+	for (int i = 0; i < kBufs; i++) {
 		if (!P.buf[i]) S3D_HIP(hipHostMalloc(reinterpret_cast<void **>(&P.buf[i]), kChunk, hipHostMallocPortable));
-	if (P.device != device) {
-		for (int i = 0; i < kBufs; i++) {
-			if (P.ev[i]) (void)hipEventDestroy(P.ev[i]);
-			P.ev[i] = nullptr;
-			S3D_HIP(hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming));
-		}
-		P.device = device;
+		if (!P.ev[i]) S3D_HIP(hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming));
 	}
 	return SIFT3D_OK;
 }
@@ -60,8 +58,9 @@ void par_memcpy(char *dst, const char *src, size_t bytes) {
 int staged_h2d(void *d_dst, const void *h_src, size_t bytes, int device, hipStream_t st) {
 	if (bytes == 0) return SIFT3D_OK;
 	if (bytes < ((size_t)1 << 20)) { S3D_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st)); return SIFT3D_OK; }
+	Pool &g_pool = pool_of(device);
 	std::lock_guard<std::mutex> lock(g_pool.mu);
-	int rc = pool_ready(g_pool, device);
+	int rc = pool_ready(g_pool);
 	if (rc) return rc;
 	size_t off = 0;
 	for (int i = 0; off < bytes; i++) {
@@ -85,8 +84,9 @@ int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStre
 		S3D_HIP(hipStreamSynchronize(st));
 		return SIFT3D_OK;
 	}
+	Pool &g_pool = pool_of(device);
 	std::lock_guard<std::mutex> lock(g_pool.mu);
-	int rc = pool_ready(g_pool, device);
+	int rc = pool_ready(g_pool);
 	if (rc) return rc;
 	const size_t nchunks = (bytes + kChunk - 1) / kChunk;
 	auto issue = [&](size_t i) -> hipError_t {

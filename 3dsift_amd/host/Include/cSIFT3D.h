@@ -8,6 +8,7 @@
 #ifndef S3D_HOST_CSIFT3D_H
 #define S3D_HOST_CSIFT3D_H
 
+#include <cstddef>
 #include <string>
 #include <vector>
 
@@ -52,8 +53,40 @@ typedef struct _cKeypoint {
 	float *desc = nullptr;  // DESC_NUMEL floats owned by the extractor: valid while the CSIFT3D lives
 } SIFT_LIBRARY_API Keypoint;
 
+// layout guard (the reference's record on LP64): binaries that copy Keypoints around, and the conversion from the
+// C-ABI's 168-byte POD in fetch_results, rely on exactly this layout
+static_assert(sizeof(Cvec) == 12, "Cvec is three packed floats");
+static_assert(sizeof(void *) != 8 || sizeof(Keypoint) == 176, "Keypoint must be 176 bytes on LP64");
+static_assert(offsetof(Keypoint, scale) == 12 && offsetof(Keypoint, octave) == 16 && offsetof(Keypoint, level) == 20 && offsetof(Keypoint, rx) == 24 &&
+              offsetof(Keypoint, win) == 36 && offsetof(Keypoint, eigvalue) == 48 && offsetof(Keypoint, eigvector) == 60 &&
+              offsetof(Keypoint, Rotation) == 96 && offsetof(Keypoint, str_tensor) == 132 && (sizeof(void *) != 8 || offsetof(Keypoint, desc) == 168),
+              "Keypoint field offsets");
+
 bool cmp_kp(const Keypoint &a, const Keypoint &b);
 bool cmp_kp_orig(const Keypoint &a, const Keypoint &b);
+
+// The remaining public records of the reference's header (Include/cSIFT3D.h:72-116): same fields and order, so user code that
+// names them compiles.  The extractor itself does not use them (its mesh is a device constant table, its levels device buffers).
+typedef struct _cTri {
+	Cvec v[3];   // vertices
+	int idx[3];  // index of each vertex in the solid
+} Tri;
+typedef struct _Mesh {
+	Tri *tri;
+	int num;
+} Mesh;
+typedef struct _cImage {
+	float *data;
+	int nx, ny, nz;
+	size_t xs, ys, zs;  // strides: xs = 1, ys = nx, zs = nx * ny
+	float ux, uy, uz;
+	size_t size;        // voxels
+	float s;            // scale-space location
+} Image;
+typedef struct _cEigenVal {
+	float val;
+	float vec[3];
+} EigenVal;
 
 class CSIFT3D {
 protected:
@@ -117,11 +150,25 @@ public:
 // The volume-level free functions of the reference's header (Include/cSIFT3D.h:208-218), on host TexImages: each call moves its
 // operands to the GPU, runs the pipeline's own kernel and copies the result back.  dst / dog are (re)sized like the reference's
 // callers size them: GaussianSmooth_3D and Sub give dst the dimensions, units and scale of src / prev; DownSample_3D fills the
-// caller-sized dst (dst(n, m, k) = src(2n, 2m, 2k)).  The per-voxel helpers of that header (IsExtrema_neighbor, cart2bary, ...)
-// have no host-side counterpart here: they live inside the device kernels.
+// caller-sized dst (dst(n, m, k) = src(2n, 2m, 2k)).
 SIFT_LIBRARY_API void DownSample_3D(TexImage *src, TexImage *dst);
 SIFT_LIBRARY_API void GaussianSmooth_3D(TexImage *src, TexImage *dst, float sigma);
 SIFT_LIBRARY_API void Sub(TexImage *prev, TexImage *cur, TexImage *dog);
+
+// The small per-voxel / per-vector helpers of the same header (Include/cSIFT3D.h:216-238), as HOST utilities on HOST data
+// (host/src/helpers.cpp).  They are not part of the extraction path -- KpSiftAlgorithm never calls them, its kernels carry their own
+// forms -- and exist so that user code which calls them directly keeps compiling and gets the reference's answers.
+SIFT_LIBRARY_API void Im_permute(TexImage *src, TexImage *dst, int dim1, int dim2);                                   // Src/cSIFT3D.cc:790-847
+SIFT_LIBRARY_API bool IsExtrema_neighbor(TexImage *prev, TexImage *cur, TexImage *next, int x, int y, int z);         // :884-911
+SIFT_LIBRARY_API bool DistinctEig(float a, float b, float c);                                                          // :1140-1150
+SIFT_LIBRARY_API int Check_intersect_faces(Mesh *mesh, Cvec *grad, Cvec *bary);                                        // :1542-1573
+SIFT_LIBRARY_API void Transpose_Matrix(float *Rot);                                                                    // :1575-1582
+SIFT_LIBRARY_API void Swap_Element(float &a, float &b);                                                                // :1584-1590
+SIFT_LIBRARY_API int cart2bary(Cvec *cart, const Tri *const tri, Cvec *const bary, float *const k);                    // :1592-1637
+SIFT_LIBRARY_API void normailize_desc(float *desc);                                                                    // :1639-1656
+// the icosahedron the descriptor histograms are binned on (Include/cUtil.h:60, Src/cUtil.cc:113-175; winding quirk included).
+// mesh->tri is malloc()ed (20 triangles); the caller free()s it.  Returns 0.
+SIFT_LIBRARY_API int Initialize_geometry(Mesh *mesh);
 
 // device selection for subsequently created extractors / matchers (default 0, or env SIFT3D_DEVICE)
 SIFT_LIBRARY_API void SetDevice(int device);

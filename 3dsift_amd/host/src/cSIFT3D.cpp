@@ -227,6 +227,15 @@ void CSIFT3D::fetch_results() {
 	}
 }
 
+// a call that needs the single-GPU handle on an extractor that has none: say why instead of returning an empty result silently
+static bool need_single(const char *what, sift3d_handle h, sift3d_sharded_handle sh) {
+	if (h) return true;
+	if (sh) fprintf(stderr, "[3dsift_amd] %s: this extractor shards its volume over several GPUs (SIFT3D_DEVICES / SIFT3D_SIM_RANKS); the "
+	                        "stage-by-stage methods and the pyramid / extrema accessors need a single-GPU extractor -- use KpSiftAlgorithm()\n", what);
+	else fprintf(stderr, "[3dsift_amd] %s: the extractor was not constructed (see the message of CreateCSIFT3D)\n", what);
+	return false;
+}
+
 static void run_to(CSIFT3D *self, sift3d_handle h, int upto, int &stage, bool &fetched, SIFT_TimerPara &tm) {
 	if (!h) return;
 	int rc = sift3d_run_stages(h, upto);
@@ -254,14 +263,14 @@ void CSIFT3D::KpSiftAlgorithm() {
 		m_timer.d_TotalTime = sec[0];
 		return;
 	}
-	run_to(this, impl->h, 5, impl->stage, impl->fetched, m_timer);
+	if (need_single("KpSiftAlgorithm", impl->h, impl->sh)) run_to(this, impl->h, 5, impl->stage, impl->fetched, m_timer);
 }
 void CSIFT3D::Initialize() {}
-void CSIFT3D::Build_Gaussian_Scale_Space() { run_to(this, impl->h, 1, impl->stage, impl->fetched, m_timer); }
-void CSIFT3D::Build_DOG_Scale_Space() { run_to(this, impl->h, 2, impl->stage, impl->fetched, m_timer); }
-void CSIFT3D::Detect_KeyPoints() { run_to(this, impl->h, 3, impl->stage, impl->fetched, m_timer); }
-void CSIFT3D::Assign_Orientation() { run_to(this, impl->h, 4, impl->stage, impl->fetched, m_timer); }
-void CSIFT3D::Extract_Description() { run_to(this, impl->h, 5, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Build_Gaussian_Scale_Space() { if (need_single("Build_Gaussian_Scale_Space", impl->h, impl->sh)) run_to(this, impl->h, 1, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Build_DOG_Scale_Space() { if (need_single("Build_DOG_Scale_Space", impl->h, impl->sh)) run_to(this, impl->h, 2, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Detect_KeyPoints() { if (need_single("Detect_KeyPoints", impl->h, impl->sh)) run_to(this, impl->h, 3, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Assign_Orientation() { if (need_single("Assign_Orientation", impl->h, impl->sh)) run_to(this, impl->h, 4, impl->stage, impl->fetched, m_timer); }
+void CSIFT3D::Extract_Description() { if (need_single("Extract_Description", impl->h, impl->sh)) run_to(this, impl->h, 5, impl->stage, impl->fetched, m_timer); }
 void CSIFT3D::Release_SIFT() { Gss_Pyramid.clear(); DoG_Pyramid.clear(); level_extrema.clear(); }
 
 void CSIFT3D::SetNumThreads(int t_num) {
@@ -291,14 +300,14 @@ static void copy_pyramid(sift3d_handle h, int is_dog, int count, std::vector<Tex
 
 std::vector<TexImage> *CSIFT3D::GET_GSS() {
 	int noct = 0;
-	if (impl->h && impl->stage >= 1 && sift3d_num_octaves(impl->h, &noct) == SIFT3D_OK)
+	if (need_single("GET_GSS", impl->h, impl->sh) && impl->stage >= 1 && sift3d_num_octaves(impl->h, &noct) == SIFT3D_OK)
 		copy_pyramid(impl->h, 0, noct * (impl->levels + 3), Gss_Pyramid);
 	return &Gss_Pyramid;
 }
 
 std::vector<TexImage> *CSIFT3D::GET_DOG() {
 	int noct = 0;
-	if (impl->h && impl->stage >= 1 && sift3d_num_octaves(impl->h, &noct) == SIFT3D_OK)
+	if (need_single("GET_DOG", impl->h, impl->sh) && impl->stage >= 1 && sift3d_num_octaves(impl->h, &noct) == SIFT3D_OK)
 		copy_pyramid(impl->h, 1, noct * (impl->levels + 2), DoG_Pyramid);
 	return &DoG_Pyramid;
 }
@@ -306,7 +315,7 @@ std::vector<TexImage> *CSIFT3D::GET_DOG() {
 std::vector<std::vector<Keypoint>> *CSIFT3D::GET_LEVEL() {
 	level_extrema.clear();
 	int n = 0, noct = 0;
-	if (!impl->h || impl->stage < 3 || sift3d_num_extrema(impl->h, &n) != SIFT3D_OK) return &level_extrema;
+	if (!need_single("GET_LEVEL", impl->h, impl->sh) || impl->stage < 3 || sift3d_num_extrema(impl->h, &n) != SIFT3D_OK) return &level_extrema;
 	sift3d_num_octaves(impl->h, &noct);
 	level_extrema.resize((size_t)noct * impl->levels);
 	std::vector<sift3d_keypoint> pod((size_t)(n > 0 ? n : 1));

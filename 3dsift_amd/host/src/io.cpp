@@ -109,7 +109,7 @@ float *readNiiFile(const char *filename, int &nx, int &ny, int &nz) {
 		}
 	} catch (...) { gzclose(f); fprintf(stderr, "readNiiFile: out of memory\n"); nx = ny = nz = 0; return nullptr; }
 	gzclose(f);
-	if (got != bytes) { fprintf(stderr, "readNiiFile: truncated payload\n"); return nullptr; }
+	if (got != bytes) { fprintf(stderr, "readNiiFile: truncated payload\n"); nx = ny = nz = 0; return nullptr; }
 	float *out = new (std::nothrow) float[n];
 	if (!out) { fprintf(stderr, "readNiiFile: out of memory\n"); nx = ny = nz = 0; return nullptr; }
 	switch (datatype) {  // NIfTI datatype codes; slope/intercept deliberately ignored (see readNii.h)
@@ -124,33 +124,36 @@ float *readNiiFile(const char *filename, int &nx, int &ny, int &nz) {
 	default:
 		fprintf(stderr, "readNiiFile: unsupported datatype %d\n", (int)datatype);
 		delete[] out;
+		nx = ny = nz = 0;
 		return nullptr;
 	}
 	return out;
 }
 
-int ReadMatrixFromDisk(const char *filename, int *m, int *n, int *p, float **volume) {
-	FILE *f = fopen(filename, "rb");
-	if (!f) return -1;
+// ---- raw matrix files (reference Include/Util/matrixIO3D.h:15-140, Src/Util/matrixIO3D.cpp): 0 = success, 1 = failure ----
+int ReadMatrixSizeFromStream(FILE *file, int *m, int *n, int *p) {
 	int32_t h[3];
-	if (fread(h, sizeof(int32_t), 3, f) != 3 || h[0] <= 0 || h[1] <= 0 || h[2] <= 0) { fclose(f); return -2; }
-	const size_t cnt = (size_t)h[0] * h[1] * h[2];
-	float *v = (float *)malloc(cnt * sizeof(float));
-	if (!v || fread(v, sizeof(float), cnt, f) != cnt) { free(v); fclose(f); return -3; }
-	fclose(f);
-	*m = h[0]; *n = h[1]; *p = h[2]; *volume = v;
+	if (!file || fread(h, sizeof(int32_t), 3, file) != 3) return 1;
+	*m = h[0]; *n = h[1]; *p = h[2];
 	return 0;
 }
 
-int WriteMatrixToDisk(const char *filename, int m, int n, int p, const float *volume) {
-	FILE *f = fopen(filename, "wb");
-	if (!f) return -1;
-	const int32_t h[3] = {m, n, p};
-	const size_t cnt = (size_t)m * n * p;
-	const bool ok = fwrite(h, sizeof(int32_t), 3, f) == 3 && fwrite(volume, sizeof(float), cnt, f) == cnt;
+int ReadMatrixSizeFromDisk(const char *filename, int *m, int *n, int *p) {
+	FILE *f = fopen(filename, "rb");
+	if (!f) return 1;
+	const int rc = ReadMatrixSizeFromStream(f, m, n, p);
 	fclose(f);
-	return ok ? 0 : -2;
+	return rc;
 }
+
+int WriteMatrixHeaderToStream(FILE *file, int m, int n, int p) {
+	const int32_t h[3] = {m, n, p};
+	return (file && fwrite(h, sizeof(int32_t), 3, file) == 3) ? 0 : 1;
+}
+
+int ReadMatrixFromDisk(const char *filename, int *m, int *n, int *p, float **volume) { return ReadMatrixFromDisk<float>(filename, m, n, p, volume); }
+
+int WriteMatrixToDisk(const char *filename, int m, int n, int p, const float *volume) { return WriteMatrixToDisk<const float>(filename, m, n, p, volume); }
 
 std::ostream &operator<<(std::ostream &os, const SIFT_TimerPara &st) {
 	os << "3D SIFT timing (s): total " << st.d_TotalTime << " | GSS+DoG " << (st.d_BuildGSS + st.d_BuildDOG) << " | detect "

@@ -56,6 +56,18 @@ typedef struct sift3d_keypoint {
 	float Rotation[9];   /* returned TRANSPOSED after the descriptor stage, like Src/cSIFT3D.cc:1214 */
 	float str_tensor[9];
 } sift3d_keypoint;
+/* layout guard of the record that crosses the boundary (SURVEY 8a-1 lists the offsets of CPUSIFT::Keypoint; this POD is that record
+ * without its trailing desc pointer): a compiler / packing change breaks the build, not the results */
+#if defined(__cplusplus)
+#define SIFT3D_STATIC_ASSERT(c, m) static_assert(c, m)
+#else
+#define SIFT3D_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#endif
+SIFT3D_STATIC_ASSERT(sizeof(sift3d_keypoint) == 168, "sift3d_keypoint must be 168 bytes");
+SIFT3D_STATIC_ASSERT(offsetof(sift3d_keypoint, scale) == 12 && offsetof(sift3d_keypoint, octave) == 16 && offsetof(sift3d_keypoint, rx) == 24 &&
+                     offsetof(sift3d_keypoint, win) == 36 && offsetof(sift3d_keypoint, eigvalue) == 48 && offsetof(sift3d_keypoint, eigvector) == 60 &&
+                     offsetof(sift3d_keypoint, Rotation) == 96 && offsetof(sift3d_keypoint, str_tensor) == 132, "sift3d_keypoint field offsets");
+SIFT3D_STATIC_ASSERT(sizeof(sift3d_params) == 24, "sift3d_params must be 24 bytes");
 
 void sift3d_default_params(sift3d_params *p);
 
@@ -247,7 +259,7 @@ enum {
 };
 int sift3d_test_hook(int which, int value);
 /* how often the rare paths ran: c[0] list regrows of the last run, c[1] keypoints whose descriptor took the second pass in
- * the last run, c[2] rows the last sift3d_match re-scored exactly (near-tie guard; process-wide), c[3] reserved */
+ * the last run, c[2] rows the calling thread's last sift3d_match re-scored exactly (near-tie guard), c[3] reserved */
 int sift3d_debug_counters(sift3d_handle h, int c[4]);
 /* Check_intersect_faces + cart2bary (Src/cSIFT3D.cc:1542-1573, 1592-1637) of k_describe on n gradient vectors (host, n*3):
  * face index (-1: none) and the three barycentric weights as the kernel forms them, through both of its routes:

@@ -336,3 +336,35 @@ def test_free_functions_of_the_public_header_run(shell, orc):
     a = (((x * 7 + y * 3 + z * 11) % 13).astype(np.float32) / np.float32(13.0)).astype(np.float32)
     want = orc.gaussian_smooth(a, 1.1).astype(np.float64).sum()
     assert abs(float(out.split("sum")[1]) - want) < 1e-4 * max(1.0, abs(want))
+
+
+def test_header_surface_helpers_against_golden_g7(shell):
+    """The small host utilities of the reference's public header (cart2bary, Check_intersect_faces, Initialize_geometry, Im_permute,
+    the TexImage members, the Tri / Mesh / Image / EigenVal records, the templated matrix IO): a program that names them compiles
+    against OUR headers, and the mesh / face / barycentric results equal golden g7 -- which the reference itself produced -- bit for bit."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g7_mesh.npz"))
+    with tempfile.TemporaryDirectory() as t:
+        exe = os.path.join(t, "helpers_check")
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-I" + os.path.join(PKG, "host"), "-o", exe,
+                               os.path.join(PKG, "host", "example", "helpers_check.cpp"), "-L" + PKG, "-lsift3d", "-lsift3d_hip",
+                               "-Wl,-rpath," + PKG])
+        dirs = np.ascontiguousarray(g["dirs"], np.float32).view(np.uint32)
+        txt = "%d\n" % len(dirs) + "\n".join("%08x %08x %08x" % tuple(r) for r in dirs) + "\n"
+        out = subprocess.run([exe, t], input=txt, capture_output=True, text=True, check=True).stdout.splitlines()
+    tri = [l.split() for l in out if l.startswith("tri ")]
+    assert len(tri) == 20
+    idx = np.array([[int(v) for v in r[1:4]] for r in tri], np.int32)
+    verts = np.array([[int(v, 16) for v in r[4:]] for r in tri], np.uint32).reshape(20, 3, 3)
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(verts, g["verts"].view(np.uint32))
+    rows = [l.split() for l in out if l.startswith("dir ")]
+    faces = np.array([int(r[1]) for r in rows], np.int32)
+    bary = np.array([[int(v, 16) for v in r[2:]] for r in rows], np.uint32)
+    assert np.array_equal(faces, g["faces"])
+    hit = faces >= 0
+    assert np.array_equal(bary[hit], g["bary"].view(np.uint32)[hit])
+    rest = {l.split()[0]: l.split()[1:] for l in out if not l.startswith(("tri ", "dir "))}
+    assert rest["tex"] == ["96", "4", "3", "2", "0", "1"]          # sizing ctor: _numsize in BYTES, scale 0, units 1 (cTexImage.cc:19-33)
+    assert rest["view"] == ["23", "13"] and rest["perm"] == ["2", "3", "4", "23"]
+    assert rest["nvox"] == ["8"] and rest["size"] == ["0", "1", "2", "3"]   # SetImageSize: _numsize in VOXELS (cTexImage.cc:76)
+    assert rest["reset"] == ["32", "2", "1"] and rest["tr"] == ["3", "6", "7", "1", "0"]
+    assert rest["dmat"] == ["0", "3", "2", "1", "5.5"] and rest["imat"] == ["0", "1", "2", "3", "6"]
