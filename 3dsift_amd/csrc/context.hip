@@ -676,9 +676,12 @@ static bool smooth_level(sift3d_ctx *c, int o, const float *src, const Level &ds
 	// wave priority: the launches of octaves >= 2 (1/64 of the work, but each octave waits for level 3 of the one above, and beside the
 	// big launches their workgroups crawl) run at the highest wave priority: 2.82 -> 2.71 ms per 512^3 pyramid.  Raising octave 1 too
 	// (S3D_PRIO=1) costs octave 0 as much as it gains.
-	static const int prio_mode = dev_tune_i("S3D_PRIO", 2);
-	const int prio = (prio_mode && c->noct > 1) ? (o >= 2 ? 2 : (o == 1 && prio_mode == 1 ? 1 : 0)) : 0;
-	const int plan_slots = c->noct > 1 ? (o == 0 ? (level > c->p.num_kp_levels ? tail_slots : 0) : bg_slots) : 0;
+	// r04 (scripts/sweep_sched3.sh, with the small octaves in one launch): octave 1 at the top priority too -- 2.20 vs 2.23 ms; its slot
+	// plan (S3D_BG1_SLOTS 256 / 384 / 512) and more slots for the octaves behind it (S3D_BG_SLOTS 512 / 768: 2.23-2.27) change nothing
+	static const int prio_mode = dev_tune_i("S3D_PRIO", 3);  // 1: octave 1 at wave priority 1; 2: at 0; 3: octave 1 at the top priority like the octaves behind it
+	static const int bg1_slots = dev_tune_i("S3D_BG1_SLOTS", 0);  // slot plan of octave 1's levels (0: bg_slots)
+	const int prio = (prio_mode && c->noct > 1) ? (o >= 2 ? 2 : (o == 1 ? (prio_mode == 1 ? 1 : (prio_mode == 3 ? 2 : 0)) : 0)) : 0;
+	const int plan_slots = c->noct > 1 ? (o == 0 ? (level > c->p.num_kp_levels ? tail_slots : 0) : (o == 1 && bg1_slots > 0 ? bg1_slots : bg_slots)) : 0;
 	// hot path: one fused pass (x, y, z blur + DoG + abs-max; kernels_march.hip); prev == src for every DoG-producing level
 	static const int fused_min = dev_tune_i("S3D_FUSED_MIN", S3D_FUSED_MIN_DEFAULT);
 	if (c->use_fused && (prev == nullptr || prev == src) && std::min(dst.nx, std::min(dst.ny, dst.nz)) >= fused_min) {
@@ -726,8 +729,70 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		// planning tried (the tail is longer than that chain).
 		static const int defer_tail = dev_tune_i("S3D_DEFER_TAIL", 0);
 		std::vector<char> half_written((size_t)c->noct + 1, 0);  // level 0 of octave o was written by the seed level's kernel of octave o - 1
+		// r04: the SMALL octaves (16^3-class and below) run in ONE launch of one workgroup that keeps the octave in LDS
+		// (kernels_small.hip) instead of ~16 launches of a few microseconds per octave on the stage's critical chain
+		int small_first = -1;
+		SmallArgs sa;
+		{
+			static const int small_on = dev_tune_i("S3D_SMALL_OCT", 1);
+			unsigned build_mask = 0, dog_mask = 0;
+			int max_hw = 0;
+			bool ok = small_on != 0 && c->use_fused && !c->slab && c->ng <= kSmallMaxLv;
+			for (int i = 1; i < c->ng && ok; i++) {
+				if (c->g_last_elide && i == c->ng - 1) continue;
+				build_mask |= 1u << i;
+				if (!(c->dog_elide && (i - 1 == 0 || i - 1 == c->nd - 1))) dog_mask |= 1u << (i - 1);
+				const Taps &t = c->taps[i];
+				for (int d = 1; d <= t.hw && ok; d++) ok = memcmp(&t.w[t.hw + d], &t.w[t.hw - d], sizeof(float)) == 0;  // symmetric bit for bit
+				max_hw = std::max(max_hw, t.hw);
+			}
+			if (ok && small_padded_hw(max_hw) > 0)
+				for (int o = 0; o < c->noct; o++) {
+					const Level &L = c->gss[(size_t)o * c->ng];
+					if (c->noct - o <= kSmallMaxOct && small_octave_fits(L.nx, L.ny, L.nz, max_hw)) { small_first = o; break; }  // (the octaves behind it are smaller)
+				}
+			if (small_first >= 0) {
+				memset(&sa, 0, sizeof(sa));
+				sa.noct = c->noct - small_first; sa.ng = c->ng; sa.nd = c->nd; sa.seed = c->p.num_kp_levels;
+				sa.build_mask = build_mask; sa.dog_mask = dog_mask;
+				sa.dogmax = c->d_dogmax + (size_t)small_first * c->nd;
+				sa.hwp = small_padded_hw(max_hw);
+				for (int i = 1; i < c->ng; i++) {
+					const Taps &t = c->taps[i];
+					if (t.hw > sa.hwp) continue;  // (a level the launch does not build)
+					for (int k = 0; k <= sa.hwp; k++) sa.w[i][k] = k >= sa.hwp - t.hw ? t.w[k - (sa.hwp - t.hw)] : 0.0f;
+				}
+				for (int o = small_first; o < c->noct; o++) {
+					SmallOct &so = sa.oct[o - small_first];
+					const Level &L = c->gss[(size_t)o * c->ng];
+					so.nx = L.nx; so.ny = L.ny; so.nz = L.nz;
+					for (int i = 0; i < c->ng; i++) so.g[i] = c->gss[(size_t)o * c->ng + i].d;
+					for (int i = 0; i < c->nd; i++) so.dog[i] = c->dog[(size_t)o * c->nd + i].d;
+				}
+			}
+		}
 		auto enqueue = [&](int o, bool head) -> int {
-			hipStream_t so = c->ostream[o];
+			// (the octaves of the small launch share the stream of the first of them)
+			hipStream_t so = c->ostream[(small_first >= 0 && o > small_first) ? small_first : o];
+			if (small_first >= 0 && o >= small_first) {
+				if (head && o > 0) {
+					S3D_HIP(hipStreamWaitEvent(so, c->ev_fork, 0));
+					S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[o - 1], 0));
+				}
+				if (head && o == small_first) {
+					const Level &L = c->gss[(size_t)o * c->ng];
+					if (o == 0) {
+						if (!c->seeded) smooth_level(c, o, c->in.d, L, c->base_taps, nullptr, nullptr, nullptr);
+					} else if (!half_written[(size_t)o]) {  // the launch decimates the parent's seed level itself (no decimation launch)
+						const Level &P = c->gss[(size_t)(o - 1) * c->ng + c->p.num_kp_levels];
+						sa.parent = P.d; sa.pnx = P.nx; sa.pny = P.ny;
+					}
+					launch_small_octaves(sa, so);
+				}
+				if (head) S3D_HIP(hipEventRecord(c->ev_seed[o], so));
+				if (!head && o > 0) S3D_HIP(hipEventRecord(c->ev_done[o], so));
+				return SIFT3D_OK;
+			}
 			if (head && o > 0) {
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_fork, 0));
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[o - 1], 0));

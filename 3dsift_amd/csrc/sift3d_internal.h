@@ -134,6 +134,22 @@ bool march_half_ok(int nx, int ny, const ZRange &zr);
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
                         hipStream_t st, int plan_slots = 0, int prio = 0, const MarchHalf *half = nullptr);
 void launch_copy16(const float *src, float *dst, size_t nfloats, hipStream_t st);  // float4 copy (bandwidth ceiling probe)
+// ---- kernels_small.hip: every level of the SMALL octaves (16^3-class and below) in one launch of one workgroup ----
+constexpr int kSmallMaxOct = 4, kSmallMaxLv = 8;
+struct SmallOct { float *g[kSmallMaxLv]; float *dog[kSmallMaxLv]; int nx, ny, nz; };  // Gaussian / DoG level buffers of one octave
+struct SmallArgs {
+	SmallOct oct[kSmallMaxOct];
+	int noct, ng, nd, seed;          // octaves in the launch; Gaussian / DoG levels per octave; the seed level (num_kp_levels)
+	unsigned build_mask, dog_mask;   // bit i: Gaussian level i is built; bit j: DoG level j is written (and its abs-max taken)
+	unsigned *dogmax;                // [octave of the launch][nd] max|DoG| bits
+	int hwp;                         // half width the launch runs every level with (6 or 8): narrower kernels are padded with zero taps
+	float w[kSmallMaxLv][9];         // w[i][k], k = hwp - |d|: tap of level i at distance |d| from the centre (symmetric kernel), 0 beyond its own half width
+	const float *parent;             // != null: level 0 of the first octave = every second voxel of this level (pnx x pny planes), formed by the launch
+	int pnx, pny;
+};
+bool small_octave_fits(int nx, int ny, int nz, int max_hw);
+int small_padded_hw(int max_hw);
+void launch_small_octaves(const SmallArgs &a, hipStream_t st);
 void launch_downsample(const float *src, int snx, int sny, float *dst, int nx, int ny, int nz, hipStream_t st);
 
 // ---- kernels_detect.hip --------------------------------------------------------------------
