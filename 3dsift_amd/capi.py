@@ -30,7 +30,7 @@ assert KP_DTYPE.itemsize == 168
 
 # every symbol include/sift3d_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "sift3d_default_params", "sift3d_create", "sift3d_destroy", "sift3d_run", "sift3d_run_stages",
+    "sift3d_default_params", "sift3d_create", "sift3d_destroy", "sift3d_run", "sift3d_run_async", "sift3d_wait", "sift3d_run_stages",
     "sift3d_stage_times", "sift3d_num_keypoints", "sift3d_get_keypoints", "sift3d_device_results",
     "sift3d_num_octaves", "sift3d_level_info", "sift3d_copy_level", "sift3d_copy_input", "sift3d_num_extrema",
     "sift3d_get_extrema", "sift3d_get_orientation_codes", "sift3d_gaussian_smooth", "sift3d_downsample", "sift3d_dog_sub", "sift3d_match",
@@ -91,6 +91,8 @@ def lib():
         L.sift3d_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int]
         L.sift3d_destroy.argtypes = [C.c_void_p]
         L.sift3d_run.argtypes = [C.c_void_p]
+        L.sift3d_run_async.argtypes = [C.c_void_p]
+        L.sift3d_wait.argtypes = [C.c_void_p]
         L.sift3d_run_stages.argtypes = [C.c_void_p, C.c_int]
         L.sift3d_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.sift3d_num_keypoints.argtypes = [C.c_void_p, _ip]
@@ -263,6 +265,15 @@ class CSIFT3D:
     # --- reference API names -------------------------------------------------------------------
     def KpSiftAlgorithm(self):
         _check(lib().sift3d_run(self._h))
+        return self
+
+    def KpSiftAlgorithmAsync(self):
+        """enqueue the whole pipeline and return (sift3d_run_async); Wait() -- or any accessor -- completes it"""
+        _check(lib().sift3d_run_async(self._h))
+        return self
+
+    def Wait(self):
+        _check(lib().sift3d_wait(self._h))
         return self
 
     def run_stages(self, upto):

@@ -227,6 +227,7 @@ struct sift3d_ctx {
 
 	// results / state
 	int stage = 0;  // highest stage run
+	bool pending = false;  // sift3d_run_async enqueued a run that sift3d_wait has not completed yet
 	unsigned n_ext = 0, n_kp = 0;
 	hipEvent_t ev[8] = {};
 	double times[8] = {};
@@ -279,6 +280,8 @@ static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
 	return SIFT3D_OK;
 }
 
+extern "C" int sift3d_wait(sift3d_handle c);
+
 extern "C" int sift3d_test_hook(int which, int value) {
 	if (which < 0 || which >= SIFT3D_HOOK_COUNT) return -1;
 	const int prev = g_hooks[which];
@@ -320,6 +323,7 @@ extern "C" const char *sift3d_last_error(void) { return g_last_error.c_str(); }
 extern "C" int sift3d_destroy(sift3d_handle c) {
 	if (!c) return SIFT3D_OK;
 	hipSetDevice(c->device);
+	c->pending = false;  // (an asynchronous run in flight is drained below, its results dropped)
 	if (c->stream) hipStreamSynchronize(c->stream);
 	if (c->own_stream && c->own_stream != c->stream) hipStreamSynchronize(c->own_stream);
 	free_lists(c);
@@ -684,7 +688,10 @@ static bool smooth_level(sift3d_ctx *c, int o, const float *src, const Level &ds
 	const int plan_slots = c->noct > 1 ? (o == 0 ? (level > c->p.num_kp_levels ? tail_slots : 0) : (o == 1 && bg1_slots > 0 ? bg1_slots : bg_slots)) : 0;
 	// hot path: one fused pass (x, y, z blur + DoG + abs-max; kernels_march.hip); prev == src for every DoG-producing level
 	static const int fused_min = dev_tune_i("S3D_FUSED_MIN", S3D_FUSED_MIN_DEFAULT);
-	if (c->use_fused && (prev == nullptr || prev == src) && std::min(dst.nx, std::min(dst.ny, dst.nz)) >= fused_min) {
+	// r04 (shape cliff #2): the plane size decides, not the depth -- a thin volume (512 x 512 x 24: common MR / CT slabs) has planes of
+	// many tiles and marches its few planes like any other chunk (the z ends are a feed order); launch_march_level declines a level
+	// whose column is shorter than its kernel (nz < 2 hw + 2), which then takes the separable passes.  Cubes of <= 32 stay separable.
+	if (c->use_fused && (prev == nullptr || prev == src) && std::min(dst.nx, dst.ny) >= fused_min) {
 		MarchHalf hf;
 		const bool want_half = S3D_FUSED_HALF && half_out != nullptr && march_half_ok(dst.nx, dst.ny, dst.zr_all());
 		if (want_half) { hf.d = half_out->d; hf.nx = half_out->nx; hf.ny = half_out->ny; hf.nz = half_out->nz; }
@@ -697,13 +704,17 @@ static bool smooth_level(sift3d_ctx *c, int o, const float *src, const Level &ds
 	return false;
 }
 
-static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
+// One run = prepare (flags of the run) -> enqueue (the whole pipeline on the handle's streams, up to the asynchronous read-back of the
+// five counters into pinned memory; no host synchronisation) -> finish (synchronise, check the list capacity, fill state and times;
+// on overflow: regrow and enqueue again).  sift3d_run / sift3d_run_stages do all three; sift3d_run_async stops behind the first
+// enqueue and sift3d_wait finishes (r04: one host thread keeps several handles in flight).
+static int run_prepare(sift3d_ctx *c, int &upto) {
 	if (c->slab) { set_last_error("a z-slab context is driven stage by stage (sift3d_slab_*)"); return SIFT3D_ERR_STATE; }
+	if (c->pending) { set_last_error("the handle has an asynchronous run in flight: call sift3d_wait first"); return SIFT3D_ERR_STATE; }
 	int rc = set_device(c->device);
 	if (rc) return rc;
 	if (upto < 1) upto = 1;
 	if (upto > 5) upto = 5;
-	hipStream_t st = c->stream;
 	// SIFT3D_HOOK_DOG_EAGER: write every DoG level
 	const bool dog_eager = hook(SIFT3D_HOOK_DOG_EAGER) != 0;
 	c->dog_elide = !dog_eager && c->nd >= 3;
@@ -713,7 +724,14 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 	c->g_last_elide = c->dog_elide && !glast_eager && c->use_fused && 2 * (2 * c->taps[c->ng - 1].hw + 1) <= kLazySlots;
 	c->g_last_built.assign((size_t)std::max(1, c->noct), 0);
 	c->n_regrow = 0;
-	for (int attempt = 0; attempt < 8; attempt++) {
+	return SIFT3D_OK;
+}
+
+static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	hipStream_t st = c->stream;
+	{
 		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(std::max(1, c->noct * c->nd) + 6), st));
 		S3D_HIP(hipEventRecord(c->ev[0], st));
 		// ---- Build_Gaussian_Scale_Space (Src/cSIFT3D.cc:268-319) with the DoG (346-360) fused into the z pass ----
@@ -911,8 +929,20 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		}
 		if (upto >= 4) launch_finalize(c->d_ext, c->d_total, c->ext_cap, upto >= 5, c->d_kpout, c->d_xyz, c->kp_cap, st);
 		S3D_HIP(hipEventRecord(c->ev[5], st));
-		unsigned *host_words = c->h_words;  // total, overflow, nkp, describe work counter, describe second passes
-		S3D_HIP(hipMemcpyAsync(host_words, c->d_total, sizeof(unsigned) * 5, hipMemcpyDeviceToHost, st));
+		// total, overflow, nkp, describe work counter, describe second passes -> pinned host words
+		S3D_HIP(hipMemcpyAsync(c->h_words, c->d_total, sizeof(unsigned) * 5, hipMemcpyDeviceToHost, st));
+	}
+	return SIFT3D_OK;
+}
+
+// synchronise with the enqueued run and take its results; again = the lists overflowed and were regrown: enqueue once more
+static int run_finish(sift3d_ctx *c, int upto, bool &again) {
+	again = false;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	hipStream_t st = c->stream;
+	{
+		unsigned *host_words = c->h_words;
 		S3D_HIP(hipStreamSynchronize(st));
 		S3D_HIP(hipGetLastError());
 		if (host_words[1] != 0 || host_words[0] > c->ext_cap) {
@@ -922,7 +952,8 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 			rc = alloc_lists(c, need);
 			if (rc) return rc;
 			c->n_regrow++;
-			continue;
+			again = true;
+			return SIFT3D_OK;
 		}
 		c->n_ext = host_words[0];
 		c->n_kp = upto >= 4 ? host_words[2] : 0;
@@ -934,13 +965,51 @@ static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 		c->times[4] = dt(2, 3); c->times[5] = dt(3, 4); c->times[6] = dt(4, 5); c->times[7] = 0;
 		return SIFT3D_OK;
 	}
+}
+
+static int run_complete(sift3d_ctx *c, int upto, bool part_orient) {  // behind an enqueue: finish, re-enqueueing while the lists overflow
+	for (int attempt = 0; attempt < 8; attempt++) {
+		bool again = false;
+		int rc = run_finish(c, upto, again);
+		if (rc) return rc;
+		if (!again) return SIFT3D_OK;
+		if ((rc = run_enqueue(c, upto, part_orient)) != SIFT3D_OK) return rc;
+	}
+	(void)hipStreamSynchronize(c->stream);
 	set_last_error("extrema list kept overflowing");
 	return SIFT3D_ERR_CAPACITY;
+}
+
+static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
+	int rc = run_prepare(c, upto);
+	if (rc) return rc;
+	if ((rc = run_enqueue(c, upto, part_orient)) != SIFT3D_OK) return rc;
+	return run_complete(c, upto, part_orient);
 }
 
 extern "C" int sift3d_run(sift3d_handle c) {
 	if (!c) return SIFT3D_ERR_ARG;
 	return run_impl(c, 5);
+}
+
+// KpSiftAlgorithm without the wait: the whole pipeline is enqueued on the handle's own streams and the call returns; sift3d_wait
+// completes it.  One host thread can so keep several handles (volumes) in flight on one GPU -- the pyramid of one volume is bound by
+// memory, the descriptors of another by instruction issue (BASELINE configs[2] / [4]: several volumes per GPU).
+extern "C" int sift3d_run_async(sift3d_handle c) {
+	if (!c) return SIFT3D_ERR_ARG;
+	int upto = 5;
+	int rc = run_prepare(c, upto);
+	if (rc) return rc;
+	if ((rc = run_enqueue(c, upto, false)) != SIFT3D_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+	c->pending = true;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_wait(sift3d_handle c) {
+	if (!c) return SIFT3D_ERR_ARG;
+	if (!c->pending) return SIFT3D_OK;  // nothing in flight (a blocking run has completed already)
+	c->pending = false;
+	return run_complete(c, 5, false);
 }
 
 extern "C" int sift3d_run_stages(sift3d_handle c, int upto) {
@@ -950,6 +1019,7 @@ extern "C" int sift3d_run_stages(sift3d_handle c, int upto) {
 
 extern "C" int sift3d_stage_times(sift3d_handle c, double t[8]) {
 	if (!c || !t) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 1) return SIFT3D_ERR_STATE;
 	memcpy(t, c->times, sizeof(double) * 8);
 	return SIFT3D_OK;
@@ -957,12 +1027,14 @@ extern "C" int sift3d_stage_times(sift3d_handle c, double t[8]) {
 
 extern "C" int sift3d_num_keypoints(sift3d_handle c, int *n) {
 	if (!c || !n) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	*n = (c->stage >= 4) ? (int)c->n_kp : 0;  // GetKeypoints before KpSiftAlgorithm returns empty
 	return SIFT3D_OK;
 }
 
 extern "C" int sift3d_get_keypoints(sift3d_handle c, sift3d_keypoint *out, float *desc) {
 	if (!c) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 4 || c->n_kp == 0) return SIFT3D_OK;
 	int rc = set_device(c->device);
 	if (rc) return rc;
@@ -975,6 +1047,7 @@ extern "C" int sift3d_get_keypoints(sift3d_handle c, sift3d_keypoint *out, float
 
 extern "C" int sift3d_device_results(sift3d_handle c, const float **d_desc, const float **d_xyz, int *n) {
 	if (!c) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 5) return SIFT3D_ERR_STATE;
 	if (d_desc) *d_desc = c->d_desc;
 	if (d_xyz) *d_xyz = c->d_xyz;
@@ -1006,6 +1079,7 @@ extern "C" int sift3d_level_info(sift3d_handle c, int is_dog, int idx, int dims3
 
 extern "C" int sift3d_copy_level(sift3d_handle c, int is_dog, int idx, float *out) {
 	if (!c || !out) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 1) return SIFT3D_ERR_STATE;
 	const Level *L = pick_level(c, is_dog, idx);
 	if (!L) return SIFT3D_ERR_ARG;
@@ -1050,6 +1124,7 @@ extern "C" int sift3d_copy_input(sift3d_handle c, float *out) {
 
 extern "C" int sift3d_num_extrema(sift3d_handle c, int *n) {
 	if (!c || !n) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	*n = c->stage >= 3 ? (int)c->n_ext : 0;
 	return SIFT3D_OK;
 }
@@ -1064,6 +1139,7 @@ static int fetch_ext(sift3d_ctx *c, std::vector<DevKp> &h) {
 
 extern "C" int sift3d_get_extrema(sift3d_handle c, sift3d_keypoint *out) {
 	if (!c || !out) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 3) return SIFT3D_ERR_STATE;
 	std::vector<DevKp> h;
 	int rc = fetch_ext(c, h);
@@ -1085,6 +1161,7 @@ extern "C" int sift3d_get_extrema(sift3d_handle c, sift3d_keypoint *out) {
 
 extern "C" int sift3d_get_orientation_codes(sift3d_handle c, int *codes) {
 	if (!c || !codes) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 4) return SIFT3D_ERR_STATE;
 	std::vector<DevKp> h;
 	int rc = fetch_ext(c, h);
@@ -1275,6 +1352,7 @@ extern "C" int sift3d_slab_min_halo(const sift3d_params *params, int *halo) {
 // only knows its own allocations can reduce / gather them
 extern "C" int sift3d_export_device(sift3d_handle c, float *d_desc_dst, float *d_xyz_dst) {
 	if (!c) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 5) return SIFT3D_ERR_STATE;
 	int rc = set_device(c->device);
 	if (rc) return rc;

@@ -109,6 +109,10 @@ public:
 	CSIFT3D &operator=(const CSIFT3D &) = delete;
 
 	SIFT_LIBRARY_API void KpSiftAlgorithm();
+	// extension (no reference counterpart): KpSiftAlgorithm split in two.  KpSiftAlgorithmAsync() enqueues the whole pipeline on the GPU
+	// and returns; Wait() -- or GetKeypoints() -- completes it.  One host thread keeps several extractors (volumes) in flight on one GPU.
+	SIFT_LIBRARY_API void KpSiftAlgorithmAsync();
+	SIFT_LIBRARY_API void Wait();
 	SIFT_LIBRARY_API void SetNumThreads(int t_num);
 	SIFT_LIBRARY_API std::vector<Keypoint> GetKeypoints();
 

@@ -99,6 +99,7 @@ struct CSIFT3D::Impl {
 	int levels = 3;
 	int stage = 0;
 	bool fetched = false;
+	bool in_flight = false;  // KpSiftAlgorithmAsync() enqueued a run that Wait() has not completed
 	unsigned long long desc_hash = 0;  // of the host descriptor block as fetched (OwnerOf: has the caller edited it since?)
 };
 
@@ -265,6 +266,27 @@ void CSIFT3D::KpSiftAlgorithm() {
 	}
 	if (need_single("KpSiftAlgorithm", impl->h, impl->sh)) run_to(this, impl->h, 5, impl->stage, impl->fetched, m_timer);
 }
+void CSIFT3D::KpSiftAlgorithmAsync() {
+	if (impl->sh) { KpSiftAlgorithm(); return; }  // (the sharded driver joins its rank threads: nothing to overlap with)
+	if (!need_single("KpSiftAlgorithmAsync", impl->h, impl->sh)) return;
+	const int rc = sift3d_run_async(impl->h);
+	complain("KpSiftAlgorithmAsync", rc);
+	impl->in_flight = rc == SIFT3D_OK;
+}
+void CSIFT3D::Wait() {
+	if (!impl->h || !impl->in_flight) return;
+	impl->in_flight = false;
+	const int rc = sift3d_wait(impl->h);
+	complain("Wait", rc);
+	if (rc != SIFT3D_OK) return;
+	impl->stage = 5;
+	impl->fetched = false;
+	double t[8];
+	if (sift3d_stage_times(impl->h, t) == SIFT3D_OK) {
+		m_timer.d_TotalTime = t[0]; m_timer.d_Allocation = t[1]; m_timer.d_BuildGSS = t[2]; m_timer.d_BuildDOG = t[3];
+		m_timer.d_Detect = t[4]; m_timer.d_AssignOrientation = t[5]; m_timer.d_Extraction = t[6]; m_timer.d_release = t[7];
+	}
+}
 void CSIFT3D::Initialize() {}
 void CSIFT3D::Build_Gaussian_Scale_Space() { if (need_single("Build_Gaussian_Scale_Space", impl->h, impl->sh)) run_to(this, impl->h, 1, impl->stage, impl->fetched, m_timer); }
 void CSIFT3D::Build_DOG_Scale_Space() { if (need_single("Build_DOG_Scale_Space", impl->h, impl->sh)) run_to(this, impl->h, 2, impl->stage, impl->fetched, m_timer); }
@@ -278,6 +300,7 @@ void CSIFT3D::SetNumThreads(int t_num) {
 }
 
 std::vector<Keypoint> CSIFT3D::GetKeypoints() {
+	Wait();
 	if (!impl->fetched) fetch_results();
 	return filter;
 }
@@ -334,6 +357,7 @@ std::vector<std::vector<Keypoint>> *CSIFT3D::GET_LEVEL() {
 
 bool CSIFT3D::GetDeviceResults(const float **d_desc, const float **d_xyz, int *n, int *device) {
 	if (!impl->h) return false;
+	Wait();
 	if (device) *device = impl->device;
 	return sift3d_device_results(impl->h, d_desc, d_xyz, n) == SIFT3D_OK;
 }

@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--no-match", action="store_true", help="skip the configs[2] matcher leg")
     ap.add_argument("--no-nonaligned", action="store_true", help="skip the non-tile-aligned volume leg")
     ap.add_argument("--nonaligned-dims", default="480x500x300", help="nx x ny x nz of the non-aligned leg")
+    ap.add_argument("--thin-dims", default="512x512x32", help="nx x ny x nz of the thin-volume leg")
     ap.add_argument("--allpairs", action="store_true", help="N>1: all-gather descriptors + all-pairs enhancedMatch (configs[4])")
     ap.add_argument("--workload", choices=["volumes", "slab"], default="volumes")
     ap.add_argument("--slab-dims", default="1024x1024x512", help="nx x ny x nz of the sharded volume (configs[3])")
@@ -401,6 +402,16 @@ def main():
         twin = leg(((nx2 + 31) // 32 * 32, (ny2 + 31) // 32 * 32, nz2))
         out["nonaligned"]["aligned_twin"] = twin
         out["nonaligned"]["pyramid_ns_per_voxel_vs_twin"] = out["nonaligned"]["pyramid_ns_per_pyramid_voxel"] / twin["pyramid_ns_per_pyramid_voxel"]
+        # ---- a THIN volume (r04, shape cliff #2): planes of many tiles, few of them; priced per pyramid voxel against the headline volume
+        tx, ty, tz = parse_dims(args.thin_dims)
+        out["thin"] = leg((tx, ty, tz))
+        out["thin"]["pyramid_ns_per_voxel_vs_headline"] = out["thin"]["pyramid_ns_per_pyramid_voxel"] / (t_pyr / pv * 1e9)
+        # a volume of this few voxels is bound by the launch chain of its small octaves whatever its shape: the CUBE of the same voxel
+        # count (edge rounded to 16) is the like-for-like comparison of what the thin shape costs
+        ce = max(16, int(round((tx * ty * tz) ** (1.0 / 3.0) / 16.0)) * 16)
+        cube = leg((ce, ce, ce))
+        out["thin"]["equal_voxel_cube"] = {k: cube[k] for k in ("workload", "ms_per_step", "stage_ms", "pyramid_ns_per_pyramid_voxel")}
+        out["thin"]["pyramid_ns_per_voxel_vs_equal_voxel_cube"] = out["thin"]["pyramid_ns_per_pyramid_voxel"] / cube["pyramid_ns_per_pyramid_voxel"]
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
         # ---- CPU baseline + parity on a bounded sample: the [0:s]^3 crop of the same volume ----
         import oracle_lib as ol  # test infrastructure, used here ONLY as the timed baseline / checker
@@ -451,7 +462,11 @@ def main():
                 ref_block = {"value": sr ** 3 / tr / 1e6, "unit": "Mvoxels/s", "cores": cores, "kind": "reference",
                              "sample": f"[0:{sr}]^3 crop of the benchmark volume, full KpSiftAlgorithm, one run {tr:.2f} s, {len(rkp)} keypoints",
                              "stages_s": {k: round(v, 3) for k, v in ro.times.items()},
-                             "port_equals_reference_on_this_crop": bool(len(rkp) == len(okp2) and np.array_equal(rkp, okp2) and np.array_equal(rdesc.view(np.uint32), odesc2.view(np.uint32)))}
+                             # (every field but the eigenvectors, which carry their solver's sign: Eigen there, Jacobi here)
+                             "port_equals_reference_on_this_crop": bool(len(rkp) == len(okp2) and all(
+                                 np.array_equal(np.ascontiguousarray(rkp[f]).view(np.uint32), np.ascontiguousarray(okp2[f]).view(np.uint32))
+                                 for f in ("x", "y", "z", "scale", "octave", "level", "rx", "ry", "rz", "win", "eigvalue", "Rotation", "str_tensor"))
+                                 and np.array_equal(rdesc.view(np.uint32), odesc2.view(np.uint32)))}
                 ro.close(); oo.close()
             except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline
                 ref_block = {"error": f"{type(e).__name__}: {e}"}
@@ -514,6 +529,24 @@ def main():
                                         "sIdx_equal": bool(np.array_equal(r["sIdx"], want["sIdx"])),
                                         "gDist_equal": bool(np.array_equal(r["gDist"], want["gDist"])),
                                         "oracle_enhancedMatch_seconds": round(tmc, 3)}
+        # ---- BASELINE configs[2] as a pipeline (r04; not part of `value`): both volumes' KpSiftAlgorithm enqueued by ONE host thread
+        # (sift3d_run_async on each handle's own streams), waited for, then enhancedMatch straight from the device-resident results
+        blk, par, tot = [], [], []
+        for _ in range(6):
+            torch.cuda.synchronize()
+            t0p = time.perf_counter(); ex.KpSiftAlgorithm(); ex2.KpSiftAlgorithm(); blk.append(time.perf_counter() - t0p)
+            t0p = time.perf_counter(); ex.KpSiftAlgorithmAsync(); ex2.KpSiftAlgorithmAsync(); ex.Wait(); ex2.Wait()
+            t1p = time.perf_counter()
+            (da, xa, na), (db, xb, nb) = ex.device_results(), ex2.device_results()
+            r2 = mt.enhancedMatch(da, xa, db, xb, 0.85, on_device=True, n=na, m=nb)
+            t2p = time.perf_counter()
+            par.append(t1p - t0p); tot.append(t2p - t0p)
+        mp, mb = float(np.median(par[1:])), float(np.median(blk[1:]))
+        out["pipeline2"] = {"workload": f"two {n}^3 volumes: KpSiftAlgorithm of both in flight on one GPU (sift3d_run_async x2 + sift3d_wait x2 from one host thread), then enhancedMatch on the device-resident descriptors",
+                            "extract2_ms_in_flight": mp * 1e3, "extract2_ms_one_after_the_other": mb * 1e3,
+                            "aggregate_Mvoxels_per_s": 2 * n ** 3 / mp / 1e6, "aggregate_Mvoxels_per_s_one_after_the_other": 2 * n ** 3 / mb / 1e6,
+                            "extract2_plus_enhancedMatch_wall_ms": float(np.median(tot[1:])) * 1e3,
+                            "same_pairs_as_the_blocking_path": bool(np.array_equal(r2["pairs"], r["pairs"]))}
         ex2.close()
     if args.allpairs and world > 1:
         # BASELINE configs[4] matching leg (not part of `value`): all-gather the device-resident descriptors

@@ -86,6 +86,14 @@ int sift3d_destroy(sift3d_handle h);
  * device until sift3d_get_keypoints.  Returns after the stream has drained. */
 int sift3d_run(sift3d_handle h);
 
+/* KpSiftAlgorithm split in two (no reference counterpart: the reference's call blocks, Src/cSIFT3D.cc:165-235): sift3d_run_async
+ * enqueues the whole pipeline on the handle's own streams and returns without waiting; sift3d_wait completes it (results, stage
+ * times, the rare list regrow + rerun).  One host thread can keep several handles in flight on one GPU -- BASELINE configs[2] / [4]
+ * extract several volumes: the pyramid of one is bound by memory while the descriptors of another are bound by instruction issue.
+ * Every accessor of a handle with a run in flight completes it first; sift3d_wait without a run in flight returns SIFT3D_OK. */
+int sift3d_run_async(sift3d_handle h);
+int sift3d_wait(sift3d_handle h);
+
 /* Replaces calling the public stage methods one by one (Include/cSIFT3D.h:157-165); `upto`:
  * 1 Initialize+Build_Gaussian_Scale_Space(+fused DoG), 2 Build_DOG_Scale_Space, 3 Detect_KeyPoints,
  * 4 Assign_Orientation, 5 Extract_Description.  Used by the parity tests. */

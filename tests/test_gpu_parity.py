@@ -80,6 +80,9 @@ def test_g4_g6_golden_keypoints(capi, synth, tag):
     ((20, 70, 192), 32, 0.3),       # nx = 192: three words per row (the loop behind the batches of eight), dense: candidates on every border
     ((45, 51, 64), 33, 0.02),       # nx % 4 == 0 with odd ny and nz: the decimation fused into the seed level's kernel drops the odd last row / plane
     ((36, 40, 300), 34, 0.1),       # nx = 300: a partial last ballot word in the lean row loop (clamped lane offsets)
+    ((24, 512, 512), 35, 0.01),     # r04: a THIN volume (planes of 256 tiles, 24 of them): the march kernel on short columns; octave 1 is 12 planes: its widest level (hw 6 > (12 - 2) / 2) takes the separable passes
+    ((40, 300, 300), 36, 0.02),     # r04: thin and not tile aligned (shifted last tile column / row), 3 octaves: 300 x 300 x 40, 150 x 150 x 20, 75 x 75 x 10
+    ((16, 96, 128), 37, 0.01),      # r04: 16 planes: hw 8 never fits, hw 6 and below do (16 >= 2 hw + 2 for hw <= 7)
 ])
 def test_full_pipeline_vs_oracle(capi, orc, synth, shape, seed, noise):
     vol = synth.blobs(shape, seed=seed, noise=noise)
@@ -528,3 +531,27 @@ def test_matcher_awkward_sizes(capi, orc):
             want = orc.match(a, ax, b, bx, 0.85, mode)
             for key in want:
                 assert np.array_equal(got[key], want[key]), (n, m, mode, key)
+
+
+def test_async_run_two_volumes_in_flight(capi, synth):
+    """sift3d_run_async / sift3d_wait (r04): one host thread enqueues KpSiftAlgorithm on TWO handles, then waits for both.  Extrema,
+    keypoints and descriptors of both volumes equal the blocking runs bit for bit (the descriptor histograms are integer sums, the
+    pyramids bit-exact: nothing may depend on what else shares the GPU); accessors complete a run in flight by themselves; a second
+    run_async without a wait in between is refused."""
+    va = synth.blobs((96, 112, 128), seed=41, noise=0.01)
+    vb = synth.blobs((128, 96, 80), seed=42, noise=0.02)
+    base = [_full_hash(capi, capi.CreateCSIFT3D(v).KpSiftAlgorithm(), with_extrema=True) for v in (va, vb)]
+    assert base[0][1] > 20 and base[1][1] > 20
+    ea, eb = capi.CreateCSIFT3D(va), capi.CreateCSIFT3D(vb)
+    for rep in range(3):
+        ea.KpSiftAlgorithmAsync(); eb.KpSiftAlgorithmAsync()
+        with pytest.raises(capi.Sift3dError):
+            ea.KpSiftAlgorithmAsync()          # a run is in flight
+        eb.Wait(); ea.Wait(); ea.Wait()        # any order; a wait with nothing in flight is a no-op
+        assert [_full_hash(capi, e, with_extrema=True) for e in (ea, eb)] == base, rep
+    ea.KpSiftAlgorithmAsync()
+    assert len(ea.GetKeypoints()[0]) == base[0][1]   # no Wait(): the accessor completes the run
+    with capi.hook("list_cap", 64):   # the regrow + rerun of an overflowing list happens inside the wait
+        ec = capi.CreateCSIFT3D(va)
+        ec.KpSiftAlgorithmAsync().Wait()
+        assert ec.debug_counters()["list_regrows"] >= 1 and _full_hash(capi, ec, with_extrema=True) == base[0]
