@@ -853,7 +853,7 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 		// the pyramid's is its wall time, the detection's is what is left of it behind the pyramid.
 		const bool two = upto >= 3 && c->det_o.size() > 1;  // masks of octaves >= 1 on a second stream beside octave 0's
 #ifndef S3D_DET_EARLY_DEFAULT
-#define S3D_DET_EARLY_DEFAULT 0  /* measured (r03, 512^3): detection 0.87 -> 0.73 ms but the pyramid stage 2.31 -> 2.40 ms -- the launches of the small octaves' chain wait for slots behind k_mark's 24 576 workgroups: 7.64 -> 7.60 ms per step, and the pyramid's roofline fraction would pay for it; queue priorities for the chain's streams (S3D_STREAM_PRIO) make every cross-stream wait slower (pyramid 3.8-4.3 ms) */
+#define S3D_DET_EARLY_DEFAULT 1  /* r04: ON -- with the small octaves in one launch the chain no longer starves behind k_mark's workgroups: detection 0.87 -> 0.82 ms, pyramid 2.18 -> 2.19 ms, step 7.41 -> 7.38 ms (r03, ~60 chain launches: detection 0.87 -> 0.73 but pyramid 2.31 -> 2.40, off) */
 #endif
 		static const int det_early_mode = dev_tune_i("S3D_DET_EARLY", S3D_DET_EARLY_DEFAULT);
 		const bool early = two && det_early_mode != 0 && c->noct > 1 && c->ostream.size() > 1 && c->ostream[1] != st;

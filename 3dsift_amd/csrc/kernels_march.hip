@@ -134,6 +134,9 @@ __device__ __forceinline__ float m_absmax(float m, float v) {
 #ifndef S3D_MARCH_YPRE
 #define S3D_MARCH_YPRE 1  /* 1: the first group of y-blur rows is requested in front of the x-blur (their latency hides behind its arithmetic) */
 #endif
+#ifndef S3D_MARCH_ZSYM
+#define S3D_MARCH_ZSYM 1  /* r04, bit-identical, 2.24 -> 2.22 ms: the z-scatter forms each product tap * v once for the two accumulators that take it (symmetric taps) */
+#endif
 #ifndef S3D_MARCH_CR_MAXHW
 #define S3D_MARCH_CR_MAXHW 5  /* DoG centre ring in LDS up to this half width (three workgroups per CU still fit); wider levels re-read the centre plane */
 #endif
@@ -168,6 +171,7 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
                                                         unsigned *__restrict__ dogmax, int nx, int ny, ZRange zr, MTaps t, MEdge ef, int ntx,
                                                         int nty, int cz, int prio, float *__restrict__ half, int hnx, int hny, int hnz) {
 	using C = MCfg<HW>;
+	constexpr bool ZSYM = S3D_MARCH_ZSYM != 0 && HW <= 6;
 	__shared__ __attribute__((aligned(1024))) float tile[2 * C::TILE_F];
 	__shared__ __attribute__((aligned(16))) float xb[2 * C::XB_F];
 	__shared__ __attribute__((aligned(16))) mf4 cring[CR ? C::CRN * C::NT : 1];
@@ -422,6 +426,24 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 				}
 			}
 			float out[4];
+			if (ZSYM) {
+				// r04: the taps are symmetric bit for bit (checked on the host: t.w[s] == t.w[2 HW - s]), so the product of v with tap s is
+				// also the product with tap 2 HW - s: HW + 1 multiplies per value instead of 2 HW + 1, the adds and their order unchanged
+				float m[HW + 1][4];
+#pragma unroll
+				for (int k = 0; k <= HW; k++)
+#pragma unroll
+					for (int c = 0; c < 4; c++) m[k][c] = t.w[k] * v[c];
+#pragma unroll
+				for (int c = 0; c < 4; c++) out[c] = A[2 * HW - 1][c] + m[0][c];
+#pragma unroll
+				for (int s = 2 * HW - 1; s >= 1; s--) {
+#pragma unroll
+					for (int c = 0; c < 4; c++) A[s][c] = A[s - 1][c] + m[s <= HW ? s : 2 * HW - s][c];
+				}
+#pragma unroll
+				for (int c = 0; c < 4; c++) A[0][c] = 0.0f + m[0][c];
+			} else {
 #pragma unroll
 			for (int c = 0; c < 4; c++) out[c] = A[2 * HW - 1][c] + t.w[2 * HW] * v[c];
 #pragma unroll
@@ -432,6 +454,7 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 			}
 #pragma unroll
 			for (int c = 0; c < 4; c++) A[0][c] = 0.0f + t.w[0] * v[c];
+			}
 
 			if (DOG && CR) cen = cring[(j % C::CRN) * C::NT + tid];  // parked HW+1 steps ago (read before this step's park below)
 #if S3D_MARCH_SCHEDB
@@ -566,6 +589,8 @@ bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogm
 	else if (half && half->d) return false;  // (the caller asks first: march_half_ok)
 	auto fits = [&](int n) { return n == 32 || n >= 32 + t.hw; };  // the shifted tile starts at n - 32: 0 or beyond the mirror zone [0, hw)
 	if (!fits(nx) || !fits(ny) || zr.nzg < 2 * t.hw + 2) return false;
+	if (S3D_MARCH_ZSYM)  // the symmetric form of the z-scatter needs what GaussianSmooth_3D's generator gives: tap[hw + d] == tap[hw - d] bit for bit
+		for (int d = 1; d <= t.hw; d++) if (memcmp(&t.w[t.hw + d], &t.w[t.hw - d], sizeof(float)) != 0) return false;
 	switch (t.hw) {
 	case 2: launch_march_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
 	case 3: launch_march_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
