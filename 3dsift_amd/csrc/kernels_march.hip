@@ -582,15 +582,22 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 // kernels of kernels_pyramid.hip
 bool march_half_ok(int nx, int ny, const ZRange &zr) { return (nx & 3) == 0 && zr.zoff == 0 && zr.nz == zr.nzg; }  // whole volumes, pieces on even x
 
+// would launch_march_level take a level of nx x ny planes, nzg of them, with this kernel?
+bool march_applicable(int nx, int ny, int nzg, const Taps &t) {
+	auto fits = [&](int n) { return n == 32 || n >= 32 + t.hw; };  // the shifted tile starts at n - 32: 0 or beyond the mirror zone [0, hw)
+	if (!fits(nx) || !fits(ny) || nzg < 2 * t.hw + 2) return false;
+	if (!(t.hw == 2 || t.hw == 3 || t.hw == 4 || t.hw == 5 || t.hw == 6 || t.hw == 8)) return false;
+	if (S3D_MARCH_ZSYM)  // the symmetric form of the z-scatter needs what GaussianSmooth_3D's generator gives: tap[hw + d] == tap[hw - d] bit for bit
+		for (int d = 1; d <= t.hw; d++) if (memcmp(&t.w[t.hw + d], &t.w[t.hw - d], sizeof(float)) != 0) return false;
+	return true;
+}
+
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
                         hipStream_t st, int plan_slots, int prio, const MarchHalf *half) {
 	MarchHalf hf;
 	if (half && half->d && march_half_ok(nx, ny, zr)) hf = *half;
 	else if (half && half->d) return false;  // (the caller asks first: march_half_ok)
-	auto fits = [&](int n) { return n == 32 || n >= 32 + t.hw; };  // the shifted tile starts at n - 32: 0 or beyond the mirror zone [0, hw)
-	if (!fits(nx) || !fits(ny) || zr.nzg < 2 * t.hw + 2) return false;
-	if (S3D_MARCH_ZSYM)  // the symmetric form of the z-scatter needs what GaussianSmooth_3D's generator gives: tap[hw + d] == tap[hw - d] bit for bit
-		for (int d = 1; d <= t.hw; d++) if (memcmp(&t.w[t.hw + d], &t.w[t.hw - d], sizeof(float)) != 0) return false;
+	if (!march_applicable(nx, ny, zr.nzg, t)) return false;
 	switch (t.hw) {
 	case 2: launch_march_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
 	case 3: launch_march_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;

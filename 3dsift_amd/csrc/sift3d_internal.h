@@ -131,6 +131,7 @@ void launch_conv_axis(int axis, const float *src, float *dst, int nx, int ny, in
 // level 0 of the next octave, written by the march kernel together with the seed level (DownSample_3D fused into the producer)
 struct MarchHalf { float *d = nullptr; int nx = 0, ny = 0, nz = 0; };
 bool march_half_ok(int nx, int ny, const ZRange &zr);
+bool march_applicable(int nx, int ny, int nzg, const Taps &t);
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
                         hipStream_t st, int plan_slots = 0, int prio = 0, const MarchHalf *half = nullptr);
 void launch_copy16(const float *src, float *dst, size_t nfloats, hipStream_t st);  // float4 copy (bandwidth ceiling probe)
