@@ -34,6 +34,7 @@ SYMBOLS = [
     "sift3d_stage_times", "sift3d_num_keypoints", "sift3d_get_keypoints", "sift3d_device_results",
     "sift3d_num_octaves", "sift3d_level_info", "sift3d_copy_level", "sift3d_copy_input", "sift3d_num_extrema",
     "sift3d_get_extrema", "sift3d_get_orientation_codes", "sift3d_gaussian_smooth", "sift3d_downsample", "sift3d_dog_sub", "sift3d_match",
+    "sift3d_match_handles",
     "sift3d_device_count", "sift3d_error_string", "sift3d_last_error",
     # multi-GPU sharding (z-slabs of octave 0 + seeded replicated tail)
     "sift3d_slab_min_halo", "sift3d_slab_arena_floats", "sift3d_slab_create", "sift3d_slab_buffer", "sift3d_slab_upload",
@@ -50,7 +51,7 @@ SYMBOLS = [
     "sift3d_test_hook", "sift3d_debug_counters", "sift3d_debug_face_lookup", "sift3d_match_times", "sift3d_debug_copy_bandwidth",
 ]
 HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "desc_nocache": 4, "match_nodma": 5, "one_stream": 6,
-         "desc_mass_shift": 7, "list_cap": 8}
+         "desc_mass_shift": 7, "list_cap": 8, "peer_copy": 9}
 ORIENT_WORDS = 34
 
 
@@ -110,6 +111,7 @@ def lib():
         L.sift3d_dog_sub.argtypes = [_fp, _fp, C.c_size_t, _fp, C.c_int]
         L.sift3d_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                    C.c_int, C.c_int, _ip, _ip, _fp, _fp, _fp, _ip, C.POINTER(C.c_double)]
+        L.sift3d_match_handles.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, _ip, _ip, _fp, _fp, _fp, _ip, C.POINTER(C.c_double)]
         L.sift3d_device_count.argtypes = [_ip]
         _sz = C.POINTER(C.c_size_t)
         L.sift3d_slab_min_halo.argtypes = [C.POINTER(Params), _ip]
@@ -614,6 +616,18 @@ class muBruteMatcher:
         L.sift3d_debug_counters(None, a)
         self.exact_rows = a[2]
         self._last = dict(gIdx=gi[:n], sIdx=si[:n], gDist=gd[:n], sDist=sd[:n], pairs=pairs[:k.value].copy())
+        return self._last
+
+    def matchExtractors(self, ref, tar, thresHold=0.85, mode="enhanced"):
+        """sift3d_match_handles: the device-resident results of two CSIFT3D objects, wherever they live (peer copy across GPUs)"""
+        n = max(len(ref.GetKeypoints(with_desc=False)[0]), 1)
+        gi = np.zeros(n, np.int32); si = np.zeros(n, np.int32); gd = np.zeros(n, np.float32); sd = np.zeros(n, np.float32)
+        pairs = np.zeros((n, 6), np.float32); k = C.c_int(0); sec = C.c_double(0)
+        _check(lib().sift3d_match_handles(ref._h, tar._h, float(thresHold), self.MODES[mode], gi.ctypes.data_as(_ip), si.ctypes.data_as(_ip),
+                                          _f(gd), _f(sd), _f(pairs), C.byref(k), C.byref(sec)))
+        self.totalTime = sec.value
+        nk = len(ref.GetKeypoints(with_desc=False)[0])
+        self._last = dict(gIdx=gi[:nk], sIdx=si[:nk], gDist=gd[:nk], sDist=sd[:nk], pairs=pairs[:k.value].copy())
         return self._last
 
     def injectMatch(self, ref_desc, ref_xyz, tar_desc, tar_xyz, thresHold=0.85, **kw):

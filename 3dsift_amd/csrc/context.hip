@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "sift3d_internal.h"
 
@@ -217,6 +218,8 @@ struct sift3d_ctx {
 	float *d_lutpool = nullptr;
 	sift3d_keypoint *d_kpout = nullptr;
 	float *d_desc = nullptr, *d_xyz = nullptr;
+	float *d_peer = nullptr;        // sift3d_match_handles: a target's descriptors + coordinates copied from another GPU (grow-only)
+	size_t peer_floats = 0;
 
 	// host tables
 	std::vector<Taps> taps;  // per GSS level index within an octave
@@ -328,6 +331,7 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	if (c->own_stream && c->own_stream != c->stream) hipStreamSynchronize(c->own_stream);
 	free_lists(c);
 	if (!c->ext_arena) hipFree(c->arena);
+	hipFree(c->d_peer);
 	hipFree(c->d_words);
 	if (c->h_words) (void)hipHostFree(c->h_words);
 	hipFree(c->d_slots_part);
@@ -626,6 +630,13 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	if (rc) { sift3d_destroy(c); return rc; }
 	CHECKED(hipStreamSynchronize(c->stream));
 #undef CHECKED
+	{
+		// first create on this device: load the kernels of every translation unit now (HIP loads a unit's code object at the first
+		// launch of one of its kernels: ~1 ms of the first KpSiftAlgorithm of a process went there, scripts/step_times_probe.py)
+		static std::atomic<unsigned long long> loaded{0};
+		const unsigned long long bit = 1ull << (device & 63);
+		if (!(loaded.fetch_or(bit) & bit)) { preload_march_kernels(); preload_small_kernels(); preload_detect_kernels(); preload_orient_kernels(); }
+	}
 	*out = c;
 	return SIFT3D_OK;
 }
@@ -1053,6 +1064,32 @@ extern "C" int sift3d_device_results(sift3d_handle c, const float **d_desc, cons
 	if (d_xyz) *d_xyz = c->d_xyz;
 	if (n) *n = (int)c->n_kp;
 	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_match_handles(sift3d_handle ref, sift3d_handle tar, double thresHold, int mode, int *gIdx, int *sIdx, float *gDist,
+                                    float *sDist, float *pairs6, int *npairs, double *seconds) {
+	if (!ref || !tar) return SIFT3D_ERR_ARG;
+	int rc;
+	if (ref->pending && (rc = sift3d_wait(ref)) != SIFT3D_OK) return rc;
+	if (tar->pending && (rc = sift3d_wait(tar)) != SIFT3D_OK) return rc;
+	if (ref->stage < 5 || tar->stage < 5) { set_last_error("sift3d_match_handles: both extractors must have run"); return SIFT3D_ERR_STATE; }
+	const int n = (int)ref->n_kp, m = (int)tar->n_kp;
+	const float *td = tar->d_desc, *tx = tar->d_xyz;
+	if ((tar->device != ref->device || hook(SIFT3D_HOOK_PEER_COPY)) && m > 0) {
+		// the target's results live on another GPU: one peer-to-peer copy (xGMI) into a scratch on the reference's device
+		if ((rc = set_device(ref->device)) != SIFT3D_OK) return rc;
+		const size_t need = (size_t)m * (kDesc + 3);
+		if (need > ref->peer_floats) {
+			if (ref->d_peer) (void)hipFree(ref->d_peer);
+			ref->d_peer = nullptr; ref->peer_floats = 0;
+			S3D_HIP(hipMalloc(&ref->d_peer, sizeof(float) * (need + need / 4)));
+			ref->peer_floats = need + need / 4;
+		}
+		S3D_HIP(hipMemcpyPeer(ref->d_peer, ref->device, tar->d_desc, tar->device, sizeof(float) * (size_t)m * kDesc));
+		S3D_HIP(hipMemcpyPeer(ref->d_peer + (size_t)m * kDesc, ref->device, tar->d_xyz, tar->device, sizeof(float) * (size_t)m * 3));
+		td = ref->d_peer; tx = ref->d_peer + (size_t)m * kDesc;
+	}
+	return sift3d_match(ref->d_desc, ref->d_xyz, n, td, tx, m, thresHold, mode, 1, ref->device, gIdx, sIdx, gDist, sDist, pairs6, npairs, seconds);
 }
 
 extern "C" int sift3d_num_octaves(sift3d_handle c, int *n) {

@@ -702,4 +702,6 @@ void launch_detect_octave(const DetectLevels &L, int nlevels, int nx, int ny, co
 	launch_detect_emit(L, nlevels, nx, ny, zr, octave, b, out, cap, st);
 }
 
+void preload_detect_kernels() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_scan)); }  // (see kernels_march.hip)
+
 }  // namespace s3d

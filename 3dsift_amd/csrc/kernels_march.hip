@@ -609,4 +609,8 @@ bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogm
 	}
 }
 
+// code-object preload (context.hip, first create on a device): HIP loads a translation unit's kernels at the first launch of one of them,
+// which used to add ~1 ms to the first KpSiftAlgorithm of a process
+void preload_march_kernels() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_march_level<2, false, false>)); }
+
 }  // namespace s3d

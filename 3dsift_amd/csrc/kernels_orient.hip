@@ -640,4 +640,6 @@ void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigne
 	hipLaunchKernelGGL(k_slots_write, dim3(kSlotBlocks), dim3(256), 0, st, kps, codes, d_count, cap, scratch, d_nkp, order, kp_cap);
 }
 
+void preload_orient_kernels() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_slots_count)); }  // (see kernels_march.hip)
+
 }  // namespace s3d

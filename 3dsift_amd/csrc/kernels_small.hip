@@ -294,4 +294,6 @@ void launch_small_octaves(const SmallArgs &a, hipStream_t st) {
 	hipLaunchKernelGGL(k_small_octaves, dim3(1), dim3(kThreads), 0, st, a);
 }
 
+void preload_small_kernels() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_small_octaves)); }
+
 }  // namespace s3d

@@ -249,6 +249,12 @@ int match_rows_device(const float *d_a, const int *d_row_ids, int nrows, const f
                       void *d_part, float *d_gd, float *d_sd, int *d_gi, int *d_si, const MatchGuard &g, hipStream_t st);
 int match_redo_rows();  // rows the last sift3d_match re-scored exactly (near-tie guard)
 
+// code-object preload of the translation units whose kernels would otherwise be loaded by the first KpSiftAlgorithm of a process
+void preload_march_kernels();
+void preload_small_kernels();
+void preload_detect_kernels();
+void preload_orient_kernels();
+
 // ---- test hooks and development switches --------------------------------------------------------
 // Test hooks (include/sift3d_hip.h, sift3d_test_hook): process-wide integers that force code paths ordinary inputs rarely
 // reach, so that the parity tests execute every branch of the product.  hook(SIFT3D_HOOK_x) reads the current value.

@@ -136,6 +136,18 @@ public:
 	// extension: the live extractor whose GetKeypoints() produced `kp` unchanged (same count, descriptor
 	// pointers and coordinates), or nullptr.  muBruteMatcher uses it to match straight from the device-resident results.
 	SIFT_LIBRARY_API static CSIFT3D *OwnerOf(const std::vector<Keypoint> &kp);
+
+	// extension (BASELINE configs[4] for a single-process C++ caller; no reference counterpart): every ORDERED pair (i, j), i != j, of
+	// extractors that have run -- typically one volume per GPU of the node (SetDevice before each CreateCSIFT3D) -- matched from their
+	// device-resident descriptors: mode 1 injectMatch, 2 bijectMatch, 3 enhancedMatch (Include/cMatcher.h:76-87).  A target on another
+	// GPU is copied peer to peer (xGMI) to the reference's GPU; the pairs of different reference GPUs run on one host thread per GPU.
+	struct PairMatch {
+		int ref = 0, tar = 0;
+		std::vector<Cvec> refMatch, tarMatch;   // as muBruteMatcher returns them
+		std::vector<int> glodenIdx;             // best target index per reference keypoint (getGlodenIdx)
+		double seconds = 0;                     // device time of the match
+	};
+	SIFT_LIBRARY_API static std::vector<PairMatch> AllPairsMatch(const std::vector<CSIFT3D *> &extractors, double thresHold = 0.85, int mode = 3);
 };
 
 class SIFT_LIBRARY_API CSIFT3DFactory {

@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../../include/sift3d_hip.h"
@@ -360,6 +362,43 @@ bool CSIFT3D::GetDeviceResults(const float **d_desc, const float **d_xyz, int *n
 	Wait();
 	if (device) *device = impl->device;
 	return sift3d_device_results(impl->h, d_desc, d_xyz, n) == SIFT3D_OK;
+}
+
+std::vector<CSIFT3D::PairMatch> CSIFT3D::AllPairsMatch(const std::vector<CSIFT3D *> &ex, double thresHold, int mode) {
+	std::vector<PairMatch> out;
+	const int n = (int)ex.size();
+	for (CSIFT3D *e : ex) {
+		if (!e || !e->impl || !e->impl->h) { fprintf(stderr, "[3dsift_amd] AllPairsMatch: every extractor must be a constructed single-GPU extractor\n"); return out; }
+		e->Wait();
+	}
+	for (int i = 0; i < n; i++)
+		for (int j = 0; j < n; j++)
+			if (i != j) { PairMatch p; p.ref = i; p.tar = j; out.push_back(p); }
+	// one host thread per reference GPU: the matcher serialises the calls of a device, different devices run side by side
+	std::map<int, std::vector<size_t>> by_dev;
+	for (size_t k = 0; k < out.size(); k++) by_dev[ex[(size_t)out[k].ref]->impl->device].push_back(k);
+	auto work = [&](const std::vector<size_t> &mine) {
+		for (size_t k : mine) {
+			PairMatch &p = out[k];
+			int nk = 0;
+			sift3d_num_keypoints(ex[(size_t)p.ref]->impl->h, &nk);
+			p.glodenIdx.assign((size_t)nk, -1);
+			std::vector<float> pairs((size_t)(nk > 0 ? nk : 1) * 6);
+			int np = 0;
+			const int rc = sift3d_match_handles(ex[(size_t)p.ref]->impl->h, ex[(size_t)p.tar]->impl->h, thresHold, mode, p.glodenIdx.data(), nullptr, nullptr,
+			                                    nullptr, pairs.data(), &np, &p.seconds);
+			if (rc != SIFT3D_OK) { fprintf(stderr, "[3dsift_amd] AllPairsMatch (%d, %d): %s (%s)\n", p.ref, p.tar, sift3d_error_string(rc), sift3d_last_error()); continue; }
+			for (int q = 0; q < np; q++) {
+				p.refMatch.push_back(Cvec(pairs[6 * q], pairs[6 * q + 1], pairs[6 * q + 2]));
+				p.tarMatch.push_back(Cvec(pairs[6 * q + 3], pairs[6 * q + 4], pairs[6 * q + 5]));
+			}
+		}
+	};
+	if (by_dev.size() <= 1) { if (!by_dev.empty()) work(by_dev.begin()->second); return out; }
+	std::vector<std::thread> th;
+	for (auto &kv : by_dev) th.emplace_back(work, std::cref(kv.second));
+	for (auto &t : th) t.join();
+	return out;
 }
 
 CSIFT3D *CSIFT3DFactory::CreateCSIFT3D(float *volume, int x_dim, int y_dim, int z_dim, int num_kp_levels, float sigma_default,

@@ -143,6 +143,13 @@ int sift3d_match(const float *ref_desc, const float *ref_xyz, int n, const float
                  const float *tar_xyz, int m, double thresHold, int mode, int on_device, int device,
                  int *gIdx, int *sIdx, float *gDist, float *sDist, float *pairs6, int *npairs,
                  double *seconds /* device time of the call, may be NULL */);
+/* The same match on the device-resident results of two extractors (sift3d_device_results), wherever they live: handles on one GPU
+ * are matched in place; with `tar` on another GPU of the node its descriptors and coordinates are first copied peer to peer (xGMI)
+ * into a scratch of `ref` on ref's device.  This is the building block of BASELINE configs[4] for a single-process C++ caller -- N
+ * extractors, one per GPU, all ordered pairs (CPUSIFT::CSIFT3D::AllPairsMatch in the C++ shell; 3dsift_amd/dist.py does the same
+ * over torch.distributed with an RCCL all-gather, one process per GPU).  Completes runs in flight on both handles first. */
+int sift3d_match_handles(sift3d_handle ref, sift3d_handle tar, double thresHold, int mode, int *gIdx, int *sIdx, float *gDist,
+                         float *sDist, float *pairs6, int *npairs, double *seconds);
 /* times of the calling thread's last sift3d_match: device_seconds = HIP events around the device work on the matcher's stream
  * (what *seconds returned), wall_seconds = host clock around the whole call (scratch reuse, H2D of host inputs, the O(N) host
  * bookkeeping of Src/cMatcher.cc:81-144 and the D2H of the results included) */
@@ -263,7 +270,8 @@ enum {
 	SIFT3D_HOOK_ONE_STREAM = 6,     /* 1: all octaves on the handle's stream (isolated kernel durations in a trace) */
 	SIFT3D_HOOK_DESC_MASS_SHIFT = 7,/* s: k_describe's first gradient-mass estimate is divided by 2^s -> the exact-unit second pass runs */
 	SIFT3D_HOOK_LIST_CAP = 8,       /* n > 0: initial capacity of the extrema / keypoint lists -> overflow, regrow, rerun */
-	SIFT3D_HOOK_COUNT = 9
+	SIFT3D_HOOK_PEER_COPY = 9,      /* 1: sift3d_match_handles stages the target's results through its peer-copy scratch even on one device */
+	SIFT3D_HOOK_COUNT = 10
 };
 int sift3d_test_hook(int which, int value);
 /* how often the rare paths ran: c[0] list regrows of the last run, c[1] keypoints whose descriptor took the second pass in

@@ -64,3 +64,28 @@ def test_config4_all_56_ordered_pairs_vs_oracle(orc):
             related += 1
             assert len(want["pairs"]) > 100, (i, j, len(want["pairs"]))   # the shifted copy: most keypoints correspond
     assert related == 8
+
+
+def test_match_handles_all_ordered_pairs_and_peer_copy_path(orc):
+    """sift3d_match_handles (r04): the native building block of configs[4] -- the device-resident results of two extractors matched
+    wherever they live.  Four live extractors, all twelve ordered pairs, every output equal to the oracle's matcher on the host copies;
+    again with the hook peer_copy, which stages the target through the peer-to-peer scratch (the path taken when the target sits on
+    another GPU: the copy itself is hipMemcpyPeer, here from the device to itself)."""
+    exs, host = [], []
+    for k in range(4):
+        vol = synth.blobs((96, 96, 96), seed=77 + k // 2, shift=(float(k % 2), 0.0, 0.0))
+        ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithmAsync()   # (runs in flight are completed by the match)
+        exs.append(ex)
+    for ex in exs:
+        kp, ds = ex.GetKeypoints()
+        assert len(kp) > 30
+        host.append((ds, np.stack([kp["rx"], kp["ry"], kp["rz"]], 1)))
+    mt = capi.muBruteMatcher()
+    for hook_on in (0, 1):
+        with capi.hook("peer_copy", hook_on):
+            for i, j in dist.ordered_pairs(4):
+                for mode, code in (("enhanced", 3), ("inject", 1)):
+                    got = mt.matchExtractors(exs[i], exs[j], 0.85, mode)
+                    want = orc.match(host[i][0], host[i][1], host[j][0], host[j][1], 0.85, code)
+                    for key in want:
+                        assert np.array_equal(got[key], want[key]), (hook_on, i, j, mode, key)

@@ -205,6 +205,49 @@ def test_cpp_matcher_uses_device_resident_results(shell, synth):
 
 
 @pytest.mark.gpu
+def test_cpp_all_pairs_match(shell, synth):
+    """CSIFT3D::AllPairsMatch (r04, configs[4] for a single-process C++ caller): three extractors, the six ordered pairs from their
+    device-resident results equal muBruteMatcher::enhancedMatch on the same keypoint vectors, pair by pair; extractors still in
+    flight (KpSiftAlgorithmAsync) are completed by the call."""
+    src = r"""
+    #include "Include/cSIFT3D.h"
+    #include "Include/cMatcher.h"
+    #include <cstdio>
+    using namespace CPUSIFT;
+    int main(int, char** a) {
+        std::vector<CSIFT3D*> ex;
+        for (int k = 1; k <= 3; k++) { ex.push_back(CSIFT3DFactory::CreateCSIFT3D(std::string(a[k]))); ex.back()->KpSiftAlgorithmAsync(); }
+        std::vector<CSIFT3D::PairMatch> all = CSIFT3D::AllPairsMatch(ex, 0.85, 3);
+        std::vector<std::vector<Keypoint>> kp;
+        for (auto e : ex) kp.push_back(e->GetKeypoints());
+        int same = (int)all.size() == 6, total = 0;
+        for (auto &p : all) {
+            muBruteMatcher m; std::vector<Cvec> r, t;
+            m.enhancedMatch(r, t, kp[p.ref], kp[p.tar], 0.85);
+            same = same && r.size() == p.refMatch.size() && m.getGlodenIdx() == p.glodenIdx;
+            for (size_t i = 0; same && i < r.size(); i++) same = r[i].x == p.refMatch[i].x && r[i].z == p.refMatch[i].z && t[i].y == p.tarMatch[i].y && t[i].x == p.tarMatch[i].x;
+            total += (int)r.size();
+        }
+        printf("pairs %zu matched %d same %d\n", all.size(), total, same);
+        for (auto e : ex) delete e;
+        return 0;
+    }"""
+    vols = [synth.blobs((64, 64, 64), seed=1234), synth.blobs((64, 64, 64), seed=1234, shift=(1.0, 0.0, 0.0)), synth.blobs((64, 64, 64), seed=99)]
+    with tempfile.TemporaryDirectory() as t:
+        names = []
+        for k, v in enumerate(vols):
+            names.append(os.path.join(t, "v%d.bin" % k))
+            with open(names[-1], "wb") as f:
+                f.write(struct.pack("<3i", 64, 64, 64) + v.tobytes())
+        open(os.path.join(t, "m.cpp"), "w").write(src)
+        subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(PKG, "host"), "-o", os.path.join(t, "m"), os.path.join(t, "m.cpp"),
+                               "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-lpthread", "-Wl,-rpath," + PKG])
+        out = subprocess.check_output([os.path.join(t, "m")] + names, stderr=subprocess.STDOUT).decode()
+    last = out.strip().splitlines()[-1].split()
+    assert last[:2] == ["pairs", "6"] and int(last[3]) > 10 and last[4:] == ["same", "1"], out
+
+
+@pytest.mark.gpu
 def test_config1_256_cubed_through_nifti(shell, orc, synth):
     """BASELINE configs[1]: two 256^3 volumes stored as NIfTI-1 files (int16 and gzip-compressed float32), read by readNiiFile, full
     KpSiftAlgorithm + enhancedMatch through the C++ shell; keypoint counts and matched pairs equal the oracle's on the same arrays."""
