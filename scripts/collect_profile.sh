@@ -26,6 +26,18 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python
 f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$f" $OUT/${TAG}_rocprofv3_kernel_stats.csv
 python3 $REPO/bench.py > $OUT/${TAG}_bench.json 2> /dev/null
+# the N = 1 record of configs[3] (the bench line's "slab" block) stamped with the kernel sources: a --gpus N run forms slab.speedup_vs_1gpu from it
+python3 - $OUT/${TAG}_bench.json $REPO/profiles/slab_1gpu.json $REPO <<'PY'
+import importlib, json, sys
+sys.path.insert(0, sys.argv[3])
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+sl = j.get("slab") or {}
+if "ms_per_step" in sl:
+    json.dump({"kernel_source_sha": importlib.import_module("3dsift_amd.capi").kernel_source_sha(), "dims": "1024x1024x512", "ms_per_step": sl["ms_per_step"],
+               "Mvoxels_per_s": sl["value"], "keypoints": sl["keypoints"], "steps": sl.get("steps"), "warmup": sl.get("warmup"),
+               "stage_ms_last_step": sl.get("last_step_ms")}, open(sys.argv[2], "w"), indent=1)
+PY
+cp $REPO/profiles/slab_1gpu.json $OUT/${TAG}_slab_1gpu.json
 head -12 $OUT/${TAG}_rocprofv3_kernel_stats.csv
 S3D_HOOKS=one_stream=1 python3 $REPO/scripts/pmc_kernel.py k_march_level 512 1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES > $OUT/${TAG}_pmc_k_march_level.json
 # z-slab workload on one GPU: the plain single-GPU run and the simulated 2- and 8-rank runs
@@ -38,5 +50,6 @@ bash $REPO/scripts/timeline_full.sh 512 > $OUT/${TAG}_timeline_full.txt 2>&1
 bash $REPO/scripts/match_kernel_times.sh > $OUT/${TAG}_match_kernels.txt 2>&1
 cd /tmp
 python3 $REPO/scripts/pmc_kernel.py k_mark 512 3 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TA_BUSY_avr > $OUT/${TAG}_pmc_k_mark.json
-python3 $REPO/scripts/small_volume_times.py > $OUT/${TAG}_small_volumes.txt 2>/dev/null
+python3 $REPO/scripts/small_volume_times.py 256 128 64 > $OUT/${TAG}_small_volumes.txt 2>/dev/null
+python3 $REPO/scripts/step_times_probe.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_step_times.txt
 cat $OUT/${TAG}_bench.json
