@@ -218,6 +218,7 @@ struct sift3d_ctx {
 	float *d_lutpool = nullptr;
 	sift3d_keypoint *d_kpout = nullptr;
 	float *d_desc = nullptr, *d_xyz = nullptr;
+	DescSplit dsplit{};             // scratch of the split descriptor windows (runs with few keypoints), one allocation at dsplit.gacc
 	float *d_peer = nullptr;        // sift3d_match_handles: a target's descriptors + coordinates copied from another GPU (grow-only)
 	size_t peer_floats = 0;
 
@@ -256,6 +257,7 @@ static void free_lists(sift3d_ctx *c) {
 	hipFree(c->d_xyz); c->d_xyz = nullptr;
 	hipFree(c->d_prov); c->d_prov = nullptr;
 	hipFree(c->d_prov2); c->d_prov2 = nullptr;
+	hipFree(c->dsplit.gacc); c->dsplit = DescSplit{};
 }
 
 static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
@@ -268,6 +270,18 @@ static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
 	S3D_HIP(hipMalloc(&c->d_kpout, sizeof(sift3d_keypoint) * (size_t)c->kp_cap));
 	S3D_HIP(hipMalloc(&c->d_desc, sizeof(float) * kDesc * (size_t)c->kp_cap));
 	S3D_HIP(hipMalloc(&c->d_xyz, sizeof(float) * 3 * (size_t)c->kp_cap));
+	{
+		// split descriptor windows: [cap][768] int accumulators | [cap][8] masses | [cap] arrivals (zeroed once: every run leaves them clean)
+		const unsigned scap = 4096;
+		const size_t words = (size_t)scap * (kDesc + 8 + 1);
+		int *base = nullptr;
+		S3D_HIP(hipMalloc(&base, sizeof(int) * words));
+		S3D_HIP(hipMemset(base, 0, sizeof(int) * words));
+		c->dsplit.gacc = base;
+		c->dsplit.gmass = reinterpret_cast<float *>(base + (size_t)scap * kDesc);
+		c->dsplit.gdone = reinterpret_cast<unsigned *>(base + (size_t)scap * (kDesc + 8));
+		c->dsplit.cap = scap;
+	}
 	S3D_HIP(hipMalloc(&c->d_prov, sizeof(unsigned) * ((size_t)c->ext_cap + 1)));
 	c->det.prov = c->d_prov; c->det.prov_count = c->d_prov + c->ext_cap; c->det.prov_cap = c->ext_cap;
 	if (c->det_o.size() > 1) {  // octaves >= 1: equal slices of a second parking list, each followed by its counter
@@ -936,7 +950,7 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 		// ---- Extract_Description (Src/cSIFT3D.cc:484-502) ----
 		if (upto >= 5) {
 			launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, c->part_rank,
-			                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st, c->desc_lut_lds);
+			                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st, c->desc_lut_lds, &c->dsplit);
 		}
 		if (upto >= 4) launch_finalize(c->d_ext, c->d_total, c->ext_cap, upto >= 5, c->d_kpout, c->d_xyz, c->kp_cap, st);
 		S3D_HIP(hipEventRecord(c->ev[5], st));
@@ -1449,7 +1463,7 @@ extern "C" int sift3d_run_describe(sift3d_handle c) {
 	S3D_HIP(hipEventRecord(c->ev[6], st));
 	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, c->d_slots_part, st);
 	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, c->part_rank,
-	                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st, c->desc_lut_lds);
+	                c->part_world, c->d_order, c->d_nkp, c->d_nkp + 1, st, c->desc_lut_lds, &c->dsplit);
 	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
 	S3D_HIP(hipEventRecord(c->ev[7], st));
 	unsigned host_words[3] = {0, 0, 0};
@@ -1749,7 +1763,7 @@ extern "C" int sift3d_slab_describe(sift3d_handle c) {
 	              c->p.corner_thresh, 0, 1, c->d_order, c->d_nkp + 3, st);
 	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, c->d_slots_part, st);
 	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, 0, 1, c->d_order, c->d_nkp,
-	                c->d_nkp + 1, st, c->desc_lut_lds);
+	                c->d_nkp + 1, st, c->desc_lut_lds, &c->dsplit);
 	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
 	bool again;
 	rc = slab_count_and_regrow(c, again);

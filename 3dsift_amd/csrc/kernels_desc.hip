@@ -317,6 +317,16 @@ __device__ unsigned long long g_dstamp[64][4][10];
 #ifndef S3D_DESC_WIDE_BELOW
 #define S3D_DESC_WIDE_BELOW 1400  /* runs with fewer keypoints than this take eight waves per keypoint (0: never); measured crossover between 1100 (0.49 vs 0.60 ms) and 1850 keypoints (0.75 vs 0.71) */
 #endif
+// r04: keypoint counts below which a window is split over 8 / 4 / 2 workgroups (DescSplit): 1024 workgroups are resident
+#ifndef S3D_DESC_SPLIT8
+#define S3D_DESC_SPLIT8 320
+#endif
+#ifndef S3D_DESC_SPLIT4
+#define S3D_DESC_SPLIT4 700
+#endif
+#ifndef S3D_DESC_SPLIT2
+#define S3D_DESC_SPLIT2 700  /* (= SPLIT4: two parts never paid off against the eight-wave variant) */
+#endif
 #ifndef S3D_DESC_UCAP
 #define S3D_DESC_UCAP 1024
 #endif
@@ -389,16 +399,20 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap,
                                                   int part_rank, int part_world, const int *__restrict__ order,
                                                   const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work, int dev_flags, unsigned nkp_min,
-                                                  unsigned nkp_max) {
+                                                  unsigned nkp_max, DescSplit sp) {
 	constexpr int NW = NT / 64;
 	static_assert(NT == 256 || NT == 512, "k_describe: 4 or 8 waves per keypoint");
 	{
+		// [nkp_min, nkp_max): the keypoint counts (of this handle's share) the EIGHT-wave variant takes; the four-wave variant takes the rest
 		const unsigned n_all = min(d_nkp[0], kp_cap);
-		if (n_all < nkp_min || n_all >= nkp_max) return;  // the other variant's run
+		const unsigned w = part_world > 1 ? (unsigned)part_world : 1u, r = part_world > 1 ? (unsigned)part_rank : 0u;
+		const unsigned n_own = n_all > r ? (n_all - r + w - 1) / w : 0u;
+		const bool wide_range = n_own >= nkp_min && n_own < nkp_max;
+		if (wide_range != (NT == 512)) return;  // the other variant's run
 	}
 	// d_work[0] = the work counter, d_work[1] = keypoints that took the second pass (sift3d_debug_counters)
 	// dev_flags (test hooks): bit 0 = recompute the chords (SIFT3D_HOOK_DESC_NOCACHE), bits 8.. = s of SIFT3D_HOOK_DESC_MASS_SHIFT
-	__shared__ unsigned s_item, s_tile;
+	__shared__ unsigned s_item, s_tile, s_last;
 	__shared__ bin_t hist[kBins * kRep];  // [bin][replica], two's-complement fixed point, units of 1 / lut.fix_scale
 	__shared__ float s_lut[LUT_LDS ? kMaxDescLut : 1];
 	__shared__ __attribute__((aligned(16))) float s_q[NW][6][kQCap];  // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
@@ -438,13 +452,21 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 				for (int i = tid; i < kDesc; i += NT) d_desc[row * kDesc + i] = 0.0f;
 			}
 	const unsigned nown = nkp > pr ? (nkp - pr + pw - 1) / pw : 0u;
+	// r04, few keypoints: a window split over S0 workgroups (see DescSplit).  S0 is a function of the keypoint count alone, the same
+	// in every workgroup.
+	int S0 = 1;
+	if (NT == 256 && sp.gacc != nullptr && nown <= sp.cap) S0 = nown < (unsigned)S3D_DESC_SPLIT8 ? 8 : (nown < (unsigned)S3D_DESC_SPLIT4 ? 4 : (nown < (unsigned)S3D_DESC_SPLIT2 ? 2 : 1));
+	const unsigned nitems = nown * (unsigned)S0;
 	for (;;) {
 		__syncthreads();
 		if (tid == 0) s_item = atomicAdd(d_work, 1u);
 		__syncthreads();
 		const unsigned item = s_item;
-		if (item >= nown) break;  // block-uniform
-		const unsigned k = (unsigned)order[item * pw + pr];  // processing order: big windows first (k_slots)
+		if (item >= nitems) break;  // block-uniform
+		const unsigned kpos = item / (unsigned)S0;  // position in the processing order
+		const int part = (int)(item % (unsigned)S0);
+		int S = S0;  // parts of THIS pass over the window (1 when the finisher repeats a split window alone with the exact unit)
+		const unsigned k = (unsigned)order[kpos * pw + pr];  // processing order: big windows first (k_slots)
 		const int slot = kps[k].slot;                        // row of the keypoint in the results (reference order)
 		const int cxi = kps[k].x, cyi = kps[k].y, czi = kps[k].z;
 		const int li = kps[k].octave * 8 + kps[k].level;
@@ -489,6 +511,10 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 
 #if defined(S3D_EXP) && S3D_EXP == 6
 		float exp_mass = 0.f; int exp_attempts = 0;
+#endif
+		bool finished = false;
+#ifdef S3D_DESC_DBGMASS
+		float dbg_mass = 0.0f;
 #endif
 		for (int attempt = 0;; attempt++) {  // block-uniform; a second pass only when the first unit was too fine
 		float msum = 0.0f;  // this lane's share of the gradient mass
@@ -578,7 +604,9 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			s_chord[ps] = chord_cached ? (colok[0] ? (unsigned)(za[0] - z0) | (unsigned)(zb[0] - z0) << 8 : 255u) |
 			                                 (colok[1] ? (unsigned)(za[1] - z0) | (unsigned)(zb[1] - z0) << 8 : 255u) << 16
 			                           : (unsigned)len;
-			if (spos == 0 && len > 0) atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u);  // key 0 = empty
+			// (a split window: part p of S marches the units u with u % S == p -- by the unit's index, not by its place in the sorted
+			// order, which differs between workgroups where lengths tie)
+			if (spos == 0 && len > 0 && (S == 1 || (u0 + uu) % S == part)) atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u);  // key 0 = empty
 		}
 		__syncthreads();
 		if (wid == 0) {  // running start of every key, longest first
@@ -608,7 +636,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			} else {
 				len = (int)s_chord[uu * kUL];
 			}
-			if (len > 0) s_units[atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u)] = (unsigned short)uu;
+			if (len > 0 && (S == 1 || (u0 + uu) % S == part)) s_units[atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u)] = (unsigned short)uu;
 		}
 		__syncthreads();
 		const int nnz = (int)s_nnz, ntiles = (nnz * kUL + 63) / 64;
@@ -794,7 +822,33 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		__syncthreads();
 		float mass_sum = (red[0] + red[1]) + (red[2] + red[3]);
 		if (NW == 8) mass_sum = mass_sum + ((red[4] + red[5]) + (red[6] + red[7]));
+		if (S > 1) {
+			// this part's integer histogram (replicas summed) and its share of the gradient mass go to the keypoint's accumulators in
+			// global memory; the part that arrives last carries on as the keypoint's finisher
+#pragma unroll
+			for (int j = 0; j < 3; j++) {
+				const int e = tid + 256 * j;
+				int a = 0;
+#pragma unroll
+				for (int r = 0; r < kRep; r++) a += (int)(sbin_t)hist[bin_index(e) * kRep + (r + tid) % kRep];
+				if (a != 0) atomicAdd(&sp.gacc[(size_t)kpos * kDesc + e], a);
+			}
+			if (tid == 0) __hip_atomic_store(&sp.gmass[kpos * 8 + part], mass_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			// arrival: the payload is device-scope atomics and one write-through store, so there is nothing in a cache to write back or to
+			// invalidate -- every wave waits for its own operations to be acknowledged, then ONE lane counts the part in.  (__threadfence()
+			// by 256 threads here and once more in the finisher cost 40-100 us per part: the split ran 2.3x slower than no split.)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			__syncthreads();
+			if (tid == 0) s_last = atomicAdd(&sp.gdone[kpos], 1u);
+			__syncthreads();
+			if (s_last != (unsigned)(S - 1)) break;  // block-uniform: another part finishes the keypoint (leaves the attempt loop; see below)
+			mass_sum = 0.0f;
+			for (int q = 0; q < S; q++) mass_sum = mass_sum + __hip_atomic_load(&sp.gmass[kpos * 8 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // part order: deterministic
+		}
 		const float mass = mass_sum * 1.001f;
+#ifdef S3D_DESC_DBGMASS
+		if (attempt == 0) dbg_mass = mass;
+#endif
 		// every bin (and replica) sum is <= mass * fix_scale + half a unit per contribution (< 2^20 contributions)
 		// ... and a first guess far ABOVE the mass (a sharp structure inside the orientation window, a flat descriptor window: the
 		// zero background of CT / MR volumes) leaves a unit that much coarser than necessary: below 1/64 of the range the keypoint is
@@ -805,11 +859,21 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 #if defined(S3D_EXP) && S3D_EXP == 6
 			exp_mass = mass; exp_attempts = attempt + 1;
 #endif
+			finished = true;
 			break;
+		}
+		if (S > 1) {
+			// a split window whose first unit failed: its finisher repeats the window ALONE with the exact unit, like an unsplit run's
+			// second pass (inline: a separate launch for these few keypoints ended the stage 0.2 ms later); the accumulators are cleared
+			// like those of a finished window
+			for (int e = tid; e < kDesc; e += NT) sp.gacc[(size_t)kpos * kDesc + e] = 0;
+			if (tid == 0) sp.gdone[kpos] = 0u;
+			S = 1;
 		}
 		if (tid == 0) atomicAdd(d_work + 1, 1u);
 		fix_scale = pick_scale(mass);  // exact bound: this pass cannot overflow
 		}
+		if (!finished) continue;  // block-uniform: not this workgroup's keypoint to finish (a split part, or sent to the redo list)
 		const double fix_inv = 1.0 / (double)fix_scale;
 		__syncthreads();
 
@@ -818,12 +882,21 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 		if (NT == 256) {
 			long long a0 = 0, a1 = 0, a2 = 0;
+			if (S > 1) {  // the finisher of a split window: the sums of all parts (the same integers an unsplit run holds in its LDS histogram)
+				int *ga = sp.gacc + (size_t)kpos * kDesc;
+				a0 = (long long)__hip_atomic_load(&ga[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				a1 = (long long)__hip_atomic_load(&ga[tid + 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				a2 = (long long)__hip_atomic_load(&ga[tid + 512], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				ga[tid] = 0; ga[tid + 256] = 0; ga[tid + 512] = 0;  // clean for the next run
+				if (tid == 0) sp.gdone[kpos] = 0u;
+			} else {
 #pragma unroll
 			for (int r = 0; r < kRep; r++) {
 				const int rr2 = (r + tid) % kRep;  // stagger the replica order across lanes
 				a0 += (long long)(sbin_t)hist[bin_index(tid) * kRep + rr2];
 				a1 += (long long)(sbin_t)hist[bin_index(tid + 256) * kRep + rr2];
 				a2 += (long long)(sbin_t)hist[bin_index(tid + 512) * kRep + rr2];
+			}
 			}
 			v0 = (float)((double)a0 * fix_inv); v1 = (float)((double)a1 * fix_inv); v2 = (float)((double)a2 * fix_inv);
 		} else {
@@ -857,6 +930,10 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		}
 		float *out = d_desc + (size_t)slot * kDesc;
 		if (tid < 256) { out[tid] = v0; out[tid + 256] = v1; out[tid + 512] = v2; }
+#ifdef S3D_DESC_DBGMASS
+		__syncthreads();
+		if (tid == 0) { out[0] = dbg_mass; out[1] = fix_scale; out[2] = (float)S; out[3] = m_est; }
+#endif
 		S3D_DSTAMP(7)  // normalise + store
 #if defined(S3D_EXP) && S3D_EXP == 6
 		__syncthreads();
@@ -898,22 +975,28 @@ void launch_face_lookup(const float *d_g3, int n, int route, int *d_face, float 
 
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels, const WinLut *d_luts,
                      const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world, const int *order,
-                     const unsigned *d_nkp, unsigned *d_work, hipStream_t st, bool lut_in_lds) {
+                     const unsigned *d_nkp, unsigned *d_work, hipStream_t st, bool lut_in_lds, const DescSplit *split) {
 	(void)hipMemsetAsync(d_work, 0, 2 * sizeof(unsigned), st);
+	DescSplit sp{};
+	static const int split_on = dev_tune_i("S3D_DESC_SPLIT", 1);
+	if (split && split->gacc && split_on && lut_in_lds && !hook(SIFT3D_HOOK_DESC_NOSPLIT)) sp = *split;
 	static const int desc_grid = dev_tune_i("S3D_DESC_GRID", 256 * 8);  // persistent workgroups (work counter)
 	static const unsigned dyn_lds = (unsigned)dev_tune_i("S3D_DESC_DYNLDS", 0);  // unused dynamic LDS per workgroup (occupancy experiments)
 	const int dev_flags = (hook(SIFT3D_HOOK_DESC_NOCACHE) ? 1 : 0) | (hook(SIFT3D_HOOK_DESC_MASS_SHIFT) & 63) << 8;
 	// few keypoints: eight waves per keypoint (see k_describe); the count lives on the device, so both variants are launched
-	const unsigned wide_below = (unsigned)S3D_DESC_WIDE_BELOW;
+	// keypoint counts [wide_lo, wide_hi) take the eight-wave variant of r03; below wide_lo a window is split over 8 / 4 four-wave
+	// workgroups (r04; scripts/split_probe.py: 0.19 / 0.22 / 0.28 / 0.32 ms for 40 / 151 / 286 / 437 keypoints against 0.25 / 0.32 / 0.38 /
+	// 0.41 with eight waves; from ~700 keypoints the eight-wave variant is ahead: 0.49 vs 0.51-0.58 ms at 1096)
+	const unsigned wide_hi = (unsigned)S3D_DESC_WIDE_BELOW, wide_lo = sp.gacc ? std::min((unsigned)S3D_DESC_SPLIT4, wide_hi) : 0u;
 	if (lut_in_lds) {
 		hipLaunchKernelGGL((k_describe<true, 256>), dim3(desc_grid), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, wide_below, 0xFFFFFFFFu);
-		if (wide_below > 0)
+		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, wide_lo, wide_hi, sp);
+		if (wide_hi > wide_lo)
 			hipLaunchKernelGGL((k_describe<true, 512>), dim3(256 * 2), dim3(512), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-			                   part_rank, part_world, order, d_nkp, d_work, dev_flags, 0u, wide_below);
+			                   part_rank, part_world, order, d_nkp, d_work, dev_flags, wide_lo, wide_hi, DescSplit{});
 	} else {
 		hipLaunchKernelGGL((k_describe<false, 256>), dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, 0u, 0xFFFFFFFFu);
+		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, 0u, 0u, DescSplit{});
 	}
 #if defined(S3D_EXP) && S3D_EXP == 21
 	{

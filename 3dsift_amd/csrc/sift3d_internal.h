@@ -227,10 +227,21 @@ void launch_slots(DevKp *kps, const int *codes, const unsigned *d_count, unsigne
 hipError_t upload_faces(const FaceConst *faces, const FaceSym *sym);  // into the current device's __constant__ memory
 // part_rank / part_world: only keypoints with slot % part_world == part_rank are described (multi-GPU split of
 // replicated octaves); 0 / 1 = all
+// r04, runs with few keypoints: one keypoint's window is marched by S workgroups (S = 8 / 4 / 2 by the keypoint count, which lives
+// on the device: every workgroup derives the same S).  Each part adds its integer histogram into gacc (global atomics: exact, order
+// free), the part that arrives last (gdone) normalises -- the same integers an unsplit run sums in LDS, so the descriptors are
+// bit-identical.  A keypoint whose first fixed-point unit fails (k_describe's second pass) is repeated by its finisher alone.
+// cap = positions (of the processing order) the scratch holds; runs with more keypoints than that are never split.
+struct DescSplit {
+	int *gacc = nullptr;            // [cap][768], zero between runs (the finisher clears what it read)
+	float *gmass = nullptr;         // [cap][8] gradient mass per part
+	unsigned *gdone = nullptr;      // [cap] parts arrived
+	unsigned cap = 0;
+};
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels,
                      const WinLut *d_luts, const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world,
                      const int *order, const unsigned *d_nkp, unsigned *d_work /* device counter, zeroed by the launch */,
-                     hipStream_t st, bool lut_in_lds = true);
+                     hipStream_t st, bool lut_in_lds = true, const DescSplit *split = nullptr);
 void launch_face_lookup(const float *d_g3, int n, int route, int *d_face, float *d_bary3, hipStream_t st);  // sift3d_debug_face_lookup
 void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, int transposed,
                      sift3d_keypoint *d_out, float *d_xyz, unsigned kp_cap, hipStream_t st);

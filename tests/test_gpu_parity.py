@@ -555,3 +555,25 @@ def test_async_run_two_volumes_in_flight(capi, synth):
         ec = capi.CreateCSIFT3D(va)
         ec.KpSiftAlgorithmAsync().Wait()
         assert ec.debug_counters()["list_regrows"] >= 1 and _full_hash(capi, ec, with_extrema=True) == base[0]
+
+
+def test_split_descriptor_windows_match_unsplit(capi, synth):
+    """r04: with few keypoints a descriptor window is marched by 8 or 4 workgroups (by the keypoint count), each adding its integer
+    histogram into the keypoint's accumulators in global memory; the part that arrives last normalises, and a keypoint whose first
+    fixed-point unit fails is repeated by its finisher alone.  The hook desc_nosplit gives every keypoint one workgroup (the form of
+    runs with many keypoints): same descriptors bit for bit, same number of second passes -- also when the hook desc_mass_shift sends
+    EVERY keypoint through the second pass."""
+    for shape, seed in (((64, 64, 64), 1234), ((96, 112, 128), 7), ((160, 160, 160), 8)):   # 40 / ~200 / ~450 keypoints: 8 and 4 parts
+        vol = synth.blobs(shape, seed=seed, noise=0.01)
+        for shift in (0, 6):
+            with capi.hook("desc_mass_shift", shift):
+                ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+                split = _full_hash(capi, ex); n_split = ex.debug_counters()["desc_second_passes"]
+                with capi.hook("desc_nosplit", 1):
+                    ex2 = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+                    plain = _full_hash(capi, ex2); n_plain = ex2.debug_counters()["desc_second_passes"]
+                # twice on one handle: the accumulators were left clean
+                again = _full_hash(capi, ex.KpSiftAlgorithm())
+            assert split == plain and split[1] > 20, (shape, shift)
+            assert n_split == n_plain and (shift == 0 or n_split > 0), (shape, shift, n_split, n_plain)
+            assert again == split, (shape, shift)
