@@ -277,6 +277,7 @@ static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
 		int *base = nullptr;
 		S3D_HIP(hipMalloc(&base, sizeof(int) * words));
 		S3D_HIP(hipMemset(base, 0, sizeof(int) * words));
+		S3D_HIP(hipStreamSynchronize(nullptr));  // (the handle's streams are non-blocking: not ordered behind the null stream's memset)
 		c->dsplit.gacc = base;
 		c->dsplit.gmass = reinterpret_cast<float *>(base + (size_t)scap * kDesc);
 		c->dsplit.gdone = reinterpret_cast<unsigned *>(base + (size_t)scap * (kDesc + 8));
