@@ -30,8 +30,9 @@ int dev_tune_i(const char *env_name, int dflt) { const char *e = getenv(env_name
 double dev_tune_d(const char *env_name, double dflt) { const char *e = getenv(env_name); return e ? atof(e) : dflt; }
 static const bool g_env_hooks = [] {
 	static const char *names[SIFT3D_HOOK_COUNT] = {"S3D_DOG_EAGER", "S3D_GLAST_EAGER", "S3D_DET_SERIAL", "S3D_SEPARABLE", "S3D_DESC_NOCACHE",
-	                                               "S3D_MATCH_NODMA", "S3D_ONE_STREAM", "S3D_DESC_MASS_SHIFT", "S3D_LIST_CAP"};
-	for (int i = 0; i < SIFT3D_HOOK_COUNT; i++) { const char *e = getenv(names[i]); if (e) g_hooks[i] = atoi(e); }
+	                                               "S3D_MATCH_NODMA", "S3D_ONE_STREAM", "S3D_DESC_MASS_SHIFT", "S3D_LIST_CAP", "S3D_PEER_COPY", "S3D_DESC_NOSPLIT"};
+	static_assert(sizeof(names) / sizeof(names[0]) == SIFT3D_HOOK_COUNT, "one environment name per hook");
+	for (int i = 0; i < SIFT3D_HOOK_COUNT; i++) { const char *e = names[i] ? getenv(names[i]) : nullptr; if (e) g_hooks[i] = atoi(e); }
 	return true;
 }();
 #else
@@ -196,6 +197,11 @@ struct sift3d_ctx {
 	// octave o >= 1 only depends on G[o-1][num_kp_levels]: each octave chain runs on its own stream so the small
 	// octaves fill the machine next to the tail of the big ones (ostream[0] == stream)
 	std::vector<hipStream_t> ostream;
+	// r04: the HEADS of the octaves >= 1 (levels up to the seed level) run on ONE stream, in order: each head waits for the seed level of
+	// the octave above anyway, and a dependency across streams costs 13-16 us (event -> barrier packet on another queue) where
+	// consecutive launches of one stream follow each other without a gap -- four hops of the 512^3 chain; the levels behind the seed
+	// level stay on the octave's own stream (cstream == nullptr: every octave wholly on its own stream, as before)
+	hipStream_t cstream = nullptr;
 	std::vector<hipEvent_t> ev_seed, ev_done;
 	hipEvent_t ev_fork = nullptr;
 	unsigned *d_words = nullptr;  // [0] input max bits, [1..] per-DoG-level max bits, then counters
@@ -360,6 +366,7 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	for (auto &e : c->ev_done) if (e) hipEventDestroy(e);
 	if (c->ev_fork) hipEventDestroy(c->ev_fork);
 	for (size_t o = 1; o < c->ostream.size(); o++) if (c->ostream[o] && c->ostream[o] != c->stream && c->ostream[o] != c->own_stream) hipStreamDestroy(c->ostream[o]);
+	if (c->cstream) hipStreamDestroy(c->cstream);
 	if (c->own_stream) hipStreamDestroy(c->own_stream);
 	delete c;
 	return SIFT3D_OK;
@@ -547,6 +554,12 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 			else
 				CHECKED(hipStreamCreateWithFlags(&c->ostream[o], hipStreamNonBlocking));
 		}
+		if (o == 1 && !one_stream && !c->slab) {
+#ifndef S3D_CHAIN_STREAM
+#define S3D_CHAIN_STREAM 1
+#endif
+			if (S3D_CHAIN_STREAM) CHECKED(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+		}
 		CHECKED(hipEventCreateWithFlags(&c->ev_seed[o], hipEventDisableTiming));
 		CHECKED(hipEventCreateWithFlags(&c->ev_done[o], hipEventDisableTiming));
 	}
@@ -696,8 +709,8 @@ extern "C" int sift3d_create(sift3d_handle *out, const float *volume, int nx, in
 // half_out (optional): level 0 of the next octave; returns true when the march kernel wrote it together with dst (the caller then
 // skips the decimation launch)
 static bool smooth_level(sift3d_ctx *c, int o, const float *src, const Level &dst, const Taps &t, const float *prev, float *dog,
-                         unsigned *dogmax, int level = 0, const Level *half_out = nullptr) {
-	hipStream_t st = c->ostream[o];
+                         unsigned *dogmax, int level = 0, const Level *half_out = nullptr, hipStream_t st_override = nullptr) {
+	hipStream_t st = st_override ? st_override : c->ostream[o];
 	// Slot planning across the octave streams (single-round launches keep every slot they take until they end): the levels of
 	// octave 0 behind the seed level G[0][num_kp_levels] leave a third of the machine to the chains of the smaller octaves, which
 	// are planned for that third; otherwise those chains starve and run as a tail after octave 0 has finished.
@@ -816,8 +829,14 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 			}
 		}
 		auto enqueue = [&](int o, bool head) -> int {
-			// (the octaves of the small launch share the stream of the first of them)
-			hipStream_t so = c->ostream[(small_first >= 0 && o > small_first) ? small_first : o];
+			// (the octaves of the small launch share the stream of the first of them; heads of octaves >= 1: the chain stream)
+			// measured (scripts/small_volume_times.py, A/B in one process per setting): 64^3 / 128^3 pyramid 0.238 / 0.348 -> 0.220 / 0.320 ms,
+			// but 256^3 0.600 -> 0.656 and 512^3 2.13 -> 2.16 ms (the heads of the big octaves are long launches that gain nothing from a
+			// gap of 8 instead of 15 us and lose the hardware queue they had to themselves): volumes of at most 4 M voxels only
+			static const int chain_mode = dev_tune_i("S3D_CHAIN", 1);  // 0 never, 1 small volumes, 2 always
+			const bool chain_on = chain_mode == 2 || (chain_mode == 1 && (size_t)c->nx * c->ny * c->nz <= ((size_t)1 << 22));
+			const bool chained = c->cstream != nullptr && chain_on && o >= 1 && (head || (small_first >= 0 && o >= small_first));
+			hipStream_t so = chained ? c->cstream : c->ostream[(small_first >= 0 && o > small_first) ? small_first : o];
 			if (small_first >= 0 && o >= small_first) {
 				if (head && o > 0) {
 					S3D_HIP(hipStreamWaitEvent(so, c->ev_fork, 0));
@@ -842,6 +861,10 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[o - 1], 0));
 			}
 			if (!head && o == 0 && defer_tail && c->noct > 1) S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[1], 0));
+			if (!head && o >= 1 && c->cstream != nullptr && chain_on) {  // the levels behind the seed level: the octave's own stream, behind its head on the chain stream
+				S3D_HIP(hipStreamWaitEvent(so, c->ev_fork, 0));
+				S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[o], 0));
+			}
 			const int i0 = head ? 0 : c->p.num_kp_levels + 1, i1 = head ? c->p.num_kp_levels + 1 : c->ng;
 			for (int i = i0; i < i1; i++) {
 				const Level &L = c->gss[(size_t)o * c->ng + i];
@@ -858,8 +881,8 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 					// the seed level also leaves decimated, as level 0 of the next octave (whole volumes, not seeded / partitioned contexts' inputs)
 					const Level *half = (i == c->p.num_kp_levels && o + 1 < c->noct) ? &c->gss[(size_t)(o + 1) * c->ng] : nullptr;
 					bool hw_ = false;
-					if (c->dog_elide && (i - 1 == 0 || i - 1 == c->nd - 1)) hw_ = smooth_level(c, o, P.d, L, c->taps[i], nullptr, nullptr, nullptr, i, half);
-					else hw_ = smooth_level(c, o, P.d, L, c->taps[i], P.d, D.d, c->d_dogmax + (size_t)o * c->nd + i - 1, i, half);
+					if (c->dog_elide && (i - 1 == 0 || i - 1 == c->nd - 1)) hw_ = smooth_level(c, o, P.d, L, c->taps[i], nullptr, nullptr, nullptr, i, half, so);
+					else hw_ = smooth_level(c, o, P.d, L, c->taps[i], P.d, D.d, c->d_dogmax + (size_t)o * c->nd + i - 1, i, half, so);
 					if (half) half_written[(size_t)o + 1] = hw_ ? 1 : 0;
 				}
 				if (i == c->p.num_kp_levels) S3D_HIP(hipEventRecord(c->ev_seed[o], so));
