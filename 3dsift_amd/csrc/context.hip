@@ -558,7 +558,9 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 #ifndef S3D_CHAIN_STREAM
 #define S3D_CHAIN_STREAM 1
 #endif
-			if (S3D_CHAIN_STREAM) CHECKED(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
+			// (only for the volumes that use it, see run_enqueue: HIP deals streams to its four hardware queues in creation order, so one more
+			// stream changes which octave streams share a queue -- 480 x 500 x 300: pyramid 1.43 -> 1.61 ms, the simulated 8-rank run 40.5 -> 43.6 ms)
+			if (S3D_CHAIN_STREAM && (size_t)c->nx * c->ny * c->nz <= ((size_t)1 << 22)) CHECKED(hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
 		}
 		CHECKED(hipEventCreateWithFlags(&c->ev_seed[o], hipEventDisableTiming));
 		CHECKED(hipEventCreateWithFlags(&c->ev_done[o], hipEventDisableTiming));
@@ -833,8 +835,8 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 			// measured (scripts/small_volume_times.py, A/B in one process per setting): 64^3 / 128^3 pyramid 0.238 / 0.348 -> 0.220 / 0.320 ms,
 			// but 256^3 0.600 -> 0.656 and 512^3 2.13 -> 2.16 ms (the heads of the big octaves are long launches that gain nothing from a
 			// gap of 8 instead of 15 us and lose the hardware queue they had to themselves): volumes of at most 4 M voxels only
-			static const int chain_mode = dev_tune_i("S3D_CHAIN", 1);  // 0 never, 1 small volumes, 2 always
-			const bool chain_on = chain_mode == 2 || (chain_mode == 1 && (size_t)c->nx * c->ny * c->nz <= ((size_t)1 << 22));
+			static const int chain_mode = dev_tune_i("S3D_CHAIN", 1);  // 0 never, 1 small volumes (the stream exists for them only)
+			const bool chain_on = chain_mode != 0;
 			const bool chained = c->cstream != nullptr && chain_on && o >= 1 && (head || (small_first >= 0 && o >= small_first));
 			hipStream_t so = chained ? c->cstream : c->ostream[(small_first >= 0 && o > small_first) ? small_first : o];
 			if (small_first >= 0 && o >= small_first) {
