@@ -513,9 +513,6 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		float exp_mass = 0.f; int exp_attempts = 0;
 #endif
 		bool finished = false;
-#ifdef S3D_DESC_DBGMASS
-		float dbg_mass = 0.0f;
-#endif
 		for (int attempt = 0;; attempt++) {  // block-uniform; a second pass only when the first unit was too fine
 		float msum = 0.0f;  // this lane's share of the gradient mass
 		__syncthreads();  // previous keypoint / pass finished with hist / s_lut
@@ -846,9 +843,6 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			for (int q = 0; q < S; q++) mass_sum = mass_sum + __hip_atomic_load(&sp.gmass[kpos * 8 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // part order: deterministic
 		}
 		const float mass = mass_sum * 1.001f;
-#ifdef S3D_DESC_DBGMASS
-		if (attempt == 0) dbg_mass = mass;
-#endif
 		// every bin (and replica) sum is <= mass * fix_scale + half a unit per contribution (< 2^20 contributions)
 		// ... and a first guess far ABOVE the mass (a sharp structure inside the orientation window, a flat descriptor window: the
 		// zero background of CT / MR volumes) leaves a unit that much coarser than necessary: below 1/64 of the range the keypoint is
@@ -930,10 +924,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		}
 		float *out = d_desc + (size_t)slot * kDesc;
 		if (tid < 256) { out[tid] = v0; out[tid + 256] = v1; out[tid + 512] = v2; }
-#ifdef S3D_DESC_DBGMASS
-		__syncthreads();
-		if (tid == 0) { out[0] = dbg_mass; out[1] = fix_scale; out[2] = (float)S; out[3] = m_est; }
-#endif
+
 		S3D_DSTAMP(7)  // normalise + store
 #if defined(S3D_EXP) && S3D_EXP == 6
 		__syncthreads();
