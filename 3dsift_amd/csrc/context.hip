@@ -936,7 +936,8 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 			S3D_HIP(hipEventRecord(c->ev_det_fork, st));  // octave 0's pyramid is complete (the main stream is its stream)
 			launch_detect_mark(DLs[0], nl, C0.nx, C0.ny, C0.zr_all(), c->p.peak_thresh, 0 + c->octave_base, c->det, st, lt);
 			S3D_HIP(hipStreamWaitEvent(sb, c->ev_det_fork, 0));
-			for (int o = 2; o < c->noct; o++) S3D_HIP(hipStreamWaitEvent(sb, c->ev_done[o], 0));  // (octave 1's own work is in sb's order)
+			// (octave 1 too: its levels are in sb's own order only when neither the chain stream nor the small-octave launch took them)
+			for (int o = 1; o < c->noct; o++) S3D_HIP(hipStreamWaitEvent(sb, c->ev_done[o], 0));
 			S3D_HIP(hipEventRecord(c->ev[1], sb));  // every octave's pyramid is complete
 			S3D_HIP(hipEventRecord(c->ev[2], sb));  // DoG is fused: zero-length stage
 		} else {

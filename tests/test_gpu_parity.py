@@ -83,6 +83,7 @@ def test_g4_g6_golden_keypoints(capi, synth, tag):
     ((24, 512, 512), 35, 0.01),     # r04: a THIN volume (planes of 256 tiles, 24 of them): the march kernel on short columns; octave 1 is 12 planes: its widest level (hw 6 > (12 - 2) / 2) takes the separable passes
     ((40, 300, 300), 36, 0.02),     # r04: thin and not tile aligned (shifted last tile column / row), 3 octaves: 300 x 300 x 40, 150 x 150 x 20, 75 x 75 x 10
     ((16, 96, 128), 37, 0.01),      # r04: 16 planes: hw 8 never fits, hw 6 and below do (16 >= 2 hw + 2 for hw <= 7)
+    ((32, 32, 32), 38, 0.05),       # r04: octave 1 is already the one-workgroup launch, on the chain stream: the early detection must wait for it
 ])
 def test_full_pipeline_vs_oracle(capi, orc, synth, shape, seed, noise):
     vol = synth.blobs(shape, seed=seed, noise=noise)
