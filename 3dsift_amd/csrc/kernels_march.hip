@@ -53,22 +53,32 @@ struct MEdge { float f[3][kMarchMaxHW + 1]; };  // x, y, z fractions of the righ
 typedef float mf4 __attribute__((ext_vector_type(4)));
 typedef float mf2 __attribute__((ext_vector_type(2)));
 
-template <int HW>
+// TX_ = 32: the r02 geometry (32 x 32 tiles, four waves).  TX_ = 64 (r04): 64 x 32 tiles, eight waves, for the big levels: the level
+// time is set by the memory skeleton of the march (scripts/microbench/tile_march.hip: tile DMA + stores + one barrier per plane, no
+// arithmetic, runs within 10 % of the kernel), and that skeleton is 9-15 % faster with 64-wide tiles (x halo 1.25x instead of 1.5x,
+// row segments of 288-320 bytes instead of 160-192).
+template <int HW, int TX_ = 32>
 struct MCfg {
-	static constexpr int TX = 32, TY = 32, NT = 256;
+	static constexpr int TX = TX_, TY = 32, NT = TX * 8, NW = NT / 64;
+	static constexpr int SEG = TX / 8;                     // x-blur items (8 outputs each) per tile row
+	static constexpr int RPW = 64 / SEG;                   // tile rows one wave of x-blur items covers
 	static constexpr int HX = ((HW + 3) / 4) * 4;          // x halo per side (floats, whole 16-byte pieces)
-	static constexpr int W = TX + 2 * HX, W4 = W / 4;      // tile row: 12 pieces (hw >= 5) or 10 (hw <= 4)
+	static constexpr int W = TX + 2 * HX, W4 = W / 4;      // tile row: 12 pieces (hw >= 5) or 10 (hw <= 4); 20 / 18 at TX 64
 	static constexpr int ROWS = TY + 2 * HW;               // row r <-> y = y0 - HW + r
 	static constexpr int NITEMS = ROWS * W4;               // 16-byte pieces per plane
 	static constexpr int NWI = (NITEMS + 63) / 64;         // DMA wave-instructions per plane (1 KiB each)
-	static constexpr int NDMA = (NWI + 3) / 4;             // ... per wave (wave w takes instructions w, w+4, ...)
+	static constexpr int NDMA = (NWI + NW - 1) / NW;       // ... per wave (wave w takes instructions w, w+NW, ...)
 	static constexpr int TILE_F = NWI * 256;               // floats per tile buffer
-	static constexpr int XP = 32, XB_F = ROWS * XP;        // x-blurred tile
+	static constexpr int XP = TX, XB_F = ROWS * XP;        // x-blurred tile
+	static constexpr bool XSW = TX == 64;                  // x-blurred tile: piece p of row r stored at p ^ (r & 1) (a row is a whole bank sweep)
 	static constexpr int WOFF = HX - HW;                   // window index of input x-hw of output 0 (the window starts at piece 2*seg)
 	static constexpr int WN4 = (WOFF + 8 + 2 * HW + 3) / 4;
 	static constexpr int CRN = HW + 1;                     // DoG centre ring: plane p is needed HW steps after it was loaded
-	static_assert(W4 % 2 == 0 && 6 + WN4 <= W4, "tile geometry");
-	static_assert(ROWS <= 48, "x-blur items of waves 0..2; wave 3 serves the bottom tiles");
+	static constexpr int NR = (ROWS + RPW - 1) / RPW;      // waves' worth of x-blur items; role NR serves the bottom tiles
+	static_assert(W4 % 2 == 0 && 2 * (SEG - 1) + WN4 <= W4, "tile geometry");
+	static_assert(NR < NW, "one wave without x-blur items serves the bottom tiles");
+	static_assert((HW + 2) * SEG <= 64, "the bottom rows are one wave's worth of items");
+	static_assert(RPW % 2 == 0, "the swizzle bit of a lane's row does not depend on its role");
 };
 
 // development diagnostics, timing only (never set in the product build; results are wrong by construction): 1 no tile DMA, 2 no stores,
@@ -166,20 +176,25 @@ constexpr int march_lb() {  // __launch_bounds__ second argument: at least the p
 	return (S3D_MARCH_VGPR_OCC > march_occ<HW, CR>() && !CR) ? S3D_MARCH_VGPR_OCC : march_occ<HW, CR>();
 }
 
-template <int HW, bool DOG, bool CR>
-__global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
+// KR (TX 64): the newest KR planes of the DoG centre ring live in REGISTERS and move on to an LDS ring of HW + 1 - KR planes (two
+// workgroups of eight waves per CU leave 80 KB each: tile + x-blurred tile + a whole ring of 64 x 32 planes do not fit at hw >= 4)
+// (the second __launch_bounds__ argument is waves per SIMD: two workgroups of eight waves = 4)
+template <int HW, bool DOG, bool CR, int TX = 32, int KR = 0>
+__global__ void __launch_bounds__(TX * 8, (TX == 64 ? 4 : march_lb<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                         unsigned *__restrict__ dogmax, int nx, int ny, ZRange zr, MTaps t, MEdge ef, int ntx,
                                                         int nty, int cz, int prio, float *__restrict__ half, int hnx, int hny, int hnz) {
-	using C = MCfg<HW>;
+	using C = MCfg<HW, TX>;
 	constexpr bool ZSYM = S3D_MARCH_ZSYM != 0 && HW <= 6;
+	constexpr int KL = C::CRN - KR;  // planes of the centre ring in LDS
+	static_assert(KR == 0 || (CR && KL >= 1), "register part of the centre ring");
 	__shared__ __attribute__((aligned(1024))) float tile[2 * C::TILE_F];
 	__shared__ __attribute__((aligned(16))) float xb[2 * C::XB_F];
-	__shared__ __attribute__((aligned(16))) mf4 cring[CR ? C::CRN * C::NT : 1];
+	__shared__ __attribute__((aligned(16))) mf4 cring[CR ? KL * C::NT : 1];
 	// DOG without the centre ring (hw >= 6): the centre piece of the plane the NEXT step completes travels by LDS-DMA as well (a
 	// compiler-tracked global load would be waited for with vmcnt(0), i.e. together with the tile DMA issued right after it)
 	__shared__ __attribute__((aligned(1024))) mf4 cenb[(DOG && !CR) ? 2 * C::NT : 1];
 	__shared__ float s_ef[3 * (kMarchMaxHW + 1)];
-	__shared__ float s_red[4];
+	__shared__ float s_red[C::NW];
 
 	// wave priority of the launch (issue arbitration between resident waves): the small octaves' launches sit on the critical chain
 	// octave -> octave while the big launches of octave 0 fill the machine; they run at a raised priority
@@ -211,7 +226,7 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 	unsigned goffb[C::NDMA];
 #pragma unroll
 	for (int i = 0; i < C::NDMA; i++) {
-		const int item = (wid + 4 * i) * 64 + lane;
+		const int item = (wid + C::NW * i) * 64 + lane;
 		const int r = item / C::W4, cs = item - r * C::W4, c = cs ^ (r & 1);
 		const int gy = y0 - HW + r, gx = x0 - C::HX + 4 * c;
 		const bool ok = item < C::NITEMS && gy >= 0 && gy < ny && gx >= 0 && gx + 3 < nx;
@@ -238,31 +253,41 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 		else { g = 1; jj = l5 - 16; }
 		g += (lane >> 5) * 2;
 		const int q = jj >> 2;
-		// W4 = 12: four consecutive rows (r*12 mod 16 = 0,12,8,4; odd rows swizzled);  W4 = 10: rows {r, r+4, r+1, r+5}
-		rs = C::W4 == 12 ? 4 * g + q : ((g & 1) * 2 + (g >> 1) * 8 + (q & 1) * 4 + (q >> 1));
-		xseg_r = jj & 3;
+		if (TX == 64) {
+			// a service group = two rows of different parity x eight segments: piece 2 seg + k of the even row and (2 seg + k) ^ 1 of the odd
+			// row cover different banks for every k (row pitch 18 or 20 pieces = 8 or 16 banks mod 64)
+			rs = 2 * g + (jj >> 3);
+			xseg_r = jj & 7;
+		} else {
+			// W4 = 12: four consecutive rows (r*12 mod 16 = 0,12,8,4; odd rows swizzled);  W4 = 10: rows {r, r+4, r+1, r+5}
+			rs = C::W4 == 12 ? 4 * g + q : ((g & 1) * 2 + (g >> 1) * 8 + (q & 1) * 4 + (q >> 1));
+			xseg_r = jj & 3;
+		}
 	}
 	// per-role activity / mirror bits of the regular items (role r: tile row 16*r + rs)
 	int amask = 0, mmask = 0;
 #pragma unroll
-	for (int r = 0; r < 3; r++) {
-		const int row = 16 * r + rs, gy = y0 - HW + row;
+	for (int r = 0; r < C::NR; r++) {
+		const int row = C::RPW * r + rs, gy = y0 - HW + row;
 		const bool act = row < C::ROWS && gy >= 0 && gy < ny && !(bottom_f && gy == ny - 1);  // row yend of a bottom tile receives E[yend]
 		amask |= (act ? 1 : 0) << r;
 		mmask |= ((act && top_f && gy >= 1 && gy <= HW) ? 1 : 0) << r;  // E[-k] = row k: second copy in the mirror row
 	}
-	const int sw_r = rs & 1;  // 16*role is even: the swizzle bit does not depend on the role
+	const int sw_r = rs & 1;  // RPW*role is even: the swizzle bit does not depend on the role
 	const int xbe_r = (rs * C::W4 + 2 * xseg_r + sw_r) * 4, xbo_r = (rs * C::W4 + 2 * xseg_r - sw_r) * 4;  // float offsets of even / odd window pieces
-	const int xout_r = rs * C::XP + xseg_r * 8;
-	const int xoutm_r = (HW - (y0 - HW + rs)) * C::XP + xseg_r * 8;
+	// (XSW: the two pieces of an item trade places in odd rows; the mirror row 2 HW - row has the row's parity)
+	const int xout_r = rs * C::XP + xseg_r * 8 + ((C::XSW && sw_r) ? 4 : 0);
+	const int xoutm_r = (HW - (y0 - HW + rs)) * C::XP + xseg_r * 8 + ((C::XSW && sw_r) ? 4 : 0);
+	const int xhi_r = (C::XSW && sw_r) ? -4 : 4;  // float offset of the second piece of an item
 	// bottom tiles: the wave with role 3 re-blurs rows yend-hw-1 .. yend (one row per 4 lanes) for the bottom extension E[yend+k]
-	const int row_h = C::TY - 2 + (lane >> 2), xseg_h = lane & 3, sw_h = row_h & 1;
-	const bool act_h = bottom_f && lane < (HW + 2) * 4;
+	const int row_h = C::TY - 2 + lane / C::SEG, xseg_h = lane % C::SEG, sw_h = row_h & 1;
+	const bool act_h = bottom_f && lane < (HW + 2) * C::SEG;
 	const int xbe_h = (row_h * C::W4 + 2 * xseg_h + sw_h) * 4, xbo_h = (row_h * C::W4 + 2 * xseg_h - sw_h) * 4;
 
 	// ---- y/z work: thread (xq, ty) owns the 16-byte piece x = x0 + 4*xq .. +3 of row y0 + ty ----
-	const int xq = tid & 7, ty = tid >> 3;
-	const int ycol = ty * C::XP + 4 * xq;
+	const int xq = tid & (C::TX / 4 - 1), ty = tid / (C::TX / 4);
+	// column offsets of this thread's piece in the x-blurred rows of ty's parity / the other parity (equal without the swizzle)
+	const int ycol = ty * C::XP + 4 * (C::XSW ? (xq ^ (ty & 1)) : xq), ycol_o = ty * C::XP + 4 * (C::XSW ? (xq ^ (ty & 1) ^ 1) : xq);
 	const unsigned out_voff = (unsigned)((y0 + ty) * sy + x0 + 4 * xq) * 4u;
 	const bool own = x0 + 4 * xq < xlim && y0 + ty < ylim;  // this thread's piece belongs to this tile (always, unless the next tile is shifted)
 	const int park_off = ((ty + HW) * C::W4 + ((C::HX / 4 + xq) ^ ((ty + HW) & 1))) * 4;  // raw centre piece in the tile
@@ -274,6 +299,9 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 		for (int c = 0; c < 4; c++) A[s][c] = 0.0f;
 	float prevx[4] = {0.f, 0.f, 0.f, 0.f};
 	float mx = 0.0f;
+	mf4 creg[KR > 0 ? KR : 1];
+#pragma unroll
+	for (int i = 0; i < (KR > 0 ? KR : 1); i++) creg[i] = mf4{0.f, 0.f, 0.f, 0.f};
 
 	// feed order (global E index e, descending): e_top = highest term of the chunk's top output
 	const int e_top = zc1 - 1 + zoff + HW, e_bot = zc0 + zoff - HW;
@@ -288,7 +316,7 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 		const unsigned dstb = lds_tile + (unsigned)(jn & 1) * (unsigned)(C::TILE_F * 4);
 #pragma unroll
 		for (int i = 0; i < C::NDMA; i++)
-			if (!(S3D_MDIAG & 1) && wid + 4 * i < C::NWI) m_dma16(pl, goffb[i], dstb + (unsigned)(i * 4096));
+			if (!(S3D_MDIAG & 1) && wid + C::NW * i < C::NWI) m_dma16(pl, goffb[i], dstb + (unsigned)(i * C::NW * 1024));
 	};
 	if (zc0 >= zc1) return;  // uniform (never for a planned grid)
 	issue_dma(0);
@@ -314,20 +342,20 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 		constexpr bool YPRE = S3D_MARCH_YPRE && HW <= 6;
 		mf4 ypre[KG];
 		if (YPRE) {  // (step 0 reads rows nobody has written: never used)
-			const float *yc0 = xb + (buf ^ 1) * C::XB_F + ycol;
+			const float *yc0 = xb + (buf ^ 1) * C::XB_F;
 #pragma unroll
-			for (int i = 0; i < KG; i++) ypre[i] = *reinterpret_cast<const mf4 *>(yc0 + (i < NTAP ? 2 * HW - i : 0) * C::XP);
+			for (int i = 0; i < KG; i++) ypre[i] = *reinterpret_cast<const mf4 *>(yc0 + ((i < NTAP && (i & 1)) ? ycol_o : ycol) + (i < NTAP ? 2 * HW - i : 0) * C::XP);
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		// ---------------- x-blur of feed j: tile[buf] -> xb[buf] ----------------
 		if (j < nsteps) {
-			const int role = S3D_MARCH_ROT ? ((wid + j) & 3) : wid;  // wave-uniform
-			const bool xhelp = role == 3;
+			const int role = S3D_MARCH_ROT ? ((wid + j) & (C::NW - 1)) : wid;  // wave-uniform
+			const bool xhelp = role == C::NR;
 			const bool xact = xhelp ? act_h : (((amask >> role) & 1) != 0);
 			const bool xmirror = !xhelp && (((mmask >> role) & 1) != 0);
 			const int xseg = xhelp ? xseg_h : xseg_r;
-			const int xbase_e = xhelp ? xbe_h : xbe_r + role * (16 * C::W4 * 4), xbase_o = xhelp ? xbo_h : xbo_r + role * (16 * C::W4 * 4);
-			const int xout = xout_r + role * (16 * C::XP), xout_m = xoutm_r - role * (16 * C::XP);
+			const int xbase_e = xhelp ? xbe_h : xbe_r + role * (C::RPW * C::W4 * 4), xbase_o = xhelp ? xbo_h : xbo_r + role * (C::RPW * C::W4 * 4);
+			const int xout = xout_r + role * (C::RPW * C::XP), xout_m = xoutm_r - role * (C::RPW * C::XP);
 			float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 			if (xact) {
 				const float *tb = tile + buf * C::TILE_F;
@@ -342,7 +370,7 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 #pragma unroll
 					for (int k = 1; k <= HW; k++) win[C::WOFF + HW - k] = win[C::WOFF + HW + k];
 				}
-				if (right_f && xseg == 3) {
+				if (right_f && xseg == C::SEG - 1) {
 					float e[HW + 1];
 #pragma unroll
 					for (int k = 0; k <= HW; k++) {
@@ -352,7 +380,7 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 #pragma unroll
 					for (int k = 0; k <= HW; k++) win[C::WOFF + HW + 7 + k] = e[k];
 				}
-				if (HW == 8 && right_f && xseg == 2) {  // the window of segment 2 ends on column xend = E[xend]
+				if (HW == 8 && right_f && xseg == C::SEG - 2) {  // the window of segment 2 ends on column xend = E[xend]
 					const float f = s_ef[0];
 					win[C::WOFF + HW + 15] = (1.0f - f) * win[C::WOFF + HW + 14] + f * win[C::WOFF + HW + 15];
 				}
@@ -366,25 +394,27 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 				if (!xhelp) {
 					float *xo = xb + buf * C::XB_F;
 					*reinterpret_cast<mf4 *>(xo + xout) = mf4{o[0], o[1], o[2], o[3]};
-					*reinterpret_cast<mf4 *>(xo + xout + 4) = mf4{o[4], o[5], o[6], o[7]};
+					*reinterpret_cast<mf4 *>(xo + xout + xhi_r) = mf4{o[4], o[5], o[6], o[7]};
 					if (xmirror) {
 						*reinterpret_cast<mf4 *>(xo + xout_m) = mf4{o[0], o[1], o[2], o[3]};
-						*reinterpret_cast<mf4 *>(xo + xout_m + 4) = mf4{o[4], o[5], o[6], o[7]};
+						*reinterpret_cast<mf4 *>(xo + xout_m + xhi_r) = mf4{o[4], o[5], o[6], o[7]};
 					}
 				}
 			}
 			if (bottom_f && xhelp) {  // wave-uniform: every lane takes part in the shuffles
 				float a[8];
 #pragma unroll
-				for (int jo = 0; jo < 8; jo++) a[jo] = __shfl_up(o[jo], 4, 64);  // the row below (same segment)
-				const int jr = lane >> 2;                                       // this lane holds x-blurred row yend-hw-1+jr
+				for (int jo = 0; jo < 8; jo++) a[jo] = __shfl_up(o[jo], C::SEG, 64);  // the row below (same segment)
+				const int jr = lane / C::SEG;                                   // this lane holds x-blurred row yend-hw-1+jr
 				if (xact && jr >= 1) {
 					const int k = HW + 1 - jr;                                  // E[yend+k] = (1-f_k) xb[yend-k-1] + f_k xb[yend-k]
 					const float f = s_ef[kMarchMaxHW + 1 + k];
-					float *xe = xb + buf * C::XB_F + (C::TY - 1 + HW + k) * C::XP + xseg * 8;
+					const int erow = C::TY - 1 + HW + k;
+					const bool esw = C::XSW && (erow & 1);
+					float *xe = xb + buf * C::XB_F + erow * C::XP + xseg * 8 + (esw ? 4 : 0);
 					*reinterpret_cast<mf4 *>(xe) = mf4{(1.0f - f) * a[0] + f * o[0], (1.0f - f) * a[1] + f * o[1], (1.0f - f) * a[2] + f * o[2],
 					                                   (1.0f - f) * a[3] + f * o[3]};
-					*reinterpret_cast<mf4 *>(xe + 4) = mf4{(1.0f - f) * a[4] + f * o[4], (1.0f - f) * a[5] + f * o[5], (1.0f - f) * a[6] + f * o[6],
+					*reinterpret_cast<mf4 *>(xe + (esw ? -4 : 4)) = mf4{(1.0f - f) * a[4] + f * o[4], (1.0f - f) * a[5] + f * o[5], (1.0f - f) * a[6] + f * o[6],
 					                                       (1.0f - f) * a[7] + f * o[7]};
 				}
 			}
@@ -393,19 +423,19 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 		// ---------------- y-blur, feed and z-scatter of feed j-1: xb[buf ^ 1] ----------------
 		int nst = 0;
 		if (j >= 1) {
-			const float *yc = xb + (buf ^ 1) * C::XB_F + ycol;
+			const float *yc = xb + (buf ^ 1) * C::XB_F;
 			float v[4] = {0.f, 0.f, 0.f, 0.f};
 			{
 				// step s = d + HW reads row ty + 2*HW - s; rows are requested a group ahead of their use (hipcc keeps only two reads
 				// in flight on its own and exposes the LDS latency nine times per plane)
 				mf4 cur[KG], nxt[KG];
 #pragma unroll
-				for (int i = 0; i < KG; i++) cur[i] = YPRE ? ypre[i] : *reinterpret_cast<const mf4 *>(yc + (i < NTAP ? 2 * HW - i : 0) * C::XP);
+				for (int i = 0; i < KG; i++) cur[i] = YPRE ? ypre[i] : *reinterpret_cast<const mf4 *>(yc + ((i < NTAP && (i & 1)) ? ycol_o : ycol) + (i < NTAP ? 2 * HW - i : 0) * C::XP);
 #pragma unroll
 				for (int g0 = 0; g0 < NTAP; g0 += KG) {
 #pragma unroll
 					for (int i = 0; i < KG; i++)
-						if (g0 + KG + i < NTAP) nxt[i] = *reinterpret_cast<const mf4 *>(yc + (2 * HW - (g0 + KG + i)) * C::XP);
+						if (g0 + KG + i < NTAP) nxt[i] = *reinterpret_cast<const mf4 *>(yc + (((g0 + KG + i) & 1) ? ycol_o : ycol) + (2 * HW - (g0 + KG + i)) * C::XP);
 #pragma unroll
 					for (int i = 0; i < KG; i++)
 						if (g0 + i < NTAP && !((S3D_MDIAG & 32) && (g0 + i) % 4 != 0)) {
@@ -456,7 +486,7 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 			for (int c = 0; c < 4; c++) A[0][c] = 0.0f + t.w[0] * v[c];
 			}
 
-			if (DOG && CR) cen = cring[(j % C::CRN) * C::NT + tid];  // parked HW+1 steps ago (read before this step's park below)
+			if (DOG && CR) cen = cring[(j % KL) * C::NT + tid];  // the centre piece of HW+1 steps ago (read before this step's park below)
 #if S3D_MARCH_SCHEDB
 			__builtin_amdgcn_sched_barrier(0);  // keep the accumulator updates in front of the stores and of the wait for the DMA
 #endif
@@ -491,7 +521,16 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 				}
 			}
 		}
-		if (DOG && CR && j < nsteps) cring[(j % C::CRN) * C::NT + tid] = *reinterpret_cast<const mf4 *>(tile + buf * C::TILE_F + park_off);
+		if (DOG && CR && j < nsteps) {
+			const mf4 fresh = *reinterpret_cast<const mf4 *>(tile + buf * C::TILE_F + park_off);
+			if (KR == 0) cring[(j % KL) * C::NT + tid] = fresh;
+			else {  // the piece that has been KR steps in registers moves to the LDS ring; the ring slot was read above
+				cring[(j % KL) * C::NT + tid] = creg[KR - 1];
+#pragma unroll
+				for (int i = KR - 1; i >= 1; i--) creg[i] = creg[i - 1];
+				creg[0] = fresh;
+			}
+		}
 
 		// the DMA of the next tile was issued before this step's stores (vmcnt retires in order)
 		if (S3D_MDIAG & 4) {}
@@ -508,7 +547,8 @@ __global__ void __launch_bounds__(256, (march_lb<HW, CR>())) k_march_level(const
 		if (lane == 0) s_red[wid] = mx;
 		__syncthreads();
 		if (tid == 0) {
-			const float r = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+			float r = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+			if (C::NW == 8) r = fmaxf(r, fmaxf(fmaxf(s_red[4], s_red[5]), fmaxf(s_red[6], s_red[7])));
 			if (r > 0.0f) atomicMax(dogmax, __float_as_uint(r));
 		}
 	}
@@ -562,7 +602,12 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	int cz3 = nzo, cz4 = nzo;
 	const double cost3 = plan(256 * (dog && kHasCR ? 3 : kOcc), cz3), cost4 = plan(256 * (dog && kHasCR ? 4 : kOcc + 1), cz4);
 	// dog + ring: three per CU unless four without the ring are clearly ahead; everything else may use the extra slot
-	const bool use_cr = dog && kHasCR && !(cost4 * 1.12 < cost3);
+	// r04: the small octaves (at most 16 tiles per plane) run BESIDE octave 0's widest level (2 x 38 KB of LDS per CU) and octave 1's
+	// (38 KB): a ring kernel's 45 / 52 KB does not fit next to them, and the head of octave 2 -- on the stage's critical chain -- waited
+	// 130 us for octave 1's last level to drain (profiles/r04e_timeline.txt); the ring-less form (33 / 35 KB) fits, and re-reading the
+	// centre plane of a 128 x 128 level costs nothing
+	const bool small_bg = plan_slots > 0 && ntiles <= 16;
+	const bool use_cr = dog && kHasCR && !small_bg && !(cost4 * 1.12 < cost3);
 	const int cz = (dog && kHasCR) ? (use_cr ? cz3 : cz4) : (cost4 < cost3 ? cz4 : cz3);
 	const int nchunks = (nzo + cz - 1) / cz;
 	MEdge ef;
@@ -575,6 +620,57 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 	else if (dog) hipLaunchKernelGGL((k_march_level<HW, true, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
+}
+
+// r04: the 64 x 32 tiles of the big levels (MCfg<HW, 64>): eight waves, two workgroups per CU, planned for 512 slots.
+#ifndef S3D_MARCH_WIDE_MIN_TILES
+#define S3D_MARCH_WIDE_MIN_TILES 100  /* 64 x 32 tiles per plane from which a level takes them (512 x 512: 128; 256 x 256 would march 16 chunks of 16 planes + ramp) */
+#endif
+static bool march_wide_ok(int nx, int ny, int hw, int plan_slots) {
+	const int mode = hook(SIFT3D_HOOK_MARCH_TILES);  // 0 product rule, 1 wherever the geometry allows (parity tests on small volumes), 2 never
+	if (mode == 2 || plan_slots > 0 || hw < 2 || hw > 6) return false;  // (a planned launch shares the machine with another octave: 32 x 32 tiles, three per CU)
+	if (!(nx == 64 || nx >= 64 + hw)) return false;  // the shifted last tile column starts at nx - 64: 0 or beyond the mirror zone
+	const int ntiles = ((nx + 63) / 64) * ((ny + 31) / 32);
+	return mode == 1 || ntiles >= S3D_MARCH_WIDE_MIN_TILES;
+}
+template <int HW>
+static void launch_march_wide(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &tg,
+                              hipStream_t st, int prio, const MarchHalf &hf) {
+	using C = MCfg<HW, 64>;
+	MTaps t;
+	for (int i = 0; i < 2 * kMarchMaxHW + 1; i++) t.w[i] = i < 2 * HW + 1 ? tg.w[i] : 0.0f;
+	const int nzo = zr.zo1 - zr.zo0;
+	if (nzo <= 0) return;
+	const int ntx = (nx + C::TX - 1) / C::TX, nty = (ny + C::TY - 1) / C::TY, ntiles = ntx * nty;
+	// z chunking as in launch_march_hw: residency rounds of at most 512 workgroups, a round costs its planes + the ramp
+	const int ramp = 2 * HW + 1, cap = 512;
+	int cz = nzo;
+	{
+		double best = 1e300;
+		for (int n = 1; n <= nzo && n <= 64; n++) {
+			const int czn = (nzo + n - 1) / n, nch = (nzo + czn - 1) / czn;
+			long left = (long)ntiles * nch;
+			double cost = 0.0;
+			while (left > 0) {
+				const long r = std::min<long>(left, cap);
+				cost += (double)(czn + ramp) * std::max(1.0, (double)r / (double)cap);
+				left -= r;
+			}
+			if (cost < best - 1e-9) { best = cost; cz = czn; }
+		}
+	}
+	const int nchunks = (nzo + cz - 1) / cz;
+	MEdge ef;
+	memset(&ef, 0, sizeof(ef));
+	march_edge_fractions(nx, HW, ef.f[0]);
+	march_edge_fractions(ny, HW, ef.f[1]);
+	march_edge_fractions(zr.nzg, HW, ef.f[2]);
+	const dim3 grid((unsigned)(ntiles * nchunks)), block(C::NT);
+	// DoG centres: a whole LDS ring up to hw 3, the newest 1 (hw 4) / 3 (hw 5) planes in registers, by one more LDS-DMA at hw 6
+	constexpr int kKR = HW == 4 ? 1 : (HW == 5 ? 3 : 0);
+	if (!dog) hipLaunchKernelGGL((k_march_level<HW, false, false, 64, 0>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
+	else if (HW <= 5) hipLaunchKernelGGL((k_march_level<HW, true, (HW <= 5), 64, kKR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
+	else hipLaunchKernelGGL((k_march_level<HW, true, false, 64, 0>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 }
 
 // false => not applicable (a plane smaller than one tile, a shifted last tile that would reach into the mirrored left / top zone, a level
@@ -598,6 +694,16 @@ bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogm
 	if (half && half->d && march_half_ok(nx, ny, zr)) hf = *half;
 	else if (half && half->d) return false;  // (the caller asks first: march_half_ok)
 	if (!march_applicable(nx, ny, zr.nzg, t)) return false;
+	if (march_wide_ok(nx, ny, t.hw, plan_slots)) {
+		switch (t.hw) {
+		case 2: launch_march_wide<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, prio, hf); return true;
+		case 3: launch_march_wide<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, prio, hf); return true;
+		case 4: launch_march_wide<4>(src, dst, dog, dogmax, nx, ny, zr, t, st, prio, hf); return true;
+		case 5: launch_march_wide<5>(src, dst, dog, dogmax, nx, ny, zr, t, st, prio, hf); return true;
+		case 6: launch_march_wide<6>(src, dst, dog, dogmax, nx, ny, zr, t, st, prio, hf); return true;
+		default: break;
+		}
+	}
 	switch (t.hw) {
 	case 2: launch_march_hw<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
 	case 3: launch_march_hw<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;

@@ -272,7 +272,8 @@ enum {
 	SIFT3D_HOOK_LIST_CAP = 8,       /* n > 0: initial capacity of the extrema / keypoint lists -> overflow, regrow, rerun */
 	SIFT3D_HOOK_PEER_COPY = 9,      /* 1: sift3d_match_handles stages the target's results through its peer-copy scratch even on one device */
 	SIFT3D_HOOK_DESC_NOSPLIT = 10,  /* 1: a descriptor window is never split over several workgroups (the form of runs with many keypoints) */
-	SIFT3D_HOOK_COUNT = 11
+	SIFT3D_HOOK_MARCH_TILES = 11,   /* 1: the 64 x 32 tiles of the pyramid kernel wherever a level's geometry allows them (default: big levels only); 2: never */
+	SIFT3D_HOOK_COUNT = 12
 };
 int sift3d_test_hook(int which, int value);
 /* how often the rare paths ran: c[0] list regrows of the last run, c[1] keypoints whose descriptor took the second pass in

@@ -322,6 +322,30 @@ def test_separable_kernels_match_fused(capi, synth):
     assert base == sep and base[1] > 20
 
 
+@pytest.mark.parametrize("shape,seed,noise,eager", [
+    ((40, 32, 64), 41, 0.02, 0),     # ONE 64 x 32 tile: left / right / top / bottom edge in the same tile
+    ((33, 96, 96), 42, 0.01, 0),     # nx = 96: the second tile column is shifted back by 32 (x0 = 32); three tile rows
+    ((48, 40, 128), 43, 0.02, 1),    # two aligned tile columns, shifted last tile row; every DoG level written (ring forms of hw 2 / 3)
+    ((36, 70, 300), 44, 0.1, 0),     # five tile columns, the last one shifted by 20; ny = 70: shifted tile row
+    ((24, 128, 192), 45, 0.01, 0),   # thin: 24 planes (hw 8 never fits, chunks of a few planes), three columns, four rows
+    ((70, 64, 72), 46, 0.05, 0),     # nx = 72 = 64 + 8: the narrowest shifted column (hw 6 <= 8), interior code on a window that is mostly overlap
+])
+def test_wide_tiles_pyramid_vs_oracle(capi, orc, synth, shape, seed, noise, eager):
+    """r04: the big levels take 64 x 32 tiles (eight waves per workgroup, DoG centres partly in registers).  The hook march_tiles = 1
+    gives every level whose geometry allows them the wide tiles, so that volumes the oracle finishes in seconds run that kernel:
+    every level bit-identical, and the same keypoints / descriptors as the 32 x 32 form (march_tiles = 2)."""
+    vol = synth.blobs(shape, seed=seed, noise=noise)
+    o = orc.extractor(vol).run(5)
+    with capi.hook("march_tiles", 1), capi.hook("dog_eager", eager), capi.hook("glast_eager", eager):
+        g = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+        compare_pyramids(g, o)
+        assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema()))
+        wide = _full_hash(capi, g, with_dog=True, with_extrema=True)
+    with capi.hook("march_tiles", 2), capi.hook("dog_eager", eager), capi.hook("glast_eager", eager):
+        narrow = _full_hash(capi, capi.CreateCSIFT3D(vol).KpSiftAlgorithm(), with_dog=True, with_extrema=True)
+    assert wide == narrow
+
+
 def test_descriptor_chord_cache_matches_recomputed_chords(capi, synth):
     """k_describe keeps the z range of every column of a window in a byte cache in LDS; windows whose ranges do not fit a byte
     (far larger than any default window) recompute them instead.  The hook desc_nocache forces that path: same descriptors, bit
