@@ -82,7 +82,8 @@ struct MCfg {
 };
 
 // development diagnostics, timing only (never set in the product build; results are wrong by construction): 1 no tile DMA, 2 no stores,
-// 4 no wait for the DMA, 8 no barriers, 16 / 32 / 64 no x / y / z blur arithmetic (the LDS traffic stays)
+// 4 no wait for the DMA, 8 no barriers, 16 / 32 / 64 no x / y / z blur arithmetic (the LDS traffic stays), 128 the y-blur reads ONE row,
+// 256 the x-blur reads ONE window piece, 512 no centre-ring traffic
 #ifndef S3D_MDIAG
 #define S3D_MDIAG 0
 #endif
@@ -176,11 +177,14 @@ constexpr int march_lb() {  // __launch_bounds__ second argument: at least the p
 	return (S3D_MARCH_VGPR_OCC > march_occ<HW, CR>() && !CR) ? S3D_MARCH_VGPR_OCC : march_occ<HW, CR>();
 }
 
+#ifndef S3D_MARCH_WIDE_OCC6_MAXHW
+#define S3D_MARCH_WIDE_OCC6_MAXHW 0  /* 64 x 32 tiles without DoG up to this half width: register budget 80 (three workgroups per CU, planned for 768 slots) */
+#endif
 // KR (TX 64): the newest KR planes of the DoG centre ring live in REGISTERS and move on to an LDS ring of HW + 1 - KR planes (two
 // workgroups of eight waves per CU leave 80 KB each: tile + x-blurred tile + a whole ring of 64 x 32 planes do not fit at hw >= 4)
 // (the second __launch_bounds__ argument is waves per SIMD: two workgroups of eight waves = 4)
 template <int HW, bool DOG, bool CR, int TX = 32, int KR = 0>
-__global__ void __launch_bounds__(TX * 8, (TX == 64 ? 4 : march_lb<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
+__global__ void __launch_bounds__(TX * 8, (TX == 64 ? ((!DOG && HW <= S3D_MARCH_WIDE_OCC6_MAXHW) ? 6 : 4) : march_lb<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                         unsigned *__restrict__ dogmax, int nx, int ny, ZRange zr, MTaps t, MEdge ef, int ntx,
                                                         int nty, int cz, int prio, float *__restrict__ half, int hnx, int hny, int hnz) {
 	using C = MCfg<HW, TX>;
@@ -344,7 +348,7 @@ __global__ void __launch_bounds__(TX * 8, (TX == 64 ? 4 : march_lb<HW, CR>())) k
 		if (YPRE) {  // (step 0 reads rows nobody has written: never used)
 			const float *yc0 = xb + (buf ^ 1) * C::XB_F;
 #pragma unroll
-			for (int i = 0; i < KG; i++) ypre[i] = *reinterpret_cast<const mf4 *>(yc0 + ((i < NTAP && (i & 1)) ? ycol_o : ycol) + (i < NTAP ? 2 * HW - i : 0) * C::XP);
+			for (int i = 0; i < KG; i++) if (!((S3D_MDIAG & 128) && i > 0)) ypre[i] = *reinterpret_cast<const mf4 *>(yc0 + ((i < NTAP && (i & 1)) ? ycol_o : ycol) + (i < NTAP ? 2 * HW - i : 0) * C::XP);
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		// ---------------- x-blur of feed j: tile[buf] -> xb[buf] ----------------
@@ -362,6 +366,7 @@ __global__ void __launch_bounds__(TX * 8, (TX == 64 ? 4 : march_lb<HW, CR>())) k
 				float win[C::WN4 * 4];
 #pragma unroll
 				for (int k = 0; k < C::WN4; k++) {
+					if ((S3D_MDIAG & 256) && k > 0) { win[4 * k] = win[0]; win[4 * k + 1] = win[1]; win[4 * k + 2] = win[2]; win[4 * k + 3] = win[3]; continue; }
 					const mf4 f = *reinterpret_cast<const mf4 *>(tb + ((k & 1) ? xbase_o : xbase_e) + 4 * k);
 					win[4 * k] = f.x; win[4 * k + 1] = f.y; win[4 * k + 2] = f.z; win[4 * k + 3] = f.w;
 				}
@@ -435,7 +440,7 @@ __global__ void __launch_bounds__(TX * 8, (TX == 64 ? 4 : march_lb<HW, CR>())) k
 				for (int g0 = 0; g0 < NTAP; g0 += KG) {
 #pragma unroll
 					for (int i = 0; i < KG; i++)
-						if (g0 + KG + i < NTAP) nxt[i] = *reinterpret_cast<const mf4 *>(yc + (((g0 + KG + i) & 1) ? ycol_o : ycol) + (2 * HW - (g0 + KG + i)) * C::XP);
+						if (g0 + KG + i < NTAP && !(S3D_MDIAG & 128)) nxt[i] = *reinterpret_cast<const mf4 *>(yc + (((g0 + KG + i) & 1) ? ycol_o : ycol) + (2 * HW - (g0 + KG + i)) * C::XP);
 #pragma unroll
 					for (int i = 0; i < KG; i++)
 						if (g0 + i < NTAP && !((S3D_MDIAG & 32) && (g0 + i) % 4 != 0)) {
@@ -486,7 +491,7 @@ __global__ void __launch_bounds__(TX * 8, (TX == 64 ? 4 : march_lb<HW, CR>())) k
 			for (int c = 0; c < 4; c++) A[0][c] = 0.0f + t.w[0] * v[c];
 			}
 
-			if (DOG && CR) cen = cring[(j % KL) * C::NT + tid];  // the centre piece of HW+1 steps ago (read before this step's park below)
+			if (DOG && CR && !(S3D_MDIAG & 512)) cen = cring[(j % KL) * C::NT + tid];  // the centre piece of HW+1 steps ago (read before this step's park below)
 #if S3D_MARCH_SCHEDB
 			__builtin_amdgcn_sched_barrier(0);  // keep the accumulator updates in front of the stores and of the wait for the DMA
 #endif
@@ -521,7 +526,7 @@ __global__ void __launch_bounds__(TX * 8, (TX == 64 ? 4 : march_lb<HW, CR>())) k
 				}
 			}
 		}
-		if (DOG && CR && j < nsteps) {
+		if (DOG && CR && j < nsteps && !(S3D_MDIAG & 512)) {
 			const mf4 fresh = *reinterpret_cast<const mf4 *>(tile + buf * C::TILE_F + park_off);
 			if (KR == 0) cring[(j % KL) * C::NT + tid] = fresh;
 			else {  // the piece that has been KR steps in registers moves to the LDS ring; the ring slot was read above
@@ -564,6 +569,9 @@ static void march_edge_fractions(int n, int hw, float *f) {  // Src/cSIFT3D.cc:7
 	}
 }
 
+#ifndef S3D_MARCH_BG_RINGLESS_TILES
+#define S3D_MARCH_BG_RINGLESS_TILES 16
+#endif
 template <int HW>
 static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &tg,
                             hipStream_t st, int plan_slots, int prio, const MarchHalf &hf) {
@@ -606,7 +614,7 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	// (38 KB): a ring kernel's 45 / 52 KB does not fit next to them, and the head of octave 2 -- on the stage's critical chain -- waited
 	// 130 us for octave 1's last level to drain (profiles/r04e_timeline.txt); the ring-less form (33 / 35 KB) fits, and re-reading the
 	// centre plane of a 128 x 128 level costs nothing
-	const bool small_bg = plan_slots > 0 && ntiles <= 16;
+	const bool small_bg = plan_slots > 0 && ntiles <= S3D_MARCH_BG_RINGLESS_TILES;
 	const bool use_cr = dog && kHasCR && !small_bg && !(cost4 * 1.12 < cost3);
 	const int cz = (dog && kHasCR) ? (use_cr ? cz3 : cz4) : (cost4 < cost3 ? cz4 : cz3);
 	const int nchunks = (nzo + cz - 1) / cz;
@@ -643,7 +651,7 @@ static void launch_march_wide(const float *src, float *dst, float *dog, unsigned
 	if (nzo <= 0) return;
 	const int ntx = (nx + C::TX - 1) / C::TX, nty = (ny + C::TY - 1) / C::TY, ntiles = ntx * nty;
 	// z chunking as in launch_march_hw: residency rounds of at most 512 workgroups, a round costs its planes + the ramp
-	const int ramp = 2 * HW + 1, cap = 512;
+	const int ramp = 2 * HW + 1, cap = (!dog && HW <= S3D_MARCH_WIDE_OCC6_MAXHW) ? 768 : 512;
 	int cz = nzo;
 	{
 		double best = 1e300;
