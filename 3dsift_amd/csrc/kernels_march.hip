@@ -634,12 +634,13 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 #ifndef S3D_MARCH_WIDE_MIN_TILES
 #define S3D_MARCH_WIDE_MIN_TILES 100  /* 64 x 32 tiles per plane from which a level takes them (512 x 512: 128; 256 x 256 would march 16 chunks of 16 planes + ramp) */
 #endif
-static bool march_wide_ok(int nx, int ny, int hw, int plan_slots) {
+static bool march_wide_ok(int nx, int ny, int nzo, int hw, int plan_slots) {
 	const int mode = hook(SIFT3D_HOOK_MARCH_TILES);  // 0 product rule, 1 wherever the geometry allows (parity tests on small volumes), 2 never
 	if (mode == 2 || plan_slots > 0 || hw < 2 || hw > 6) return false;  // (a planned launch shares the machine with another octave: 32 x 32 tiles, three per CU)
 	if (!(nx == 64 || nx >= 64 + hw)) return false;  // the shifted last tile column starts at nx - 64: 0 or beyond the mirror zone
 	const int ntiles = ((nx + 63) / 64) * ((ny + 31) / 32);
-	return mode == 1 || ntiles >= S3D_MARCH_WIDE_MIN_TILES;
+	// (short columns: four chunks of a few planes + the ramp cost what three chunks of the 32 x 32 form do -- 512 x 512 x 32: 0.384 vs 0.376 ms)
+	return mode == 1 || (ntiles >= S3D_MARCH_WIDE_MIN_TILES && nzo / std::max(1, 512 / ntiles) >= 24);  // planes per chunk
 }
 template <int HW>
 static void launch_march_wide(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &tg,
@@ -702,7 +703,7 @@ bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogm
 	if (half && half->d && march_half_ok(nx, ny, zr)) hf = *half;
 	else if (half && half->d) return false;  // (the caller asks first: march_half_ok)
 	if (!march_applicable(nx, ny, zr.nzg, t)) return false;
-	if (march_wide_ok(nx, ny, t.hw, plan_slots)) {
+	if (march_wide_ok(nx, ny, zr.zo1 - zr.zo0, t.hw, plan_slots)) {
 		switch (t.hw) {
 		case 2: launch_march_wide<2>(src, dst, dog, dogmax, nx, ny, zr, t, st, prio, hf); return true;
 		case 3: launch_march_wide<3>(src, dst, dog, dogmax, nx, ny, zr, t, st, prio, hf); return true;
