@@ -223,12 +223,48 @@ __device__ __forceinline__ int cvt_rpi(float x) {
 // R = the transposed rotation (rows R0..R8), fix_scale = 2^k of the histogram's fixed point.  The queue holds the WEIGHTED, NOT YET
 // ROTATED gradient of voxels that passed a slightly relaxed magnitude test; the rotation and the reference's exact test
 // (Src/cSIFT3D.cc:1323-1325, 1468) run here, on the compacted voxels only.
+#ifndef S3D_DESC_FASTCELL
+#define S3D_DESC_FASTCELL 1  /* r04: cell coordinates of the march as one fused multiply-add per axis, the reference's arithmetic only next to a discontinuity (accumulate_voxel) */
+#endif
+// r04 (S3D_DESC_FASTCELL): the queue carries the cell coordinates MINUS 1.5, formed by the march as one fused multiply-add per axis from
+// per-column constants (a few 1e-7 off the reference's five roundings per axis; the march keeps every voxel with max |c| < 2 + band).
+// The descriptor is a discontinuous function of the cell coordinates b = c + 1.5 in two places only: the faces of the 4x4x4 cube
+// (!(b <= -0.5 || b >= 3.5), Src/cSIFT3D.cc:1299-1303) and b = 0 on every axis (the cell index truncates toward zero while the
+// fraction uses floor: at b = -eps the weights eps and 1 - eps trade places).  A batch with a lane inside a band of kCellBand around
+// one of them recovers the integer voxel offsets (R^T applied to the coordinates, rounded: errors of 1e-4 voxel) and repeats the
+// reference's arithmetic for those lanes: the decisions are the reference's, everywhere else the weights move by ~1e-7.
+struct CellGeom { float desc_hw, bin_fctr, inv_bin, u, inv_u; };
+constexpr float kCellBand = 1.0e-4f;
 __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by, float bz, float gx, float gy, float gz,
                                                  float R0, float R1, float R2, float R3, float R4, float R5, float R6, float R7, float R8,
                                                  float fix_scale, const int *s_fidx, const int4 *s_sym, bin_t *hist_rep,
-                                                 int spread /* lane constant: bits 0..2 = r */) {
+                                                 int spread /* lane constant: bits 0..2 = r */, const CellGeom &cg) {
 #if defined(S3D_DDIAG) && (S3D_DDIAG & 2)  // timing only: march and queue without the heavy part
 	return 0.0f;
+#endif
+#if S3D_DESC_FASTCELL
+	{
+		const float m = fmaxf(fmaxf(fabsf(bx), fabsf(by)), fabsf(bz));  // (bx, by, bz hold c = b - 1.5 here)
+		bx = bx + 1.5f; by = by + 1.5f; bz = bz + 1.5f;
+		const float z3 = fminf(fminf(fabsf(bx), fabsf(by)), fabsf(bz));
+		const bool amb = valid && (!(m < 2.0f - kCellBand) || z3 < kCellBand);
+		if (__any(amb)) {  // wave-uniform, a few per cent of the batches
+			const float px = (bx + 0.5f) * cg.inv_bin - cg.desc_hw, py = (by + 0.5f) * cg.inv_bin - cg.desc_hw, pz = (bz + 0.5f) * cg.inv_bin - cg.desc_hw;
+			const float vxd = rintf((R0 * px + R3 * py + R6 * pz) * cg.inv_u) * cg.u;  // (dx, dy, dz) * unit, exact
+			const float vyd = rintf((R1 * px + R4 * py + R7 * pz) * cg.inv_u) * cg.u;
+			const float vzd = rintf((R2 * px + R5 * py + R8 * pz) * cg.inv_u) * cg.u;
+			// the reference's order: (R0 vx + R1 vy) + R2 vz, + desc_hw, * bin_fctr, - 0.5 (Src/cSIFT3D.cc:1286-1297)
+			float ex = R0 * vxd + R1 * vyd, ey = R3 * vxd + R4 * vyd, ez = R6 * vxd + R7 * vyd;
+			ex = ex + R2 * vzd; ey = ey + R5 * vzd; ez = ez + R8 * vzd;
+			ex = (ex + cg.desc_hw) * cg.bin_fctr; ey = (ey + cg.desc_hw) * cg.bin_fctr; ez = (ez + cg.desc_hw) * cg.bin_fctr;
+			ex = ex - 0.5f; ey = ey - 0.5f; ez = ez - 0.5f;
+			// per LANE: a voxel's coordinates must not depend on which voxels share its batch (the batches form differently from run to run)
+			if (amb) {
+				bx = ex; by = ey; bz = ez;
+				valid = fminf(fminf(bx, by), bz) > -0.5f && fmaxf(fmaxf(bx, by), bz) < 3.5f;
+			}
+		}
+	}
 #endif
 	// The rotated gradient is formed exactly like the reference's (separate multiplies and adds, left to right): the face lookup
 	// below is a DISCONTINUOUS function of its direction -- Initialize_geometry swaps the coordinates of the first two vertices of
@@ -534,6 +570,8 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		// for the outer rows of a unit; see "Sorted units" above).  (One column per lane: 4 vector-memory instructions per voxel, 7.2 ms.)
 		// chord of the lane's two columns (xa, xa + 1) of window row ly: in-sphere range clipped to the rotated 4x4x4 cube
 		const float rr3[3] = {R2 * u, R5 * u, R8 * u};  // z step of the three rotated coordinates (per keypoint)
+		const float qxk = rr3[0] * bin_fctr, qyk = rr3[1] * bin_fctr, qzk = rr3[2] * bin_fctr;  // ... of the three cell coordinates
+		const CellGeom cg = {desc_hw, bin_fctr, desc_width * 0.25f, u, __frcp_rn(u)};
 		const float rr3_inv[3] = {__frcp_rn(rr3[0]), __frcp_rn(rr3[1]), __frcp_rn(rr3[2])};
 		auto setup_pair = [&](int lxa, int ly, bool lane_ok, int (&rr)[2], int (&za)[2], int (&zb)[2], float (&px)[2], float (&py)[2],
 		                      float (&pz)[2], bool (&colok)[2]) {
@@ -698,10 +736,15 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			f2g edC = f2g{0.f, 0.f};
 			if (top || bot) edC = *reinterpret_cast<g2p>(c + e_off);  // the strip's outer row of plane z
 			int z = zA;
-#if S3D_DDIAG_V & 256
-			float bx0[2], by0[2], bz0[2];
+#if S3D_DESC_FASTCELL
+			// cell coordinate - 1.5 of column k at plane z: c = cx0[k] + (z - czi) * qx (one fused multiply-add per axis and voxel)
+			float cx0[2], cy0[2], cz0[2];
+			unsigned zlo[2], zspan[2];
 #pragma unroll
-			for (int k = 0; k < 2; k++) { bx0[k] = (px[k] + desc_hw) * bin_fctr - 0.5f; by0[k] = (py[k] + desc_hw) * bin_fctr - 0.5f; bz0[k] = (pz[k] + desc_hw) * bin_fctr - 0.5f; }
+			for (int k = 0; k < 2; k++) {
+				cx0[k] = (px[k] + desc_hw) * bin_fctr - 2.0f; cy0[k] = (py[k] + desc_hw) * bin_fctr - 2.0f; cz0[k] = (pz[k] + desc_hw) * bin_fctr - 2.0f;
+				zlo[k] = (unsigned)(za[k] - zA); zspan[k] = (unsigned)(zb[k] - za[k]);  // empty column (2^28, -2^28): never inside
+			}
 #endif
 			for (int step = 0; step < maxlen; step++) {
 				// software pipeline: the row piece of plane z+2 and the y rows of plane z+1 are requested now; clamped addresses stay
@@ -729,27 +772,32 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 #if defined(S3D_EXP) && S3D_EXP == 21
 				st_acc[8]++;
 #endif
-#if S3D_DDIAG_V & 256
-				const float qxk = R2 * bin_fctr, qyk = R5 * bin_fctr, qzk = R8 * bin_fctr;
-#endif
 				const int dz = z - czi;
 				const int dz2 = __mul24(dz, dz);  // |dz| < 2^11 (full-rate 24-bit multiply; v_mul_lo_u32 issues at quarter rate)
+#if S3D_DESC_FASTCELL
+				const float dzf = (float)dz;
+#else
 				const float vzd = (float)dz * u;
+#endif
 				float bxk[2], byk[2], bzk[2], rxk[2], ryk[2], rzk[2];
 				bool actk[2];
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
-					const bool in = ((int)(step < zlen) & (int)((unsigned)(z - za[k]) <= (unsigned)(zb[k] - za[k]))) != 0;  // empty column: za = 2^28, zb = -2^28
-#if S3D_DDIAG_V & 256  // timing only: the cell coordinates as one fused multiply-add per axis from per-column constants
-					float bx = __fmaf_rn(vzd, qxk, bx0[k]), by = __fmaf_rn(vzd, qyk, by0[k]), bz = __fmaf_rn(vzd, qzk, bz0[k]);
+#if S3D_DESC_FASTCELL
+					// (z - za <= zb - za as unsigned: inside the column's chord, which lies inside the unit's range: step < zlen is implied)
+					const bool in = (unsigned)((unsigned)step - zlo[k]) <= zspan[k];
+					const float bx = __fmaf_rn(dzf, qxk, cx0[k]), by = __fmaf_rn(dzf, qyk, cy0[k]), bz = __fmaf_rn(dzf, qzk, cz0[k]);  // b - 1.5
+					// inside the cube or within the band the heavy part decides exactly (accumulate_voxel)
+					const bool act = ((int)in & (int)(fmaxf(fmaxf(fabsf(bx), fabsf(by)), fabsf(bz)) < 2.0f + kCellBand)) != 0;
 #else
+					const bool in = ((int)(step < zlen) & (int)((unsigned)(z - za[k]) <= (unsigned)(zb[k] - za[k]))) != 0;  // empty column: za = 2^28, zb = -2^28
 					float bx = px[k] + R2 * vzd, by = py[k] + R5 * vzd, bz = pz[k] + R8 * vzd;
 					bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
 					bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
-#endif
 					// inside the 4x4x4 cube: the reference's !(b <= -0.5 || b >= 3.5) per axis (Src/cSIFT3D.cc:1299-1303)
 					// (bitwise &: straight-line compares; && makes hipcc wrap each operand in an exec-mask branch)
 					const bool act = ((int)in & (int)(fminf(fminf(bx, by), bz) > -0.5f) & (int)(fmaxf(fmaxf(bx, by), bz) < 3.5f)) != 0;
+#endif
 					const float w = LUT_LDS ? s_lut[in ? rr[k] + dz2 : 0] : lut_g[in ? rr[k] + dz2 : 0];
 					const float nxm = k ? rowC.y : rowC.x, nxp = k ? rowC.w : rowC.z;
 					const float nym = k ? ymC.y : ymC.x, nyp = k ? ypC.y : ypC.x;
@@ -785,10 +833,10 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 						const int pos = (qhead + lane) & (kQCap - 1);
 						if (S3D_DESC_QAOS) {
 							const qf4 ea = qa[pos]; const qf2 eb = qb[pos];
-							msum += accumulate_voxel(true, ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale, s_fidx, s_sym, hist_rep, spread);
+							msum += accumulate_voxel(true, ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale, s_fidx, s_sym, hist_rep, spread, cg);
 						} else
 						msum += accumulate_voxel(true, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale,
-						                 s_fidx, s_sym, hist_rep, spread);
+						                 s_fidx, s_sym, hist_rep, spread, cg);
 						qhead = (qhead + 64) & (kQCap - 1);
 						qcount -= 64;
 #if defined(S3D_EXP) && S3D_EXP == 21
@@ -805,10 +853,10 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			const bool valid = lane < qcount;
 			if (S3D_DESC_QAOS) {
 				const qf4 ea = qa[pos]; const qf2 eb = qb[pos];
-				msum += accumulate_voxel(valid, ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale, s_fidx, s_sym, hist_rep, spread);
+				msum += accumulate_voxel(valid, ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale, s_fidx, s_sym, hist_rep, spread, cg);
 			} else
 			msum += accumulate_voxel(valid, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale,
-			                 s_fidx, s_sym, hist_rep, spread);
+			                 s_fidx, s_sym, hist_rep, spread, cg);
 		}
 		S3D_DSTAMP(6)  // drain
 		// gradient mass of the window (block sum; fp32 sums of non-negative terms, 1e-4 relative at worst: covered by the margins)
