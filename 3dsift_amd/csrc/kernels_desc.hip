@@ -223,6 +223,9 @@ __device__ __forceinline__ int cvt_rpi(float x) {
 // R = the transposed rotation (rows R0..R8), fix_scale = 2^k of the histogram's fixed point.  The queue holds the WEIGHTED, NOT YET
 // ROTATED gradient of voxels that passed a slightly relaxed magnitude test; the rotation and the reference's exact test
 // (Src/cSIFT3D.cc:1323-1325, 1468) run here, on the compacted voxels only.
+#ifndef S3D_DESC_PK
+#define S3D_DESC_PK 0  /* measured, off: the 36 weight products of a voxel as 18 v_pk_mul_f32 -- bit-identical, 3.40 -> 3.45 ms (10 spilled registers; a packed fp32 multiply does not issue faster than two plain ones here) */
+#endif
 #ifndef S3D_DESC_FASTCELL
 #define S3D_DESC_FASTCELL 1  /* r04: cell coordinates of the march as one fused multiply-add per axis, the reference's arithmetic only next to a discontinuity (accumulate_voxel) */
 #endif
@@ -310,23 +313,40 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 	// (24-bit multiplies: full rate; v_mul_lo_u32 issues at a quarter of it)
 	const int base = __mul24(ix + (qx ? 1 : 0), kSX * kRep) + __mul24(iy + (qy ? 1 : 0), kSY * kRep) + __mul24(iz + (qz ? 1 : 0), kSZ * kRep);
 #endif
+#if S3D_DESC_PK
+	// r04, measured and off: the 36 weight products as 18 packed multiplies (v_pk_mul_f32: two IEEE fp32 products per lane and
+	// instruction, same roundings): (ax_i ay_0, ax_i ay_1), times (az_0, az_1) per xy pair, times (m0, m1) per cell and times m2 per cell pair
+	typedef float pf2 __attribute__((ext_vector_type(2)));
+	const pf2 ay2 = {ay[0], ay[1]}, az2 = {az[0], az[1]}, m01 = {m0, m1};
+	const pf2 pxy0 = ax[0] * ay2, pxy1 = ax[1] * ay2;                       // (ddx, ddy) = (0,0) (0,1) | (1,0) (1,1)
+	const pf2 wq[4] = {pxy0.x * az2, pxy0.y * az2, pxy1.x * az2, pxy1.y * az2};  // [ddx*2 + ddy] -> (ddz 0, ddz 1)
+	const pf2 w2q[4] = {wq[0] * m2, wq[1] * m2, wq[2] * m2, wq[3] * m2};
+#else
 	const float pxy[4] = {ax[0] * ay[0], ax[0] * ay[1], ax[1] * ay[0], ax[1] * ay[1]};  // index ddx*2 + ddy
+#endif
 	char *hb = reinterpret_cast<char *>(hist_rep + base);
 	bin_t *h0 = reinterpret_cast<bin_t *>(hb + o0), *h1 = reinterpret_cast<bin_t *>(hb + o1), *h2 = reinterpret_cast<bin_t *>(hb + o2);
 #pragma unroll
 	for (int d = 0; d < 8; d++) {
 		const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;
 		if (badx[ddx] || bady[ddy] || badz[ddz]) continue;
+#if S3D_DESC_PK
+		const float wgt = ddz ? wq[ddx * 2 + ddy].y : wq[ddx * 2 + ddy].x;
+		const pf2 p01 = wgt * m01;
+		const float p0 = p01.x, p1 = p01.y, p2 = ddz ? w2q[ddx * 2 + ddy].y : w2q[ddx * 2 + ddy].x;
+#else
 		const float wgt = pxy[ddx * 2 + ddy] * az[ddz];
+		const float p0 = wgt * m0, p1 = wgt * m1, p2 = wgt * m2;
+#endif
 		const int off = ((ddx ? stx : 0) + (ddy ? sty : 0) + (ddz ? stz : 0)) * (int)sizeof(bin_t);  // bytes: a lane constant, hoisted
 #if defined(S3D_DDIAG) && (S3D_DDIAG & 1)  // timing only: the 24 adds are computed but not sent to the LDS
-		asm volatile("" ::"v"(reinterpret_cast<char *>(h0) + off), "v"(cvt_rpi(wgt * m0)));
-		asm volatile("" ::"v"(reinterpret_cast<char *>(h1) + off), "v"(cvt_rpi(wgt * m1)));
-		asm volatile("" ::"v"(reinterpret_cast<char *>(h2) + off), "v"(cvt_rpi(wgt * m2)));
+		asm volatile("" ::"v"(reinterpret_cast<char *>(h0) + off), "v"(cvt_rpi(p0)));
+		asm volatile("" ::"v"(reinterpret_cast<char *>(h1) + off), "v"(cvt_rpi(p1)));
+		asm volatile("" ::"v"(reinterpret_cast<char *>(h2) + off), "v"(cvt_rpi(p2)));
 #else
-		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h0) + off), (bin_t)(sbin_t)cvt_rpi(wgt * m0));
-		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h1) + off), (bin_t)(sbin_t)cvt_rpi(wgt * m1));
-		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h2) + off), (bin_t)(sbin_t)cvt_rpi(wgt * m2));
+		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h0) + off), (bin_t)(sbin_t)cvt_rpi(p0));
+		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h1) + off), (bin_t)(sbin_t)cvt_rpi(p1));
+		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h2) + off), (bin_t)(sbin_t)cvt_rpi(p2));
 #endif
 	}
 	return mag;
