@@ -236,7 +236,7 @@ __device__ __forceinline__ int cvt_rpi(float x) {
 // fraction uses floor: at b = -eps the weights eps and 1 - eps trade places).  A batch with a lane inside a band of kCellBand around
 // one of them recovers the integer voxel offsets (R^T applied to the coordinates, rounded: errors of 1e-4 voxel) and repeats the
 // reference's arithmetic for those lanes: the decisions are the reference's, everywhere else the weights move by ~1e-7.
-struct CellGeom { float desc_hw, bin_fctr, inv_bin, u, inv_u; };
+struct CellGeom { float desc_hw, bin_fctr, inv_bin, u, inv_u, band; };  // band: kCellBand, or huge (hook desc_exact_cells: every voxel takes the exact path)
 constexpr float kCellBand = 1.0e-4f;
 __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by, float bz, float gx, float gy, float gz,
                                                  float R0, float R1, float R2, float R3, float R4, float R5, float R6, float R7, float R8,
@@ -250,7 +250,7 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 		const float m = fmaxf(fmaxf(fabsf(bx), fabsf(by)), fabsf(bz));  // (bx, by, bz hold c = b - 1.5 here)
 		bx = bx + 1.5f; by = by + 1.5f; bz = bz + 1.5f;
 		const float z3 = fminf(fminf(fabsf(bx), fabsf(by)), fabsf(bz));
-		const bool amb = valid && (!(m < 2.0f - kCellBand) || z3 < kCellBand);
+		const bool amb = valid && (!(m < 2.0f - cg.band) || z3 < cg.band);
 		if (__any(amb)) {  // wave-uniform, a few per cent of the batches
 			const float px = (bx + 0.5f) * cg.inv_bin - cg.desc_hw, py = (by + 0.5f) * cg.inv_bin - cg.desc_hw, pz = (bz + 0.5f) * cg.inv_bin - cg.desc_hw;
 			const float vxd = rintf((R0 * px + R3 * py + R6 * pz) * cg.inv_u) * cg.u;  // (dx, dy, dz) * unit, exact
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		if (wide_range != (NT == 512)) return;  // the other variant's run
 	}
 	// d_work[0] = the work counter, d_work[1] = keypoints that took the second pass (sift3d_debug_counters)
-	// dev_flags (test hooks): bit 0 = recompute the chords (SIFT3D_HOOK_DESC_NOCACHE), bits 8.. = s of SIFT3D_HOOK_DESC_MASS_SHIFT
+	// dev_flags (test hooks): bit 0 = recompute the chords (SIFT3D_HOOK_DESC_NOCACHE), bit 1 = SIFT3D_HOOK_DESC_EXACT_CELLS, bits 8.. = s of SIFT3D_HOOK_DESC_MASS_SHIFT
 	__shared__ unsigned s_item, s_tile, s_last;
 	__shared__ bin_t hist[kBins * kRep];  // [bin][replica], two's-complement fixed point, units of 1 / lut.fix_scale
 	__shared__ float s_lut[LUT_LDS ? kMaxDescLut : 1];
@@ -591,7 +591,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		// chord of the lane's two columns (xa, xa + 1) of window row ly: in-sphere range clipped to the rotated 4x4x4 cube
 		const float rr3[3] = {R2 * u, R5 * u, R8 * u};  // z step of the three rotated coordinates (per keypoint)
 		const float qxk = rr3[0] * bin_fctr, qyk = rr3[1] * bin_fctr, qzk = rr3[2] * bin_fctr;  // ... of the three cell coordinates
-		const CellGeom cg = {desc_hw, bin_fctr, desc_width * 0.25f, u, __frcp_rn(u)};
+		const CellGeom cg = {desc_hw, bin_fctr, desc_width * 0.25f, u, __frcp_rn(u), (dev_flags & 2) ? 1.0e30f : kCellBand};
 		const float rr3_inv[3] = {__frcp_rn(rr3[0]), __frcp_rn(rr3[1]), __frcp_rn(rr3[2])};
 		auto setup_pair = [&](int lxa, int ly, bool lane_ok, int (&rr)[2], int (&za)[2], int (&zb)[2], float (&px)[2], float (&py)[2],
 		                      float (&pz)[2], bool (&colok)[2]) {
@@ -1041,7 +1041,7 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
 	if (split && split->gacc && split_on && lut_in_lds && !hook(SIFT3D_HOOK_DESC_NOSPLIT)) sp = *split;
 	static const int desc_grid = dev_tune_i("S3D_DESC_GRID", 256 * 8);  // persistent workgroups (work counter)
 	static const unsigned dyn_lds = (unsigned)dev_tune_i("S3D_DESC_DYNLDS", 0);  // unused dynamic LDS per workgroup (occupancy experiments)
-	const int dev_flags = (hook(SIFT3D_HOOK_DESC_NOCACHE) ? 1 : 0) | (hook(SIFT3D_HOOK_DESC_MASS_SHIFT) & 63) << 8;
+	const int dev_flags = (hook(SIFT3D_HOOK_DESC_NOCACHE) ? 1 : 0) | (hook(SIFT3D_HOOK_DESC_EXACT_CELLS) ? 2 : 0) | (hook(SIFT3D_HOOK_DESC_MASS_SHIFT) & 63) << 8;
 	// few keypoints: eight waves per keypoint (see k_describe); the count lives on the device, so both variants are launched
 	// keypoint counts [wide_lo, wide_hi) take the eight-wave variant of r03; below wide_lo a window is split over 8 / 4 four-wave
 	// workgroups (r04; scripts/split_probe.py: 0.19 / 0.22 / 0.28 / 0.32 ms for 40 / 151 / 286 / 437 keypoints against 0.25 / 0.32 / 0.38 /

@@ -582,6 +582,29 @@ def test_async_run_two_volumes_in_flight(capi, synth):
         assert ec.debug_counters()["list_regrows"] >= 1 and _full_hash(capi, ec, with_extrema=True) == base[0]
 
 
+def test_descriptor_exact_cell_path_everywhere(capi, orc, synth):
+    """k_describe forms a voxel's cell coordinates with one fused multiply-add per axis and repeats the reference's arithmetic only for
+    voxels within 1e-4 of a discontinuity (a face of the 4x4x4 cube, b = 0): that path recovers the voxel's integer offsets from the
+    coordinates.  The hook desc_exact_cells sends EVERY voxel through it -- a wrong recovery would scramble whole descriptors, not one
+    voxel in a thousand: the descriptors must stay inside the oracle's bars and within 2e-6 of the default run's (fixed-point units
+    that round the other way), with identical keypoint records and gradient masses (same second passes)."""
+    vol = synth.blobs((96, 104, 112), seed=21, noise=0.02)
+    o = orc.extractor(vol).run(5)
+    okp, odesc = o.keypoints()
+    ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+    kp, ds = ex.GetKeypoints()
+    passes = ex.debug_counters()["desc_second_passes"]
+    assert len(kp) > 100
+    with capi.hook("desc_exact_cells", 1):
+        ee = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+        kpe, dse = ee.GetKeypoints()
+        assert ee.debug_counters()["desc_second_passes"] == passes
+    assert kp.tobytes() == kpe.tobytes()
+    compare_keypoints(kpe, dse, okp, odesc)
+    compare_keypoints(kp, ds, okp, odesc)
+    assert float(np.abs(ds - dse).max()) <= 2e-6, float(np.abs(ds - dse).max())
+
+
 def test_split_descriptor_windows_match_unsplit(capi, synth):
     """r04: with few keypoints a descriptor window is marched by 8 or 4 workgroups (by the keypoint count), each adding its integer
     histogram into the keypoint's accumulators in global memory; the part that arrives last normalises, and a keypoint whose first
