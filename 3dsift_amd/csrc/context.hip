@@ -840,6 +840,12 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 			const bool chain_on = chain_mode != 0;
 			const bool chained = c->cstream != nullptr && chain_on && o >= 1 && (head || (small_first >= 0 && o >= small_first));
 			hipStream_t so = chained ? c->cstream : c->ostream[(small_first >= 0 && o > small_first) ? small_first : o];
+			// late r04: HIP deals the streams onto its four hardware queues in the pattern 1 2 3 4 4 3 2 1 (profiles/r04e_timeline.txt, queue
+			// ids), so with the small launch on stream 4 (256^3-class volumes: six octaves) the levels behind the seed level of octave 3 sat in
+			// the same hardware queue BEHIND that launch and ended the stage 25 us after it.  They go to the stream of the octave above
+			// (idle by then: its own last level is a 128^3-class launch that ended long before) -- off the critical chain either way
+			const bool tail_moved = !head && small_first >= 3 && o == small_first - 1 && c->cstream == nullptr;
+			if (tail_moved) so = c->ostream[o - 1];
 			if (small_first >= 0 && o >= small_first) {
 				if (head && o > 0) {
 					S3D_HIP(hipStreamWaitEvent(so, c->ev_fork, 0));
@@ -864,7 +870,7 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[o - 1], 0));
 			}
 			if (!head && o == 0 && defer_tail && c->noct > 1) S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[1], 0));
-			if (!head && o >= 1 && c->cstream != nullptr && chain_on) {  // the levels behind the seed level: the octave's own stream, behind its head on the chain stream
+			if (!head && o >= 1 && ((c->cstream != nullptr && chain_on) || tail_moved)) {  // the levels behind the seed level: the octave's own stream, behind its head on the chain stream
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_fork, 0));
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[o], 0));
 			}
