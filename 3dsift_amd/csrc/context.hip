@@ -216,7 +216,7 @@ struct sift3d_ctx {
 	std::vector<DetectBufs> det_o;
 	unsigned long long *d_masks2 = nullptr;
 	unsigned *d_counts2 = nullptr, *d_offsets2 = nullptr, *d_prov2 = nullptr;
-	hipEvent_t ev_det_fork = nullptr, ev_det_join = nullptr;
+	hipEvent_t ev_det_fork = nullptr, ev_det_join = nullptr, ev_det_fork2 = nullptr, ev_det_join2 = nullptr;
 	DevKp *d_ext = nullptr;
 	int *d_codes = nullptr, *d_order = nullptr;  // d_order: slot -> extremum index
 	unsigned ext_cap = 0, kp_cap = 0;
@@ -361,6 +361,8 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	hipFree(c->d_masks2); hipFree(c->d_counts2); hipFree(c->d_offsets2);
 	if (c->ev_det_fork) hipEventDestroy(c->ev_det_fork);
 	if (c->ev_det_join) hipEventDestroy(c->ev_det_join);
+	if (c->ev_det_fork2) hipEventDestroy(c->ev_det_fork2);
+	if (c->ev_det_join2) hipEventDestroy(c->ev_det_join2);
 	hipFree(c->d_levels); hipFree(c->d_luts); hipFree(c->d_lutpool);
 	for (auto &e : c->ev) if (e) hipEventDestroy(e);
 	for (auto &e : c->ev_seed) if (e) hipEventDestroy(e);
@@ -633,6 +635,8 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 			}
 			CHECKED(hipEventCreateWithFlags(&c->ev_det_fork, hipEventDisableTiming));
 			CHECKED(hipEventCreateWithFlags(&c->ev_det_join, hipEventDisableTiming));
+			CHECKED(hipEventCreateWithFlags(&c->ev_det_fork2, hipEventDisableTiming));
+			CHECKED(hipEventCreateWithFlags(&c->ev_det_join2, hipEventDisableTiming));
 		}
 	}
 
@@ -910,6 +914,7 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 		// (ev[1] is recorded on the second detection stream after it has waited for all of them), so the stage times stay honest:
 		// the pyramid's is its wall time, the detection's is what is left of it behind the pyramid.
 		const bool two = upto >= 3 && c->det_o.size() > 1;  // masks of octaves >= 1 on a second stream beside octave 0's
+		static const int det_three_mode = dev_tune_i("S3D_DET_THREE", 1);
 #ifndef S3D_DET_EARLY_DEFAULT
 #define S3D_DET_EARLY_DEFAULT 1  /* r04: ON -- with the small octaves in one launch the chain no longer starves behind k_mark's workgroups: detection 0.87 -> 0.82 ms, pyramid 2.18 -> 2.19 ms, step 7.41 -> 7.38 ms (r03, ~60 chain launches: detection 0.87 -> 0.73 but pyramid 2.31 -> 2.40, off) */
 #endif
@@ -956,11 +961,17 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 		if (upto >= 3) {
 			if (two && !early) { S3D_HIP(hipEventRecord(c->ev_det_fork, st)); S3D_HIP(hipStreamWaitEvent(sb, c->ev_det_fork, 0)); }
 			if (two) {
+				// late r04: the masks of the octaves >= 2 (twelve launches of a few microseconds at 512^3) on a THIRD stream beside octave
+				// 1's: they used to queue behind octave 1's candidate pass (0.35 ms beside octave 0's masks) and ended the stage 0.13 ms
+				// after octave 0's emit (profiles/r04e_timeline_full.txt); every octave has its own scratch
+				hipStream_t sc = (det_three_mode != 0 && c->noct > 2 && c->ostream.size() > 2 && c->ostream[2] != st && c->ostream[2] != sb) ? c->ostream[2] : sb;
+				if (sc != sb) { S3D_HIP(hipEventRecord(c->ev_det_fork2, sb)); S3D_HIP(hipStreamWaitEvent(sc, c->ev_det_fork2, 0)); }  // every pyramid is complete
 				for (int o = 1; o < c->noct; o++) {
 					const Level &C = c->dog[(size_t)o * c->nd + 1];
-					launch_detect_mark(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, c->det_o[(size_t)o], sb, lt);
+					launch_detect_mark(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, c->det_o[(size_t)o], o == 1 ? sb : sc, lt);
 				}
 				S3D_HIP(hipEventRecord(c->ev_det_join, sb));
+				if (sc != sb) { S3D_HIP(hipEventRecord(c->ev_det_join2, sc)); S3D_HIP(hipStreamWaitEvent(sb, c->ev_det_join2, 0)); S3D_HIP(hipEventRecord(c->ev_det_join, sb)); }
 			}
 			std::vector<DetectEmitItem> rest;  // two streams: the octaves behind the first one are emitted by one scan + one emit launch
 			for (int o = 0; o < c->noct; o++) {
