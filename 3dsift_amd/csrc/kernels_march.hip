@@ -637,7 +637,7 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 static bool march_wide_ok(int nx, int ny, int nzo, int hw, int plan_slots) {
 	const int mode = hook(SIFT3D_HOOK_MARCH_TILES);  // 0 product rule, 1 wherever the geometry allows (parity tests on small volumes), 2 never
 	if (mode == 2 || plan_slots > 0 || hw < 2 || hw > 6) return false;  // (a planned launch shares the machine with another octave: 32 x 32 tiles, three per CU)
-	if (!(nx == 64 || nx >= 64 + hw)) return false;  // the shifted last tile column starts at nx - 64: 0 or beyond the mirror zone
+	if (!(nx == 64 || nx >= 64 + ((hw + 3) / 4) * 4)) return false;  // the shifted last tile column starts at nx - 64: 0 or beyond the left halo (march_applicable)
 	const int ntiles = ((nx + 63) / 64) * ((ny + 31) / 32);
 	// (short columns: four chunks of a few planes + the ramp cost what three chunks of the 32 x 32 form do -- 512 x 512 x 32: 0.384 vs 0.376 ms)
 	return mode == 1 || (ntiles >= S3D_MARCH_WIDE_MIN_TILES && nzo / std::max(1, 512 / ntiles) >= 24);  // planes per chunk
@@ -689,8 +689,12 @@ bool march_half_ok(int nx, int ny, const ZRange &zr) { return (nx & 3) == 0 && z
 
 // would launch_march_level take a level of nx x ny planes, nzg of them, with this kernel?
 bool march_applicable(int nx, int ny, int nzg, const Taps &t) {
-	auto fits = [&](int n) { return n == 32 || n >= 32 + t.hw; };  // the shifted tile starts at n - 32: 0 or beyond the mirror zone [0, hw)
-	if (!fits(nx) || !fits(ny) || nzg < 2 * t.hw + 2) return false;
+	// the shifted last tile starts at n - 32: 0, or beyond the mirror zone [0, hw) -- and along x beyond the whole left halo of HX =
+	// 4 or 8 columns: the tile travels in 16-byte pieces from x0 - HX, and a piece that straddles column 0 is not loaded at all (late
+	// r04, found by test_wide_tiles_match_the_32x32_form_on_many_shapes: widths 34, 35 at hw 2 / 3 and 37 .. 39 at hw 5 / 6 read junk
+	// for their first columns since r03; no test or bench shape had such a level)
+	const int hx = ((t.hw + 3) / 4) * 4;
+	if (!(nx == 32 || nx >= 32 + hx) || !(ny == 32 || ny >= 32 + t.hw) || nzg < 2 * t.hw + 2) return false;
 	if (!(t.hw == 2 || t.hw == 3 || t.hw == 4 || t.hw == 5 || t.hw == 6 || t.hw == 8)) return false;
 	if (S3D_MARCH_ZSYM)  // the symmetric form of the z-scatter needs what GaussianSmooth_3D's generator gives: tap[hw + d] == tap[hw - d] bit for bit
 		for (int d = 1; d <= t.hw; d++) if (memcmp(&t.w[t.hw + d], &t.w[t.hw - d], sizeof(float)) != 0) return false;

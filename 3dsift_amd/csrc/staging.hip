@@ -63,6 +63,7 @@ int staged_h2d(void *d_dst, const void *h_src, size_t bytes, int device, hipStre
 	int rc = pool_ready(g_pool);
 	if (rc) return rc;
 	size_t off = 0;
+	int nrec = 0;  // buffers whose event was recorded by THIS call
 	for (int i = 0; off < bytes; i++) {
 		const int b = i % kBufs;
 		const size_t n = std::min(kChunk, bytes - off);
@@ -70,9 +71,13 @@ int staged_h2d(void *d_dst, const void *h_src, size_t bytes, int device, hipStre
 		par_memcpy(g_pool.buf[b], static_cast<const char *>(h_src) + off, n);
 		S3D_HIP(hipMemcpyAsync(static_cast<char *>(d_dst) + off, g_pool.buf[b], n, hipMemcpyHostToDevice, st));
 		S3D_HIP(hipEventRecord(g_pool.ev[b], st));
+		nrec = std::max(nrec, b + 1);
 		off += n;
 	}
-	for (int b = 0; b < kBufs; b++) S3D_HIP(hipEventSynchronize(g_pool.ev[b]));  // the pool is free for the next caller
+	// the pool is free for the next caller.  Only the events this call recorded: the other one may have been recorded last on a stream
+	// that no longer exists (a closed handle's), and HIP refuses to synchronise with such an event (late r04: a one-chunk upload after a
+	// two-chunk upload of a handle that had been closed failed with hipErrorCapturedEvent)
+	for (int b = 0; b < nrec; b++) S3D_HIP(hipEventSynchronize(g_pool.ev[b]));
 	return SIFT3D_OK;
 }
 

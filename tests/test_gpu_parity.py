@@ -84,6 +84,8 @@ def test_g4_g6_golden_keypoints(capi, synth, tag):
     ((40, 300, 300), 36, 0.02),     # r04: thin and not tile aligned (shifted last tile column / row), 3 octaves: 300 x 300 x 40, 150 x 150 x 20, 75 x 75 x 10
     ((16, 96, 128), 37, 0.01),      # r04: 16 planes: hw 8 never fits, hw 6 and below do (16 >= 2 hw + 2 for hw <= 7)
     ((32, 32, 32), 38, 0.05),       # r04: octave 1 is already the one-workgroup launch, on the chain stream: the early detection must wait for it
+    ((20, 40, 35), 39, 0.05),       # late r04: nx = 35 -- a shifted tile would start at x0 = 3, inside its own 4-column left halo (pieces that straddle column 0 are not loaded): hw 2 / 3 take the separable passes, hw >= 4 does not fit 35 either
+    ((24, 44, 38), 40, 0.05),       # nx = 38: x0 = 6 -- fine for hw <= 4 (halo 4), inside the 8-column halo of hw 5 / 6
 ])
 def test_full_pipeline_vs_oracle(capi, orc, synth, shape, seed, noise):
     vol = synth.blobs(shape, seed=seed, noise=noise)
@@ -344,6 +346,39 @@ def test_wide_tiles_pyramid_vs_oracle(capi, orc, synth, shape, seed, noise, eage
     with capi.hook("march_tiles", 2), capi.hook("dog_eager", eager), capi.hook("glast_eager", eager):
         narrow = _full_hash(capi, capi.CreateCSIFT3D(vol).KpSiftAlgorithm(), with_dog=True, with_extrema=True)
     assert wide == narrow
+
+
+def _pyramid_hash(capi, vol):
+    import hashlib
+    ex = capi.CSIFT3D(vol)
+    ex.run_stages(2)
+    h = hashlib.sha1()
+    for o in range(ex.num_octaves):
+        for i in range(6):
+            h.update(ex.gss(o, i).tobytes())
+        for i in range(5):
+            h.update(ex.dog(o, i).tobytes())
+    ex.close()
+    return h.hexdigest()
+
+
+def test_wide_tiles_match_the_32x32_form_on_many_shapes(capi):
+    """Shapes around every limit of the 64 x 32 tiles, random data (no flat regions that would hide an indexing slip), every Gaussian and
+    DoG level of every octave hashed: the wide form (hook march_tiles = 1) equals the 32 x 32 form (= 2), which the oracle tests pin.
+    Widths: 64 (one tile), 64 + hw ... (the narrowest shifted column for hw 2 .. 6: 66 .. 70), 71, 100, 127, 128, 129, 190, 256, 260;
+    heights 32, 33 + hw, 50, 64, 96, 97; depths from 14 (hw 6 barely fits: 2 hw + 2) to 130 (several chunks)."""
+    rng = np.random.default_rng(7)
+    shapes = [(14, 32, 64), (20, 40, 66), (30, 45, 67), (26, 64, 68), (40, 50, 69), (33, 96, 70), (47, 97, 71), (64, 33, 100), (21, 64, 127),
+              (130, 64, 128), (35, 70, 129), (50, 48, 190), (96, 96, 256), (18, 128, 260)]
+    for shape in shapes:
+        vol = rng.random(shape, dtype=np.float32)
+        for eager in (0, 1):
+            with capi.hook("dog_eager", eager), capi.hook("glast_eager", eager):
+                with capi.hook("march_tiles", 1):
+                    wide = _pyramid_hash(capi, vol)
+                with capi.hook("march_tiles", 2):
+                    narrow = _pyramid_hash(capi, vol)
+            assert wide == narrow, (shape, eager)
 
 
 def test_descriptor_chord_cache_matches_recomputed_chords(capi, synth):
