@@ -348,6 +348,28 @@ def test_wide_tiles_pyramid_vs_oracle(capi, orc, synth, shape, seed, noise, eage
     assert wide == narrow
 
 
+def test_random_shapes_vs_oracle(capi, orc, synth):
+    """Ten volumes whose dimensions are drawn around the limits of the kernels (one tile, one tile + halo, shifted tiles, the small-
+    octave launch, columns barely longer than a kernel): the whole pipeline against the oracle.  (late r04: the many-shapes test of the
+    wide tiles found two bugs that no hand-picked shape had met; this is the same net under the rest of the pipeline.)"""
+    rng = np.random.default_rng(20261004)
+    pool = list(range(17, 25)) + list(range(30, 42)) + [47, 48, 49] + list(range(62, 74)) + [80]
+    for case in range(10):
+        shape = tuple(int(rng.choice(pool)) for _ in range(3))
+        vol = synth.blobs(shape, seed=100 + case, noise=float(rng.choice([0.0, 0.02, 0.1])))
+        g = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+        o = orc.extractor(vol).run(5)
+        try:
+            compare_pyramids(g, o)
+            assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema()))
+            kp, desc = g.GetKeypoints()
+            okp, odesc = o.keypoints()
+            compare_keypoints(kp, desc, okp, odesc)
+        except AssertionError as e:
+            raise AssertionError((case, shape, e))
+        g.close()
+
+
 def _pyramid_hash(capi, vol):
     import hashlib
     ex = capi.CSIFT3D(vol)
