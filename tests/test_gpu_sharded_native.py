@@ -45,6 +45,32 @@ def test_simulated_ranks_equal_the_single_volume(vol_and_single, ranks, octs):
     sh.close()
 
 
+def test_random_native_plans_equal_the_single_volume():
+    """Six random (shape, simulated ranks, sharded octaves) draws through the native driver: keypoints and descriptors bit-identical
+    to the single-volume extractor (uneven slabs, odd depths, slabs thinner than the halo)."""
+    rng = np.random.default_rng(808)
+    done = 0
+    for case in range(40):
+        if done == 6:
+            break
+        nz = int(rng.integers(48, 150)); ny = int(rng.choice([48, 64, 70, 96])); nx = int(rng.choice([48, 64, 72, 96, 130]))
+        ranks = int(rng.integers(2, 7)); octs = int(rng.integers(1, 3))
+        vol = synth.blobs((nz, ny, nx), seed=900 + case, noise=0.01)
+        try:
+            sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs)
+        except capi.Sift3dError:
+            continue   # (too few planes for that many slabs)
+        ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+        kp, ds = ex.GetKeypoints()
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        tag = ((nz, ny, nx), ranks, octs, sh.info())
+        sh.close(); ex.close()
+        assert np.array_equal(k2, kp), tag
+        assert np.array_equal(d2, ds), tag
+        done += 1
+    assert done == 6
+
+
 def test_rccl_transport_world_of_one(vol_and_single):
     vol, kp, ds = vol_and_single
     sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=0, sharded_octaves=2)   # one real rank: every collective goes through librccl

@@ -69,6 +69,36 @@ def test_slab_equals_single_volume(shape, world, sharded):
     ref.close()
 
 
+def test_random_slab_plans_equal_the_single_volume():
+    """Eight random (shape, ranks, sharded octaves) draws -- odd depths, uneven slabs, slabs thinner than the halo, planes of one tile
+    and of shifted tiles: keypoints and descriptors of the sharded run equal the single-volume extractor's, bit for bit."""
+    rng = np.random.default_rng(404)
+    done = 0
+    for case in range(40):
+        if done == 8:
+            break
+        nz = int(rng.integers(48, 150)); ny = int(rng.choice([48, 64, 70, 96, 100])); nx = int(rng.choice([48, 64, 72, 96, 130]))
+        world = int(rng.integers(2, 7)); sharded = int(rng.integers(1, 3))
+        try:
+            ex = slab.SlabExtractor((nx, ny, nz), slab.SimComm(world), sharded_octaves=sharded)
+        except ValueError:
+            continue   # (too few planes for that many slabs)
+        vol = _volume((nz, ny, nx), seed=500 + case)
+        ref = _single(vol)
+        kp_ref, ds_ref = ref.GetKeypoints()
+        ex.load(volume=vol)
+        ex.KpSiftAlgorithm()
+        kp, ds = ex.GetKeypoints()
+        tag = ((nz, ny, nx), world, sharded, ex.S)
+        assert len(kp) == len(kp_ref), tag
+        for f in kp_ref.dtype.names:
+            assert np.array_equal(kp[f], kp_ref[f]), (tag, f)
+        assert np.array_equal(ds, ds_ref), tag
+        ex.close(); ref.close()
+        done += 1
+    assert done == 8
+
+
 def test_config3_1024x1024x512_eight_slabs_equal_the_single_volume():
     """BASELINE configs[3] at full size: 1024 x 1024 x 512 over 8 (simulated) ranks, two sharded octaves (64- and 32-plane slabs, both
     thinner than the 38-plane halo) + replicated tail, against the single-volume extractor: same keypoints, same descriptors, bit
