@@ -569,6 +569,9 @@ static void march_edge_fractions(int n, int hw, float *f) {  // Src/cSIFT3D.cc:7
 	}
 }
 
+#ifndef S3D_MARCH_CR6_KR
+#define S3D_MARCH_CR6_KR 0  /* measured, off: 3 = the hybrid ring for octave 0's widest level -- bit-identical, would take its 0.54 GB centre re-read out of the traffic (1.11x -> ~1.05x), but the stage is 1.5 % slower on the bench volume (1.93-1.97 -> 1.97-1.99 ms; +-0 on random data) */
+#endif
 #ifndef S3D_MARCH_BG_RINGLESS_TILES
 #define S3D_MARCH_BG_RINGLESS_TILES 16
 #endif
@@ -625,7 +628,12 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	march_edge_fractions(zr.nzg, HW, ef.f[2]);
 	const dim3 grid((unsigned)(ntiles * nchunks)), block(C::NT);
 	// DoG centre ring in LDS where three workgroups per CU still fit (hw <= 5); otherwise the centre piece travels by LDS-DMA
-	if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
+	// late r04, measured and off (S3D_MARCH_CR6_KR): octave 0's widest level (hw 6, planned for two workgroups per CU beside the chain of
+	// the small octaves) re-reads its DoG centre plane: 0.54 GB of the pyramid's 8.9 GB of traffic.  Its ring as 3 planes in registers
+	// + 4 in LDS (16 KB: 46 KB per workgroup, so octave 1's ring kernels still fit beside two of them; 139 registers)
+	if (HW == 6 && S3D_MARCH_CR6_KR > 0 && dog && !use_cr && plan_slots >= 512 && ntiles >= 64)
+		hipLaunchKernelGGL((k_march_level<HW, true, true, 32, (HW == 6 ? S3D_MARCH_CR6_KR : 0)>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
+	else if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 	else if (dog) hipLaunchKernelGGL((k_march_level<HW, true, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 }
