@@ -288,6 +288,42 @@ def test_nondefault_parameters(capi, orc, synth, params):
     compare_keypoints(kp, desc, okp, odesc)
 
 
+def test_random_parameters_and_shapes_vs_oracle(capi, orc, synth):
+    """Nine random draws of (shape, num_kp_levels, sigma_default, sigma_n_default, peak_thresh, tile form): other half widths (hw 2 .. 8 and
+    the generic separable kernels), other level counts in the one-workgroup octaves, other window sizes in orientation and descriptor;
+    half of the draws with the 64 x 32 tiles forced wherever they fit.  Everything against the oracle."""
+    rng = np.random.default_rng(77)
+    pool = [40, 48, 56, 64, 66, 70, 72, 80, 96]
+    for case in range(9):
+        shape = tuple(int(rng.choice(pool)) for _ in range(3))
+        levels = int(rng.integers(1, 5))
+        sd = float(np.round(rng.uniform(1.2, 2.6), 2))
+        params = dict(num_kp_levels=levels, sigma_default=sd, sigma_n_default=float(np.round(rng.uniform(0.5, min(1.15, sd - 0.2)), 2)),
+                      peak_thresh=float(np.round(rng.uniform(0.04, 0.25), 3)))
+        vol = synth.blobs(shape, seed=300 + case, noise=0.02)
+        with capi.hook("march_tiles", case & 1):
+            try:
+                g = capi.CreateCSIFT3D(vol, **params).KpSiftAlgorithm()
+            except capi.Sift3dError as e:   # the one documented limit: Gaussian kernels of more than 65 taps (one level per octave with a wide sigma) are refused
+                assert "65 taps" in str(e) and levels == 1, (params, e)
+                continue
+            o = orc.extractor(vol, **params).run(5)
+            try:
+                assert g.num_octaves == o.num_octaves
+                for oc in range(g.num_octaves):
+                    for i in range(levels + 3):
+                        assert np.array_equal(bits(g.gss(oc, i)), bits(o.gss(oc, i))), ("gss", oc, i)
+                    for i in range(levels + 2):
+                        assert np.array_equal(bits(g.dog(oc, i)), bits(o.dog(oc, i))), ("dog", oc, i)
+                assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema()))
+                kp, desc = g.GetKeypoints()
+                okp, odesc = o.keypoints()
+                compare_keypoints(kp, desc, okp, odesc)
+            except AssertionError as e:
+                raise AssertionError((case, shape, params, e))
+            g.close()
+
+
 def _full_hash(capi, ex, with_dog=False, with_extrema=False):
     import hashlib
     h = hashlib.sha1()
