@@ -62,7 +62,8 @@ def test_random_native_plans_equal_the_single_volume():
             continue   # (too few planes for that many slabs)
         ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
         kp, ds = ex.GetKeypoints()
-        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        with capi.hook("march_tiles", done & 1):   # every second plan with the 64 x 32 tiles wherever a slab's levels fit them
+            k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
         tag = ((nz, ny, nx), ranks, octs, sh.info())
         sh.close(); ex.close()
         assert np.array_equal(k2, kp), tag

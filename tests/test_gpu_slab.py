@@ -86,9 +86,10 @@ def test_random_slab_plans_equal_the_single_volume():
         vol = _volume((nz, ny, nx), seed=500 + case)
         ref = _single(vol)
         kp_ref, ds_ref = ref.GetKeypoints()
-        ex.load(volume=vol)
-        ex.KpSiftAlgorithm()
-        kp, ds = ex.GetKeypoints()
+        with capi.hook("march_tiles", done & 1):   # every second plan with the 64 x 32 tiles wherever a slab's levels fit them (global-z feed order, halo planes)
+            ex.load(volume=vol)
+            ex.KpSiftAlgorithm()
+            kp, ds = ex.GetKeypoints()
         tag = ((nz, ny, nx), world, sharded, ex.S)
         assert len(kp) == len(kp_ref), tag
         for f in kp_ref.dtype.names:
