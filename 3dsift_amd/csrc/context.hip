@@ -532,7 +532,7 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 	c->taps.resize(c->ng);
 	bool ok = build_taps(base_sigma, c->base_taps);
 	for (int i = 1; i < c->ng; i++) ok = ok && build_taps(sig[i], c->taps[i]);
-	if (!ok) { delete c; set_last_error("Gaussian kernel wider than the supported 65 taps"); return SIFT3D_ERR_ARG; }
+	if (!ok) { delete c; set_last_error("Gaussian kernel wider than the supported 129 taps"); return SIFT3D_ERR_ARG; }
 
 #define CHECKED(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_last_error(std::string(#call) + ": " + hipGetErrorString(e_)); sift3d_destroy(c); return SIFT3D_ERR_HIP; } } while (0)
 	CHECKED(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));

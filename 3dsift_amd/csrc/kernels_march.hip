@@ -631,9 +631,14 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	// late r04, measured and off (S3D_MARCH_CR6_KR): octave 0's widest level (hw 6, planned for two workgroups per CU beside the chain of
 	// the small octaves) re-reads its DoG centre plane: 0.54 GB of the pyramid's 8.9 GB of traffic.  Its ring as 3 planes in registers
 	// + 4 in LDS (16 KB: 46 KB per workgroup, so octave 1's ring kernels still fit beside two of them; 139 registers)
-	if (HW == 6 && S3D_MARCH_CR6_KR > 0 && dog && !use_cr && plan_slots >= 512 && ntiles >= 64)
-		hipLaunchKernelGGL((k_march_level<HW, true, true, 32, (HW == 6 ? S3D_MARCH_CR6_KR : 0)>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
-	else if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
+	constexpr bool kHybrid6 = HW == 6 && S3D_MARCH_CR6_KR > 0;
+	if constexpr (kHybrid6) {
+		if (dog && !use_cr && plan_slots >= 512 && ntiles >= 64) {
+			hipLaunchKernelGGL((k_march_level<HW, true, true, 32, (kHybrid6 ? S3D_MARCH_CR6_KR : 0)>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
+			return;
+		}
+	}
+	if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 	else if (dog) hipLaunchKernelGGL((k_march_level<HW, true, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 }

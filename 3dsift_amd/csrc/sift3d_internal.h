@@ -17,9 +17,9 @@
 namespace s3d {
 
 #ifndef S3D_MAX_HW
-#define S3D_MAX_HW 32
+#define S3D_MAX_HW 64
 #endif
-constexpr int kMaxHW = S3D_MAX_HW;              // largest Gaussian half width supported (65 taps; num_kp_levels = 1 needs 17)
+constexpr int kMaxHW = S3D_MAX_HW;              // largest Gaussian half width supported (129 taps: num_kp_levels = 1 with sigma_default 2.6 needs 54; the defaults 8)
 constexpr int kMaxTaps = 2 * kMaxHW + 1;
 constexpr int kDesc = SIFT3D_DESC_NUMEL;
 constexpr int kFaces = 20;
