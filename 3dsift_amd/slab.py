@@ -365,6 +365,25 @@ class SlabExtractor:
         self.hws = [w0.ctx.level_hw(i) for i in range(self.ng)]       # half width of the Gaussian producing G[i]
         self.times = {}
 
+    def halo_bytes(self):
+        """bytes every rank RECEIVES per KpSiftAlgorithm from its z-neighbours (the same plan KpSiftAlgorithm posts: per level the planes
+        the next level marches first, the keypoint-window halo of G[1..levels] and one DoG plane; the all-gather of the tail's seed level
+        is not a halo).  -> list per rank"""
+        w0 = next(iter(self.workers.values()))
+        recv = [0] * self.world
+        for s in range(self.S):
+            st = w0.stages[s]
+            bounds, nzs = st.bounds, st.dims[2]
+            plane = st.dims[0] * st.dims[1] * 4
+            for i in range(self.ng):
+                urgent_h = self.hws[i + 1] + 1 if i + 1 < self.ng else 0
+                ts = halo_transfers(bounds, nzs, KIND_GSS, i, 0, urgent_h, s) + halo_transfers(bounds, nzs, KIND_GSS, i, urgent_h, self.need[i], s)
+                if 1 <= i - 1 <= self.levels:
+                    ts += halo_transfers(bounds, nzs, KIND_DOG, i - 1, 0, 1, s)
+                for t in ts:
+                    recv[t.dst] += (t.zg1 - t.zg0) * plane
+        return recv
+
     # workers as the list the communicator expects ([mine] for DistComm, all ranks for SimComm)
     def _wl(self):
         if isinstance(self.comm, SimComm):

@@ -168,6 +168,8 @@ def run_slab(dims, world, rank, local, dev, steps, warmup, sim_ranks=0, seed=432
            "keypoints": count(), "last_step_ms": detail()}
     if nranks > 1:
         res["halo_planes"] = ex.halo
+        hb = ex.halo_bytes()
+        res["halo_GB_received_per_rank_per_step"] = {"max": round(max(hb) / 1e9, 3), "per_side_of_an_inner_rank": round(max(hb) / 2e9, 3)}
         res["sharded_octaves"] = ex.S
         res["slab_planes"] = [b[1] - b[0] for b in ex.bounds]
     ex.close()
