@@ -226,6 +226,7 @@ struct sift3d_ctx {
 	sift3d_keypoint *d_kpout = nullptr;
 	float *d_desc = nullptr, *d_xyz = nullptr;
 	DescSplit dsplit{};             // scratch of the split descriptor windows (runs with few keypoints), one allocation at dsplit.gacc
+	bool dsplit_dirty = false;      // a run ended in an error: the "every run leaves the scratch clean" invariant is re-established by the next run
 	float *d_peer = nullptr;        // sift3d_match_handles: a target's descriptors + coordinates copied from another GPU (grow-only)
 	size_t peer_floats = 0;
 
@@ -283,8 +284,14 @@ static int alloc_lists(sift3d_ctx *c, unsigned ext_cap) {
 		const size_t words = (size_t)scap * (kDesc + 8 + 1);
 		int *base = nullptr;
 		S3D_HIP(hipMalloc(&base, sizeof(int) * words));
-		S3D_HIP(hipMemset(base, 0, sizeof(int) * words));
-		S3D_HIP(hipStreamSynchronize(nullptr));  // (the handle's streams are non-blocking: not ordered behind the null stream's memset)
+		// on the handle's own stream: the legacy null stream would synchronise with every blocking stream of the host application
+		hipError_t me = hipMemsetAsync(base, 0, sizeof(int) * words, c->stream);
+		if (me == hipSuccess) me = hipStreamSynchronize(c->stream);
+		if (me != hipSuccess) {
+			hipFree(base);
+			set_last_error(std::string("HIP error: ") + hipGetErrorString(me) + " (clearing the split-window scratch)");
+			return SIFT3D_ERR_HIP;
+		}
 		c->dsplit.gacc = base;
 		c->dsplit.gmass = reinterpret_cast<float *>(base + (size_t)scap * kDesc);
 		c->dsplit.gdone = reinterpret_cast<unsigned *>(base + (size_t)scap * (kDesc + 8));
@@ -777,6 +784,10 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 	int rc = set_device(c->device);
 	if (rc) return rc;
 	hipStream_t st = c->stream;
+	if (c->dsplit_dirty && c->dsplit.gacc) {  // (a run cut short by an error may have left partial sums / arrival counts behind)
+		S3D_HIP(hipMemsetAsync(c->dsplit.gacc, 0, sizeof(int) * (size_t)c->dsplit.cap * (kDesc + 8 + 1), st));
+		c->dsplit_dirty = false;
+	}
 	{
 		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(std::max(1, c->noct * c->nd) + 6), st));
 		S3D_HIP(hipEventRecord(c->ev[0], st));
@@ -813,8 +824,15 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 			if (ok && small_padded_hw(max_hw) > 0)
 				for (int o = 0; o < c->noct; o++) {
 					const Level &L = c->gss[(size_t)o * c->ng];
-					if (c->noct - o <= kSmallMaxOct && small_octave_fits(L.nx, L.ny, L.nz, max_hw)) { small_first = o; break; }  // (the octaves behind it are smaller)
+					if (c->noct - o <= kSmallMaxOct && small_octave_fits(L.nx, L.ny, L.nz, max_hw)) { small_first = o; break; }
 				}
+			// EVERY octave of the launch must satisfy hw <= n - 2 (the extended-line form of the boundary rule): the octaves behind the first
+			// are smaller, which makes the capacity limits easier and THIS one harder (sigma_default 1.7: hw 7 at the 8^3 octave of a
+			// power-of-two volume; the glast_eager hook: hw 8).  One that fails sends the whole chain down the separable kernels.
+			for (int o = small_first; small_first >= 0 && o < c->noct; o++) {
+				const Level &L = c->gss[(size_t)o * c->ng];
+				if (!small_octave_fits(L.nx, L.ny, L.nz, max_hw)) small_first = -1;
+			}
 			if (small_first >= 0) {
 				memset(&sa, 0, sizeof(sa));
 				sa.noct = c->noct - small_first; sa.ng = c->ng; sa.nd = c->nd; sa.seed = c->p.num_kp_levels;
@@ -1053,8 +1071,9 @@ static int run_complete(sift3d_ctx *c, int upto, bool part_orient) {  // behind 
 static int run_impl(sift3d_ctx *c, int upto, bool part_orient = false) {
 	int rc = run_prepare(c, upto);
 	if (rc) return rc;
-	if ((rc = run_enqueue(c, upto, part_orient)) != SIFT3D_OK) return rc;
-	return run_complete(c, upto, part_orient);
+	if ((rc = run_enqueue(c, upto, part_orient)) == SIFT3D_OK) rc = run_complete(c, upto, part_orient);
+	if (rc) c->dsplit_dirty = true;
+	return rc;
 }
 
 extern "C" int sift3d_run(sift3d_handle c) {
@@ -1070,7 +1089,7 @@ extern "C" int sift3d_run_async(sift3d_handle c) {
 	int upto = 5;
 	int rc = run_prepare(c, upto);
 	if (rc) return rc;
-	if ((rc = run_enqueue(c, upto, false)) != SIFT3D_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+	if ((rc = run_enqueue(c, upto, false)) != SIFT3D_OK) { (void)hipStreamSynchronize(c->stream); c->dsplit_dirty = true; return rc; }
 	c->pending = true;
 	return SIFT3D_OK;
 }
@@ -1079,7 +1098,9 @@ extern "C" int sift3d_wait(sift3d_handle c) {
 	if (!c) return SIFT3D_ERR_ARG;
 	if (!c->pending) return SIFT3D_OK;  // nothing in flight (a blocking run has completed already)
 	c->pending = false;
-	return run_complete(c, 5, false);
+	const int rc = run_complete(c, 5, false);
+	if (rc) c->dsplit_dirty = true;
+	return rc;
 }
 
 extern "C" int sift3d_run_stages(sift3d_handle c, int upto) {
@@ -1360,6 +1381,7 @@ extern "C" int sift3d_debug_copy_bandwidth(size_t bytes, int iters, int device, 
 
 extern "C" int sift3d_debug_counters(sift3d_handle c, int out[4]) {
 	if (!out) return SIFT3D_ERR_ARG;
+	if (c && c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	out[0] = c ? c->n_regrow : 0;
 	out[1] = c ? c->n_desc_redo : 0;
 	out[2] = match_redo_rows();
@@ -1406,6 +1428,7 @@ extern "C" int sift3d_create_seeded(sift3d_handle *out, int nx, int ny, int nz, 
 
 extern "C" int sift3d_seed_upload(sift3d_handle c, const float *level0, int on_device) {
 	if (!c || !level0 || !c->seeded) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->noct <= 0) return SIFT3D_OK;
 	int rc = set_device(c->device);
 	if (rc) return rc;
@@ -1462,6 +1485,7 @@ extern "C" int sift3d_export_device(sift3d_handle c, float *d_desc_dst, float *d
 // partitioned describe), so that sift3d_get_keypoints / sift3d_device_results / sift3d_match see complete rows
 extern "C" int sift3d_import_descriptors_device(sift3d_handle c, const float *d_desc_src) {
 	if (!c || !d_desc_src) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 5) return SIFT3D_ERR_STATE;
 	int rc = set_device(c->device);
 	if (rc) return rc;
@@ -1479,6 +1503,7 @@ extern "C" int sift3d_run_partial_orientation(sift3d_handle c) {
 
 extern "C" int sift3d_export_orientation_device(sift3d_handle c, int *d_dst) {
 	if (!c || !d_dst) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 4) return SIFT3D_ERR_STATE;
 	int rc = set_device(c->device);
 	if (rc) return rc;
@@ -1489,6 +1514,7 @@ extern "C" int sift3d_export_orientation_device(sift3d_handle c, int *d_dst) {
 
 extern "C" int sift3d_import_orientation_device(sift3d_handle c, const int *d_src) {
 	if (!c || !d_src) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 4) return SIFT3D_ERR_STATE;
 	int rc = set_device(c->device);
 	if (rc) return rc;
@@ -1501,6 +1527,7 @@ extern "C" int sift3d_import_orientation_device(sift3d_handle c, const int *d_sr
 // handle's share of the descriptors, final records
 extern "C" int sift3d_run_describe(sift3d_handle c) {
 	if (!c) return SIFT3D_ERR_ARG;
+	if (c->pending) { int wrc = sift3d_wait(c); if (wrc) return wrc; }  // an asynchronous run in flight is completed first
 	if (c->stage < 4 || c->slab) return SIFT3D_ERR_STATE;
 	int rc = set_device(c->device);
 	if (rc) return rc;

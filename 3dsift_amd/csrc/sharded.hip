@@ -188,14 +188,22 @@ struct sift3d_sharded {
 	// communicator.  Ranks hold comm_mu shared while they ISSUE RCCL calls (short, host side) and the aborter takes it exclusively,
 	// so that no thread is inside a call on a communicator while it is torn down.
 	std::atomic<bool> failed{false};
+	std::atomic<bool> comms_aborted{false};  // abort_all ran: the communicators are gone (their pointers are left alone)
 	std::shared_timed_mutex comm_mu;
 };
 
 namespace {
 
-#define SH_HIP(w, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (w).err = std::string(#call) + ": " + hipGetErrorString(e_); return SIFT3D_ERR_HIP; } } while (0)
-#define SH_ABI(w, call) do { int r_ = (call); if (r_ != SIFT3D_OK) { (w).err = std::string(#call) + ": " + sift3d_error_string(r_) + " (" + sift3d_last_error() + ")"; return r_; } } while (0)
-#define SH_NCCL(w, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { (w).err = std::string(#call) + ": " + g_rccl.GetErrorString(r_); return SIFT3D_ERR_HIP; } } while (0)
+// A worker's error slot keeps its FIRST error; the rank's thread and the tail's thread may both report (one mutex for all slots: errors are rare).
+std::mutex g_err_mu;
+template <class W>
+void set_err(W &w, const std::string &msg) {
+	std::lock_guard<std::mutex> g(g_err_mu);
+	if (w.err.empty()) w.err = msg;
+}
+#define SH_HIP(w, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { set_err((w), std::string(#call) + ": " + hipGetErrorString(e_)); return SIFT3D_ERR_HIP; } } while (0)
+#define SH_ABI(w, call) do { int r_ = (call); if (r_ != SIFT3D_OK) { set_err((w), std::string(#call) + ": " + sift3d_error_string(r_) + " (" + sift3d_last_error() + ")"); return r_; } } while (0)
+#define SH_NCCL(w, call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { set_err((w), std::string(#call) + ": " + g_rccl.GetErrorString(r_)); return SIFT3D_ERR_HIP; } } while (0)
 
 // The first failing rank: mark the handle dead and abort every communicator so that no peer stays blocked in a receive, a
 // reduction or a broadcast whose partner will never arrive.  The exclusive lock is awaited for a bounded time only: a peer stuck
@@ -203,12 +211,15 @@ namespace {
 void abort_all(sift3d_sharded *H) {
 	if (H->sim || H->failed.exchange(true)) return;
 	const bool locked = H->comm_mu.try_lock_for(std::chrono::seconds(2));
+	// The communicator POINTERS are never written after creation: a rank that reads one (under the shared lock, after SH_LIVE) cannot see
+	// a pointer in the middle of a store.  A rank already inside an RCCL call when the wait above timed out is what the abort is for.
+	H->comms_aborted.store(true);  // (ncclCommAbort frees the communicator: destroy must not hand it to ncclCommDestroy again)
 	for (Worker &w : H->workers)
-		for (ncclComm_t *c : {&w.c_urgent, &w.c_deferred, &w.c_tail})
-			if (*c) { (void)g_rccl.CommAbort(*c); *c = nullptr; }
+		for (ncclComm_t c : {w.c_urgent, w.c_deferred, w.c_tail})
+			if (c) (void)g_rccl.CommAbort(c);
 	if (locked) H->comm_mu.unlock();
 }
-#define SH_LIVE(H, w) do { if ((H)->failed.load()) { if ((w).err.empty()) (w).err = "aborted: another rank failed"; return SIFT3D_ERR_STATE; } } while (0)
+#define SH_LIVE(H, w) do { if ((H)->failed.load()) { set_err((w), "aborted: another rank failed"); return SIFT3D_ERR_STATE; } } while (0)
 
 // posts the transfers this set of local workers takes part in.  SIM: device copies on the shared stream.  RCCL: one group of
 // sends / receives of the one local rank on `comm` / `stream` of the given flow (0 urgent, 1 deferred).
@@ -219,7 +230,7 @@ int exchange(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<Tra
 		for (const Transfer &t : ts) {
 			Stage &s = H->workers[(size_t)t.src].stages[(size_t)t.stage], &d = H->workers[(size_t)t.dst].stages[(size_t)t.stage];
 			float *sp = s.view(t.kind, t.idx, t.zg0, t.zg1), *dp = d.view(t.kind, t.idx, t.zg0, t.zg1);
-			if (!sp || !dp) { w0.err = "halo transfer outside a level buffer"; return SIFT3D_ERR_STATE; }
+			if (!sp || !dp) { set_err(w0, "halo transfer outside a level buffer"); return SIFT3D_ERR_STATE; }
 			SH_HIP(w0, hipMemcpyAsync(dp, sp, sizeof(float) * s.plane * (size_t)(t.zg1 - t.zg0), hipMemcpyDeviceToDevice, w0.stream));
 		}
 		return SIFT3D_OK;
@@ -232,13 +243,12 @@ int exchange(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<Tra
 	if (!any) return SIFT3D_OK;
 	std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
 	SH_LIVE(H, w);
-	comm = flow ? w.c_deferred : w.c_urgent;  // (read under the lock: the aborter nulls it)
 	SH_NCCL(w, g_rccl.GroupStart());
 	for (const Transfer &t : ts) {
 		if (t.src != w.rank && t.dst != w.rank) continue;
 		Stage &s = w.stages[(size_t)t.stage];
 		float *p = s.view(t.kind, t.idx, t.zg0, t.zg1);
-		if (!p) { (void)g_rccl.GroupEnd(); w.err = "halo transfer outside a level buffer"; return SIFT3D_ERR_STATE; }
+		if (!p) { (void)g_rccl.GroupEnd(); set_err(w, "halo transfer outside a level buffer"); return SIFT3D_ERR_STATE; }
 		const size_t cnt = s.plane * (size_t)(t.zg1 - t.zg0);
 		if (t.src == w.rank) SH_NCCL(w, g_rccl.Send(p, cnt, ncclFloat, t.dst, comm, st));
 		else SH_NCCL(w, g_rccl.Recv(p, cnt, ncclFloat, t.src, comm, st));
@@ -321,7 +331,7 @@ int run_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		const size_t n = (size_t)next[0] * SIFT3D_ORIENT_WORDS;
 		std::vector<int> sum(n, 0), t(n);
 		for (size_t i = 0; i < ws.size() && n; i++) {
-			if (next[i] != next[0]) { w0.err = "replicated tails disagree on the number of extrema"; rc = SIFT3D_ERR_STATE; break; }
+			if (next[i] != next[0]) { set_err(w0, "replicated tails disagree on the number of extrema"); rc = SIFT3D_ERR_STATE; break; }
 			if (hipMemcpy(t.data(), rows[i], sizeof(int) * n, hipMemcpyDeviceToHost) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
 			for (size_t k = 0; k < n; k++) sum[k] += t[k];
 		}
@@ -333,13 +343,13 @@ int run_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		ncclResult_t r = ncclSuccess;
 		{
 			std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
-			if (H->failed.load() || !w.c_tail) { w.err = "aborted: another rank failed"; rc = SIFT3D_ERR_STATE; }
+			if (H->failed.load() || !w.c_tail) { set_err(w, "aborted: another rank failed"); rc = SIFT3D_ERR_STATE; }
 			else r = g_rccl.AllReduce(rows[0], rows[0], (size_t)next[0] * SIFT3D_ORIENT_WORDS, ncclInt32, ncclSum, w.c_tail, ts);
 		}
 		if (rc != SIFT3D_OK) {}
-		else if (r != ncclSuccess) { w.err = std::string("ncclAllReduce (tail): ") + g_rccl.GetErrorString(r); rc = SIFT3D_ERR_HIP; }
-		else if (hipStreamSynchronize(ts) != hipSuccess) { w.err = "tail all-reduce did not complete"; rc = SIFT3D_ERR_HIP; }
-		if (rc == SIFT3D_OK && H->failed.load()) { w.err = "aborted: another rank failed"; rc = SIFT3D_ERR_STATE; }  // an aborted collective leaves garbage rows
+		else if (r != ncclSuccess) { set_err(w, std::string("ncclAllReduce (tail): ") + g_rccl.GetErrorString(r)); rc = SIFT3D_ERR_HIP; }
+		else if (hipStreamSynchronize(ts) != hipSuccess) { set_err(w, "tail all-reduce did not complete"); rc = SIFT3D_ERR_HIP; }
+		if (rc == SIFT3D_OK && H->failed.load()) { set_err(w, "aborted: another rank failed"); rc = SIFT3D_ERR_STATE; }  // an aborted collective leaves garbage rows
 	}
 	for (size_t i = 0; i < ws.size(); i++) {
 		Worker *w = ws[i];
@@ -434,7 +444,7 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	}
 	if (rc != SIFT3D_OK) abort_all(H);               // (the tail thread may sit in its all-reduce waiting for ranks that will not come)
 	if (tail_thread.joinable()) tail_thread.join();  // joined whatever happened above: it calls into contexts destroy would free
-	if (rc == SIFT3D_OK && H->failed.load()) { w0.err = "aborted: another rank failed"; rc = SIFT3D_ERR_STATE; }  // halos of an aborted exchange are garbage
+	if (rc == SIFT3D_OK && H->failed.load()) { set_err(w0, "aborted: another rank failed"); rc = SIFT3D_ERR_STATE; }  // halos of an aborted exchange are garbage
 	if (has_tail && H->sim && rc == SIFT3D_OK) tail_rc = run_tail(H, ws);
 	if (rc == SIFT3D_OK) rc = tail_rc;
 	if (rc != SIFT3D_OK) return rc;
@@ -463,7 +473,7 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 // phase 0: everything that may still enqueue on or wait for a stream; phase 1: the streams (simulated ranks SHARE rank 0's stream: it
 // must outlive the contexts of every rank -- destroying it with rank 0 made the other ranks synchronise a dead stream, which hung
 // about one run in ten)
-void destroy_worker(Worker &w, int phase) {
+void destroy_worker(Worker &w, int phase, bool comms_aborted) {
 	(void)hipSetDevice(w.device);
 	if (phase == 0) {
 		if (w.stream) (void)hipStreamSynchronize(w.stream);
@@ -483,9 +493,11 @@ void destroy_worker(Worker &w, int phase) {
 		if (w.ev_def) (void)hipEventDestroy(w.ev_def);
 		if (w.ev_seed) (void)hipEventDestroy(w.ev_seed);
 		w.ev_level = w.ev_def = w.ev_seed = nullptr;
-		if (w.c_urgent) (void)g_rccl.CommDestroy(w.c_urgent);
-		if (w.c_deferred) (void)g_rccl.CommDestroy(w.c_deferred);
-		if (w.c_tail) (void)g_rccl.CommDestroy(w.c_tail);
+		if (!comms_aborted) {
+			if (w.c_urgent) (void)g_rccl.CommDestroy(w.c_urgent);
+			if (w.c_deferred) (void)g_rccl.CommDestroy(w.c_deferred);
+			if (w.c_tail) (void)g_rccl.CommDestroy(w.c_tail);
+		}
 		w.c_urgent = w.c_deferred = w.c_tail = nullptr;
 	} else {
 		if (w.dstream) (void)hipStreamDestroy(w.dstream);
@@ -511,7 +523,7 @@ std::vector<int> described_rows(const std::vector<sift3d_keypoint> &kp, int rank
 extern "C" int sift3d_sharded_destroy(sift3d_sharded_handle H) {
 	if (!H) return SIFT3D_OK;
 	for (int phase = 0; phase < 2; phase++)
-		for (Worker &w : H->workers) destroy_worker(w, phase);
+		for (Worker &w : H->workers) destroy_worker(w, phase, H->comms_aborted.load());
 	delete H;
 	return SIFT3D_OK;
 }

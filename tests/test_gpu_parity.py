@@ -351,6 +351,29 @@ def test_dog_elision_matches_eager_build(capi, synth):
     assert base == eager == glast and base[1] > 20
 
 
+@pytest.mark.parametrize("params,eager", [
+    (dict(sigma_default=1.7), 0),   # half width 7 at level 4: fits the 16^3 octave of a 64^3 volume, not its 8^3 octave
+    (dict(), 1),                    # default schedule with the last Gaussian level built: half width 8 at the 8^3 octave
+    (dict(sigma_default=1.74), 1),
+])
+def test_small_octave_launch_checks_every_octave(capi, orc, params, eager):
+    """the one-workgroup launch of the small octaves (kernels_small.hip) needs hw <= n - 2 on every axis of EVERY octave
+    it takes; the octaves behind the first are smaller.  Power-of-two cubes end in an 8^3 octave: every level against the oracle
+    (Src/cSIFT3D.cc:745-765 is the boundary term that differed)."""
+    rng = np.random.default_rng(5)
+    vol = rng.random((64, 64, 64), dtype=np.float32)
+    with capi.hook("glast_eager", eager):
+        g = capi.CreateCSIFT3D(vol, **params).KpSiftAlgorithm()
+        o = orc.extractor(vol, **params).run(5)
+        assert g.num_octaves == o.num_octaves == 4
+        for oc in range(g.num_octaves):
+            for i in range(6):
+                assert np.array_equal(bits(g.gss(oc, i)), bits(o.gss(oc, i))), ("gss", oc, i)
+            for i in range(5):
+                assert np.array_equal(bits(g.dog(oc, i)), bits(o.dog(oc, i))), ("dog", oc, i)
+        assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema()))
+
+
 def test_separable_kernels_match_fused(capi, synth):
     """hook separable: every level by the generic three-pass kernels (the path of half widths without a fused instantiation)"""
     vol = synth.blobs((64, 96, 72), seed=13, noise=0.01)
