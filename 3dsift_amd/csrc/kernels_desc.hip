@@ -14,8 +14,9 @@
 //   * a lane owns two adjacent (x, y) COLUMNS of the window and marches along z over their in-sphere, cube-clipped chord; eight lanes
 //     (2 column pairs x 4 rows) form a unit that marches in lock step, the units of a window are sorted by the length of their z
 //     range and dealt to the four waves longest first ("Sorted units" below)
-//   * per step a lane loads one 16-byte row piece (x-1 .. x+2, two planes ahead); the rows y-1 / y+1 come from the lanes beside it
-//     (DPP row shifts), only the outer rows of a unit from memory; the centre column is carried in registers (z-1, z, z+1)
+//   * per step a lane loads one 16-byte row piece (x-1 .. x+2); the rows y-1 / y+1 come from the lanes beside it (DPP row shifts),
+//     only the outer rows of a unit from memory; the centre column is carried in registers (z-1, z, z+1).  The loads travel through
+//     a RING of two planes in flight (r05, "A ring of planes in flight" below): untracked loads into fixed registers, counted waits
 //   * the Gaussian weight / in-sphere test come from the host-built table indexed by the integer
 //     squared offset, staged in LDS (bit-identical to the CPU expf; no device exp on the path)
 //   * lane compaction: chords are ragged and many voxels are inactive, so each wave pushes its ACTIVE voxels
@@ -70,23 +71,14 @@ constexpr float kBaryEps = (float)(FLT_EPSILON * 1E1);  // Src/cSIFT3D.cc:23
 // of both evaluations (measured: the two routes differ by <= 3e-7).  6e-6 leaves a factor of three; the ordered scan behind it costs
 // ~900 instructions per wave that has one such lane (2e-5: 0.17 ms of 3.4 at 512^3; tests/test_gpu_parity.py samples the zone densely).
 constexpr float kFastMargin = 6.0e-6f;
-#ifndef S3D_DESC_REP
-#define S3D_DESC_REP 4
-#endif
-// Four waves per SIMD (r03): with the face tables gone the kernel fits 128 registers without spilling, and a fourth workgroup per
-// CU (4 x 38 KB of LDS) hides more of the march's load latency: 3.68 -> 3.32 ms at 512^3.  (r02: the same limit forced spills, 5.5 ms.)
-#ifndef S3D_DESC_WPE
-#define S3D_DESC_WPE 4
-#endif
-#ifndef S3D_DESC_CLIPM
-#define S3D_DESC_CLIPM 0.25f /* widening of the cube clip of a column's z range, voxels */
-#endif
-#ifndef S3D_DESC_ATTR
-#define S3D_DESC_ATTR __attribute__((amdgpu_waves_per_eu(S3D_DESC_WPE, S3D_DESC_WPE)))
-#endif
+// Four waves per SIMD (r03): a fourth workgroup per CU (4 x 39 KB of LDS) hides more of the march's load latency: 3.68 -> 3.32 ms at
+// 512^3.  r05: 120 registers + the ring's 12 fixed ones, no scratch (profiles/r05_kernel_resources.txt; scripts/kernel_resources.py
+// --check fails the build of the evidence set when a VGPR spills)
+#define S3D_DESC_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+constexpr float kClipMargin = 0.25f;  // widening of the cube clip of a column's z range, voxels
 typedef unsigned bin_t;
 typedef int sbin_t;
-constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = bin * kRep + replica of the lane)
+constexpr int kRep = 4;  // histogram replicas (bin-major: address = bin * kRep + replica of the lane)
 // Bank spreading (r02).  The voxels that leave the march side by side mostly share the cell AND the face, so every one of the 24 adds
 // sent all lanes to the SAME bin -- R replicas = R banks, 64/R lanes queued on each (an LDS atomic costs ~1.9 cycles per lane on the
 // busiest bank; measured 16 cycles per ds_add with 8 replicas).  Now lane l walks the 8 cells of its voxel in the order d ^ r,
@@ -97,32 +89,15 @@ constexpr int kRep = S3D_DESC_REP;  // histogram replicas (bin-major: address = 
 // vertex-major: idx = 72 v + ix + 18 iy + 4 iz.  The cell strides have the residues 1, 2, 4 modulo 8 (and ix + 4 iz < 16 <= 18), the
 // vertex stride is 0 modulo 8: the bank of an add depends on the cell and the replica only, not on the face of the voxel
 // (864 bins = 13.8 KB with 4 replicas; the cell-major layout 17 ix + 74 iy + 300 iz + v: 1200 bins, 19.2 KB, 24 % more conflict cycles).
-#ifndef S3D_DESC_PARITY
-#define S3D_DESC_PARITY 0
-#endif
-#if S3D_DESC_PARITY
-// Parity layout (r03, measured and NOT the default): idx = 64 v + 32 (iz >> 1) + 16 (iy >> 1) + 8 (ix >> 1) + 4 (iz & 1) + 2 (iy & 1) + (ix & 1).
-// The eight cells a voxel adds to have eight different parities, and lane l visits them in the order d ^ r ^ p (r = l & 7 as before,
-// p = the parity of the voxel's own base cell), i.e. at step d it is on parity d ^ r: the eight lanes of a group (one replica) are on
-// eight different banks WHATEVER their cells and faces are (after the compaction through the queue a group mixes voxels of several
-// units; with the data-independent order their banks collide by chance).  Counters at 512^3: bank-conflict cycles 453 M -> 87 M
-// (share 0.43 -> 0.12), LDS-active cycles 1 064 M -> 698 M -- but the data-dependent order costs 52 VALU instructions per batch
-// (2 255 M -> 2 524 M) and the kernel is bound by VALU issue: 3.32 -> 3.55 ms.
-constexpr int kSV = 64, kBins = 12 * kSV;
-__device__ __forceinline__ int cell_index(int ix, int iy, int iz) {
-	return 32 * (iz >> 1) + 16 * (iy >> 1) + 8 * (ix >> 1) + 4 * (iz & 1) + 2 * (iy & 1) + (ix & 1);
-}
-__device__ __forceinline__ int bin_index(int j) {  // descriptor element j = (ix + 4 iy + 16 iz) * 12 + v  ->  histogram index
-	const int c = j / 12, v = j - c * 12;
-	return cell_index(c & 3, (c >> 2) & 3, c >> 4) + v * kSV;
-}
-#else
 constexpr int kSX = 1, kSY = 18, kSZ = 4, kSV = 72, kBins = 12 * kSV;
+// (r05) the 24 adds of a voxel are straight-line code: a cell outside the 4x4x4 block gets a ZERO weight -- an integer add of 0 -- instead
+// of an exec-mask branch per cell; a cell coordinate of 4 addresses up to bin 4 + 18 * 4 + 4 * 4 + 72 * 11 = 884, so the array is
+// padded for those adds of 0 to stay inside it
+constexpr int kBinsAlloc = kBins + 24;
 __device__ __forceinline__ int bin_index(int j) {  // descriptor element j = (ix + 4 iy + 16 iz) * 12 + v  ->  histogram index
 	const int c = j / 12, v = j - c * 12;
 	return (c & 3) * kSX + ((c >> 2) & 3) * kSY + (c >> 4) * kSZ + v * kSV;
 }
-#endif
 
 // literal Check_intersect_faces: first face in mesh order that passes (wave-uniform loop, constant memory)
 __device__ __forceinline__ int intersect_scan(float gx, float gy, float gz, float &b0, float &b1, float &b2) {
@@ -195,9 +170,6 @@ __device__ __forceinline__ int face_lookup(bool valid, float rx, float ry, float
 		const int4 e = s_sym[type * 8 + bits];
 		o0 = e.x; o1 = e.y; o2 = e.z; pk = e.w; f = e.w & 31;
 		slow = scan_only || !(fminf(fminf(b0, b1), b2) >= kFastMargin);
-#if defined(S3D_DDIAG) && (S3D_DDIAG & 128)  // timing only: never the ordered scan
-		slow = scan_only;
-#endif
 	}
 	if (__any(slow)) {
 		if (slow) {
@@ -223,13 +195,7 @@ __device__ __forceinline__ int cvt_rpi(float x) {
 // R = the transposed rotation (rows R0..R8), fix_scale = 2^k of the histogram's fixed point.  The queue holds the WEIGHTED, NOT YET
 // ROTATED gradient of voxels that passed a slightly relaxed magnitude test; the rotation and the reference's exact test
 // (Src/cSIFT3D.cc:1323-1325, 1468) run here, on the compacted voxels only.
-#ifndef S3D_DESC_PK
-#define S3D_DESC_PK 0  /* measured, off: the 36 weight products of a voxel as 18 v_pk_mul_f32 -- bit-identical, 3.40 -> 3.45 ms (10 spilled registers; a packed fp32 multiply does not issue faster than two plain ones here) */
-#endif
-#ifndef S3D_DESC_FASTCELL
-#define S3D_DESC_FASTCELL 1  /* r04: cell coordinates of the march as one fused multiply-add per axis, the reference's arithmetic only next to a discontinuity (accumulate_voxel) */
-#endif
-// r04 (S3D_DESC_FASTCELL): the queue carries the cell coordinates MINUS 1.5, formed by the march as one fused multiply-add per axis from
+// r04: the queue carries the cell coordinates MINUS 1.5, formed by the march as one fused multiply-add per axis from
 // per-column constants (a few 1e-7 off the reference's five roundings per axis; the march keeps every voxel with max |c| < 2 + band).
 // The descriptor is a discontinuous function of the cell coordinates b = c + 1.5 in two places only: the faces of the 4x4x4 cube
 // (!(b <= -0.5 || b >= 3.5), Src/cSIFT3D.cc:1299-1303) and b = 0 on every axis (the cell index truncates toward zero while the
@@ -245,7 +211,6 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 #if defined(S3D_DDIAG) && (S3D_DDIAG & 2)  // timing only: march and queue without the heavy part
 	return 0.0f;
 #endif
-#if S3D_DESC_FASTCELL
 	{
 		const float m = fmaxf(fmaxf(fabsf(bx), fabsf(by)), fabsf(bz));  // (bx, by, bz hold c = b - 1.5 here)
 		bx = bx + 1.5f; by = by + 1.5f; bz = bz + 1.5f;
@@ -268,7 +233,6 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 			}
 		}
 	}
-#endif
 	// The rotated gradient is formed exactly like the reference's (separate multiplies and adds, left to right): the face lookup
 	// below is a DISCONTINUOUS function of its direction -- Initialize_geometry swaps the coordinates of the first two vertices of
 	// a face whose normal points inwards but not their bin indices (Src/cUtil.cc:164-171), so across an edge between such a face
@@ -291,153 +255,119 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 	const float wx0 = 1.0f - fx, wy0 = 1.0f - fy, wz0 = 1.0f - fz;
 	const float ms = mag * fix_scale;                               // exact (power of two)
 	const float m0 = ms * b0, m1 = ms * b1, m2 = ms * b2;
-	// cells ix+ddx etc. are >= 0 by construction; only the upper bound can fail (skip cells outside [0,3])
-	const bool okx = ix < 3, oky = iy < 3, okz = iz < 3;
-#if S3D_DESC_PARITY
-	// step d of this lane is the cell offset d ^ q, q = r ^ parity of the base cell: weights and address steps swap roles per axis where
-	// the bit of q is set.  Per axis the index term of coordinate c is (c >> 1) * B + (c & 1) * P (B = 8 / 16 / 32, P = 1 / 2 / 4): going
-	// from c to c + 1 adds P from an even c and B - P from an odd one.
-	const int pxb = ix & 1, pyb = iy & 1, pzb = iz & 1;
-	const bool qx = ((spread ^ pxb) & 1) != 0, qy = (((spread >> 1) ^ pyb) & 1) != 0, qz = (((spread >> 2) ^ pzb) & 1) != 0;
-	const float ax[2] = {qx ? fx : wx0, qx ? wx0 : fx}, ay[2] = {qy ? fy : wy0, qy ? wy0 : fy}, az[2] = {qz ? fz : wz0, qz ? wz0 : fz};
-	const bool badx[2] = {qx && !okx, !qx && !okx}, bady[2] = {qy && !oky, !qy && !oky}, badz[2] = {qz && !okz, !qz && !okz};
-	const int dxs = (pxb ? 8 - 1 : 1) * kRep, dys = (pyb ? 16 - 2 : 2) * kRep, dzs = (pzb ? 32 - 4 : 4) * kRep;   // c -> c + 1, elements
-	const int stx = qx ? -dxs : dxs, sty = qy ? -dys : dys, stz = qz ? -dzs : dzs;
-	const int base = cell_index(ix, iy, iz) * kRep + (qx ? dxs : 0) + (qy ? dys : 0) + (qz ? dzs : 0);
-#else
+	// cells ix+ddx etc. are >= 0 by construction; only the upper bound can fail.  The upper cell of an axis whose base cell is 3 lies
+	// outside the block (Src/cSIFT3D.cc:1493-1497 skips it): its weight becomes 0, every product of the cell is then +-0, cvt_rpi gives
+	// the integer 0 and the add changes nothing -- straight-line code instead of an exec-mask branch per cell (r05: -40 scalar
+	// instructions and eight branches per batch; 3.31 -> 3.27 ms, same integers)
+	const float fxe = ix < 3 ? fx : 0.0f, fye = iy < 3 ? fy : 0.0f, fze = iz < 3 ? fz : 0.0f;
 	// step d of this lane is the cell offset d ^ r: weights and cell strides swap roles per axis where the bit of r is set
 	const bool qx = spread & 1, qy = spread & 2, qz = spread & 4;
-	const float ax[2] = {qx ? fx : wx0, qx ? wx0 : fx}, ay[2] = {qy ? fy : wy0, qy ? wy0 : fy}, az[2] = {qz ? fz : wz0, qz ? wz0 : fz};
-	const bool badx[2] = {qx && !okx, !qx && !okx}, bady[2] = {qy && !oky, !qy && !oky}, badz[2] = {qz && !okz, !qz && !okz};
+	const float ax[2] = {qx ? fxe : wx0, qx ? wx0 : fxe}, ay[2] = {qy ? fye : wy0, qy ? wy0 : fye}, az[2] = {qz ? fze : wz0, qz ? wz0 : fze};
 	const int stx = qx ? -kSX * kRep : kSX * kRep, sty = qy ? -kSY * kRep : kSY * kRep, stz = qz ? -kSZ * kRep : kSZ * kRep;
 	// (24-bit multiplies: full rate; v_mul_lo_u32 issues at a quarter of it)
 	const int base = __mul24(ix + (qx ? 1 : 0), kSX * kRep) + __mul24(iy + (qy ? 1 : 0), kSY * kRep) + __mul24(iz + (qz ? 1 : 0), kSZ * kRep);
-#endif
-#if S3D_DESC_PK
-	// r04, measured and off: the 36 weight products as 18 packed multiplies (v_pk_mul_f32: two IEEE fp32 products per lane and
-	// instruction, same roundings): (ax_i ay_0, ax_i ay_1), times (az_0, az_1) per xy pair, times (m0, m1) per cell and times m2 per cell pair
-	typedef float pf2 __attribute__((ext_vector_type(2)));
-	const pf2 ay2 = {ay[0], ay[1]}, az2 = {az[0], az[1]}, m01 = {m0, m1};
-	const pf2 pxy0 = ax[0] * ay2, pxy1 = ax[1] * ay2;                       // (ddx, ddy) = (0,0) (0,1) | (1,0) (1,1)
-	const pf2 wq[4] = {pxy0.x * az2, pxy0.y * az2, pxy1.x * az2, pxy1.y * az2};  // [ddx*2 + ddy] -> (ddz 0, ddz 1)
-	const pf2 w2q[4] = {wq[0] * m2, wq[1] * m2, wq[2] * m2, wq[3] * m2};
-#else
 	const float pxy[4] = {ax[0] * ay[0], ax[0] * ay[1], ax[1] * ay[0], ax[1] * ay[1]};  // index ddx*2 + ddy
-#endif
 	char *hb = reinterpret_cast<char *>(hist_rep + base);
-	bin_t *h0 = reinterpret_cast<bin_t *>(hb + o0), *h1 = reinterpret_cast<bin_t *>(hb + o1), *h2 = reinterpret_cast<bin_t *>(hb + o2);
+	char *h0 = hb + o0, *h1 = hb + o1, *h2 = hb + o2;
 #pragma unroll
 	for (int d = 0; d < 8; d++) {
 		const int ddx = d >> 2, ddy = (d >> 1) & 1, ddz = d & 1;
-		if (badx[ddx] || bady[ddy] || badz[ddz]) continue;
-#if S3D_DESC_PK
-		const float wgt = ddz ? wq[ddx * 2 + ddy].y : wq[ddx * 2 + ddy].x;
-		const pf2 p01 = wgt * m01;
-		const float p0 = p01.x, p1 = p01.y, p2 = ddz ? w2q[ddx * 2 + ddy].y : w2q[ddx * 2 + ddy].x;
-#else
 		const float wgt = pxy[ddx * 2 + ddy] * az[ddz];
 		const float p0 = wgt * m0, p1 = wgt * m1, p2 = wgt * m2;
-#endif
 		const int off = ((ddx ? stx : 0) + (ddy ? sty : 0) + (ddz ? stz : 0)) * (int)sizeof(bin_t);  // bytes: a lane constant, hoisted
 #if defined(S3D_DDIAG) && (S3D_DDIAG & 1)  // timing only: the 24 adds are computed but not sent to the LDS
-		asm volatile("" ::"v"(reinterpret_cast<char *>(h0) + off), "v"(cvt_rpi(p0)));
-		asm volatile("" ::"v"(reinterpret_cast<char *>(h1) + off), "v"(cvt_rpi(p1)));
-		asm volatile("" ::"v"(reinterpret_cast<char *>(h2) + off), "v"(cvt_rpi(p2)));
+		asm volatile("" ::"v"(h0 + off), "v"(cvt_rpi(p0)));
+		asm volatile("" ::"v"(h1 + off), "v"(cvt_rpi(p1)));
+		asm volatile("" ::"v"(h2 + off), "v"(cvt_rpi(p2)));
 #else
-		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h0) + off), (bin_t)(sbin_t)cvt_rpi(p0));
-		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h1) + off), (bin_t)(sbin_t)cvt_rpi(p1));
-		atomicAdd(reinterpret_cast<bin_t *>(reinterpret_cast<char *>(h2) + off), (bin_t)(sbin_t)cvt_rpi(p2));
+		atomicAdd(reinterpret_cast<bin_t *>(h0 + off), (bin_t)(sbin_t)cvt_rpi(p0));
+		atomicAdd(reinterpret_cast<bin_t *>(h1 + off), (bin_t)(sbin_t)cvt_rpi(p1));
+		atomicAdd(reinterpret_cast<bin_t *>(h2 + off), (bin_t)(sbin_t)cvt_rpi(p2));
 #endif
 	}
 	return mag;
 }
 
-#if defined(S3D_EXP) && S3D_EXP == 21
-// in-kernel stamps (development): cycles per phase, summed per wave over the whole kernel, for the first 64 workgroups
-__device__ unsigned long long g_dstamp[64][4][10];
-#define S3D_DSTAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_last; st_last = t_; }
-#else
-#define S3D_DSTAMP(i)
-#endif
-#ifdef S3D_DDIAG  // timing-only builds (wrong results): 1 no histogram adds, 2 no heavy part, 32 one address per unit column, 64 no outer-row load
-#define S3D_DDIAG_V S3D_DDIAG
-#else
-#define S3D_DDIAG_V 0
-#endif
+// timing-only builds (wrong results, same control flow; never set in the product build): -DS3D_DDIAG=1 no histogram adds, 2 no heavy part
 // Sorted units.  A lane marches two adjacent columns (x, x+1).  A unit is a block of kPX such pairs by kSH rows on
 // kPX * kSH consecutive lanes.  The units of a window -- in chunks of kPairCap pairs, row-major -- are sorted by the length of
 // their z range and dealt to the waves 64 lanes at a time, longest first: the lanes of a wave finish together.  (A fixed 16 x 8
 // tiling of the circular footprint leaves 35-45 % of the lane-steps idle: rim tiles march their longest chord with most lanes
 // outside the sphere.  Measured at 512^3, k_describe: tiles 4.92 ms, sorted single pairs 4.71, 1x4 units 4.39, 2x4 units 4.26,
 // 2x2 / 4x2 4.32, 4x4 4.46, 1x8 4.50.)
-#ifndef S3D_DESC_WIDE_BELOW
-#define S3D_DESC_WIDE_BELOW 1400  /* runs with fewer keypoints than this take eight waves per keypoint (0: never); measured crossover between 1100 (0.49 vs 0.60 ms) and 1850 keypoints (0.75 vs 0.71) */
-#endif
-// r04: keypoint counts below which a window is split over 8 / 4 / 2 workgroups (DescSplit): 1024 workgroups are resident
-#ifndef S3D_DESC_SPLIT8
-#define S3D_DESC_SPLIT8 320
-#endif
-#ifndef S3D_DESC_SPLIT4
-#define S3D_DESC_SPLIT4 700
-#endif
-#ifndef S3D_DESC_SPLIT2
-#define S3D_DESC_SPLIT2 700  /* (= SPLIT4: two parts never paid off against the eight-wave variant) */
-#endif
-#ifndef S3D_DESC_UCAP
-#define S3D_DESC_UCAP 1024
-#endif
-#ifndef S3D_DESC_LSHIFT
-#define S3D_DESC_LSHIFT 0
-#endif
+// runs with fewer keypoints than this take eight waves per keypoint; measured crossover between 1100 (0.49 vs 0.60 ms) and 1850 keypoints (0.75 vs 0.71)
+constexpr unsigned kWideBelow = 1400;
+// r04: keypoint counts below which a window is split over 8 / 4 workgroups (DescSplit; 1024 workgroups are resident; two parts never
+// paid off against the eight-wave variant)
+constexpr unsigned kSplit8Below = 320, kSplit4Below = 700;
 // The lanes of a unit march the union of their z ranges in lock step, so the y neighbours of a pair are
 // the centre values the lanes kPX below / above hold in registers (DPP row shifts); only the first / last row of a unit loads its
 // outer row from memory: two vector-memory instructions per step, the second with a quarter of the lanes, instead of three.  The
 // march is bound by the cache lines its loads touch (timing-only builds, S3D_DDIAG): wider units share the lines of a row.
-#ifndef S3D_DESC_SH
-#define S3D_DESC_SH 4
-#endif
-#ifndef S3D_DESC_PX
-#define S3D_DESC_PX 2
-#endif
-constexpr int kPairCap = S3D_DESC_UCAP, kLenBins = 128, kLenShift = S3D_DESC_LSHIFT, kSH = S3D_DESC_SH, kPX = S3D_DESC_PX;
+constexpr int kPairCap = 1024, kLenBins = 128, kSH = 4, kPX = 2;
 constexpr int kUL = kPX * kSH;  // lanes of a unit: kPX pairs wide, kSH rows high, row-major on consecutive lanes
 static_assert(kSH >= 2 && kPX >= 1 && kUL <= 16 && (kSH & (kSH - 1)) == 0 && (kPX & (kPX - 1)) == 0, "a unit is a power of two of lanes within a DPP row");
-// value of the lane below / above in the 16-lane row.  Inline asm and volatile: hipcc sinks __builtin_amdgcn_update_dpp into the
-// branch it makes of a following select, where the source lanes are masked off and the DPP read returns 0.  (s_nop: a VALU
-// write of the source needs two wait states before a DPP read, and the hazard pass does not look into inline asm.)
-template <int N>
-__device__ __forceinline__ float dpp_from_lane_below(float v) {  // lane - N of the row
-	float r;
-	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shr:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N), "0"(0.0f));
-	return r;
-}
-template <int N>
-__device__ __forceinline__ float dpp_from_lane_above(float v) {  // lane + N of the row
-	float r;
-	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(N), "0"(0.0f));
-	return r;
-}
 typedef float f4g __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2g __attribute__((ext_vector_type(2), aligned(4)));
-// r04: the four neighbour moves of a march step behind ONE pair of wait states (each single move carried its own s_nop 1)
-#ifndef S3D_DESC_DPP4
-#define S3D_DESC_DPP4 1
-#endif
+// values of the lanes N below / above in the 16-lane row.  Inline asm and volatile: hipcc sinks __builtin_amdgcn_update_dpp into the
+// branch it makes of a following select, where the source lanes are masked off and the DPP read returns 0.  (s_nop: a VALU write of
+// the source needs two wait states before a DPP read, and the hazard pass does not look into inline asm; r04: the four moves of a step
+// behind ONE pair of wait states.)  bound_ctrl (r05): a lane whose source lies outside its row reads 0 instead of keeping its
+// destination -- no initialised destinations, four v_mov fewer per step; those lanes are the first / last row of a unit or of the
+// 16-lane row and take their outer row from memory anyway.
 template <int N>
 __device__ __forceinline__ void dpp_neighbours(float a, float b, f2g &below, f2g &above) {
 	float r0, r1, r2, r3;
-	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %4 row_shr:%6 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %5 row_shr:%6 row_mask:0xf bank_mask:0xf\n\t"
-	             "v_mov_b32_dpp %2, %4 row_shl:%6 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %5 row_shl:%6 row_mask:0xf bank_mask:0xf"
-	             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a), "v"(b), "n"(N), "0"(0.0f), "1"(0.0f), "2"(0.0f), "3"(0.0f));
+	asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %4 row_shr:%6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %1, %5 row_shr:%6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+	             "v_mov_b32_dpp %2, %4 row_shl:%6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\tv_mov_b32_dpp %3, %5 row_shl:%6 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+	             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a), "v"(b), "n"(N));
 	below = f2g{r0, r1}; above = f2g{r2, r3};
 }
+// ---- r05: A ring of planes in flight ----
+// hipcc copies a loop-carried load result at the loop's back-edge and waits for it there (s_waitcnt vmcnt(0)): the row piece the r02
+// form requested at the top of a march step was waited for at the bottom of the SAME step.  Now the loads are inline asm the compiler
+// does not track, into a ring of two slots (a slot = the 16-byte row piece of a plane + the 8-byte outer row of the plane below it),
+// the step loop is unrolled by two so that each slot has a fixed name, and a step waits with a COUNTED vmcnt for its slot only: vmcnt
+// counts in order and every step issues exactly two loads, so a slot is complete when at most two loads are outstanding.
+// The slots live in FIXED physical registers (operand constraints "{v[a:b]}"), and ONE asm statement waits for a slot, copies it out
+// component by component and requests the next plane into the same registers: with wait, copy and reload as separate statements hipcc
+// copied the slot into other registers IN FRONT of the wait (it believes a load's result is there when the statement ends) -- reading
+// registers whose load was still in flight.  The only reader of a slot is inside the block that waits for it; between two turns the
+// slot is a live value the compiler has no reason to touch.  scripts/check_desc_ring.py verifies on the generated code that no
+// instruction outside these blocks reads or writes the ring's registers and that the kernel has no scratch (scratch traffic counts in
+// vmcnt too); tests/test_cabi_cpu.py runs it.
+// Edge mask: the lanes that own an outer row (first / last row of a unit); never empty (lane 0 of a wave is a first row), so a step
+// always issues its two loads.  s_and_saveexec writes SCC: declared (a ring of three was first built without the clobber and its
+// loop-entry compare, scheduled in front of the prologue's loads, read a clobbered SCC -- zero descriptors, no fault).
+// Measured at 512^3 (scripts/ab_full.py, same hash): two planes in flight 3.31 -> 3.21 ms, three 3.22; with the march at raised wave
+// priority (s_setprio around the heavy part) 3.19 -> 3.15.
+typedef const float __attribute__((address_space(1))) *gcf_p;
+#define S3D_RING_LOAD(P, E, PREG, EREG, prow, pedge, emask)                                                                              \
+	do {                                                                                                                                  \
+		unsigned long long sv_;                                                                                                           \
+		asm volatile("s_and_saveexec_b64 %[sv], %[em]\n\tglobal_load_dwordx2 %[e], %[ea], off\n\ts_mov_b64 exec, %[sv]\n\t"                   \
+		             "global_load_dwordx4 %[p], %[pa], off offset:-4"                                                                      \
+		             : [p] "={" PREG "}"(P), [e] "={" EREG "}"(E), [sv] "=&s"(sv_)                                                         \
+		             : [pa] "v"(prow), [ea] "v"(pedge), [em] "s"(emask)                                                                   \
+		             : "memory", "scc");  /* s_and_saveexec writes SCC */                                                                   \
+	} while (0)
+#define S3D_RING_TURN(N, P, E, PREG, EREG, P0, P1, P2, P3, E0, E1, rout, eout, prow, pedge, emask)                                        \
+	do {                                                                                                                                  \
+		unsigned long long sv_;                                                                                                           \
+		asm volatile("s_waitcnt vmcnt(" #N ")\n\t"                                                                                        \
+		             "v_mov_b32 %[r0], " P0 "\n\tv_mov_b32 %[r1], " P1 "\n\tv_mov_b32 %[r2], " P2 "\n\tv_mov_b32 %[r3], " P3 "\n\t"            \
+		             "v_mov_b32 %[o0], " E0 "\n\tv_mov_b32 %[o1], " E1 "\n\t"                                                            \
+		             "s_and_saveexec_b64 %[sv], %[em]\n\tglobal_load_dwordx2 %[e], %[ea], off\n\ts_mov_b64 exec, %[sv]\n\t"                   \
+		             "global_load_dwordx4 %[p], %[pa], off offset:-4"                                                                      \
+		             : [p] "+{" PREG "}"(P), [e] "+{" EREG "}"(E), [r0] "=&v"(rout.x), [r1] "=&v"(rout.y), [r2] "=&v"(rout.z), [r3] "=&v"(rout.w), \
+		               [o0] "=&v"(eout.x), [o1] "=&v"(eout.y), [sv] "=&s"(sv_)                                                             \
+		             : [pa] "v"(prow), [ea] "v"(pedge), [em] "s"(emask)                                                                   \
+		             : "memory", "scc");  /* s_and_saveexec writes SCC */                                                                   \
+	} while (0)
 constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <= 64, a pop removes exactly 64
 // r04: a queue entry is a 16-byte piece (bx, by, bz, gx) + an 8-byte piece (gy, gz) in two arrays instead of six 4-byte arrays: a push
 // is 2 LDS writes instead of 6, a pop 2 reads instead of 6 (consecutive ranks -> consecutive pieces: conflict-free) -- 8 fewer
 // instructions per march step, 4 fewer per batch, of a kernel that is bound by instruction issue
-#ifndef S3D_DESC_QAOS
-#define S3D_DESC_QAOS 1
-#endif
 typedef float qf4 __attribute__((ext_vector_type(4)));
 typedef float qf2 __attribute__((ext_vector_type(2)));
 
@@ -469,7 +399,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 	// d_work[0] = the work counter, d_work[1] = keypoints that took the second pass (sift3d_debug_counters)
 	// dev_flags (test hooks): bit 0 = recompute the chords (SIFT3D_HOOK_DESC_NOCACHE), bit 1 = SIFT3D_HOOK_DESC_EXACT_CELLS, bits 8.. = s of SIFT3D_HOOK_DESC_MASS_SHIFT
 	__shared__ unsigned s_item, s_tile, s_last;
-	__shared__ bin_t hist[kBins * kRep];  // [bin][replica], two's-complement fixed point, units of 1 / lut.fix_scale
+	__shared__ bin_t hist[kBinsAlloc * kRep];  // [bin][replica], two's-complement fixed point, units of 1 / lut.fix_scale
 	__shared__ float s_lut[LUT_LDS ? kMaxDescLut : 1];
 	__shared__ __attribute__((aligned(16))) float s_q[NW][6][kQCap];  // per-wave queue of active voxels: bx,by,bz,rx,ry,rz
 	__shared__ int4 s_sym[32];
@@ -484,12 +414,8 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 
 	stage_face_tables(tid, s_fidx, s_sym);
 	int cur_lut = -1;
-#if defined(S3D_EXP) && S3D_EXP == 21
-	unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_readcyclecounter();
-#endif
-	float(*q)[kQCap] = s_q[wid];
-	qf4 *qa = reinterpret_cast<qf4 *>(&s_q[wid][0][0]);  // S3D_DESC_QAOS: [kQCap] x (bx, by, bz, gx) in the first four rows' storage
-	qf2 *qb = reinterpret_cast<qf2 *>(&s_q[wid][4][0]);  //                 [kQCap] x (gy, gz) in the last two
+	qf4 *qa = reinterpret_cast<qf4 *>(&s_q[wid][0][0]);  // [kQCap] x (bx, by, bz, gx) in the first four rows' storage
+	qf2 *qb = reinterpret_cast<qf2 *>(&s_q[wid][4][0]);  // [kQCap] x (gy, gz) in the last two
 	// eight consecutive lanes (voxels that left the march side by side: one unit, mostly one cell) take the eight cell orders and share a
 	// replica; the next eight use the next replica.  Lanes from different units -- different cells -- then never meet on a bank.
 	bin_t *hist_rep = &hist[(lane >> 3) % kRep];
@@ -511,7 +437,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 	// r04, few keypoints: a window split over S0 workgroups (see DescSplit).  S0 is a function of the keypoint count alone, the same
 	// in every workgroup.
 	int S0 = 1;
-	if (NT == 256 && sp.gacc != nullptr && nown <= sp.cap) S0 = nown < (unsigned)S3D_DESC_SPLIT8 ? 8 : (nown < (unsigned)S3D_DESC_SPLIT4 ? 4 : (nown < (unsigned)S3D_DESC_SPLIT2 ? 2 : 1));
+	if (NT == 256 && sp.gacc != nullptr && nown <= sp.cap) S0 = nown < kSplit8Below ? 8 : (nown < kSplit4Below ? 4 : 1);
 	const unsigned nitems = nown * (unsigned)S0;
 	for (;;) {
 		__syncthreads();
@@ -565,9 +491,6 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		const gfloat_p Ld = as_global(L.d);  // global_load instead of flat_load: in-order vmcnt, loads stay in flight
 		const gfloat_p centre = Ld + (size_t)cxi + (size_t)sy * (size_t)cyi + (size_t)sz * (size_t)(czi - L.zoff);  // always valid
 
-#if defined(S3D_EXP) && S3D_EXP == 6
-		float exp_mass = 0.f; int exp_attempts = 0;
-#endif
 		bool finished = false;
 		for (int attempt = 0;; attempt++) {  // block-uniform; a second pass only when the first unit was too fine
 		float msum = 0.0f;  // this lane's share of the gradient mass
@@ -581,7 +504,6 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		const gfloat_p lut_g = as_global(lutpool) + lut.off;
 		__syncthreads();
 
-		S3D_DSTAMP(0)  // keypoint fetch, histogram clear, barriers
 		int qhead = 0, qcount = 0;  // wave-uniform (every lane executes every push / pop below)
 		// All control flow from here to the drain is wave-uniform: lanes without work are predicated, never branched
 		// away, because the queue bookkeeping must see every ballot.
@@ -612,7 +534,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 					h += (h + 1) * (h + 1) <= nin - rr[k] ? 1 : 0;
 					h -= h * h > nin - rr[k] ? 1 : 0;
 					za[k] = max(z0, czi - h); zb[k] = min(z1, czi + h);
-					// clip the z range to the rotated 4x4x4 cube (iteration-count optimisation only, widened by S3D_DESC_CLIPM voxels:
+					// clip the z range to the rotated 4x4x4 cube (iteration-count optimisation only, widened by kClipMargin voxels:
 					// the reference's exact fp32 test still runs on every visited voxel)
 					float lo = (float)(za[k] - czi), hi = (float)(zb[k] - czi);
 					const float pr[3] = {px[k], py[k], pz[k]};
@@ -621,8 +543,8 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 						if (fabsf(rr3[r]) > 1e-6f * desc_hw) {
 							const float inv = rr3_inv[r];
 							const float t0 = (-desc_hw - pr[r]) * inv, t1 = (desc_hw - pr[r]) * inv;
-							lo = fmaxf(lo, fminf(t0, t1) - S3D_DESC_CLIPM);
-							hi = fminf(hi, fmaxf(t0, t1) + S3D_DESC_CLIPM);
+							lo = fmaxf(lo, fminf(t0, t1) - kClipMargin);
+							hi = fminf(hi, fmaxf(t0, t1) + kClipMargin);
 						} else if (fabsf(pr[r]) > desc_hw * 1.001f + 1.0f) {
 							hi = lo - 1.0f;  // this row never enters the cube
 						}
@@ -661,7 +583,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			                           : (unsigned)len;
 			// (a split window: part p of S marches the units u with u % S == p -- by the unit's index, not by its place in the sorted
 			// order, which differs between workgroups where lengths tie)
-			if (spos == 0 && len > 0 && (S == 1 || (u0 + uu) % S == part)) atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u);  // key 0 = empty
+			if (spos == 0 && len > 0 && (S == 1 || (u0 + uu) % S == part)) atomicAdd(&s_cnt[min(len, kLenBins - 1)], 1u);  // key 0 = empty
 		}
 		__syncthreads();
 		if (wid == 0) {  // running start of every key, longest first
@@ -691,7 +613,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			} else {
 				len = (int)s_chord[uu * kUL];
 			}
-			if (len > 0 && (S == 1 || (u0 + uu) % S == part)) s_units[atomicAdd(&s_cnt[min((len + (1 << kLenShift) - 1) >> kLenShift, kLenBins - 1)], 1u)] = (unsigned short)uu;
+			if (len > 0 && (S == 1 || (u0 + uu) % S == part)) s_units[atomicAdd(&s_cnt[min(len, kLenBins - 1)], 1u)] = (unsigned short)uu;
 		}
 		__syncthreads();
 		const int nnz = (int)s_nnz, ntiles = (nnz * kUL + 63) / 64;
@@ -740,7 +662,6 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
 			maxlen = __builtin_amdgcn_readfirstlane(maxlen);
-			S3D_DSTAMP(1)  // batch setup (chord, cube clip)
 			if (maxlen == 0) continue;  // wave-uniform
 			// lanes without a column march on the keypoint's own column (always in bounds) and are masked.  Column a of a lane
 			// satisfies 1 <= x <= nx-2 whenever one of its columns is valid, so x-1 .. x+2 stays inside the level (x+2 = nx is the
@@ -748,15 +669,6 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			// first element of the next plane -- of the next LEVEL of the arena for a window in the far corner; keypoint levels are
 			// never the last level of the arena).
 			gfloat_p c = zlen > 0 ? Ld + (size_t)xa + (size_t)sy * (size_t)y + (size_t)sz * (size_t)(zA - L.zoff) : centre;
-			typedef const f4g __attribute__((address_space(1))) *g4p;
-			typedef const f2g __attribute__((address_space(1))) *g2p;
-			f4g rowC = *reinterpret_cast<g4p>(c - 1);         // plane z:   x-1, a, b, x+2
-			f4g rowN = *reinterpret_cast<g4p>(c + sz - 1);    // plane z+1 (centres of both columns in .y .z)
-			f2g cmv = *reinterpret_cast<g2p>(c - sz);         // centres of plane z-1
-			f2g edC = f2g{0.f, 0.f};
-			if (top || bot) edC = *reinterpret_cast<g2p>(c + e_off);  // the strip's outer row of plane z
-			int z = zA;
-#if S3D_DESC_FASTCELL
 			// cell coordinate - 1.5 of column k at plane z: c = cx0[k] + (z - czi) * qx (one fused multiply-add per axis and voxel)
 			float cx0[2], cy0[2], cz0[2];
 			unsigned zlo[2], zspan[2];
@@ -765,59 +677,24 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 				cx0[k] = (px[k] + desc_hw) * bin_fctr - 2.0f; cy0[k] = (py[k] + desc_hw) * bin_fctr - 2.0f; cz0[k] = (pz[k] + desc_hw) * bin_fctr - 2.0f;
 				zlo[k] = (unsigned)(za[k] - zA); zspan[k] = (unsigned)(zb[k] - za[k]);  // empty column (2^28, -2^28): never inside
 			}
-#endif
-			for (int step = 0; step < maxlen; step++) {
-				// software pipeline: the row piece of plane z+2 and the y rows of plane z+1 are requested now; clamped addresses stay
-				// inside the planes zA-1 .. zB+1 of the window
-				const bool more = step + 1 < zlen;
-				const gfloat_p cn = more ? c + sz : c;
-#if S3D_DDIAG_V & 32  // timing only: the lanes of a unit column request ONE address (fewer cache lines per instruction)
-				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1 - (ptrdiff_t)sy * (spos / kPX));
-#else
-				const f4g rowNN = *reinterpret_cast<g4p>(cn + sz - 1);
-#endif
-				f2g edN = edC;
-#if !(S3D_DDIAG_V & 64)  // timing only: no outer-row load
-				if (top || bot) edN = *reinterpret_cast<g2p>(cn + e_off);
-#endif
+			// one march step on the planes held in registers: rowC = the row piece of plane z (x-1, a, b, x+2), rowN = of plane z+1 (its centres),
+			// cmv = the centres of plane z-1, edC = the unit's outer row of plane z (first / last row of the unit only); dz = z - czi
+			auto step_body = [&](const int step, const int dz, const f4g &rowC, const f4g &rowN, const f2g &cmv, const f2g &edC) {
 				// y neighbours of plane z: the centre values of the lanes beside this one (same unit, same plane)
-#if S3D_DESC_DPP4
 				f2g dn, up;
 				dpp_neighbours<kPX>(rowC.y, rowC.z, dn, up);
-#else
-				const f2g dn = f2g{dpp_from_lane_below<kPX>(rowC.y), dpp_from_lane_below<kPX>(rowC.z)}, up = f2g{dpp_from_lane_above<kPX>(rowC.y), dpp_from_lane_above<kPX>(rowC.z)};
-#endif
 				const f2g ymC = top ? edC : dn, ypC = bot ? edC : up;
-				S3D_DSTAMP(2)  // back-edge + issue of the next step's loads
-#if defined(S3D_EXP) && S3D_EXP == 21
-				st_acc[8]++;
-#endif
-				const int dz = z - czi;
 				const int dz2 = __mul24(dz, dz);  // |dz| < 2^11 (full-rate 24-bit multiply; v_mul_lo_u32 issues at quarter rate)
-#if S3D_DESC_FASTCELL
 				const float dzf = (float)dz;
-#else
-				const float vzd = (float)dz * u;
-#endif
 				float bxk[2], byk[2], bzk[2], rxk[2], ryk[2], rzk[2];
 				bool actk[2];
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
-#if S3D_DESC_FASTCELL
 					// (z - za <= zb - za as unsigned: inside the column's chord, which lies inside the unit's range: step < zlen is implied)
 					const bool in = (unsigned)((unsigned)step - zlo[k]) <= zspan[k];
 					const float bx = __fmaf_rn(dzf, qxk, cx0[k]), by = __fmaf_rn(dzf, qyk, cy0[k]), bz = __fmaf_rn(dzf, qzk, cz0[k]);  // b - 1.5
 					// inside the cube or within the band the heavy part decides exactly (accumulate_voxel)
 					const bool act = ((int)in & (int)(fmaxf(fmaxf(fabsf(bx), fabsf(by)), fabsf(bz)) < 2.0f + kCellBand)) != 0;
-#else
-					const bool in = ((int)(step < zlen) & (int)((unsigned)(z - za[k]) <= (unsigned)(zb[k] - za[k]))) != 0;  // empty column: za = 2^28, zb = -2^28
-					float bx = px[k] + R2 * vzd, by = py[k] + R5 * vzd, bz = pz[k] + R8 * vzd;
-					bx = (bx + desc_hw) * bin_fctr; by = (by + desc_hw) * bin_fctr; bz = (bz + desc_hw) * bin_fctr;
-					bx = bx - 0.5f; by = by - 0.5f; bz = bz - 0.5f;
-					// inside the 4x4x4 cube: the reference's !(b <= -0.5 || b >= 3.5) per axis (Src/cSIFT3D.cc:1299-1303)
-					// (bitwise &: straight-line compares; && makes hipcc wrap each operand in an exec-mask branch)
-					const bool act = ((int)in & (int)(fminf(fminf(bx, by), bz) > -0.5f) & (int)(fmaxf(fmaxf(bx, by), bz) < 3.5f)) != 0;
-#endif
 					const float w = LUT_LDS ? s_lut[in ? rr[k] + dz2 : 0] : lut_g[in ? rr[k] + dz2 : 0];
 					const float nxm = k ? rowC.y : rowC.x, nxp = k ? rowC.w : rowC.z;
 					const float nym = k ? ymC.y : ymC.x, nyp = k ? ypC.y : ypC.x;
@@ -832,9 +709,6 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 					actk[k] = ((int)act & (int)!(g2 < kBaryEps * 0.99f)) != 0;
 					bxk[k] = bx; byk[k] = by; bzk[k] = bz; rxk[k] = gx; ryk[k] = gy; rzk[k] = gz;
 				}
-				cmv = f2g{rowC.y, rowC.z}; rowC = rowN; rowN = rowNN; edC = edN;
-				c = cn; z += more ? 1 : 0;
-				S3D_DSTAMP(3)  // step arithmetic
 #pragma unroll
 				for (int k = 0; k < 2; k++) {
 					// ---- push the active lanes into the wave's queue (compaction by ballot rank) ----
@@ -842,43 +716,77 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 					if (m) {
 						if (actk[k]) {
 							const int pos = (qhead + qcount + (int)__popcll(m & ((1ull << lane) - 1ull))) & (kQCap - 1);
-							if (S3D_DESC_QAOS) { qa[pos] = qf4{bxk[k], byk[k], bzk[k], rxk[k]}; qb[pos] = qf2{ryk[k], rzk[k]}; }
-							else { q[0][pos] = bxk[k]; q[1][pos] = byk[k]; q[2][pos] = bzk[k]; q[3][pos] = rxk[k]; q[4][pos] = ryk[k]; q[5][pos] = rzk[k]; }
+							qa[pos] = qf4{bxk[k], byk[k], bzk[k], rxk[k]}; qb[pos] = qf2{ryk[k], rzk[k]};
 						}
 						qcount += (int)__popcll(m);
 					}
-					S3D_DSTAMP(4)  // push
 					// ---- a full wave of active voxels is ready: run the heavy part on all 64 lanes ----
 					if (qcount >= 64) {
 						const int pos = (qhead + lane) & (kQCap - 1);
-						if (S3D_DESC_QAOS) {
-							const qf4 ea = qa[pos]; const qf2 eb = qb[pos];
-							msum += accumulate_voxel(true, ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale, s_fidx, s_sym, hist_rep, spread, cg);
-						} else
-						msum += accumulate_voxel(true, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale,
-						                 s_fidx, s_sym, hist_rep, spread, cg);
+						// the march runs at raised wave priority, the heavy part at the base priority (r05: a wave that is about to request its
+						// next planes goes first on the SIMD; 3.19 -> 3.15 ms, the other way round 3.26)
+						__builtin_amdgcn_s_setprio(0);
+						const qf4 ea = qa[pos]; const qf2 eb = qb[pos];
+						msum += accumulate_voxel(true, ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale, s_fidx, s_sym, hist_rep, spread, cg);
+						__builtin_amdgcn_s_setprio(2);
 						qhead = (qhead + 64) & (kQCap - 1);
 						qcount -= 64;
-#if defined(S3D_EXP) && S3D_EXP == 21
-						st_acc[9]++;
-#endif
 					}
-					S3D_DSTAMP(5)  // pop (accumulate 64 voxels)
 				}
+			};
+			{
+				// The ring ("A ring of planes in flight" above).  Rotate at the TOP of a step: before step s the registers hold plane s-1 in rowC
+				// -- of which only the centres are used -- and plane s in rowN; slot s % 2 holds plane s+1 and the outer row of plane s.
+				// Every load of the loop and of its prologue is untracked: a tracked one pending at the loop's head makes hipcc wait with
+				// vmcnt(0) inside the loop, which would drain the ring at every step.
+				const unsigned long long emask = __ballot(top || bot);
+				f4g rowC, rowN = f4g{0.f, 0.f, 0.f, 0.f};
+				f2g cmv = f2g{0.f, 0.f}, edC = f2g{0.f, 0.f}, cm0 = f2g{0.f, 0.f};
+				asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off offset:-4" : "+v"(cm0), "+v"(rowN) : "v"(c - sz), "v"(c) : "memory");  // centres of plane zA - 1, plane zA
+				f4g P0, P1;  // (first written by the prologue's loads; an outer-row slot is only defined in the lanes that own an outer row)
+				f2g E0, E1;
+				gcf_p pf = c;  // plane of the youngest row piece requested: min(step + 2, zlen) planes above zA (zlen: the plane zB + 1, the last one read)
+				{
+					gcf_p pe = pf + e_off;
+					pf += 1 <= zlen ? sz : 0;
+					S3D_RING_LOAD(P0, E0, "v[112:115]", "v[116:117]", pf, pe, emask);
+					pe = pf + e_off;
+					pf += 2 <= zlen ? sz : 0;
+					S3D_RING_LOAD(P1, E1, "v[120:123]", "v[118:119]", pf, pe, emask);
+				}
+				asm volatile("s_waitcnt vmcnt(4)" : "+v"(cm0), "+v"(rowN));  // the two prologue loads; the ring's four stay in flight
+				rowC = f4g{0.f, cm0.x, cm0.y, 0.f};
+				const int dz0 = zA - czi;
+				// a turn: the slot (plane step + 1, outer row of plane step) is copied out, then plane step + 3 and the outer row of plane step + 2 are
+				// requested into it (clamped to the planes of the unit's range; a clamped outer-row address belongs to a step beyond the range, whose
+				// value nobody uses)
+#define S3D_RING_STEP(STEP, P, E, PREG, EREG, P0_, P1_, P2_, P3_, E0_, E1_)                                             \
+				{                                                                                                       \
+					const int st_ = (STEP);                                                                             \
+					cmv = f2g{rowC.y, rowC.z}; rowC = rowN;                                                             \
+					const gcf_p pe_ = pf + e_off; /* (outer row of the plane BELOW the one requested next) */          \
+					pf += st_ + 3 <= zlen ? sz : 0;                                                                     \
+					S3D_RING_TURN(2, P, E, PREG, EREG, P0_, P1_, P2_, P3_, E0_, E1_, rowN, edC, pf, pe_, emask);        \
+					step_body(st_, dz0 + st_, rowC, rowN, cmv, edC);                                                   \
+				}
+				__builtin_amdgcn_s_setprio(2);
+				for (int step = 0; step < maxlen; step += 2) {
+					S3D_RING_STEP(step, P0, E0, "v[112:115]", "v[116:117]", "v112", "v113", "v114", "v115", "v116", "v117")
+					if (step + 1 < maxlen) S3D_RING_STEP(step + 1, P1, E1, "v[120:123]", "v[118:119]", "v120", "v121", "v122", "v123", "v118", "v119")
+				}
+#undef S3D_RING_STEP
+				// nothing may still be in flight into the ring when its registers are given to somebody else
+				asm volatile("s_waitcnt vmcnt(0)" : "+{v[112:115]}"(P0), "+{v[120:123]}"(P1), "+{v[116:117]}"(E0), "+{v[118:119]}"(E1));
+				__builtin_amdgcn_s_setprio(0);
 			}
 		}
 		}  // chunk of units
 		if (qcount > 0) {  // drain (wave-uniform)
 			const int pos = (qhead + lane) & (kQCap - 1);
 			const bool valid = lane < qcount;
-			if (S3D_DESC_QAOS) {
-				const qf4 ea = qa[pos]; const qf2 eb = qb[pos];
-				msum += accumulate_voxel(valid, ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale, s_fidx, s_sym, hist_rep, spread, cg);
-			} else
-			msum += accumulate_voxel(valid, q[0][pos], q[1][pos], q[2][pos], q[3][pos], q[4][pos], q[5][pos], R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale,
-			                 s_fidx, s_sym, hist_rep, spread, cg);
+			const qf4 ea = qa[pos]; const qf2 eb = qb[pos];
+			msum += accumulate_voxel(valid, ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, R0, R1, R2, R3, R4, R5, R6, R7, R8, fix_scale, s_fidx, s_sym, hist_rep, spread, cg);
 		}
-		S3D_DSTAMP(6)  // drain
 		// gradient mass of the window (block sum; fp32 sums of non-negative terms, 1e-4 relative at worst: covered by the margins)
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) msum = msum + __shfl_xor(msum, o, 64);
@@ -887,15 +795,19 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		__syncthreads();
 		float mass_sum = (red[0] + red[1]) + (red[2] + red[3]);
 		if (NW == 8) mass_sum = mass_sum + ((red[4] + red[5]) + (red[6] + red[7]));
+		// (r05) the thread index of the epilogue is opaque: its lane constants (bin indices, result addresses: ~20 registers) were hoisted
+		// out of the KEYPOINT loop and lived through the march, which is where the kernel's registers are short (9 spilled VGPRs, 128 used)
+		int te = tid;
+		asm volatile("" : "+v"(te));
 		if (S > 1) {
 			// this part's integer histogram (replicas summed) and its share of the gradient mass go to the keypoint's accumulators in
 			// global memory; the part that arrives last carries on as the keypoint's finisher
 #pragma unroll
 			for (int j = 0; j < 3; j++) {
-				const int e = tid + 256 * j;
+				const int e = te + 256 * j;
 				int a = 0;
 #pragma unroll
-				for (int r = 0; r < kRep; r++) a += (int)(sbin_t)hist[bin_index(e) * kRep + (r + tid) % kRep];
+				for (int r = 0; r < kRep; r++) a += (int)(sbin_t)hist[bin_index(e) * kRep + (r + te) % kRep];
 				if (a != 0) atomicAdd(&sp.gacc[(size_t)kpos * kDesc + e], a);
 			}
 			if (tid == 0) __hip_atomic_store(&sp.gmass[kpos * 8 + part], mass_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -918,9 +830,6 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		const bool overflow = !(mass * fix_scale + 1048576.0f < 2147483648.0f);
 		const bool coarse = mass * fix_scale < 2147483648.0f / 64.0f && pick_scale(mass) > fix_scale;
 		if (attempt == 1 || !(overflow || coarse)) {
-#if defined(S3D_EXP) && S3D_EXP == 6
-			exp_mass = mass; exp_attempts = attempt + 1;
-#endif
 			finished = true;
 			break;
 		}
@@ -936,6 +845,8 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		fix_scale = pick_scale(mass);  // exact bound: this pass cannot overflow
 		}
 		if (!finished) continue;  // block-uniform: not this workgroup's keypoint to finish (a split part, or sent to the redo list)
+		int te = tid;  // (opaque, see above)
+		asm volatile("" : "+v"(te));
 		const double fix_inv = 1.0 / (double)fix_scale;
 		__syncthreads();
 
@@ -946,32 +857,32 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			long long a0 = 0, a1 = 0, a2 = 0;
 			if (S > 1) {  // the finisher of a split window: the sums of all parts (the same integers an unsplit run holds in its LDS histogram)
 				int *ga = sp.gacc + (size_t)kpos * kDesc;
-				a0 = (long long)__hip_atomic_load(&ga[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				a1 = (long long)__hip_atomic_load(&ga[tid + 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				a2 = (long long)__hip_atomic_load(&ga[tid + 512], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				ga[tid] = 0; ga[tid + 256] = 0; ga[tid + 512] = 0;  // clean for the next run
+				a0 = (long long)__hip_atomic_load(&ga[te], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				a1 = (long long)__hip_atomic_load(&ga[te + 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				a2 = (long long)__hip_atomic_load(&ga[te + 512], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				ga[te] = 0; ga[te + 256] = 0; ga[te + 512] = 0;  // clean for the next run
 				if (tid == 0) sp.gdone[kpos] = 0u;
 			} else {
 #pragma unroll
 			for (int r = 0; r < kRep; r++) {
-				const int rr2 = (r + tid) % kRep;  // stagger the replica order across lanes
-				a0 += (long long)(sbin_t)hist[bin_index(tid) * kRep + rr2];
-				a1 += (long long)(sbin_t)hist[bin_index(tid + 256) * kRep + rr2];
-				a2 += (long long)(sbin_t)hist[bin_index(tid + 512) * kRep + rr2];
+				const int rr2 = (r + te) % kRep;  // stagger the replica order across lanes
+				a0 += (long long)(sbin_t)hist[bin_index(te) * kRep + rr2];
+				a1 += (long long)(sbin_t)hist[bin_index(te + 256) * kRep + rr2];
+				a2 += (long long)(sbin_t)hist[bin_index(te + 512) * kRep + rr2];
 			}
 			}
 			v0 = (float)((double)a0 * fix_inv); v1 = (float)((double)a1 * fix_inv); v2 = (float)((double)a2 * fix_inv);
 		} else {
 			// every thread converts its bins (exact integer sums), the first 256 threads then normalise exactly like the 256-thread variant
 			float *vbuf = &s_q[0][0][0];  // (the queues are idle: every wave has drained)
-			for (int e = tid; e < kDesc; e += NT) {
+			for (int e = te; e < kDesc; e += NT) {
 				long long a = 0;
 #pragma unroll
 				for (int r = 0; r < kRep; r++) a += (long long)(sbin_t)hist[bin_index(e) * kRep + (r + e) % kRep];
 				vbuf[e] = (float)((double)a * fix_inv);
 			}
 			__syncthreads();
-			if (tid < 256) { v0 = vbuf[tid]; v1 = vbuf[tid + 256]; v2 = vbuf[tid + 512]; }
+			if (te < 256) { v0 = vbuf[te]; v1 = vbuf[te + 256]; v2 = vbuf[te + 512]; }
 		}
 		for (int pass = 0; pass < 2; pass++) {
 			float s = v0 * v0 + v1 * v1 + v2 * v2;
@@ -991,18 +902,9 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			}
 		}
 		float *out = d_desc + (size_t)slot * kDesc;
-		if (tid < 256) { out[tid] = v0; out[tid + 256] = v1; out[tid + 512] = v2; }
+		if (te < 256) { out[te] = v0; out[te + 256] = v1; out[te + 512] = v2; }
 
-		S3D_DSTAMP(7)  // normalise + store
-#if defined(S3D_EXP) && S3D_EXP == 6
-		__syncthreads();
-		if (tid == 0) { out[0] = exp_mass; out[1] = m_est; out[2] = (float)exp_attempts; out[3] = fix_scale; }
-#endif
 	}
-#if defined(S3D_EXP) && S3D_EXP == 21
-	if (blockIdx.x < 64 && lane == 0)
-		for (int i = 0; i < 10; i++) if (wid < 4) g_dstamp[blockIdx.x][wid][i] = st_acc[i];
-#endif
 }
 
 // sift3d_debug_face_lookup: the face lookup of k_describe on caller-provided gradients (unit parity against golden g7)
@@ -1046,7 +948,7 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
 	// keypoint counts [wide_lo, wide_hi) take the eight-wave variant of r03; below wide_lo a window is split over 8 / 4 four-wave
 	// workgroups (r04; scripts/split_probe.py: 0.19 / 0.22 / 0.28 / 0.32 ms for 40 / 151 / 286 / 437 keypoints against 0.25 / 0.32 / 0.38 /
 	// 0.41 with eight waves; from ~700 keypoints the eight-wave variant is ahead: 0.49 vs 0.51-0.58 ms at 1096)
-	const unsigned wide_hi = (unsigned)S3D_DESC_WIDE_BELOW, wide_lo = sp.gacc ? std::min((unsigned)S3D_DESC_SPLIT4, wide_hi) : 0u;
+	const unsigned wide_hi = kWideBelow, wide_lo = sp.gacc ? std::min(kSplit4Below, wide_hi) : 0u;
 	if (lut_in_lds) {
 		hipLaunchKernelGGL((k_describe<true, 256>), dim3(desc_grid), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
 		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, wide_lo, wide_hi, sp);
@@ -1057,22 +959,6 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
 		hipLaunchKernelGGL((k_describe<false, 256>), dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
 		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, 0u, 0u, DescSplit{});
 	}
-#if defined(S3D_EXP) && S3D_EXP == 21
-	{
-		hipStreamSynchronize(st);
-		static unsigned long long h[64][4][10];
-		hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dstamp), sizeof(h));
-		const char *nm[8] = {"kp setup", "batch setup", "backedge+loads", "step math", "push", "pop", "drain", "normalise"};
-		double tot = 0, a[8] = {0};
-		for (int i = 0; i < 8; i++) { for (int b = 0; b < 64; b++) for (int w = 0; w < 4; w++) a[i] += (double)h[b][w][i]; tot += a[i]; }
-		fprintf(stderr, "DSTAMP share of wave time:");
-		for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * a[i] / tot);
-		double nst = 0, npop = 0;
-		for (int b = 0; b < 64; b++) for (int w = 0; w < 4; w++) { nst += (double)h[b][w][8]; npop += (double)h[b][w][9]; }
-		fprintf(stderr, " | cycles per wave %.0f | steps/wave %.0f pops/wave %.0f | cycles per step (2+3+4) %.0f per pop %.0f\n", tot / 256.0, nst / 256.0,
-		        npop / 256.0, (a[2] + a[3] + a[4]) / nst, a[5] / npop);
-	}
-#endif
 }
 
 // final keypoint records (Keypoint fields incl. rx,ry,rz = x*2^octave, Src/cSIFT3D.cc:1377-1379)

@@ -19,7 +19,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     kp, ds = ex.GetKeypoints()
     med = {k: 1e3 * float(np.median([t[k] for t in ts[2:]])) for k in ("d_TotalTime", "d_BuildGSS", "d_Detect", "d_AssignOrientation", "d_Extraction")}
     h = hashlib.sha1(kp.tobytes() + ds.tobytes()).hexdigest()[:12]
-    print("%-32s total %.2f pyr %.2f det %.2f ori %.2f desc %.2f ms  kp %d hash %s" % (os.path.basename(os.environ.get("S3D_LIB") or "default"), med["d_TotalTime"], med["d_BuildGSS"], med["d_Detect"], med["d_AssignOrientation"], med["d_Extraction"], len(kp), h), flush=True)
+    try:
+        redo = ex.debug_counters()["desc_second_passes"]
+    except Exception:
+        redo = -1
+    print("%-32s total %.2f pyr %.2f det %.2f ori %.2f desc %.2f ms  kp %d hash %s redo %d" % (os.path.basename(os.environ.get("S3D_LIB") or "default"), med["d_TotalTime"], med["d_BuildGSS"], med["d_Detect"], med["d_AssignOrientation"], med["d_Extraction"], len(kp), h, redo), flush=True)
     sys.exit(0)
 for lib in [None] + sys.argv[1:]:
     env = dict(os.environ)

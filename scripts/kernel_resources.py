@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Compile-time resource report of every kernel of the product library (CPU box: hipcc cross-compiles gfx950).
+
+    python3 scripts/kernel_resources.py [--out profiles/rNN_kernel_resources.txt] [--check]
+
+Compiles each kernel source with the product flags of 3dsift_amd/csrc/Makefile plus -Rpass-analysis=kernel-resource-usage and prints one
+line per kernel: VGPRs, AGPRs, SGPRs, spilled VGPRs / SGPRs, scratch bytes per lane, LDS bytes per workgroup, occupancy (waves per SIMD).
+--check exits non-zero when one of the hot kernels (k_describe, k_march_level, k_orient, k_mark, k_lazy_next, k_scores_topk2) reports a
+spilled VGPR, scratch, or more than 16 spilled SGPRs (VERDICT r04 #1a: a spill regression in the kernel that is 46 % of the step went
+unnoticed for a round).  scripts/collect_profile.sh runs the check before it spends GPU time."""
+import argparse, os, re, subprocess, sys, tempfile
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "3dsift_amd", "csrc")
+SRCS = ["kernels_pyramid", "kernels_march", "kernels_small", "kernels_detect", "kernels_orient", "kernels_desc", "kernels_match"]
+NOSLP = {"kernels_march", "kernels_small", "kernels_desc", "kernels_orient"}
+FLAGS = "-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math".split()
+HOT = ("k_describe", "k_march_level", "k_orient", "k_mark", "k_lazy_next", "k_scores_topk2")
+FIELDS = [("VGPRs", "VGPRs"), ("AGPRs", "AGPRs"), ("SGPRs", "TotalSGPRs"), ("vspill", "VGPRs Spill"), ("sspill", "SGPRs Spill"),
+          ("scratch", "ScratchSize [bytes/lane]"), ("LDS", "LDS Size [bytes/block]"), ("occ", "Occupancy [waves/SIMD]")]
+
+
+def demangle(names):
+    try:
+        out = subprocess.run(["c++filt"], input="\n".join(names) + "\n", capture_output=True, text=True, check=True).stdout.split("\n")
+        return [re.sub(r"\(.*", "", o).replace("void ", "").replace("s3d::", "").replace("(anonymous namespace)::", "") for o in out[:len(names)]]
+    except Exception:
+        return names
+
+
+def one(src, extra):
+    with tempfile.TemporaryDirectory() as td:
+        cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + extra + (["-fno-slp-vectorize"] if src in NOSLP else []) + \
+              ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", os.path.join(CSRC, src + ".hip"), "-o", os.path.join(td, "o.o")]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise SystemExit(f"{src}: compile failed\n{r.stderr[-2000:]}")
+    rows, cur = [], None
+    for line in r.stderr.split("\n"):
+        m = re.search(r"remark: (?:\S+: )?\s*Function Name: (\S+)", line)
+        if m:
+            cur = {"mangled": m.group(1), "src": src}
+            rows.append(cur)
+            continue
+        for key, label in FIELDS:
+            m = re.search(r"remark:\s+" + re.escape(label) + r": (\d+)", line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out")
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--extra", default="", help="extra compiler flags (variant builds), e.g. '-DS3D_DESC_X=1'")
+    a = ap.parse_args()
+    extra = a.extra.split()
+    with ThreadPoolExecutor(4) as ex:
+        rows = [r for rs in ex.map(lambda s: one(s, extra), SRCS) for r in rs]
+    names = demangle([r["mangled"] for r in rows])
+    lines = ["# kernel resource usage, hipcc -Rpass-analysis=kernel-resource-usage, flags of 3dsift_amd/csrc/Makefile" + (" + " + a.extra if a.extra else ""),
+             "# %-96s %5s %5s %5s %6s %6s %7s %6s %3s" % ("kernel", "VGPR", "AGPR", "SGPR", "vspill", "sspill", "scratch", "LDS", "occ")]
+    bad = []
+    for r, n in zip(rows, names):
+        lines.append("%-98s %5d %5d %5d %6d %6d %7d %6d %3d" % (n[:98], r.get("VGPRs", -1), r.get("AGPRs", -1), r.get("SGPRs", -1), r.get("vspill", -1),
+                                                              r.get("sspill", -1), r.get("scratch", -1), r.get("LDS", -1), r.get("occ", -1)))
+        if any(n.startswith(h) for h in HOT) and (r.get("vspill", 0) > 0 or r.get("scratch", 0) > 0 or r.get("sspill", 0) > 16):
+            bad.append(lines[-1])
+    text = "\n".join(lines) + "\n"
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(text)
+    print(text, end="")
+    if bad:
+        print("\nhot kernels over the spill limits (no VGPR spill, no scratch, <= 16 SGPR spills):", file=sys.stderr)
+        for b in bad:
+            print("  " + b, file=sys.stderr)
+        if a.check:
+            sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

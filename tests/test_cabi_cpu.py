@@ -68,3 +68,18 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"oracle_lib|liboracle|oracle/|orc_[a-z]+\(|ref_[a-z]+\(", txt):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_describe_ring_contract():
+    """k_describe's march keeps two planes in flight in FIXED registers behind untracked loads (kernels_desc.hip, "A ring of planes in
+    flight"): on the generated gfx950 code no instruction outside the ring's asm blocks may touch those registers inside the march loop,
+    the kernel must have no scratch (scratch traffic counts in vmcnt like the ring's loads) and no SGPR spill inside the loop."""
+    import shutil
+    import subprocess
+    import sys
+
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_desc_ring.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("0 outside accesses, 0 scratch instructions") == 3, r.stdout
