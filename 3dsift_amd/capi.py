@@ -44,6 +44,10 @@ SYMBOLS = [
     "sift3d_export_device", "sift3d_import_descriptors_device", "sift3d_run_partial_orientation",
     "sift3d_export_orientation_device", "sift3d_import_orientation_device", "sift3d_run_describe",
     "sift3d_set_stream", "sift3d_slab_export_dogmax_device", "sift3d_slab_import_dogmax_device", "sift3d_slab_decimate_async",
+    # r05: descriptor windows split along z over the ranks (partial integer histograms)
+    "sift3d_slab_set_desc_partial", "sift3d_slab_min_halo_partial", "sift3d_slab_record_bytes", "sift3d_slab_desc_reach", "sift3d_slab_orient",
+    "sift3d_slab_export_records", "sift3d_slab_describe_partial", "sift3d_slab_describe_finish", "sift3d_slab_orient_launch",
+    "sift3d_slab_orient_count",
     # test hooks / debug accessors / matcher timing
     # native driver of the z-slab sharding
     "sift3d_sharded_create", "sift3d_sharded_run", "sift3d_sharded_num_keypoints", "sift3d_sharded_get_keypoints", "sift3d_sharded_info",
@@ -129,6 +133,18 @@ def lib():
         L.sift3d_slab_set_dogmax.argtypes = [C.c_void_p, _fp]
         L.sift3d_slab_detect.argtypes = [C.c_void_p]
         L.sift3d_slab_describe.argtypes = [C.c_void_p]
+        L.sift3d_slab_set_desc_partial.argtypes = [C.c_void_p, C.c_int]
+        L.sift3d_slab_min_halo_partial.argtypes = [C.POINTER(Params), _ip]
+        L.sift3d_slab_record_bytes.argtypes = [_ip]
+        L.sift3d_slab_desc_reach.argtypes = [C.c_void_p, _ip]
+        L.sift3d_slab_orient.argtypes = [C.c_void_p]
+        L.sift3d_slab_export_records.argtypes = [C.c_void_p, C.c_void_p]
+        L.sift3d_slab_describe_partial.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                                   C.POINTER(C.c_void_p), _ip, _ip]
+        L.sift3d_slab_describe_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
+                                                  C.c_int, C.c_void_p, C.c_void_p, _ip]
+        L.sift3d_slab_orient_launch.argtypes = [C.c_void_p]
+        L.sift3d_slab_orient_count.argtypes = [C.c_void_p, _ip]
         L.sift3d_slab_decimate.argtypes = [C.c_void_p, C.c_void_p]
         L.sift3d_slab_decimate_async.argtypes = [C.c_void_p, C.c_void_p]
         L.sift3d_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -370,6 +386,21 @@ def slab_min_halo(**kw):
     return h.value
 
 
+def slab_min_halo_partial(**kw):
+    """planes per side a slab's level buffers need when the descriptor windows are split along z over the ranks (r05)"""
+    p = _params(kw); h = C.c_int(0)
+    _check(lib().sift3d_slab_min_halo_partial(C.byref(p), C.byref(h)))
+    return h.value
+
+
+def slab_record_words():
+    """int32 words of one keypoint record of the partial-window exchange (opaque to the driver)"""
+    n = C.c_int(0)
+    _check(lib().sift3d_slab_record_bytes(C.byref(n)))
+    assert n.value % 4 == 0
+    return n.value // 4
+
+
 class SeededCSIFT3D(CSIFT3D):
     """Octaves octave_base.. of a volume whose G[octave_base][0] the caller provides (multi-GPU tail, see slab.py).
     shape = (nz, ny, nx) of that level."""
@@ -492,6 +523,60 @@ class SlabCSIFT3D(CSIFT3D):
 
     def describe(self):
         _check(lib().sift3d_slab_describe(self._h))
+
+    # ---- r05: descriptor windows split along z over the ranks (include/sift3d_hip.h) ----
+    def set_desc_partial(self, on=True):
+        _check(lib().sift3d_slab_set_desc_partial(self._h, int(bool(on))))
+
+    def desc_reach(self):
+        n = C.c_int(0)
+        _check(lib().sift3d_slab_desc_reach(self._h, C.byref(n)))
+        return n.value
+
+    def orient(self):
+        """orientation of the owned extrema -> number of accepted keypoints"""
+        _check(lib().sift3d_slab_orient(self._h))
+        n = C.c_int(0)
+        _check(lib().sift3d_num_keypoints(self._h, C.byref(n)))
+        return n.value
+
+    def export_records(self, dst_ptr):
+        _check(lib().sift3d_slab_export_records(self._h, C.c_void_p(int(dst_ptr))))
+
+    def describe_partial(self, lists):
+        """lists: [(records ptr, n, units ptr or None, hist ptr, mass ptr, owner z0, owner z1), ...] -- one launch (include/sift3d_hip.h)"""
+        k = len(lists)
+        if not k:
+            return
+        vp = C.c_void_p * k
+        ia = C.c_int * k
+        recs = vp(*[C.c_void_p(int(t[0])) if t[1] else None for t in lists])
+        ns = ia(*[int(t[1]) for t in lists])
+        units = vp(*[C.c_void_p(int(t[2])) if t[2] else None for t in lists])
+        hist = vp(*[C.c_void_p(int(t[3])) if t[1] else None for t in lists])
+        mass = vp(*[C.c_void_p(int(t[4])) if t[1] else None for t in lists])
+        z0 = ia(*[int(t[5]) for t in lists]); z1 = ia(*[int(t[6]) for t in lists])
+        _check(lib().sift3d_slab_describe_partial(self._h, k, recs, ns, units, hist, mass, z0, z1))
+
+    def describe_finish(self, rec_ptr, n, parts, units_ptr=None, final_round=False, redo_ptr=None, units_next_ptr=None):
+        """parts: [(hist ptr, mass ptr), ...] of the n records, ascending rank -> records flagged for the second round"""
+        k = C.c_int(0)
+        vp = C.c_void_p * max(1, len(parts))
+        hs = vp(*[C.c_void_p(int(h)) for h, _ in parts]) if parts else vp()
+        ms = vp(*[C.c_void_p(int(m)) for _, m in parts]) if parts else vp()
+        _check(lib().sift3d_slab_describe_finish(self._h, C.c_void_p(int(rec_ptr)) if n else None, int(n), len(parts), hs, ms,
+                                                 C.c_void_p(int(units_ptr)) if units_ptr else None, int(bool(final_round)),
+                                                 C.c_void_p(int(redo_ptr)) if redo_ptr else None,
+                                                 C.c_void_p(int(units_next_ptr)) if units_next_ptr else None, C.byref(k)))
+        return k.value
+
+    def orient_launch(self):
+        _check(lib().sift3d_slab_orient_launch(self._h))
+
+    def orient_count(self):
+        n = C.c_int(0)
+        _check(lib().sift3d_slab_orient_count(self._h, C.byref(n)))
+        return n.value
 
     def decimate(self, dst_ptr, wait=True):
         fn = lib().sift3d_slab_decimate if wait else lib().sift3d_slab_decimate_async

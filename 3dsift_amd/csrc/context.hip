@@ -226,6 +226,7 @@ struct sift3d_ctx {
 	sift3d_keypoint *d_kpout = nullptr;
 	float *d_desc = nullptr, *d_xyz = nullptr;
 	DescSplit dsplit{};             // scratch of the split descriptor windows (runs with few keypoints), one allocation at dsplit.gacc
+	bool desc_partial = false;      // slab contexts (r05): descriptor windows are split along z over the ranks -- the halo of G[1..levels] only has to carry the orientation windows
 	bool dsplit_dirty = false;      // a run ended in an error: the "every run leaves the scratch clean" invariant is re-established by the next run
 	float *d_peer = nullptr;        // sift3d_match_handles: a target's descriptors + coordinates copied from another GPU (grow-only)
 	size_t peer_floats = 0;
@@ -1671,7 +1672,12 @@ extern "C" int sift3d_slab_halo_planes(sift3d_handle c, int i, int *planes) {
 		// orientation / descriptor windows of the keypoints of level i live on G[i]: the z reach of ITS descriptor window (r03; before:
 		// the reach of the widest level for all of them: 3 x 38 planes per side instead of 24 + 30 + 38 with the default parameters)
 		const float radius = 2.0f * (c->dog[(size_t)i].scale * 7.071067812f);
-		need = std::max(need, (int)ceilf(__builtin_fabsf(radius) / c->dog[(size_t)i].unit) + 2);
+		const int desc_reach = (int)ceilf(__builtin_fabsf(radius) / c->dog[(size_t)i].unit) + 2;
+		// r05, partial descriptor windows: every rank marches the window planes it OWNS (plus one plane either side for the central
+		// difference), so the halo of G[i] only carries the orientation window of a keypoint on the slab's face: sphere of
+		// 3 * 1.5 * scale (Src/cSIFT3D.cc:925-955), i.e. floor(4.5 scale / unit) planes, + 1 for the central difference
+		const int ori_reach = (int)floorf(4.5f * c->dog[(size_t)i].scale / c->dog[(size_t)i].unit) + 1;
+		need = std::max(need, c->desc_partial ? ori_reach : desc_reach);
 	}
 	*planes = std::min(need, c->halo);
 	return SIFT3D_OK;
@@ -1841,6 +1847,168 @@ extern "C" int sift3d_slab_describe(sift3d_handle c) {
 	rc = slab_count_and_regrow(c, again);
 	if (rc) return rc;
 	c->stage = 5;
+	return SIFT3D_OK;
+}
+
+// ---- r05: descriptor windows split along z over the ranks of a sharded volume (partial integer histograms) ----------------
+// No reference counterpart (the reference is one process, Src/cSIFT3D.cc:484-502 walks whole windows).  Instead of shipping the 24 / 30 /
+// 38-plane halos of G[1..3] that whole descriptor windows reach, the ranks ship RECORDS (a keypoint's coordinates, level, scale,
+// rotation, structure tensor: 164 bytes) to the z-neighbours a window reaches into; every rank marches, for its own and for the foreign
+// records, the window planes it OWNS and returns 768 int32 sums + the part's gradient mass; the owner adds the parts -- the same
+// integers the single-volume run adds in its LDS histogram -- and normalises.  kernels_desc.hip: k_describe<.., PARTIAL>, k_describe_finish.
+extern "C" int sift3d_slab_set_desc_partial(sift3d_handle c, int on) {
+	if (!c || !c->slab) return SIFT3D_ERR_ARG;
+	c->desc_partial = on != 0;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_min_halo_partial(const sift3d_params *params, int *halo) {
+	if (!halo) return SIFT3D_ERR_ARG;
+	sift3d_params p;
+	if (params) p = *params; else sift3d_default_params(&p);
+	if (p.num_kp_levels < 1 || p.num_kp_levels > 5) return SIFT3D_ERR_ARG;
+	const double sigma0 = (double)p.sigma_default * pow(2.0, -1.0 / 3.0);
+	const float scale = (float)(pow(2.0, (double)p.num_kp_levels / (double)p.num_kp_levels) * sigma0);  // DoG level num_kp_levels, octave 0
+	int h = (int)floorf(4.5f * scale) + 2;  // orientation window of the widest keypoint level + the central difference (+ 1 spare)
+	std::vector<float> sig;
+	float base_sigma;
+	level_sigmas(p, sig, base_sigma);
+	for (size_t i = 1; i < sig.size(); i++) {
+		Taps t;
+		if (!build_taps(sig[i], t)) return SIFT3D_ERR_ARG;
+		h = std::max(h, t.hw + 1);
+	}
+	*halo = h;
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_slab_record_bytes(int *bytes) {
+	if (!bytes) return SIFT3D_ERR_ARG;
+	*bytes = (int)sizeof(DevKp);
+	return SIFT3D_OK;
+}
+
+// planes (of this context's octave) the widest descriptor window reaches beyond its keypoint, central difference included: ranks whose
+// owned planes lie within this distance of a slab take part in its keypoints' windows
+extern "C" int sift3d_slab_desc_reach(sift3d_handle c, int *planes) {
+	if (!c || !c->slab || !planes) return SIFT3D_ERR_ARG;
+	int reach = 0;
+	for (int i = 1; i <= c->p.num_kp_levels; i++) {
+		const float radius = 2.0f * (c->dog[(size_t)i].scale * 7.071067812f);
+		reach = std::max(reach, (int)ceilf(__builtin_fabsf(radius) / c->dog[(size_t)i].unit) + 1);
+	}
+	*planes = reach;
+	return SIFT3D_OK;
+}
+
+// Assign_Orientation (Src/cSIFT3D.cc:427-482) of the slab's extrema; the accepted keypoints are counted (sift3d_num_keypoints)
+extern "C" int sift3d_slab_orient_launch(sift3d_handle c);
+extern "C" int sift3d_slab_orient_count(sift3d_handle c, int *n_kp);
+extern "C" int sift3d_slab_orient(sift3d_handle c) {
+	int n = 0;
+	const int rc = sift3d_slab_orient_launch(c);
+	return rc ? rc : sift3d_slab_orient_count(c, &n);
+}
+
+// the accepted keypoints' records in PROCESSING order (large windows first, kernels_orient.hip k_slots) -> n_kp * record_bytes at d_dst
+extern "C" int sift3d_slab_export_records(sift3d_handle c, void *d_dst) {
+	if (!c || !c->slab || !d_dst) return SIFT3D_ERR_ARG;
+	if (c->stage < 4) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	if (c->n_kp) launch_export_records(c->d_ext, c->d_order, c->n_kp, static_cast<DevKp *>(d_dst), c->stream);
+	return SIFT3D_OK;
+}
+
+// this rank's z part of the windows of nlists record lists -- its own keypoints and those of the z-neighbours whose windows reach into it
+// (the tables of a neighbour's context of the same octave are the same) -- in ONE launch.  List i: n[i] records at d_records[i], whose
+// owner owns the planes [owner_z0[i], owner_z1[i]) (this context's own range marks its own list); out: d_hist[i][n[i]][768] int32,
+// d_mass[i][n[i]].  d_units: null, or per list null / the units of the second round (entries <= 0: first-pass rule).  Which planes of a
+// window a rank marches: DescPartial (sift3d_internal.h).
+extern "C" int sift3d_slab_describe_partial(sift3d_handle c, int nlists, const void *const *d_records, const int *n, const float *const *d_units,
+                                            int *const *d_hist, float *const *d_mass, const int *owner_z0, const int *owner_z1) {
+	if (!c || !c->slab || nlists < 0 || (nlists > 0 && (!d_records || !n || !d_hist || !d_mass || !owner_z0 || !owner_z1))) return SIFT3D_ERR_ARG;
+	if (c->stage < 3) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	for (int i0 = 0; i0 < nlists; i0 += kDescSegs) {  // (more lists than a launch takes: slabs much thinner than a window's reach)
+		DescPartial pp;
+		pp.zc0 = c->own0; pp.zc1 = c->own1;
+		for (int l = 1; l <= c->p.num_kp_levels && l < 8; l++) {
+			int planes = 0;
+			if ((rc = sift3d_slab_halo_planes(c, l, &planes)) != SIFT3D_OK) return rc;
+			pp.H[l] = std::max(0, planes - 1);  // (the outermost halo plane only serves the central difference)
+		}
+		unsigned first = 0;
+		for (int i = i0; i < std::min(nlists, i0 + kDescSegs); i++) {
+			if (n[i] < 0 || (n[i] > 0 && (!d_records[i] || !d_hist[i] || !d_mass[i]))) return SIFT3D_ERR_ARG;
+			if (n[i] == 0) continue;
+			DescSeg &sg = pp.seg[pp.nseg++];
+			sg.recs = static_cast<const DevKp *>(d_records[i]); sg.units = d_units ? d_units[i] : nullptr;
+			sg.hist = d_hist[i]; sg.mass = d_mass[i]; sg.first = first; sg.n = (unsigned)n[i]; sg.o0 = owner_z0[i]; sg.o1 = owner_z1[i];
+			first += (unsigned)n[i];
+		}
+		launch_describe_partial(c->d_levels, c->d_luts, c->d_lutpool, pp, c->d_nkp + 1, c->stream, c->desc_lut_lds);
+	}
+	return SIFT3D_OK;
+}
+
+// the owner's finish of n of its records (all of them, or the second round's subset): nparts partial results (its own part and its
+// z-neighbours', in ascending rank order: the integer histograms are added, the masses in that order).  Rows go to the descriptor table
+// (sift3d_get_keypoints / sift3d_device_results); records whose unit failed are flagged (d_redo[k] = 1, d_units_next[k]) and counted in
+// *n_redo unless final_round.  With nothing left to redo the keypoint records are finalised.
+extern "C" int sift3d_slab_describe_finish(sift3d_handle c, const void *d_records, int n, int nparts, const int *const *d_hist,
+                                           const float *const *d_mass, const float *d_units, int final_round, int *d_redo, float *d_units_next,
+                                           int *n_redo) {
+	if (!c || !c->slab || n < 0 || !n_redo || nparts < 0 || nparts > kDescSegs || (n > 0 && (!d_records || !d_hist || !d_mass || nparts < 1)))
+		return SIFT3D_ERR_ARG;
+	if (!final_round && n > 0 && (!d_redo || !d_units_next)) return SIFT3D_ERR_ARG;
+	if (c->stage < 4) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	hipStream_t st = c->stream;
+	unsigned *counter = c->d_nkp + 4;  // (d_total + 6: a spare word behind the orientation's redo counter)
+	S3D_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
+	launch_describe_finish(static_cast<const DevKp *>(d_records), (unsigned)n, c->d_luts, nparts, d_hist, d_mass, d_units, final_round != 0, c->d_desc,
+	                       d_redo, d_units_next, counter, st);
+	unsigned host = 0;
+	if (!final_round) {  // (a final round flags nothing)
+		S3D_HIP(hipMemcpyAsync(&host, counter, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+		S3D_HIP(hipStreamSynchronize(st));
+		S3D_HIP(hipGetLastError());
+	}
+	*n_redo = (int)host;
+	if (final_round) c->n_desc_redo = n; else c->n_desc_redo = 0;
+	if (host == 0) {
+		launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
+		S3D_HIP(hipStreamSynchronize(st));  // results are complete when the call returns (sift3d_get_keypoints copies on the handle's own stream)
+		S3D_HIP(hipGetLastError());
+		c->stage = 5;
+	}
+	return SIFT3D_OK;
+}
+
+// the launch and the read-back of sift3d_slab_orient as two calls: a driver with several ranks in one process (simulated ranks) enqueues
+// every rank's orientation before it waits for the first count
+extern "C" int sift3d_slab_orient_launch(sift3d_handle c) {
+	if (!c || !c->slab || c->stage < 3) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	hipStream_t st = c->stream;
+	launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
+	              c->p.corner_thresh, 0, 1, c->d_order, c->d_nkp + 3, st);
+	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, c->d_slots_part, st);
+	return SIFT3D_OK;
+}
+extern "C" int sift3d_slab_orient_count(sift3d_handle c, int *n_kp) {
+	if (!c || !c->slab || c->stage < 3 || !n_kp) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	bool again;
+	rc = slab_count_and_regrow(c, again);
+	if (rc) return rc;
+	c->stage = 4;
+	*n_kp = (int)c->n_kp;
 	return SIFT3D_OK;
 }
 

@@ -371,6 +371,55 @@ constexpr int kQCap = 128;  // per-wave queue capacity (entries); a push adds <=
 typedef float qf4 __attribute__((ext_vector_type(4)));
 typedef float qf2 __attribute__((ext_vector_type(2)));
 
+// Fixed-point unit of a keypoint's 32-bit histogram (see k_describe): the largest power of two <= 2^31 / mass, clamped to [the unit that is
+// provable for any data of this window size, 2^29]
+__device__ __forceinline__ float pick_scale_d(float mass, float provable) {
+	const float q = __fdiv_rn(2147483648.0f * 0.98f, fmaxf(mass, 1e-30f));
+	const float p2 = __uint_as_float(__float_as_uint(q) & 0xFF800000u);
+	return fminf(fmaxf(p2, provable), 536870912.0f);
+}
+// ... of the FIRST pass: from an estimate of the gradient mass (rms gradient of the orientation window, from the structure tensor, times
+// the descriptor window's weight sum, with 4x head room) -- a function of the keypoint's record and the level's tables alone, so every
+// GPU that marches a part of the window (PARTIAL) uses the same unit.  dev_flags bits 8..: the hook SIFT3D_HOOK_DESC_MASS_SHIFT (estimate / 2^s)
+__device__ __forceinline__ float first_pass_unit(const DevKp &kp, const WinLut &lut_o, const WinLut &lut, int dev_flags) {
+	const float st_tr = fmaxf(kp.st[0] + kp.st[4] + kp.st[8], 0.0f);
+	const float m_est = __fsqrt_rn(__fdiv_rn(st_tr, lut_o.wsum)) * lut.wsum;
+	return pick_scale_d(m_est * 4.0f * __uint_as_float((unsigned)(127 - ((dev_flags >> 8) & 63)) << 23), lut.fix_scale);
+}
+// does a pass whose unit was fix_scale have to be repeated with the exact unit?  mass = the window's gradient mass * 1.001.  Every bin
+// (and replica) sum is <= mass * fix_scale + half a unit per contribution (< 2^20 contributions): overflow.  And a first guess far ABOVE
+// the mass (a sharp structure inside the orientation window, a flat descriptor window: the zero background of CT / MR volumes) leaves a
+// unit that much coarser than necessary: below 1/64 of the range the keypoint is redone as well, whenever the exact bound gives a finer
+// unit (rounding noise per bin stays < 1e-5 of the descriptor norm)
+__device__ __forceinline__ bool unit_fails(float mass, float fix_scale, float provable) {
+	const bool overflow = !(mass * fix_scale + 1048576.0f < 2147483648.0f);
+	const bool coarse = mass * fix_scale < 2147483648.0f / 64.0f && pick_scale_d(mass, provable) > fix_scale;
+	return overflow || coarse;
+}
+// normalise -> clamp -> normalise (Src/cSIFT3D.cc:1350-1358, 1639-1656) of the 768 values the first 256 threads of a workgroup hold
+// three each (elements te, te + 256, te + 512), and the store of the descriptor row.  Every thread of the workgroup calls it (barriers).
+__device__ __forceinline__ void normalise_store(float v0, float v1, float v2, int te, int lane, int wid, float *red /*[>= 4]*/, float *out) {
+	const float trunc_thresh = (float)(0.2 * 128 / kDesc);
+	for (int pass = 0; pass < 2; pass++) {
+		float s = v0 * v0 + v1 * v1 + v2 * v2;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) s = s + __shfl_xor(s, o, 64);
+		__syncthreads();
+		if (lane == 0) red[wid] = s;
+		__syncthreads();
+		float norm = (red[0] + red[1]) + (red[2] + red[3]);  // (waves 0..3 hold the 768 elements in every variant)
+		norm = (float)((double)__fsqrt_rn(norm) + DBL_EPSILON);
+		const float inv = (float)(1.0 / (double)norm);
+		v0 = v0 * inv; v1 = v1 * inv; v2 = v2 * inv;
+		if (pass == 0) {
+			v0 = v0 < trunc_thresh ? v0 : trunc_thresh;
+			v1 = v1 < trunc_thresh ? v1 : trunc_thresh;
+			v2 = v2 < trunc_thresh ? v2 : trunc_thresh;
+		}
+	}
+	if (te < 256) { out[te] = v0; out[te + 256] = v1; out[te + 512] = v2; }
+}
+
 // LUT_LDS: the window's weight table is staged in LDS (default parameters: 1293 entries).  Larger windows (sigma_default well
 // above 1.6) read the table from global memory instead (L2-resident, a few KB): slower, but no size limit.
 // NT threads per workgroup (= per keypoint): 256, or 512 for runs with few keypoints (r03: a keypoint's window is marched by ONE
@@ -379,16 +428,24 @@ typedef float qf2 __attribute__((ext_vector_type(2)));
 // eight waves halve it).  Both variants are launched; the one whose range [nkp_min, nkp_max) does not hold the keypoint count
 // returns at once (the count is only known on the device).  Results are bit-identical: the histograms are integer sums, and the
 // final normalisation always runs on the first 256 threads in the same order.
-template <bool LUT_LDS, int NT>
+// PARTIAL (r05, the z-slab sharding of one volume over several GPUs): the launch marches, for each of kp_cap RECORDS -- the keypoints of
+// this rank and of the z-neighbours whose windows reach into it, in up to kDescSegs lists (DescPartial::seg) -- this rank's PART of the
+// descriptor window and leaves the integer histogram (768 sums in descriptor order) and the part's gradient mass in the list's
+// hist / mass; nothing is normalised.  The planes of a window are partitioned over the ranks: the OWNER of a keypoint takes the planes
+// its level buffer holds, [o0 - H, o1 + H) with H = the halo of the keypoint's level minus the plane of the central difference (the halo
+// is there for the orientation windows anyway), every other rank the planes it owns outside that range.  Every contribution is the
+// integer the single-volume run adds, so the parts of all ranks sum to that run's histogram bit for bit (k_describe_finish).
+template <bool LUT_LDS, int NT, bool PARTIAL = false>
 __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__restrict__ kps, const unsigned *__restrict__ d_count, unsigned cap,
                                                   const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts,
                                                   const float *__restrict__ lutpool, float *__restrict__ d_desc, unsigned kp_cap,
                                                   int part_rank, int part_world, const int *__restrict__ order,
                                                   const unsigned *__restrict__ d_nkp, unsigned *__restrict__ d_work, int dev_flags, unsigned nkp_min,
-                                                  unsigned nkp_max, DescSplit sp) {
+                                                  unsigned nkp_max, DescSplit sp, DescPartial pp) {
 	constexpr int NW = NT / 64;
 	static_assert(NT == 256 || NT == 512, "k_describe: 4 or 8 waves per keypoint");
-	{
+	static_assert(!PARTIAL || NT == 256, "partial windows: four waves per record");
+	if (!PARTIAL) {
 		// [nkp_min, nkp_max): the keypoint counts (of this handle's share) the EIGHT-wave variant takes; the four-wave variant takes the rest
 		const unsigned n_all = min(d_nkp[0], kp_cap);
 		const unsigned w = part_world > 1 ? (unsigned)part_world : 1u, r = part_world > 1 ? (unsigned)part_rank : 0u;
@@ -409,7 +466,6 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 	__shared__ unsigned s_chord[kPairCap];        // z ranges of a pair's two columns: (za0, zb0, za1, zb1) - z0, one byte each
 	__shared__ unsigned s_cnt[kLenBins];          // counting sort: pairs per length, then the running start of each length
 	__shared__ unsigned s_nnz;
-	const unsigned count = min(d_count[0], cap);
 	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
 	stage_face_tables(tid, s_fidx, s_sym);
@@ -424,9 +480,9 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 	// The accepted keypoints (slot -> extremum list from k_slots) are handed out one at a time through a global counter:
 	// window sizes differ 4x between keypoint levels, so a static deal leaves a long tail.  A partitioned run (multi-GPU
 	// split of replicated octaves) takes the slots rank, rank + world, ... and zeroes the rows of the other ranks.
-	(void)count;
-	const unsigned nkp = min(d_nkp[0], kp_cap);
-	const unsigned pw = part_world > 1 ? (unsigned)part_world : 1u, pr = part_world > 1 ? (unsigned)part_rank : 0u;
+	(void)d_count; (void)cap;
+	const unsigned nkp = PARTIAL ? kp_cap : min(d_nkp[0], kp_cap);
+	const unsigned pw = (!PARTIAL && part_world > 1) ? (unsigned)part_world : 1u, pr = (!PARTIAL && part_world > 1) ? (unsigned)part_rank : 0u;
 	if (pw > 1)
 		for (unsigned pos = blockIdx.x; pos < nkp; pos += gridDim.x)
 			if (pos % pw != pr) {
@@ -437,7 +493,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 	// r04, few keypoints: a window split over S0 workgroups (see DescSplit).  S0 is a function of the keypoint count alone, the same
 	// in every workgroup.
 	int S0 = 1;
-	if (NT == 256 && sp.gacc != nullptr && nown <= sp.cap) S0 = nown < kSplit8Below ? 8 : (nown < kSplit4Below ? 4 : 1);
+	if (!PARTIAL && NT == 256 && sp.gacc != nullptr && nown <= sp.cap) S0 = nown < kSplit8Below ? 8 : (nown < kSplit4Below ? 4 : 1);
 	const unsigned nitems = nown * (unsigned)S0;
 	for (;;) {
 		__syncthreads();
@@ -448,17 +504,24 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		const unsigned kpos = item / (unsigned)S0;  // position in the processing order
 		const int part = (int)(item % (unsigned)S0);
 		int S = S0;  // parts of THIS pass over the window (1 when the finisher repeats a split window alone with the exact unit)
-		const unsigned k = (unsigned)order[kpos * pw + pr];  // processing order: big windows first (k_slots)
-		const int slot = kps[k].slot;                        // row of the keypoint in the results (reference order)
-		const int cxi = kps[k].x, cyi = kps[k].y, czi = kps[k].z;
-		const int li = kps[k].octave * 8 + kps[k].level;
-		const float scale = kps[k].scale;
+		// PARTIAL: the list the record belongs to (block-uniform scalar walk over at most kDescSegs lists) and its place in it
+		int sg = 0;
+		if (PARTIAL)
+			while (sg + 1 < pp.nseg && kpos >= pp.seg[sg + 1].first) sg++;
+		const DevKp *__restrict__ kpb = PARTIAL ? pp.seg[sg].recs : kps;
+		const unsigned k = PARTIAL ? kpos - pp.seg[sg].first : (unsigned)order[kpos * pw + pr];  // processing order: big windows first (k_slots)
+		int *const p_hist = PARTIAL ? pp.seg[sg].hist + (size_t)k * kDesc : nullptr;
+		float *const p_mass = PARTIAL ? pp.seg[sg].mass + k : nullptr;
+		const int slot = kpb[k].slot;                        // row of the keypoint in the results (reference order)
+		const int cxi = kpb[k].x, cyi = kpb[k].y, czi = kpb[k].z;
+		const int li = kpb[k].octave * 8 + kpb[k].level;
+		const float scale = kpb[k].scale;
 		const LevelRef L = levels[li];
 		const WinLut lut = luts[li * 2 + 1];
 		// R <- R^T (Transpose_Matrix, Src/cSIFT3D.cc:1214)
-		const float R0 = kps[k].rot[0], R1 = kps[k].rot[3], R2 = kps[k].rot[6];
-		const float R3 = kps[k].rot[1], R4 = kps[k].rot[4], R5 = kps[k].rot[7];
-		const float R6 = kps[k].rot[2], R7 = kps[k].rot[5], R8 = kps[k].rot[8];
+		const float R0 = kpb[k].rot[0], R1 = kpb[k].rot[3], R2 = kpb[k].rot[6];
+		const float R3 = kpb[k].rot[1], R4 = kpb[k].rot[4], R5 = kpb[k].rot[7];
+		const float R6 = kpb[k].rot[2], R7 = kpb[k].rot[5], R8 = kpb[k].rot[8];
 		// window constants, Src/cSIFT3D.cc:1155-1159
 		const float sigma = scale * 7.071067812f;
 		const float win_radius = 2.0f * sigma;
@@ -471,19 +534,27 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		// gradient of the orientation window, from the structure tensor, times the descriptor window's weight sum, with 4x head
 		// room), sums the true M on the way and, should the estimate have been too small, the keypoint is redone once with the
 		// exact bound.  WinLut::fix_scale (provable for ANY data of this window size) is the coarsest unit ever used.
-		const WinLut lut_o = luts[li * 2];
-		const float st_tr = fmaxf(kps[k].st[0] + kps[k].st[4] + kps[k].st[8], 0.0f);
-		const float m_est = __fsqrt_rn(__fdiv_rn(st_tr, lut_o.wsum)) * lut.wsum;
-		auto pick_scale = [&](float mass) {  // largest power of two <= 2^31 / mass, clamped to [provable, 2^29]
-			const float q = __fdiv_rn(2147483648.0f * 0.98f, fmaxf(mass, 1e-30f));
-			const float p2 = __uint_as_float(__float_as_uint(q) & 0xFF800000u);
-			return fminf(fmaxf(p2, lut.fix_scale), 536870912.0f);
-		};
-		float fix_scale = pick_scale(m_est * 4.0f * __uint_as_float((unsigned)(127 - ((dev_flags >> 8) & 63)) << 23));  // hook: estimate / 2^s
+		float fix_scale = first_pass_unit(kpb[k], luts[li * 2], lut, dev_flags);
+		if (PARTIAL && pp.seg[sg].units != nullptr && pp.seg[sg].units[k] > 0.0f) fix_scale = pp.seg[sg].units[k];  // second round: the exact unit, from the owner
 		int x0, x1, y0, y1, z0, z1;
 		win_bounds_d((float)cxi, win_radius, u, L.nx, x0, x1);
 		win_bounds_d((float)cyi, win_radius, u, L.ny, y0, y1);
 		win_bounds_d((float)czi, win_radius, u, L.nz, z0, z1);
+		if (PARTIAL) {
+			// this rank's z part of the window (the chords below are clipped to it; the planes z0 - 1 and z1 + 1 the gradient reads lie in
+			// the buffer's halo).  Nothing of the window here: zeros, and on to the next record (block-uniform).
+			const int o0 = pp.seg[sg].o0, o1 = pp.seg[sg].o1, H = pp.H[kpb[k].level & 7];
+			int c0, c1;  // [c0, c1)
+			if (o0 == pp.zc0 && o1 == pp.zc1) { c0 = o0 - H; c1 = o1 + H; }                 // the owner's part
+			else if (pp.zc1 <= o0) { c0 = pp.zc0; c1 = min(pp.zc1, o0 - H); }               // a rank below the owner
+			else { c0 = max(pp.zc0, o1 + H); c1 = pp.zc1; }                                  // a rank above
+			z0 = max(z0, c0); z1 = min(z1, c1 - 1);
+			if (z1 < z0) {
+				for (int e = tid; e < kDesc; e += NT) p_hist[e] = 0;
+				if (tid == 0) *p_mass = 0.0f;
+				continue;
+			}
+		}
 		const int wx = x1 - x0 + 1, wy = y1 - y0 + 1;
 		const int ncol = (wx > 0 && wy > 0) ? wx * wy : 0;
 		const int sy = L.nx, sz = L.nx * L.ny;  // levels are < 2^31 voxels
@@ -795,6 +866,21 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		__syncthreads();
 		float mass_sum = (red[0] + red[1]) + (red[2] + red[3]);
 		if (NW == 8) mass_sum = mass_sum + ((red[4] + red[5]) + (red[6] + red[7]));
+		if (PARTIAL) {
+			// (red[] was read by every thread above; the LDS histogram is complete: the barriers of the mass reduction lie behind every wave's drain)
+			int tp = tid;  // (opaque: keeps the bin indices out of the registers that live through the march, like `te` below)
+			asm volatile("" : "+v"(tp));
+#pragma unroll
+			for (int j = 0; j < 3; j++) {
+				const int e = tp + 256 * j;
+				int a = 0;
+#pragma unroll
+				for (int r = 0; r < kRep; r++) a += (int)(sbin_t)hist[bin_index(e) * kRep + (r + tp) % kRep];
+				p_hist[e] = a;
+			}
+			if (tid == 0) *p_mass = mass_sum;
+			break;  // (leaves the attempt loop with finished == false: the owner decides about a second round)
+		}
 		// (r05) the thread index of the epilogue is opaque: its lane constants (bin indices, result addresses: ~20 registers) were hoisted
 		// out of the KEYPOINT loop and lived through the march, which is where the kernel's registers are short (9 spilled VGPRs, 128 used)
 		int te = tid;
@@ -823,13 +909,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			for (int q = 0; q < S; q++) mass_sum = mass_sum + __hip_atomic_load(&sp.gmass[kpos * 8 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // part order: deterministic
 		}
 		const float mass = mass_sum * 1.001f;
-		// every bin (and replica) sum is <= mass * fix_scale + half a unit per contribution (< 2^20 contributions)
-		// ... and a first guess far ABOVE the mass (a sharp structure inside the orientation window, a flat descriptor window: the
-		// zero background of CT / MR volumes) leaves a unit that much coarser than necessary: below 1/64 of the range the keypoint is
-		// redone as well, whenever the exact bound gives a finer unit (rounding noise per bin stays < 1e-5 of the descriptor norm)
-		const bool overflow = !(mass * fix_scale + 1048576.0f < 2147483648.0f);
-		const bool coarse = mass * fix_scale < 2147483648.0f / 64.0f && pick_scale(mass) > fix_scale;
-		if (attempt == 1 || !(overflow || coarse)) {
+		if (attempt == 1 || !unit_fails(mass, fix_scale, lut.fix_scale)) {
 			finished = true;
 			break;
 		}
@@ -842,7 +922,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			S = 1;
 		}
 		if (tid == 0) atomicAdd(d_work + 1, 1u);
-		fix_scale = pick_scale(mass);  // exact bound: this pass cannot overflow
+		fix_scale = pick_scale_d(mass, lut.fix_scale);  // exact bound: this pass cannot overflow
 		}
 		if (!finished) continue;  // block-uniform: not this workgroup's keypoint to finish (a split part, or sent to the redo list)
 		int te = tid;  // (opaque, see above)
@@ -850,8 +930,6 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		const double fix_inv = 1.0 / (double)fix_scale;
 		__syncthreads();
 
-		// normalise -> clamp -> normalise (Src/cSIFT3D.cc:1350-1358, 1639-1656)
-		const float trunc_thresh = (float)(0.2 * 128 / kDesc);
 		float v0 = 0.f, v1 = 0.f, v2 = 0.f;
 		if (NT == 256) {
 			long long a0 = 0, a1 = 0, a2 = 0;
@@ -884,25 +962,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			__syncthreads();
 			if (te < 256) { v0 = vbuf[te]; v1 = vbuf[te + 256]; v2 = vbuf[te + 512]; }
 		}
-		for (int pass = 0; pass < 2; pass++) {
-			float s = v0 * v0 + v1 * v1 + v2 * v2;
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) s = s + __shfl_xor(s, o, 64);
-			__syncthreads();
-			if (lane == 0) red[wid] = s;
-			__syncthreads();
-			float norm = (red[0] + red[1]) + (red[2] + red[3]);  // (waves 0..3 hold the 768 elements in both variants)
-			norm = (float)((double)__fsqrt_rn(norm) + DBL_EPSILON);
-			const float inv = (float)(1.0 / (double)norm);
-			v0 = v0 * inv; v1 = v1 * inv; v2 = v2 * inv;
-			if (pass == 0) {
-				v0 = v0 < trunc_thresh ? v0 : trunc_thresh;
-				v1 = v1 < trunc_thresh ? v1 : trunc_thresh;
-				v2 = v2 < trunc_thresh ? v2 : trunc_thresh;
-			}
-		}
-		float *out = d_desc + (size_t)slot * kDesc;
-		if (te < 256) { out[te] = v0; out[te + 256] = v1; out[te + 512] = v2; }
+		normalise_store(v0, v1, v2, te, lane, wid, red, d_desc + (size_t)slot * kDesc);
 
 	}
 }
@@ -951,14 +1011,99 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
 	const unsigned wide_hi = kWideBelow, wide_lo = sp.gacc ? std::min(kSplit4Below, wide_hi) : 0u;
 	if (lut_in_lds) {
 		hipLaunchKernelGGL((k_describe<true, 256>), dim3(desc_grid), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, wide_lo, wide_hi, sp);
+		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, wide_lo, wide_hi, sp, DescPartial{});
 		if (wide_hi > wide_lo)
 			hipLaunchKernelGGL((k_describe<true, 512>), dim3(256 * 2), dim3(512), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-			                   part_rank, part_world, order, d_nkp, d_work, dev_flags, wide_lo, wide_hi, DescSplit{});
+			                   part_rank, part_world, order, d_nkp, d_work, dev_flags, wide_lo, wide_hi, DescSplit{}, DescPartial{});
 	} else {
 		hipLaunchKernelGGL((k_describe<false, 256>), dim3(256 * 8), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
-		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, 0u, 0u, DescSplit{});
+		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, 0u, 0u, DescSplit{}, DescPartial{});
 	}
+}
+
+// ---- r05: descriptor windows split along z over the GPUs of a node (DescPartial; SURVEY 8e, no reference counterpart) ----
+// The owner of a keypoint adds the parts' integer histograms (its own and its z-neighbours': plain int32 sums) and their gradient masses
+// in the order the parts are given (ascending rank), and finishes: the unit the parts used either stands -- normalise, clamp, normalise,
+// store the row (the same arithmetic as k_describe's epilogue: normalise_store) -- or fails the test of k_describe's first pass, in which
+// case the record is flagged for a second round with the exact unit (units_next) unless this already is that round.
+struct FinishParts {
+	int nparts = 0;
+	const int *hist[kDescSegs] = {};
+	const float *mass[kDescSegs] = {};
+};
+__global__ void __launch_bounds__(256) k_describe_finish(const DevKp *__restrict__ recs, unsigned n, const WinLut *__restrict__ luts, FinishParts fp,
+                                                          const float *__restrict__ units, int final_round, int dev_flags,
+                                                          float *__restrict__ d_desc, int *__restrict__ redo, float *__restrict__ units_next,
+                                                          unsigned *__restrict__ d_counters) {
+	__shared__ float red[4];
+	const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+	for (unsigned k = blockIdx.x; k < n; k += gridDim.x) {  // block-uniform
+		const int li = recs[k].octave * 8 + recs[k].level;
+		const WinLut lut = luts[li * 2 + 1];
+		float fix_scale = first_pass_unit(recs[k], luts[li * 2], lut, dev_flags);
+		if (units != nullptr && units[k] > 0.0f) fix_scale = units[k];
+		float msum = 0.0f;
+		for (int p = 0; p < fp.nparts; p++) msum = msum + fp.mass[p][k];
+		const float m = msum * 1.001f;
+		if (!final_round && unit_fails(m, fix_scale, lut.fix_scale)) {
+			if (tid == 0) { redo[k] = 1; units_next[k] = pick_scale_d(m, lut.fix_scale); atomicAdd(d_counters, 1u); }
+			continue;
+		}
+		if (tid == 0 && redo != nullptr) redo[k] = 0;
+		const double fix_inv = 1.0 / (double)fix_scale;
+		long long a0 = 0, a1 = 0, a2 = 0;
+		for (int p = 0; p < fp.nparts; p++) {
+			const int *h = fp.hist[p] + (size_t)k * kDesc;
+			a0 += (long long)h[tid]; a1 += (long long)h[tid + 256]; a2 += (long long)h[tid + 512];
+		}
+		const float v0 = (float)((double)a0 * fix_inv), v1 = (float)((double)a1 * fix_inv), v2 = (float)((double)a2 * fix_inv);
+		normalise_store(v0, v1, v2, tid, lane, wid, red, d_desc + (size_t)recs[k].slot * kDesc);
+		__syncthreads();  // red[] is reused by the next record
+	}
+}
+
+// records of the accepted keypoints in processing order: dst[pos] = ext[order[pos]] (sift3d_slab_export_records)
+__global__ void __launch_bounds__(256) k_export_records(const DevKp *__restrict__ ext, const int *__restrict__ order, unsigned n, DevKp *__restrict__ dst) {
+	constexpr unsigned W = sizeof(DevKp) / 4;
+	static_assert(sizeof(DevKp) % 4 == 0, "records are copied word by word");
+	const unsigned total = n * W;
+	for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+		const unsigned pos = i / W, w = i - pos * W;
+		reinterpret_cast<unsigned *>(dst)[i] = reinterpret_cast<const unsigned *>(ext + order[pos])[w];
+	}
+}
+void launch_export_records(const DevKp *ext, const int *order, unsigned n, DevKp *dst, hipStream_t st) {
+	if (n == 0) return;
+	const unsigned total = n * (unsigned)(sizeof(DevKp) / 4);
+	hipLaunchKernelGGL(k_export_records, dim3((int)std::min((total + 255u) / 256u, 2048u)), dim3(256), 0, st, ext, order, n, dst);
+}
+
+void launch_describe_partial(const LevelRef *d_levels, const WinLut *d_luts, const float *d_lutpool, const DescPartial &pp, unsigned *d_work,
+                             hipStream_t st, bool lut_in_lds) {
+	unsigned n = 0;
+	for (int i = 0; i < pp.nseg; i++) n += pp.seg[i].n;
+	if (n == 0) return;
+	(void)hipMemsetAsync(d_work, 0, 2 * sizeof(unsigned), st);
+	const int dev_flags = (hook(SIFT3D_HOOK_DESC_NOCACHE) ? 1 : 0) | (hook(SIFT3D_HOOK_DESC_EXACT_CELLS) ? 2 : 0) | (hook(SIFT3D_HOOK_DESC_MASS_SHIFT) & 63) << 8;
+	const int grid = (int)std::min(n, 256u * 8u);
+	if (lut_in_lds)
+		hipLaunchKernelGGL((k_describe<true, 256, true>), dim3(grid), dim3(256), 0, st, (const DevKp *)nullptr, (const unsigned *)nullptr, 0u, d_levels, d_luts,
+		                   d_lutpool, (float *)nullptr, n, 0, 1, (const int *)nullptr, (const unsigned *)nullptr, d_work, dev_flags, 0u, 0u, DescSplit{}, pp);
+	else
+		hipLaunchKernelGGL((k_describe<false, 256, true>), dim3(grid), dim3(256), 0, st, (const DevKp *)nullptr, (const unsigned *)nullptr, 0u, d_levels, d_luts,
+		                   d_lutpool, (float *)nullptr, n, 0, 1, (const int *)nullptr, (const unsigned *)nullptr, d_work, dev_flags, 0u, 0u, DescSplit{}, pp);
+}
+
+void launch_describe_finish(const DevKp *recs, unsigned n, const WinLut *d_luts, int nparts, const int *const *d_hist, const float *const *d_mass,
+                            const float *d_units, bool final_round, float *d_desc, int *d_redo, float *d_units_next, unsigned *d_counters,
+                            hipStream_t st) {
+	if (n == 0) return;
+	FinishParts fp;
+	fp.nparts = nparts;
+	for (int p = 0; p < nparts; p++) { fp.hist[p] = d_hist[p]; fp.mass[p] = d_mass[p]; }
+	const int dev_flags = (hook(SIFT3D_HOOK_DESC_MASS_SHIFT) & 63) << 8;
+	hipLaunchKernelGGL(k_describe_finish, dim3((int)std::min(n, 4096u)), dim3(256), 0, st, recs, n, d_luts, fp, d_units, final_round ? 1 : 0, dev_flags,
+	                   d_desc, d_redo, d_units_next, d_counters);
 }
 
 // final keypoint records (Keypoint fields incl. rx,ry,rz = x*2^octave, Src/cSIFT3D.cc:1377-1379)

@@ -238,6 +238,35 @@ struct DescSplit {
 	unsigned *gdone = nullptr;      // [cap] parts arrived
 	unsigned cap = 0;
 };
+// r05, the z-slab sharding: this rank's z PART of descriptor windows.  Records come in up to kDescSegs lists -- the rank's own keypoints and
+// those of the z-neighbours whose windows reach into it.  [zc0, zc1): the planes this rank owns (global z of the level); a list's
+// [o0, o1): the planes its OWNER owns.  The owner marches [o0 - H[level], o1 + H[level]) -- what its level buffer holds --, every other
+// rank its owned planes outside that range.  hist[n][768] int32 (descriptor element order, the fixed-point sums of this part), mass[n]
+// (its gradient mass); units: per-record fixed-point unit of a second round (entries <= 0 and a null pointer: the first-pass rule, a
+// function of the record alone).
+constexpr int kDescSegs = 6;
+struct DescSeg {
+	const DevKp *recs = nullptr;
+	const float *units = nullptr;
+	int *hist = nullptr;
+	float *mass = nullptr;
+	unsigned first = 0, n = 0;  // first = records of the lists in front of this one
+	int o0 = 0, o1 = 0;
+};
+struct DescPartial {
+	int zc0 = 0, zc1 = 0, nseg = 0;
+	int H[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per keypoint level
+	DescSeg seg[kDescSegs];
+};
+void launch_export_records(const DevKp *ext, const int *order, unsigned n, DevKp *dst, hipStream_t st);
+void launch_describe_partial(const LevelRef *d_levels, const WinLut *d_luts, const float *d_lutpool, const DescPartial &pp,
+                             unsigned *d_work /* two device words, zeroed by the launch */, hipStream_t st, bool lut_in_lds = true);
+// the owner's finish: nparts <= kDescSegs partial results of its n records (its own part and its neighbours', ascending rank: the masses
+// are added in that order); rows go to d_desc[recs[k].slot]; records whose unit failed get redo[k] = 1, units_next[k] = the exact unit,
+// and are counted in d_counters[0] (unless final_round)
+void launch_describe_finish(const DevKp *recs, unsigned n, const WinLut *d_luts, int nparts, const int *const *d_hist, const float *const *d_mass,
+                            const float *d_units, bool final_round, float *d_desc, int *d_redo, float *d_units_next, unsigned *d_counters,
+                            hipStream_t st);
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels,
                      const WinLut *d_luts, const float *d_lutpool, float *d_desc, unsigned kp_cap, int part_rank, int part_world,
                      const int *order, const unsigned *d_nkp, unsigned *d_work /* device counter, zeroed by the launch */,

@@ -17,6 +17,14 @@ pipeline, with results equal to the single-GPU run (pyramid / extrema bit for bi
              replicated in a SEEDED context; their orientation work is dealt by extremum index (integer all-reduce(SUM)
              of zero-padded rows restores it exactly), their descriptor work by keypoint and stays distributed.
 
+Descriptor windows (r05, `desc_partial`, the default): a window reaches up to 38 planes beyond its keypoint, so whole windows need
+24 / 30 / 38-plane halos of G[1..3] -- 92 of the 108 planes a rank received per side and octave.  Instead the ranks exchange keypoint
+RECORDS (164 bytes) with the z-neighbours a window reaches into, every rank marches the window planes it OWNS for its own and for
+the foreign records and returns 768 int32 sums + the part's gradient mass, and the owner adds the parts: the same integers the
+single-volume run sums, so the descriptors stay bit-identical.  (The owner itself takes the window planes its level buffers hold,
+its halo included; the other ranks their owned planes beyond that.)  The halos of G[1..3] shrink to the orientation window's reach
+(8 / 10 / 12 planes).  A record whose fixed-point unit fails is repeated once, by every part, with the exact unit.
+
 Ordering (r02): all device work of a rank's sharded octaves is enqueued on ONE torch stream, which the slab contexts adopt
 (sift3d_set_stream); the exchanges are posted in that stream's order (RCCL work is ordered behind the current stream and
 `Work.wait()` makes the stream -- not the host -- wait), the DoG maxima are all-reduced as a device tensor, and the host only
@@ -89,6 +97,16 @@ def halo_transfers(bounds, nz, kind, idx, lo, hi, stage=0):
     return out
 
 
+def window_neighbours(bounds, reach):
+    """neigh[r] = the ranks q != r whose owned planes a descriptor window of a keypoint of rank r can reach into: the keypoints of r sit
+    in [z0_r, z1_r), their windows cover at most `reach` planes either side.  Symmetric; ranks with empty ranges take no part."""
+    out = []
+    for r, (z0, z1) in enumerate(bounds):
+        lo, hi = z0 - reach, z1 - 1 + reach
+        out.append([q for q, (q0, q1) in enumerate(bounds) if q != r and z1 > z0 and q1 > q0 and q0 <= hi and q1 - 1 >= lo])
+    return out
+
+
 def capi_words():
     from . import capi
     return capi.ORIENT_WORDS
@@ -138,6 +156,17 @@ class SimComm:
 
     def wait(self, handle):
         pass  # the copies are ordered on the stream they were issued on
+
+    def exchange_tensors(self, items):
+        """items: (src rank, dst rank, tensor at the source, tensor at the destination), the same list in the same order on every
+        rank (tensors of ranks living elsewhere are None)."""
+        for _src, _dst, a, b in items:
+            b.copy_(a)
+        return None
+
+    def allgather_ints(self, per_worker):
+        """per_worker: one int per local worker (rank order) -> the ints of all ranks"""
+        return [int(v) for v in per_worker]
 
     def sync(self):
         import torch
@@ -216,6 +245,27 @@ class DistComm:
         for r in handle or []:
             r.wait()  # RCCL: the current stream waits; gloo: the host waits
 
+    def exchange_tensors(self, items):
+        """see SimComm.exchange_tensors: this rank posts its sends and receives as ONE batched group, in list order"""
+        dist = self.dist
+        ops = []
+        for src, dst, a, b in items:
+            if src == self.rank and dst != self.rank:
+                ops.append(dist.P2POp(dist.isend, a, dst))
+            elif dst == self.rank and src != self.rank:
+                ops.append(dist.P2POp(dist.irecv, b, src))
+        if not ops:
+            return []
+        return dist.batch_isend_irecv(ops)
+
+    def allgather_ints(self, per_worker):
+        import torch
+        dev = "cuda" if (self.dist.get_backend() == "nccl") else "cpu"
+        mine = torch.tensor([int(per_worker[0])], dtype=torch.int64, device=dev)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [int(t.item()) for t in out]
+
     def allreduce_max(self, per_worker):
         import torch
         a = np.asarray(per_worker[0], np.float32)
@@ -261,7 +311,7 @@ class DistComm:
 class SlabStage:
     """one sharded octave of one rank: slab context + the torch-owned arena its level buffers live in"""
 
-    def __init__(self, rank, octave, dims, bounds, halo, noct, device, params):
+    def __init__(self, rank, octave, dims, bounds, halo, noct, device, params, desc_partial=False):
         import torch
         from . import capi
         nx, ny, nz = dims
@@ -274,6 +324,8 @@ class SlabStage:
         torch.cuda.synchronize(dev)
         self.ctx = capi.SlabCSIFT3D(nx, ny, nz, self.z0, self.z1, halo, noct, self.arena.data_ptr(), n, device=device,
                                     octave=octave, **params)
+        if desc_partial:
+            self.ctx.set_desc_partial(True)
         self._buf = {}
 
     def view(self, kind, idx, zg0, zg1):
@@ -289,14 +341,15 @@ class SlabStage:
 class SlabWorker:
     """The sharded octaves (SlabStage each) + the seeded, replicated tail context of one rank."""
 
-    def __init__(self, rank, world, dims, device=0, halo=None, sharded_octaves=1, stream=None, **params):
+    def __init__(self, rank, world, dims, device=0, halo=None, sharded_octaves=1, stream=None, desc_partial=True, **params):
         import torch
         from . import capi
         nx, ny, nz = dims
         self.rank, self.world, self.dims, self.device = rank, world, dims, device
         self.params = params
+        self.desc_partial = bool(desc_partial)
         self.levels = params.get("num_kp_levels", 3)
-        self.halo = int(halo) if halo is not None else capi.slab_min_halo(**params)
+        self.halo = int(halo) if halo is not None else (capi.slab_min_halo_partial(**params) if desc_partial else capi.slab_min_halo(**params))
         self.noct = octaves_total(nx, ny, nz)
         # octaves sharded as slabs: at most all but none below the fused kernel's minimum extent (40 voxels in x, y: one 32 x 32 tile + the widest half width)
         S = max(1, min(sharded_octaves, self.noct))
@@ -308,7 +361,7 @@ class SlabWorker:
         b = slab_bounds(nz, world, align=1 << S)
         d = (nx, ny, nz)
         for o in range(S):
-            self.stages.append(SlabStage(rank, o, d, b, self.halo, self.noct, device, params))
+            self.stages.append(SlabStage(rank, o, d, b, self.halo, self.noct, device, params, desc_partial=self.desc_partial))
             b = halve_bounds(b, d[2])
             d = (d[0] // 2, d[1] // 2, d[2] // 2)
         self.bounds = self.stages[0].bounds
@@ -349,14 +402,17 @@ class SlabWorker:
 class SlabExtractor:
     """CSIFT3D for a volume sharded over `world` ranks.  `comm.local_ranks()` are the ranks living in this process."""
 
-    def __init__(self, dims, comm, device=0, halo=None, sharded_octaves=2, **params):
+    def __init__(self, dims, comm, device=0, halo=None, sharded_octaves=2, desc_partial=True, **params):
         self.dims, self.comm = dims, comm
+        self.desc_partial = bool(desc_partial)
+        self.kp_counts = {}   # stage -> accepted keypoints per rank of the last run (sizes of the record / histogram messages)
         self.world = comm.world
         import torch
         devs = device if isinstance(device, (list, tuple)) else [device] * len(comm.local_ranks())
         # simulated ranks share ONE stream (their "sends" are copies between the workers' buffers, ordered on that stream)
         shared = torch.cuda.Stream(device=torch.device("cuda", devs[0])) if isinstance(comm, SimComm) else None
-        self.workers = {r: SlabWorker(r, self.world, dims, device=d, halo=halo, sharded_octaves=sharded_octaves, stream=shared, **params)
+        self.workers = {r: SlabWorker(r, self.world, dims, device=d, halo=halo, sharded_octaves=sharded_octaves, stream=shared,
+                                      desc_partial=desc_partial, **params)
                         for r, d in zip(comm.local_ranks(), devs)}
         w0 = next(iter(self.workers.values()))
         self.bounds, self.halo, self.levels, self.noct, self.S = w0.bounds, w0.halo, w0.levels, w0.noct, w0.S
@@ -509,8 +565,12 @@ class SlabExtractor:
             for s in range(self.S):
                 for w in ws:
                     w.stages[s].ctx.detect()
-                for w in ws:
-                    w.stages[s].ctx.describe()
+                if self.desc_partial:
+                    with torch.cuda.stream(cur):
+                        self._describe_partial(s, ws)
+                else:
+                    for w in ws:
+                        w.stages[s].ctx.describe()
             self.times["keypoints_sharded"] = time.perf_counter() - t1
         finally:
             if th is not None:
@@ -520,6 +580,124 @@ class SlabExtractor:
         self.times["tail"] = time.perf_counter() - t2
         self.times["total"] = time.perf_counter() - t0
         return self
+
+    # ---- r05: descriptor windows split along z over the ranks ------------------------------------------------------------------------
+    def _describe_partial(self, s, ws):
+        """Orientation of the owned extrema, then the descriptors of sharded octave s from partial integer histograms (module docstring)."""
+        import torch
+        from . import capi
+        comm = self.comm
+        sts = {w.rank: w.stages[s] for w in ws}
+        for w in ws:
+            sts[w.rank].ctx.orient_launch()
+        counts = comm.allgather_ints([sts[w.rank].ctx.orient_count() for w in ws])
+        self.kp_counts[s] = list(counts)
+        RW = capi.slab_record_words()
+        neigh = window_neighbours(ws[0].stages[s].bounds, ws[0].stages[s].ctx.desc_reach())
+        recs = {}
+        for w in ws:
+            recs[w.rank] = torch.empty((counts[w.rank], RW), dtype=torch.int32, device=w.arena.device)
+            if counts[w.rank]:
+                sts[w.rank].ctx.export_records(recs[w.rank].data_ptr())
+        n_redo, redo, units_next = self._partial_round(ws, sts, neigh, counts, recs, None, False)
+        tot = comm.allgather_ints([n_redo[w.rank] for w in ws])
+        if any(tot):   # rare: records whose first fixed-point unit failed are repeated, by every part, with the exact unit
+            recs2, units2 = {}, {}
+            for w in ws:
+                idx = torch.nonzero(redo[w.rank], as_tuple=False).flatten() if tot[w.rank] else torch.zeros(0, dtype=torch.int64, device=w.arena.device)
+                recs2[w.rank] = recs[w.rank].index_select(0, idx).contiguous()
+                units2[w.rank] = units_next[w.rank].index_select(0, idx).contiguous()
+            self._partial_round(ws, sts, neigh, tot, recs2, units2, True)
+
+    def _partial_round(self, ws, sts, neigh, counts, recs, units, final):
+        import torch
+        from . import capi
+        comm = self.comm
+        RW = capi.slab_record_words()
+        local = {w.rank: w for w in ws}
+        dev = {w.rank: w.arena.device for w in ws}
+        # 1. records (and the second round's units) to the ranks their windows reach into
+        inbox = {q: {} for q in local}
+        items = []
+        for r in range(self.world):
+            for q in neigh[r]:
+                if not counts[r]:
+                    continue
+                a = recs[r] if r in local else None
+                b = torch.empty((counts[r], RW), dtype=torch.int32, device=dev[q]) if q in local else None
+                items.append((r, q, a, b))
+                ub = None
+                if units is not None:
+                    ub = torch.empty(counts[r], dtype=torch.float32, device=dev[q]) if q in local else None
+                    items.append((r, q, units[r] if r in local else None, ub))
+                if q in local:
+                    inbox[q][r] = (b, ub)
+        comm.wait(comm.exchange_tensors(items))
+        # 2. every rank marches its part of the windows -- its own records and the foreign ones -- in one launch
+        parts = {q: {} for q in local}
+        bounds = next(iter(sts.values())).bounds
+        for q in local:
+            lists = []
+            for r in [q] + sorted(neigh[q]):
+                if not counts[r]:
+                    continue
+                rec, un = (recs[q], units[q] if units is not None else None) if r == q else inbox[q][r]
+                h = torch.empty((counts[r], 768), dtype=torch.int32, device=dev[q])
+                m = torch.empty(counts[r], dtype=torch.float32, device=dev[q])
+                lists.append((rec.data_ptr(), counts[r], un.data_ptr() if un is not None else None, h.data_ptr(), m.data_ptr(), bounds[r][0], bounds[r][1]))
+                parts[q][r] = (h, m)
+            sts[q].ctx.describe_partial(lists)
+        # 3. the parts back to their owners
+        got = {r: {} for r in local}
+        items = []
+        for q in range(self.world):
+            for r in neigh[q]:
+                if not counts[r]:
+                    continue
+                ha, ma = parts[q][r] if q in local else (None, None)
+                hb = torch.empty((counts[r], 768), dtype=torch.int32, device=dev[r]) if r in local else None
+                mb = torch.empty(counts[r], dtype=torch.float32, device=dev[r]) if r in local else None
+                items.append((q, r, ha, hb))
+                items.append((q, r, ma, mb))
+                if r in local:
+                    got[r][q] = (hb, mb)
+        comm.wait(comm.exchange_tensors(items))
+        if not comm.stream_ordered:
+            comm.sync()
+        # 4. the owner's finish: the parts' integers are added, the masses in rank order (sift3d_slab_describe_finish)
+        n_redo, redo, units_next = {}, {}, {}
+        for r in local:
+            n = counts[r]
+            redo[r] = torch.zeros(n, dtype=torch.int32, device=dev[r])
+            units_next[r] = torch.zeros(n, dtype=torch.float32, device=dev[r])
+            ps = [parts[r][r] if q == r else got[r][q] for q in sorted(neigh[r] + [r])] if n else []
+            if len(ps) > 6:   # slabs much thinner than a window's reach: more parts than one finish launch takes -- added here, in the same order
+                th, tm = ps[0][0].clone(), ps[0][1].clone()
+                for h, m in ps[1:]:
+                    th += h
+                    tm += m
+                ps = [(th, tm)]
+            n_redo[r] = sts[r].ctx.describe_finish(recs[r].data_ptr() if n else 0, n, [(h.data_ptr(), m.data_ptr()) for h, m in ps],
+                                                   units[r].data_ptr() if (units is not None and n) else None, final,
+                                                   redo[r].data_ptr() if n else None, units_next[r].data_ptr() if n else None)
+        return n_redo, redo, units_next
+
+    def window_bytes(self):
+        """bytes every rank RECEIVED for the partial descriptor windows of the last run (records in, histograms + masses back) -> list per
+        rank; zeros before the first run or without desc_partial"""
+        recv = [0] * self.world
+        if not self.desc_partial:
+            return recv
+        from . import capi
+        rb = capi.slab_record_words() * 4
+        w0 = next(iter(self.workers.values()))
+        for s, counts in self.kp_counts.items():
+            neigh = window_neighbours(w0.stages[s].bounds, w0.stages[s].ctx.desc_reach())
+            for r in range(self.world):
+                for q in neigh[r]:
+                    recv[q] += counts[r] * rb               # r's records arrive at q
+                    recv[r] += counts[r] * (768 * 4 + 4)    # q's part of r's windows comes back
+        return recv
 
     def num_local_keypoints(self):
         """keypoints this process holds records for: the sharded octaves of its slabs (+ the replicated tail records once)"""

@@ -168,8 +168,11 @@ def run_slab(dims, world, rank, local, dev, steps, warmup, sim_ranks=0, seed=432
            "keypoints": count(), "last_step_ms": detail()}
     if nranks > 1:
         res["halo_planes"] = ex.halo
-        hb = ex.halo_bytes()
-        res["halo_GB_received_per_rank_per_step"] = {"max": round(max(hb) / 1e9, 3), "per_side_of_an_inner_rank": round(max(hb) / 2e9, 3)}
+        hb, wb = ex.halo_bytes(), ex.window_bytes()   # plane halos (from the posted plan) + records / partial histograms of the descriptor windows (r05, last step's counts)
+        tot = [a + b for a, b in zip(hb, wb)]
+        res["halo_GB_received_per_rank_per_step"] = {"max": round(max(tot) / 1e9, 3), "per_side_of_an_inner_rank": round(max(tot) / 2e9, 3),
+                                                     "plane_halos_max": round(max(hb) / 1e9, 3), "window_records_and_histograms_max": round(max(wb) / 1e9, 3),
+                                                     "descriptor_windows": "partial integer histograms" if ex.desc_partial else "whole windows on plane halos"}
         res["sharded_octaves"] = ex.S
         res["slab_planes"] = [b[1] - b[0] for b in ex.bounds]
     ex.close()

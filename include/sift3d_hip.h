@@ -207,6 +207,31 @@ int sift3d_slab_get_dogmax(sift3d_handle h, float *max5);          /* local maxi
 int sift3d_slab_set_dogmax(sift3d_handle h, const float *max5);    /* global maxima after the all-reduce */
 int sift3d_slab_detect(sift3d_handle h);                            /* extrema of the owned planes (DoG halos of 1 plane exchanged) */
 int sift3d_slab_describe(sift3d_handle h);                          /* orientation + descriptors; results via sift3d_get_keypoints */
+/* r05 -- descriptor windows split along z over the ranks (no reference counterpart: Src/cSIFT3D.cc:484-502 walks whole windows in one
+ * process).  Instead of the 24 / 30 / 38-plane halos of G[1..3] that whole windows reach, the ranks exchange keypoint RECORDS
+ * (sift3d_slab_record_bytes each) with the z-neighbours within sift3d_slab_desc_reach planes; every rank marches, for its own and for
+ * the foreign records, its part of the window planes (sift3d_slab_describe_partial: 768 int32 sums + the part's gradient mass per record);
+ * the owner adds the parts' integers -- the sums the single-volume run forms -- and the masses in rank order, and finishes
+ * (sift3d_slab_describe_finish).  A record whose fixed-point unit fails is flagged and repeated once by all parts with the exact unit.
+ * sift3d_slab_set_desc_partial makes sift3d_slab_halo_planes answer with the orientation window's reach for G[1..levels]. */
+int sift3d_slab_set_desc_partial(sift3d_handle h, int on);
+int sift3d_slab_min_halo_partial(const sift3d_params *params, int *halo);  /* planes per side a level buffer needs in that mode */
+int sift3d_slab_record_bytes(int *bytes);
+int sift3d_slab_desc_reach(sift3d_handle h, int *planes);
+int sift3d_slab_orient(sift3d_handle h);                            /* orientation of the owned extrema; then sift3d_num_keypoints */
+int sift3d_slab_export_records(sift3d_handle h, void *d_dst);       /* accepted keypoints, processing order, device memory */
+/* nlists record lists in one launch: the rank's own keypoints and those of its z-neighbours.  owner_z0/1[i]: the planes list i's owner owns
+ * (the owner marches the window planes its level buffers hold, every other rank its owned planes outside that range). */
+int sift3d_slab_describe_partial(sift3d_handle h, int nlists, const void *const *d_records, const int *n,
+                                 const float *const *d_units /* NULL, or per list NULL / the second round's units */,
+                                 int *const *d_hist /* [n[i]][768] each */, float *const *d_mass /* [n[i]] each */, const int *owner_z0,
+                                 const int *owner_z1);
+int sift3d_slab_describe_finish(sift3d_handle h, const void *d_records, int n, int nparts /* <= 6 */,
+                                const int *const *d_hist /* the parts of the n records: the owner's and its neighbours', ascending rank */,
+                                const float *const *d_mass, const float *d_units, int final_round, int *d_redo /* [n] out */,
+                                float *d_units_next /* [n] out */, int *n_redo);
+int sift3d_slab_orient_launch(sift3d_handle h);                     /* sift3d_slab_orient as two calls (several ranks in one process) */
+int sift3d_slab_orient_count(sift3d_handle h, int *n_kp);
 /* DownSample_3D of the owned planes of G[octave][num_kp_levels] -> d_dst = (nx/2) x (ny/2) x ((z1-z0)/2) floats (device):
  * the owned planes of level 0 of the next octave (a sharded slab context of octave+1, or the all-gather buffer of the tail) */
 int sift3d_slab_decimate(sift3d_handle h, float *d_dst);

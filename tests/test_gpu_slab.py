@@ -23,19 +23,25 @@ def _single(vol):
     return s
 
 
-@pytest.mark.parametrize("shape,world,sharded", [((128, 128, 128), 2, 1), ((128, 128, 128), 4, 2), ((160, 80, 96), 3, 2),
-                                                 ((128, 128, 128), 2, 2), ((64, 64, 64), 8, 2), ((64, 64, 64), 8, 1)])
-def test_slab_equals_single_volume(shape, world, sharded):
+@pytest.mark.parametrize("shape,world,sharded,partial", [((128, 128, 128), 2, 1, True), ((128, 128, 128), 4, 2, True), ((160, 80, 96), 3, 2, True),
+                                                         ((128, 128, 128), 2, 2, True), ((64, 64, 64), 8, 2, True), ((64, 64, 64), 8, 1, True),
+                                                         ((128, 128, 128), 4, 2, False), ((160, 80, 96), 3, 2, False), ((64, 64, 64), 8, 1, False)])
+def test_slab_equals_single_volume(shape, world, sharded, partial):
+    """partial (r05, the default of the driver): descriptor windows split along z over the ranks -- records out, partial integer
+    histograms back, 13-plane halos; not partial: whole windows on 38-plane halos (r02).  Both bit-identical to the single volume."""
     vol = _volume(shape, seed=11 + world)
     nz, ny, nx = shape
     ref = _single(vol)
     kp_ref, ds_ref = ref.GetKeypoints()
     assert len(kp_ref) > 10
 
-    ex = slab.SlabExtractor((nx, ny, nz), slab.SimComm(world), sharded_octaves=sharded)
+    ex = slab.SlabExtractor((nx, ny, nz), slab.SimComm(world), sharded_octaves=sharded, desc_partial=partial)
     assert ex.S == sharded
+    assert ex.halo == (13 if partial else 38)
     ex.load(volume=vol)
     ex.KpSiftAlgorithm()
+    if partial:
+        assert sum(ex.window_bytes()) > 0
 
     # pyramids of the sharded octaves: owned planes of every level, bit for bit
     ng, nd = ref.levels + 3, ref.levels + 2
@@ -98,6 +104,31 @@ def test_random_slab_plans_equal_the_single_volume():
         ex.close(); ref.close()
         done += 1
     assert done == 8
+
+
+def test_partial_windows_second_round_with_the_exact_unit():
+    """The hook desc_mass_shift makes the first fixed-point unit of EVERY keypoint too fine (the estimate of the gradient mass is divided by
+    2^s), so every record is flagged by its owner and repeated by all parts with the exact unit (the second exchange of the partial
+    descriptor windows); the single-volume run takes its own second pass under the same hook.  Bit-identical descriptors."""
+    shape, world = (128, 128, 128), 4
+    vol = _volume(shape, seed=23)
+    nz, ny, nx = shape
+    with capi.hook("desc_mass_shift", 9):
+        ref = _single(vol)
+        kp_ref, ds_ref = ref.GetKeypoints()
+        assert ref.debug_counters()["desc_second_passes"] > len(kp_ref) // 4
+        ex = slab.SlabExtractor((nx, ny, nz), slab.SimComm(world), sharded_octaves=2)
+        ex.load(volume=vol)
+        ex.KpSiftAlgorithm()
+        redone = sum(st.ctx.debug_counters()["desc_second_passes"] for w in ex._wl() for st in w.stages)
+        kp, ds = ex.GetKeypoints()
+    assert redone > 10
+    assert len(kp) == len(kp_ref) > 50
+    for f in kp_ref.dtype.names:
+        assert np.array_equal(kp[f], kp_ref[f]), f
+    assert np.array_equal(ds, ds_ref)
+    ex.close()
+    ref.close()
 
 
 def test_config3_1024x1024x512_eight_slabs_equal_the_single_volume():

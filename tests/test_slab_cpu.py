@@ -173,3 +173,106 @@ def test_gloo_world2_halo_exchange_and_reductions():
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_window_neighbours_plan():
+    """r05: which ranks take part in the descriptor windows of a rank's keypoints (owned planes within the window's reach)"""
+    b = slab.slab_bounds(512, 8, align=4)          # 64-plane slabs, reach 39: one neighbour either side
+    n = slab.window_neighbours(b, 39)
+    assert n[0] == [1] and n[3] == [2, 4] and n[7] == [6]
+    b2 = slab.halve_bounds(b, 512)                 # 32-plane slabs of octave 1: two hops
+    n2 = slab.window_neighbours(b2, 39)
+    assert n2[0] == [1, 2] and n2[4] == [2, 3, 5, 6]
+    for nn in (n, n2):                             # symmetric
+        for r, qs in enumerate(nn):
+            assert all(r in nn[q] for q in qs)
+    assert slab.window_neighbours([(0, 10), (10, 10), (10, 30)], 5) == [[2], [], [0]]   # an empty slab takes no part
+
+
+PARTIAL_WORKER = textwrap.dedent("""
+    import ctypes, importlib, os, sys, types, numpy as np, torch
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    d = importlib.import_module("3dsift_amd.dist")
+    slab = importlib.import_module("3dsift_amd.slab")
+    capi = importlib.import_module("3dsift_amd.capi")
+    rank, world = d.init_from_env(backend="gloo")
+    RW = capi.slab_record_words()
+
+    def arr(ptr, n, ct, dt):
+        return np.frombuffer((ct * n).from_address(ptr), dtype=dt) if n else np.zeros(0, dt)
+
+    class FakeCtx:
+        # the z part of rank `me`: hist[k][e] = 1000 * record id + 10 * me + e %% 7 (+ 500 with a second-round unit), mass = id + me / 8
+        def __init__(self, me): self.me, self.finished = me, []
+        def describe_partial(self, lists):
+            assert lists[0][5:7] == bounds[self.me]                 # this rank's own list comes first ...
+            assert [t[5:7] for t in lists[1:]] == [bounds[1 - self.me]]   # ... then its neighbour's, each with its owner's planes
+            for rec_ptr, n, units_ptr, hist_ptr, mass_ptr, _z0, _z1 in lists:
+                rec = arr(rec_ptr, n * RW, ctypes.c_int32, np.int32).reshape(n, RW)
+                h = arr(hist_ptr, n * 768, ctypes.c_int32, np.int32).reshape(n, 768)
+                m = arr(mass_ptr, n, ctypes.c_float, np.float32)
+                un = arr(units_ptr, n, ctypes.c_float, np.float32) if units_ptr else None
+                for k in range(n):
+                    h[k] = 1000 * rec[k, 0] + 10 * self.me + np.arange(768) %% 7 + (500 if un is not None and un[k] == 0.25 else 0)
+                    m[k] = rec[k, 0] + self.me / 8.0
+        def describe_finish(self, rec_ptr, n, parts, units_ptr=None, final_round=False, redo_ptr=None, units_next_ptr=None):
+            rec = arr(rec_ptr, n * RW, ctypes.c_int32, np.int32).reshape(n, RW).copy() if n else np.zeros((0, RW), np.int32)
+            assert len(parts) == (2 if n else 0)            # the owner's part and its neighbour's, ascending rank
+            h = sum(arr(hp, n * 768, ctypes.c_int32, np.int32).reshape(n, 768).astype(np.int64) for hp, _ in parts) if n else None
+            m = None
+            for _, mp in parts:                              # (the library adds the masses in the order given)
+                t = arr(mp, n, ctypes.c_float, np.float32).copy()
+                m = t if m is None else (m + t).astype(np.float32)
+            self.finished.append((rec, h, m, final_round))
+            k = 0
+            if n and not final_round:
+                redo = arr(redo_ptr, n, ctypes.c_int32, np.int32); nxt = arr(units_next_ptr, n, ctypes.c_float, np.float32)
+                for i in range(n):
+                    if rec[i, 1] == 1: redo[i] = 1; nxt[i] = 0.25; k += 1
+            return k
+
+    bounds = [(0, 20), (20, 40)]
+    neigh = slab.window_neighbours(bounds, 6)
+    assert neigh == [[1], [0]]
+    counts = [3, 2]
+    me = types.SimpleNamespace(rank=rank, arena=types.SimpleNamespace(device=torch.device("cpu")))
+    ctx = FakeCtx(rank)
+    sts = {rank: types.SimpleNamespace(ctx=ctx, bounds=bounds)}
+    rec = torch.zeros((counts[rank], RW), dtype=torch.int32)
+    rec[:, 0] = 100 * (rank + 1) + torch.arange(counts[rank], dtype=torch.int32)   # record id
+    rec[:, 1] = torch.tensor([0, 1, 0][: counts[rank]], dtype=torch.int32)          # "the first unit fails"
+    ex = types.SimpleNamespace(comm=slab.DistComm(), world=world)
+    n_redo, redo, units_next = slab.SlabExtractor._partial_round(ex, [me], sts, neigh, counts, {rank: rec}, None, False)
+    assert n_redo[rank] == 1 and redo[rank].tolist() == [0, 1, 0][: counts[rank]]
+    frec, h, m, fin = ctx.finished[0]
+    assert not fin and np.array_equal(frec, rec.numpy())
+    for k in range(counts[rank]):
+        rid = int(rec[k, 0])
+        assert np.array_equal(h[k], 2 * 1000 * rid + 10 * (0 + 1) + 2 * (np.arange(768) %% 7)), (rank, k)     # both parts' integers
+        assert m[k] == np.float32(np.float32(rid + 0 / 8.0) + np.float32(rid + 1 / 8.0))                       # masses in rank order
+    tot = ex.comm.allgather_ints([n_redo[rank]])
+    assert tot == [1, 1]
+    idx = torch.nonzero(redo[rank]).flatten()
+    rec2, un2 = rec.index_select(0, idx).contiguous(), units_next[rank].index_select(0, idx).contiguous()
+    slab.SlabExtractor._partial_round(ex, [me], sts, neigh, tot, {rank: rec2}, {rank: un2}, True)
+    frec, h, m, fin = ctx.finished[1]
+    assert fin and len(frec) == 1 and int(frec[0, 0]) == 100 * (rank + 1) + 1
+    assert np.array_equal(h[0], 2 * 1000 * int(frec[0, 0]) + 10 + 2 * (np.arange(768) %% 7) + 1000)   # both parts saw the owner's unit
+    dist.barrier()
+    print("rank", rank, "ok")
+""") % ROOT
+
+
+def test_gloo_world2_partial_descriptor_windows_protocol():
+    """r05: records to the z-neighbours, partial integer histograms + masses back, the owner's sums in rank order, the second round of
+    the flagged records with the owner's units -- the driver code of slab.py over gloo with a stand-in for the device context."""
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", PARTIAL_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
