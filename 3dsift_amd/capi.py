@@ -55,7 +55,7 @@ SYMBOLS = [
     "sift3d_test_hook", "sift3d_debug_counters", "sift3d_debug_face_lookup", "sift3d_match_times", "sift3d_debug_copy_bandwidth",
 ]
 HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "desc_nocache": 4, "match_nodma": 5, "one_stream": 6,
-         "desc_mass_shift": 7, "list_cap": 8, "peer_copy": 9, "desc_nosplit": 10, "march_tiles": 11, "desc_exact_cells": 12}
+         "desc_mass_shift": 7, "list_cap": 8, "peer_copy": 9, "desc_nosplit": 10, "march_tiles": 11, "desc_exact_cells": 12, "lazy_generic": 13}
 ORIENT_WORDS = 34
 
 

@@ -290,19 +290,107 @@ __device__ __forceinline__ void lazy_tap_src(int p, int d, int n, int &lo, int &
 constexpr int kLT = kLazySlots / 2 - 1;   // taps at most (17)
 constexpr int kLR = kLT + 1;              // real samples an axis reads: one contiguous range of at most 2 hw + 2 indices
 constexpr int kLP = kLR + 1;              // x pitch of the staged block (odd: lanes = rows read conflict-free)
-#ifndef S3D_LAZY_BATCHES
-#define S3D_LAZY_BATCHES 1  /* the 17^3 block of a candidate is requested in this many batches (1: 20 loads per thread in flight, 201 registers, two workgroups per CU) */
-#endif
-#ifndef S3D_LAZY_OCC
-#define S3D_LAZY_OCC 2
-#endif
-__global__ void __launch_bounds__(256, S3D_LAZY_OCC) k_lazy_next(DetectLevels L, Taps t, int nx, int ny, ZRange zr, int nyb,
+// ---- r05: k_lazy_wave -- ONE WAVE per parked candidate that is interior along all three axes, default half width 8 ----
+// (r02-r04: one 256-thread workgroup per candidate, 189 registers, two workgroups per CU, five barriers, y-blur on 17 threads and z-blur
+// on one: ~15 us per candidate with 512 candidates in flight -- 1.3 ms of kernel time per 512^3 step over three queues, 0.29 ms of it on
+// the detection stage's critical path.)  The 17 x 17 rows of 17 samples the three passes reach travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no registers, all 23 instructions of a candidate in flight at once): a row is staged as FIVE 16-byte pieces
+// (20 floats: the 17 samples and three more, shifted left where they would cross the end of the row), piece p = 5 * row + q of the
+// wave's buffer, lane constants for the 23 offsets.  Then 289 x-chains (lane = row, five rounds), 17 y-chains, one z-chain: the chains
+// of k_conv_axis's interior rule, acc = acc + tap[k] * sample(p - (k - hw)) for k = 0 .. 2 hw, bit for bit; a row's result overwrites the
+// row's first sample (only the row's own lane reads it).  23.5 KB of LDS per wave, two waves per workgroup, three workgroups per CU.
+constexpr int kLwN = 17, kLwPieces = kLwN * kLwN * 5, kLwInstr = (kLwPieces + 63) / 64, kLwFloats = kLwInstr * 256, kLwWaves = 2;
+__global__ void __launch_bounds__(64 * kLwWaves) k_lazy_wave(DetectLevels L, Taps t, int nx, int ny, ZRange zr, int nyb,
+                                                            const unsigned *__restrict__ prov, const unsigned *__restrict__ prov_count,
+                                                            unsigned prov_cap, unsigned long long *__restrict__ masks,
+                                                            unsigned *__restrict__ block_counts) {
+	__shared__ __attribute__((aligned(1024))) float s_buf[kLwWaves][kLwFloats];
+	constexpr int H = 8, N = kLwN;
+	const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	float *blk = s_buf[wid];
+	const unsigned lds_base = (unsigned)(size_t)blk;  // LDS byte address of the wave's buffer
+	const unsigned count = min(*prov_count, prov_cap);
+	const int lvl = L.nextl_slot;
+	const float *__restrict__ src = L.lazy_src;
+	const float *__restrict__ cur = L.cur[lvl];
+	const int wpr = (nx + 63) >> 6, nzs = zr.zo1 - zr.zo0, nzg = zr.nzg;
+	const size_t sy = (size_t)nx, sz = (size_t)nx * ny;
+	// byte offset of this lane's piece of DMA instruction j from the block's first sample (lane constants: the block's shape is fixed)
+	unsigned voff[kLwInstr];
+#pragma unroll
+	for (int j = 0; j < kLwInstr; j++) {
+		const int p = min(64 * j + lane, kLwPieces - 1), row = p / 5, q = p - 5 * row, zi = row / N, yi = row - zi * N;
+		voff[j] = (unsigned)(((size_t)zi * sz + (size_t)yi * sy + (size_t)(4 * q)) * sizeof(float));
+	}
+	const unsigned nwaves = gridDim.x * kLwWaves;
+	for (unsigned e = blockIdx.x * kLwWaves + (unsigned)wid; e < count; e += nwaves) {  // wave-uniform
+		const unsigned ent = prov[e];
+		const size_t ic = (size_t)(ent & 0x7FFFFFFFu);
+		const bool as_max = (ent >> 31) != 0;
+		const int zl = (int)(ic / sz), rem = (int)(ic - (size_t)zl * sz), y = rem / nx, x = rem - y * nx;
+		const int zg = zl + zr.zoff;  // global plane
+		if (!(x >= H && x <= nx - 2 - H && y >= H && y <= ny - 2 - H && zg >= H && zg <= nzg - 2 - H)) continue;  // k_lazy_next's
+		// the 20 floats of a row start at x - 8 - shift: shift = how far x + 11 would reach beyond the row's last sample
+		const int shift = max(0, x + 11 - (nx - 1));
+		const float *base = src + ic - (size_t)H * sz - (size_t)H * sy - (size_t)(H + shift);
+#pragma unroll
+		for (int j = 0; j < kLwInstr; j++) {
+			unsigned keep;
+			asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+			             : "=&s"(keep) : "v"(voff[j]), "s"(base), "s"(lds_base + 1024u * (unsigned)j) : "memory");
+		}
+		const float centre = src[ic], v = cur[ic];
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_wave_barrier();
+		// x-blur: tap k reads x - (k - H), i.e. sample 2H - k of the row (+ shift)
+#pragma unroll
+		for (int rq = 0; rq < (N * N + 63) / 64; rq++) {
+			const int row = min(lane + 64 * rq, N * N - 1);
+			const float *r = blk + row * 20 + shift;
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < N; k++) acc = acc + t.w[k] * r[2 * H - k];
+			if (lane + 64 * rq < N * N) blk[row * 20] = acc;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		{  // y-blur per plane: lanes 0 .. 16 (the others repeat plane 16's chain and store nothing)
+			const int pl = min(lane, N - 1);
+			const float *c = blk + pl * N * 20;
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < N; k++) acc = acc + t.w[k] * c[(2 * H - k) * 20];
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			if (lane < N) blk[pl * N * 20] = acc;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		{
+			float acc = 0.0f;
+#pragma unroll
+			for (int k = 0; k < N; k++) acc = acc + t.w[k] * blk[(2 * H - k) * N * 20];
+			const float n7 = (acc - centre) * (-1.0f);  // Sub, Src/cSIFT3D.cc:875
+			if (lane == 0 && (as_max ? (v > n7) : (v < n7))) {
+				const int zi = zl - zr.zo0;
+				atomicOr(&masks[((size_t)(lvl * nzs + zi) * ny + y) * wpr + (x >> 6)], 1ull << (x & 63));
+				atomicAdd(&block_counts[(lvl * nzs + zi) * nyb + y / kRows], 1u);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();  // the buffer is rewritten by the next candidate's DMA
+	}
+}
+
+// the other parked candidates (next to a border of the level, or half widths other than 8): one WORKGROUP per candidate
+__global__ void __launch_bounds__(256) k_lazy_next(DetectLevels L, Taps t, int nx, int ny, ZRange zr, int nyb,
                                                    const unsigned *__restrict__ prov, const unsigned *__restrict__ prov_count,
                                                    unsigned prov_cap, unsigned long long *__restrict__ masks,
-                                                   unsigned *__restrict__ block_counts) {
-	// one WORKGROUP per parked candidate: the block of real samples the three passes reach (at most 18^3 voxels, rows contiguous in
-	// memory) is staged in LDS with coalesced loads -- one wave per candidate with a window per lane touched 64 cache lines per load
-	// instruction and was bound by the texture addresser (0.45 ms per 512^3 run) -- then x-blur per (row, plane), y-blur per plane, z-blur
+                                                   unsigned *__restrict__ block_counts, int skip_interior) {
+	// the block of real samples the three passes reach (at most 18^3 voxels, rows contiguous in memory) is staged in LDS with
+	// coalesced loads, then x-blur per (row, plane), y-blur per plane, z-blur
 	__shared__ float s_blk[kLR * kLR * kLP];
 	__shared__ float s_x[kLR * kLR];
 	__shared__ float s_y[kLR];
@@ -326,65 +414,7 @@ __global__ void __launch_bounds__(256, S3D_LAZY_OCC) k_lazy_next(DetectLevels L,
 		const int zg = zl + zr.zoff;  // global plane
 		const bool ix = x >= hw && x <= nx - 2 - hw, iy = y >= hw && y <= ny - 2 - hw, iz = zg >= hw && zg <= nzg - 2 - hw;
 		__syncthreads();  // the previous candidate is finished with the LDS arrays
-		if (hw == 8 && ix && iy && iz) {
-			// interior voxel, default half width (block-uniform): the block is exactly 17^3, every index is a compile-time constant --
-			// no tap tables, the LDS reads of a chain are independent of each other
-			constexpr int H = 8, N = 17;
-			const float *base = src + ic - (size_t)H * sz - (size_t)H * sy - (size_t)H;
-			{
-				// all loads of a thread first, then the LDS writes: a load -> store loop serialises on the memory latency (20 round trips)
-				constexpr int NS = (N * N * N + 255) / 256, NB = S3D_LAZY_BATCHES, NSB = (NS + NB - 1) / NB;
-#pragma unroll
-				for (int bq = 0; bq < NB; bq++) {
-					float v[NSB];
-#pragma unroll
-					for (int q = 0; q < NSB; q++) {
-						const int i = min(tid + 256 * (bq * NSB + q), N * N * N - 1);
-						const int xi = i % N, r = i / N, yi = r % N, zi2 = r / N;
-						v[q] = base[sz * (size_t)zi2 + sy * (size_t)yi + (size_t)xi];
-					}
-#pragma unroll
-					for (int q = 0; q < NSB; q++) {
-						const int i = tid + 256 * (bq * NSB + q);
-						if (i < N * N * N) {
-							const int xi = i % N, r = i / N, yi = r % N, zi2 = r / N;
-							s_blk[(zi2 * kLR + yi) * kLP + xi] = v[q];
-						}
-					}
-				}
-			}
-			__syncthreads();
-			for (int s = tid; s < N * N; s += 256) {
-				const int zi2 = s / N, yi = s - zi2 * N;
-				const float *row = &s_blk[(zi2 * kLR + yi) * kLP];
-				float acc = 0.0f;
-#pragma unroll
-				for (int k = 0; k < N; k++) acc = acc + t.w[k] * row[2 * H - k];  // tap k reads x - (k - H)
-				s_x[zi2 * kLR + yi] = acc;
-			}
-			__syncthreads();
-			if (tid < N) {
-				const float *col = &s_x[tid * kLR];
-				float acc = 0.0f;
-#pragma unroll
-				for (int k = 0; k < N; k++) acc = acc + t.w[k] * col[2 * H - k];
-				s_y[tid] = acc;
-			}
-			__syncthreads();
-			if (tid == 0) {
-				float acc = 0.0f;
-#pragma unroll
-				for (int k = 0; k < N; k++) acc = acc + t.w[k] * s_y[2 * H - k];
-				const float n7 = (acc - src[ic]) * (-1.0f);  // Sub, Src/cSIFT3D.cc:875
-				const float v = cur[ic];
-				if (as_max ? (v > n7) : (v < n7)) {
-					const int zi = zl - zr.zo0;
-					atomicOr(&masks[((size_t)(lvl * nzs + zi) * ny + y) * wpr + (x >> 6)], 1ull << (x & 63));
-					atomicAdd(&block_counts[(lvl * nzs + zi) * nyb + y / kRows], 1u);
-				}
-			}
-			continue;
-		}
+		if (skip_interior && ix && iy && iz) continue;  // k_lazy_wave's candidate (block-uniform)
 		if (tid < 3 * nt) {  // tap tables of the three axes (boundary_term's source samples; interior: lo = hi = p - d, frac 0)
 			const int ax = tid / nt, k = tid - ax * nt;
 			int lo, hi; float fr;
@@ -649,9 +679,16 @@ void launch_detect_mark(const DetectLevels &L, int nlevels, int nx, int ny, cons
 	const size_t mask_lds = sizeof(unsigned long long) * (kThreads / 64) * (kRows / 4) * (size_t)std::min((nx + 63) >> 6, 64);
 	hipLaunchKernelGGL(k_mark, dim3(nblocks), dim3(kThreads), mask_lds, st, L, nx, ny, zr, nyb, peak_thresh, b.masks, b.block_counts, b.prov,
 	                   b.prov_count, b.prov_cap, b.total);
-	static const int lazy_grid = dev_tune_i("S3D_LAZY_GRID", 256 * S3D_LAZY_OCC);  // = the resident workgroups (201 VGPRs: two per CU); 512 / 1280 / 5120: detection 0.95 / 0.99 / 1.02 ms
-	if (lazy) hipLaunchKernelGGL(k_lazy_next, dim3(lazy_grid), dim3(256), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
-	                             b.masks, b.block_counts);
+	if (lazy) {
+		// interior candidates of the default half width: one wave each (k_lazy_wave: 768 workgroups of two waves are resident); the rest
+		// (next to a border, other half widths): one workgroup each
+		const bool wave_form = lazy_taps->hw == 8 && !hook(SIFT3D_HOOK_LAZY_GENERIC);
+		if (wave_form)
+			hipLaunchKernelGGL(k_lazy_wave, dim3(256 * 3), dim3(64 * kLwWaves), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
+			                   b.masks, b.block_counts);
+		hipLaunchKernelGGL(k_lazy_next, dim3(wave_form ? 256 : 1024), dim3(256), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
+		                   b.masks, b.block_counts, wave_form ? 1 : 0);
+	}
 	static const bool dbg = dev_tune_i("S3D_LAZY_DEBUG", 0) != 0;
 	if (lazy && dbg) {
 		unsigned n = 0;

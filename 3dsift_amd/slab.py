@@ -218,6 +218,10 @@ class DistComm:
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.stream_ordered = dist.get_backend() == "nccl"
+        # the replicated tail runs on a second host thread and has its own collective (the integer SUM all-reduce of the orientation
+        # rows) while the main thread exchanges the records / partial histograms of the sharded octaves' descriptor windows (r05):
+        # operations of ONE communicator must be issued in the same order on every rank, so the tail gets its own
+        self.tail_group = dist.new_group(ranks=list(range(self.world)))
 
     def local_ranks(self):
         return [self.rank]
@@ -297,7 +301,7 @@ class DistComm:
     def allreduce_sum_(self, per_worker_tensor):
         t = per_worker_tensor[0]
         if t.numel():
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.tail_group)   # (the tail's thread: see __init__)
 
     def gather_objects(self, per_worker):
         out = [None] * self.world

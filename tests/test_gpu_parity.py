@@ -374,6 +374,23 @@ def test_small_octave_launch_checks_every_octave(capi, orc, params, eager):
         assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema()))
 
 
+def test_lazy_last_level_wave_form_matches_the_workgroup_form(capi, orc, synth):
+    """The last Gaussian level is evaluated only at the parked candidates of the last keypoint level (Src/cSIFT3D.cc:889-896 reads its
+    centre value through DoG[nd-1]): interior candidates one WAVE each (k_lazy_wave, r05: LDS-DMA staged 17^3 block), candidates next to a
+    border one workgroup each (k_lazy_next); the hook lazy_generic sends all of them down the workgroup form.  Same extrema either way,
+    and equal to the oracle's; shapes with rows shorter than x + 11 (the staged row is shifted) and a noise volume dense in candidates."""
+    rng = np.random.default_rng(9)
+    for vol in (synth.blobs((96, 80, 72), seed=5, noise=0.02), rng.random((64, 56, 120), dtype=np.float32), synth.blobs((40, 128, 44), seed=6, noise=0.01)):
+        g = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+        with capi.hook("lazy_generic", 1):
+            h = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+        o = orc.extractor(vol).run(3)
+        a, b, c = extrema_table(g.extrema()), extrema_table(h.extrema()), extrema_table(o.extrema())
+        assert len(a) > 20 and np.array_equal(a, b) and np.array_equal(a, c)
+        lvl3 = int((a[:, 1] == 3).sum())
+        assert lvl3 > 0, "no extremum of the last keypoint level: the lazy level was not exercised"
+
+
 def test_separable_kernels_match_fused(capi, synth):
     """hook separable: every level by the generic three-pass kernels (the path of half widths without a fused instantiation)"""
     vol = synth.blobs((64, 96, 72), seed=13, noise=0.01)
