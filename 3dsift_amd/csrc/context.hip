@@ -678,7 +678,7 @@ static int create_common(sift3d_handle *out, const CreateCfg &cfg, const sift3d_
 		// launch of one of its kernels: ~1 ms of the first KpSiftAlgorithm of a process went there, scripts/step_times_probe.py)
 		static std::atomic<unsigned long long> loaded{0};
 		const unsigned long long bit = 1ull << (device & 63);
-		if (!(loaded.fetch_or(bit) & bit)) { preload_march_kernels(); preload_small_kernels(); preload_detect_kernels(); preload_orient_kernels(); }
+		if (!(loaded.fetch_or(bit) & bit)) { preload_march_kernels(); preload_small_kernels(); preload_detect_kernels(); preload_orient_kernels(); preload_desc_kernels(); preload_match_kernels(); }
 	}
 	*out = c;
 	return SIFT3D_OK;

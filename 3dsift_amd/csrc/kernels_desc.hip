@@ -1141,4 +1141,6 @@ void launch_finalize(const DevKp *kps, const unsigned *d_count, unsigned cap, in
 	hipLaunchKernelGGL(k_finalize, dim3(256), dim3(256), 0, st, kps, d_count, cap, transposed, d_out, d_xyz, kp_cap);
 }
 
+void preload_desc_kernels() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_finalize)); }  // (see kernels_march.hip)
+
 }  // namespace s3d

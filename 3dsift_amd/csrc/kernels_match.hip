@@ -770,6 +770,23 @@ size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 namespace s3d { int match_redo_rows() { return t_match_redo_rows; } }
 
+// First use of the matcher on a device, ahead of time (muBruteMatcher's constructor, sift3d_create): the translation unit's code object is
+// loaded (HIP loads it at the first launch of one of its kernels: the first pass of a process took 2.48 ms instead of 1.70), the
+// stream and the events exist.  Never fails loudly: a device that cannot be prepared fails in sift3d_match.
+namespace s3d {
+void preload_match_kernels() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_scores_topk2)); }
+}
+extern "C" int sift3d_match_warmup(int device) {
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_last_error("no HIP device visible: no CPU fallback"); return SIFT3D_ERR_NO_DEVICE; }
+	if (device < 0 || device >= ndev || device >= kMaxDev) return SIFT3D_ERR_ARG;
+	S3D_HIP(hipSetDevice(device));
+	s3d::preload_match_kernels();
+	MatchState &S = g_match[device];
+	std::lock_guard<std::mutex> lock(S.mu);
+	return ensure(S, 0, 0, 0);  // (stream and events; the scratch is sized by the first call)
+}
+
 extern "C" int sift3d_match_times(double *device_seconds, double *wall_seconds) {
 	if (device_seconds) *device_seconds = t_match_dev;
 	if (wall_seconds) *wall_seconds = t_match_wall;

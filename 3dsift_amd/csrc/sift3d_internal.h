@@ -294,6 +294,8 @@ void preload_march_kernels();
 void preload_small_kernels();
 void preload_detect_kernels();
 void preload_orient_kernels();
+void preload_desc_kernels();
+void preload_match_kernels();
 
 // ---- test hooks and development switches --------------------------------------------------------
 // Test hooks (include/sift3d_hip.h, sift3d_test_hook): process-wide integers that force code paths ordinary inputs rarely

@@ -9,7 +9,7 @@
 
 namespace CPUSIFT {
 
-muBruteMatcher::muBruteMatcher() {}
+muBruteMatcher::muBruteMatcher() { (void)sift3d_match_warmup(0); }  // the matcher's kernels, stream and scratch exist before the first call
 float muBruteMatcher::getCalculationTime() { return totalTime; }
 std::vector<float> muBruteMatcher::getGlodenDistSquare() { return glodenDistSquare; }
 std::vector<float> muBruteMatcher::getSilverDistSquare() { return silverDistSquare; }

@@ -154,6 +154,8 @@ int sift3d_match_handles(sift3d_handle ref, sift3d_handle tar, double thresHold,
  * (what *seconds returned), wall_seconds = host clock around the whole call (scratch reuse, H2D of host inputs, the O(N) host
  * bookkeeping of Src/cMatcher.cc:81-144 and the D2H of the results included) */
 int sift3d_match_times(double *device_seconds, double *wall_seconds);
+/* muBruteMatcher's constructor (Include/cMatcher.h:30): the matcher's kernels, stream and first scratch exist before the first call */
+int sift3d_match_warmup(int device);
 
 int sift3d_device_count(int *n);
 
