@@ -799,11 +799,10 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 		// Enqueue order: head(0), head(1), tail(0), head(2), tail(1), ... -- head(o) = the levels of octave o up to its seed level
 		// G[o][num_kp_levels], tail(o) = the levels behind it.  The critical path of the stage is the chain of heads (every octave
 		// waits for the seed level of the one above); the tail of octave 0 (its widest Gaussian) is machine-filling work that is off
-		// that path and starts together with head(1).  Measured and rejected (r03, S3D_DEFER_TAIL=1): tail(0) waiting for the seed of
+		// that path and starts together with head(1).  Measured and rejected (r03, again r04): tail(0) waiting for the seed of
 		// octave 1, so that head(1) -- 351 us alone, 604 us beside tail(0) in the rocprofv3 timeline -- runs undisturbed and tail(0)
 		// fills the machine under the launch-latency chain of the small octaves instead: 2.36 -> 2.51 ms at 512^3 for every slot
 		// planning tried (the tail is longer than that chain).
-		static const int defer_tail = dev_tune_i("S3D_DEFER_TAIL", 0);
 		std::vector<char> half_written((size_t)c->noct + 1, 0);  // level 0 of octave o was written by the seed level's kernel of octave o - 1
 		// r04: the SMALL octaves (16^3-class and below) run in ONE launch of one workgroup that keeps the octave in LDS
 		// (kernels_small.hip) instead of ~16 launches of a few microseconds per octave on the stage's critical chain
@@ -892,7 +891,6 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_fork, 0));
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[o - 1], 0));
 			}
-			if (!head && o == 0 && defer_tail && c->noct > 1) S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[1], 0));
 			if (!head && o >= 1 && ((c->cstream != nullptr && chain_on) || tail_moved)) {  // the levels behind the seed level: the octave's own stream, behind its head on the chain stream
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_fork, 0));
 				S3D_HIP(hipStreamWaitEvent(so, c->ev_seed[o], 0));
@@ -933,7 +931,6 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 		// (ev[1] is recorded on the second detection stream after it has waited for all of them), so the stage times stay honest:
 		// the pyramid's is its wall time, the detection's is what is left of it behind the pyramid.
 		const bool two = upto >= 3 && c->det_o.size() > 1;  // masks of octaves >= 1 on a second stream beside octave 0's
-		static const int det_three_mode = dev_tune_i("S3D_DET_THREE", 1);
 #ifndef S3D_DET_EARLY_DEFAULT
 #define S3D_DET_EARLY_DEFAULT 1  /* r04: ON -- with the small octaves in one launch the chain no longer starves behind k_mark's workgroups: detection 0.87 -> 0.82 ms, pyramid 2.18 -> 2.19 ms, step 7.41 -> 7.38 ms (r03, ~60 chain launches: detection 0.87 -> 0.73 but pyramid 2.31 -> 2.40, off) */
 #endif
@@ -983,7 +980,7 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 				// late r04: the masks of the octaves >= 2 (twelve launches of a few microseconds at 512^3) on a THIRD stream beside octave
 				// 1's: they used to queue behind octave 1's candidate pass (0.35 ms beside octave 0's masks) and ended the stage 0.13 ms
 				// after octave 0's emit (profiles/r04e_timeline_full.txt); every octave has its own scratch
-				hipStream_t sc = (det_three_mode != 0 && c->noct > 2 && c->ostream.size() > 2 && c->ostream[2] != st && c->ostream[2] != sb) ? c->ostream[2] : sb;
+				hipStream_t sc = (c->noct > 2 && c->ostream.size() > 2 && c->ostream[2] != st && c->ostream[2] != sb) ? c->ostream[2] : sb;
 				if (sc != sb) { S3D_HIP(hipEventRecord(c->ev_det_fork2, sb)); S3D_HIP(hipStreamWaitEvent(sc, c->ev_det_fork2, 0)); }  // every pyramid is complete
 				for (int o = 1; o < c->noct; o++) {
 					const Level &C = c->dog[(size_t)o * c->nd + 1];

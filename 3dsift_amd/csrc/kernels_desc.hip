@@ -999,10 +999,8 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
                      const unsigned *d_nkp, unsigned *d_work, hipStream_t st, bool lut_in_lds, const DescSplit *split) {
 	(void)hipMemsetAsync(d_work, 0, 2 * sizeof(unsigned), st);
 	DescSplit sp{};
-	static const int split_on = dev_tune_i("S3D_DESC_SPLIT", 1);
-	if (split && split->gacc && split_on && lut_in_lds && !hook(SIFT3D_HOOK_DESC_NOSPLIT)) sp = *split;
+	if (split && split->gacc && lut_in_lds && !hook(SIFT3D_HOOK_DESC_NOSPLIT)) sp = *split;
 	static const int desc_grid = dev_tune_i("S3D_DESC_GRID", 256 * 8);  // persistent workgroups (work counter)
-	static const unsigned dyn_lds = (unsigned)dev_tune_i("S3D_DESC_DYNLDS", 0);  // unused dynamic LDS per workgroup (occupancy experiments)
 	const int dev_flags = (hook(SIFT3D_HOOK_DESC_NOCACHE) ? 1 : 0) | (hook(SIFT3D_HOOK_DESC_EXACT_CELLS) ? 2 : 0) | (hook(SIFT3D_HOOK_DESC_MASS_SHIFT) & 63) << 8;
 	// few keypoints: eight waves per keypoint (see k_describe); the count lives on the device, so both variants are launched
 	// keypoint counts [wide_lo, wide_hi) take the eight-wave variant of r03; below wide_lo a window is split over 8 / 4 four-wave
@@ -1010,7 +1008,7 @@ void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, co
 	// 0.41 with eight waves; from ~700 keypoints the eight-wave variant is ahead: 0.49 vs 0.51-0.58 ms at 1096)
 	const unsigned wide_hi = kWideBelow, wide_lo = sp.gacc ? std::min(kSplit4Below, wide_hi) : 0u;
 	if (lut_in_lds) {
-		hipLaunchKernelGGL((k_describe<true, 256>), dim3(desc_grid), dim3(256), dyn_lds, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
+		hipLaunchKernelGGL((k_describe<true, 256>), dim3(desc_grid), dim3(256), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,
 		                   part_rank, part_world, order, d_nkp, d_work, dev_flags, wide_lo, wide_hi, sp, DescPartial{});
 		if (wide_hi > wide_lo)
 			hipLaunchKernelGGL((k_describe<true, 512>), dim3(256 * 2), dim3(512), 0, st, kps, d_count, cap, d_levels, d_luts, d_lutpool, d_desc, kp_cap,

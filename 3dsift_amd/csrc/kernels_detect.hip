@@ -689,13 +689,6 @@ void launch_detect_mark(const DetectLevels &L, int nlevels, int nx, int ny, cons
 		hipLaunchKernelGGL(k_lazy_next, dim3(wave_form ? 256 : 1024), dim3(256), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
 		                   b.masks, b.block_counts, wave_form ? 1 : 0);
 	}
-	static const bool dbg = dev_tune_i("S3D_LAZY_DEBUG", 0) != 0;
-	if (lazy && dbg) {
-		unsigned n = 0;
-		hipStreamSynchronize(st);
-		hipMemcpy(&n, b.prov_count, sizeof(unsigned), hipMemcpyDeviceToHost);
-		fprintf(stderr, "lazy level: octave %d, %u parked candidates (%d x %d x %d)\n", octave, n, nx, ny, nzl);
-	}
 }
 
 // second half: ordered compaction into the extrema list (appends after everything emitted before: octaves in order, one stream)

@@ -94,33 +94,18 @@ __device__ __forceinline__ void m_barrier() {
 template <int N>
 __device__ __forceinline__ void m_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// cache-policy bits of the output stores and of the tile DMA loads (measurement builds: S3D_MARCH_ST_POL / S3D_MARCH_LD_POL = 0 default,
-// 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt)
-#ifndef S3D_MARCH_ST_POL
-#define S3D_MARCH_ST_POL 1  /* nt: the outputs are streamed, they should not displace the tile rows neighbouring workgroups re-read from the L2 (2.35 -> 2.32 ms; nt LOADS: 3.48 ms -- the L2 does absorb most of the halo re-reads) */
-#endif
-#ifndef S3D_MARCH_LD_POL
-#define S3D_MARCH_LD_POL 0
-#endif
-#define S3D_POL_STR_0 ""
-#define S3D_POL_STR_1 " nt"
-#define S3D_POL_STR_2 " sc1"
-#define S3D_POL_STR_3 " sc0 sc1"
-#define S3D_POL_STR_4 " sc0 sc1 nt"
-#define S3D_POL_CAT(a, b) a##b
-#define S3D_POL_STR(n) S3D_POL_CAT(S3D_POL_STR_, n)
-#define S3D_MARCH_ST_POLICY S3D_POL_STR(S3D_MARCH_ST_POL)
-#define S3D_MARCH_LD_POLICY S3D_POL_STR(S3D_MARCH_LD_POL)
+// The output stores are non-temporal (streamed: they should not displace the tile rows neighbouring workgroups re-read from the L2;
+// 2.35 -> 2.32 ms at 512^3); the tile DMA loads are plain (nt LOADS: 3.48 ms -- the L2 does absorb most of the halo re-reads).
 // LDS-DMA: lane l's 16 bytes at base + voff land at lds_dst + 16*l.  M0 carries the wave-uniform LDS byte address (restored).
 __device__ __forceinline__ void m_dma16(const float *base, unsigned voff, unsigned lds_dst) {
 	unsigned keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" S3D_MARCH_LD_POLICY "\n\ts_mov_b32 m0, %0"
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
 	             : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 // untracked store (hipcc would make later loads that re-use the data registers wait for the store to COMPLETE); nothing reads
 // dst / dog back in this kernel.  The wait states cover the hardware's read of the four data registers.
 __device__ __forceinline__ void m_store16(float *base, unsigned voff, mf4 d) {
-	asm volatile("global_store_dwordx4 %0, %1, %2" S3D_MARCH_ST_POLICY "\n\ts_nop 2" ::"v"(voff), "v"(d), "s"(base));
+	asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 2" ::"v"(voff), "v"(d), "s"(base));
 }
 
 __device__ __forceinline__ float m_absmax(float m, float v) {
@@ -128,67 +113,28 @@ __device__ __forceinline__ float m_absmax(float m, float v) {
 	return (a > m) ? a : m;
 }
 
-// workgroups per CU the register budget and the chunk planning are set for, per half width (DOG instantiations with the centre
-// ring in LDS fit three)
-#ifndef S3D_MARCH_SCHEDB
-#define S3D_MARCH_SCHEDB 0
-#endif
-#ifndef S3D_MARCH_ROT
-#define S3D_MARCH_ROT 1
-#endif
-#ifndef S3D_MARCH_VGPR_OCC
-#define S3D_MARCH_VGPR_OCC 4  /* > 0 (kernels without the centre ring): register budget for that many workgroups per CU although the grids are planned for march_occ (room for the small octaves' workgroups beside a big launch) */
-#endif
-#ifndef S3D_MARCH_YG
-#define S3D_MARCH_YG 4  /* y-blur rows requested per group (6 spills at hw 8 under the 128-register budget) */
-#endif
-#ifndef S3D_MARCH_YPRE
-#define S3D_MARCH_YPRE 1  /* 1: the first group of y-blur rows is requested in front of the x-blur (their latency hides behind its arithmetic) */
-#endif
-#ifndef S3D_MARCH_ZSYM
-#define S3D_MARCH_ZSYM 1  /* r04, bit-identical, 2.24 -> 2.22 ms: the z-scatter forms each product tap * v once for the two accumulators that take it (symmetric taps) */
-#endif
-#ifndef S3D_MARCH_CR_MAXHW
-#define S3D_MARCH_CR_MAXHW 5  /* DoG centre ring in LDS up to this half width (three workgroups per CU still fit); wider levels re-read the centre plane */
-#endif
-// workgroups per CU a launch is planned for (residency rounds) and the register budget that goes with it
-#ifndef S3D_MOCC_2
-#define S3D_MOCC_2 3
-#endif
-#ifndef S3D_MOCC_3
-#define S3D_MOCC_3 3
-#endif
-#ifndef S3D_MOCC_4
-#define S3D_MOCC_4 3
-#endif
-#ifndef S3D_MOCC_5
-#define S3D_MOCC_5 3
-#endif
-#ifndef S3D_MOCC_6
-#define S3D_MOCC_6 3
-#endif
-#ifndef S3D_MOCC_8
-#define S3D_MOCC_8 3
-#endif
+// Workgroups per CU a 32 x 32 launch is planned for (residency rounds): three, for every half width.  The kernels without the DoG centre
+// ring get the register budget of FOUR (128): the fourth slot is where the small octaves' workgroups run beside a big launch.
+// (Measured and closed, r03 / r04: four to six workgroups per CU for the light levels, 64 x 32 tiles at three per CU: no gain.)
+constexpr int kMarchOcc = 3;
 template <int HW, bool CR>
-constexpr int march_occ() { return CR ? 3 : (HW == 2 ? S3D_MOCC_2 : (HW == 3 ? S3D_MOCC_3 : (HW == 4 ? S3D_MOCC_4 : (HW == 5 ? S3D_MOCC_5 : (HW == 6 ? S3D_MOCC_6 : S3D_MOCC_8))))); }
+constexpr int march_occ() { return kMarchOcc; }
 template <int HW, bool CR>
-constexpr int march_lb() {  // __launch_bounds__ second argument: at least the planned workgroups per CU, the fourth slot for kernels without the ring
-	return (S3D_MARCH_VGPR_OCC > march_occ<HW, CR>() && !CR) ? S3D_MARCH_VGPR_OCC : march_occ<HW, CR>();
-}
+constexpr int march_lb() { return CR ? kMarchOcc : 4; }  // __launch_bounds__ second argument
+constexpr int kMarchYG = 4;          // y-blur rows requested per group (6 spills at hw 8 under the 128-register budget)
+constexpr int kMarchCrMaxHW = 5;     // DoG centre ring in LDS up to this half width (three workgroups per CU still fit); wider levels re-read the centre plane
+constexpr int kMarchBgRinglessTiles = 16;  // launches planned beside another octave with at most this many tiles per plane take the ring-less form (LDS fit)
+constexpr int kMarchWideMinTiles = 100;    // 64 x 32 tiles per plane from which a level takes them (512 x 512: 128; 256 x 256 would march 16 chunks of 16 planes + ramp)
 
-#ifndef S3D_MARCH_WIDE_OCC6_MAXHW
-#define S3D_MARCH_WIDE_OCC6_MAXHW 0  /* 64 x 32 tiles without DoG up to this half width: register budget 80 (three workgroups per CU, planned for 768 slots) */
-#endif
 // KR (TX 64): the newest KR planes of the DoG centre ring live in REGISTERS and move on to an LDS ring of HW + 1 - KR planes (two
 // workgroups of eight waves per CU leave 80 KB each: tile + x-blurred tile + a whole ring of 64 x 32 planes do not fit at hw >= 4)
 // (the second __launch_bounds__ argument is waves per SIMD: two workgroups of eight waves = 4)
 template <int HW, bool DOG, bool CR, int TX = 32, int KR = 0>
-__global__ void __launch_bounds__(TX * 8, (TX == 64 ? ((!DOG && HW <= S3D_MARCH_WIDE_OCC6_MAXHW) ? 6 : 4) : march_lb<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
+__global__ void __launch_bounds__(TX * 8, (TX == 64 ? 4 : march_lb<HW, CR>())) k_march_level(const float *__restrict__ src, float *__restrict__ dst, float *__restrict__ dog,
                                                         unsigned *__restrict__ dogmax, int nx, int ny, ZRange zr, MTaps t, MEdge ef, int ntx,
                                                         int nty, int cz, int prio, float *__restrict__ half, int hnx, int hny, int hnz) {
 	using C = MCfg<HW, TX>;
-	constexpr bool ZSYM = S3D_MARCH_ZSYM != 0 && HW <= 6;
+	constexpr bool ZSYM = HW <= 6;  // (r04: the z-scatter forms each product tap * v once for the two pending sums that take it: symmetric taps, bit-identical)
 	constexpr int KL = C::CRN - KR;  // planes of the centre ring in LDS
 	static_assert(KR == 0 || (CR && KL >= 1), "register part of the centre ring");
 	__shared__ __attribute__((aligned(1024))) float tile[2 * C::TILE_F];
@@ -281,7 +227,6 @@ __global__ void __launch_bounds__(TX * 8, (TX == 64 ? ((!DOG && HW <= S3D_MARCH_
 	const int xbe_r = (rs * C::W4 + 2 * xseg_r + sw_r) * 4, xbo_r = (rs * C::W4 + 2 * xseg_r - sw_r) * 4;  // float offsets of even / odd window pieces
 	// (XSW: the two pieces of an item trade places in odd rows; the mirror row 2 HW - row has the row's parity)
 	const int xout_r = rs * C::XP + xseg_r * 8 + ((C::XSW && sw_r) ? 4 : 0);
-	const int xoutm_r = (HW - (y0 - HW + rs)) * C::XP + xseg_r * 8 + ((C::XSW && sw_r) ? 4 : 0);
 	const int xhi_r = (C::XSW && sw_r) ? -4 : 4;  // float offset of the second piece of an item
 	// bottom tiles: the wave with role 3 re-blurs rows yend-hw-1 .. yend (one row per 4 lanes) for the bottom extension E[yend+k]
 	const int row_h = C::TY - 2 + lane / C::SEG, xseg_h = lane % C::SEG, sw_h = row_h & 1;
@@ -342,8 +287,8 @@ __global__ void __launch_bounds__(TX * 8, (TX == 64 ? ((!DOG && HW <= S3D_MARCH_
 		}
 		if (j + 1 < nsteps) issue_dma(j + 1);
 
-		constexpr int KG = S3D_MARCH_YG, NTAP = 2 * HW + 1;
-		constexpr bool YPRE = S3D_MARCH_YPRE && HW <= 6;
+		constexpr int KG = kMarchYG, NTAP = 2 * HW + 1;
+		constexpr bool YPRE = HW <= 6;  // the first group of y-blur rows is requested in front of the x-blur (their latency hides behind its arithmetic; hw 8 has no registers left)
 		mf4 ypre[KG];
 		if (YPRE) {  // (step 0 reads rows nobody has written: never used)
 			const float *yc0 = xb + (buf ^ 1) * C::XB_F;
@@ -353,13 +298,18 @@ __global__ void __launch_bounds__(TX * 8, (TX == 64 ? ((!DOG && HW <= S3D_MARCH_
 		}
 		// ---------------- x-blur of feed j: tile[buf] -> xb[buf] ----------------
 		if (j < nsteps) {
-			const int role = S3D_MARCH_ROT ? ((wid + j) & (C::NW - 1)) : wid;  // wave-uniform
+			const int role = (wid + j) & (C::NW - 1);  // wave-uniform: the x-blur roles rotate over the waves with the step
 			const bool xhelp = role == C::NR;
 			const bool xact = xhelp ? act_h : (((amask >> role) & 1) != 0);
 			const bool xmirror = !xhelp && (((mmask >> role) & 1) != 0);
 			const int xseg = xhelp ? xseg_h : xseg_r;
 			const int xbase_e = xhelp ? xbe_h : xbe_r + role * (C::RPW * C::W4 * 4), xbase_o = xhelp ? xbo_h : xbo_r + role * (C::RPW * C::W4 * 4);
-			const int xout = xout_r + role * (C::RPW * C::XP), xout_m = xoutm_r - role * (C::RPW * C::XP);
+			const int xout = xout_r + role * (C::RPW * C::XP);
+			// the mirror row of tile row `row` of a top tile (y0 = 0: gy = row - HW) is row 2 HW - row, same column: formed from xout where it is
+			// stored (r05: as a lane constant of its own it was the one register too many of the hw-5 / hw-6 wide kernels -- spilled, and
+			// reloaded inside the plane loop behind an s_waitcnt vmcnt(0) that also drained the tile DMA)
+			static_assert((C::XP & (C::XP - 1)) == 0 && (C::SEG - 1) * 8 + 4 < C::XP, "row index = offset / XP");
+			const int xout_m = xout + 2 * C::XP * HW - 2 * (xout & ~(C::XP - 1));
 			float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 			if (xact) {
 				const float *tb = tile + buf * C::TILE_F;
@@ -492,9 +442,6 @@ __global__ void __launch_bounds__(TX * 8, (TX == 64 ? ((!DOG && HW <= S3D_MARCH_
 			}
 
 			if (DOG && CR && !(S3D_MDIAG & 512)) cen = cring[(j % KL) * C::NT + tid];  // the centre piece of HW+1 steps ago (read before this step's park below)
-#if S3D_MARCH_SCHEDB
-			__builtin_amdgcn_sched_barrier(0);  // keep the accumulator updates in front of the stores and of the wait for the DMA
-#endif
 			// stores this WAVE issues in this step (the counted wait below): a store instruction is issued when any lane of the wave
 			// owns its piece -- in the tile in front of a shifted one some lanes, or whole waves (rows), do not
 			nst = __any(emit && !((S3D_MDIAG & 2) && out[0] != 12345.678f)) ? (DOG ? 2 : 1) : 0;
@@ -569,12 +516,6 @@ static void march_edge_fractions(int n, int hw, float *f) {  // Src/cSIFT3D.cc:7
 	}
 }
 
-#ifndef S3D_MARCH_CR6_KR
-#define S3D_MARCH_CR6_KR 0  /* measured, off: 3 = the hybrid ring for octave 0's widest level -- bit-identical, would take its 0.54 GB centre re-read out of the traffic (1.11x -> ~1.05x), but the stage is 1.5 % slower on the bench volume (1.93-1.97 -> 1.97-1.99 ms; +-0 on random data) */
-#endif
-#ifndef S3D_MARCH_BG_RINGLESS_TILES
-#define S3D_MARCH_BG_RINGLESS_TILES 16
-#endif
 template <int HW>
 static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &tg,
                             hipStream_t st, int plan_slots, int prio, const MarchHalf &hf) {
@@ -588,7 +529,7 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	// buys nothing at 512^3), so a residency round of R workgroups costs (planes marched) x max(1, R / 768); what the fourth slot does
 	// buy is ONE round instead of two when a level has more tiles than 768 (1024^2 levels: 1024 tiles -- the z-slabs of configs[3]).
 	// Kernels with the DoG centre ring in LDS fit three per CU; where a fourth slot saves a round the ring-less instantiation runs.
-	constexpr bool kHasCR = HW <= S3D_MARCH_CR_MAXHW;
+	constexpr bool kHasCR = HW <= kMarchCrMaxHW;
 	const int ramp = 2 * HW + 1;
 	const int sat = (dog && kHasCR) ? 3 : march_occ<HW, false>();  // workgroups per CU at which a CU's plane rate saturates
 	auto plan = [&](int cap, int &cz_out) {
@@ -617,7 +558,7 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	// (38 KB): a ring kernel's 45 / 52 KB does not fit next to them, and the head of octave 2 -- on the stage's critical chain -- waited
 	// 130 us for octave 1's last level to drain (profiles/r04e_timeline.txt); the ring-less form (33 / 35 KB) fits, and re-reading the
 	// centre plane of a 128 x 128 level costs nothing
-	const bool small_bg = plan_slots > 0 && ntiles <= S3D_MARCH_BG_RINGLESS_TILES;
+	const bool small_bg = plan_slots > 0 && ntiles <= kMarchBgRinglessTiles;
 	const bool use_cr = dog && kHasCR && !small_bg && !(cost4 * 1.12 < cost3);
 	const int cz = (dog && kHasCR) ? (use_cr ? cz3 : cz4) : (cost4 < cost3 ? cz4 : cz3);
 	const int nchunks = (nzo + cz - 1) / cz;
@@ -628,32 +569,21 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 	march_edge_fractions(zr.nzg, HW, ef.f[2]);
 	const dim3 grid((unsigned)(ntiles * nchunks)), block(C::NT);
 	// DoG centre ring in LDS where three workgroups per CU still fit (hw <= 5); otherwise the centre piece travels by LDS-DMA
-	// late r04, measured and off (S3D_MARCH_CR6_KR): octave 0's widest level (hw 6, planned for two workgroups per CU beside the chain of
-	// the small octaves) re-reads its DoG centre plane: 0.54 GB of the pyramid's 8.9 GB of traffic.  Its ring as 3 planes in registers
-	// + 4 in LDS (16 KB: 46 KB per workgroup, so octave 1's ring kernels still fit beside two of them; 139 registers)
-	constexpr bool kHybrid6 = HW == 6 && S3D_MARCH_CR6_KR > 0;
-	if constexpr (kHybrid6) {
-		if (dog && !use_cr && plan_slots >= 512 && ntiles >= 64) {
-			hipLaunchKernelGGL((k_march_level<HW, true, true, 32, (kHybrid6 ? S3D_MARCH_CR6_KR : 0)>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
-			return;
-		}
-	}
+	// (late r04, measured and closed: octave 0's widest level with a hybrid centre ring -- 3 planes in registers + 4 in LDS instead of
+	// re-reading its centre plane, 0.54 GB of the pyramid's 8.9 GB of traffic -- bit-identical, stage 1.5 % slower on the bench volume)
 	if (dog && use_cr) hipLaunchKernelGGL((k_march_level<HW, true, kHasCR>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 	else if (dog) hipLaunchKernelGGL((k_march_level<HW, true, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 	else hipLaunchKernelGGL((k_march_level<HW, false, false>), grid, block, 0, st, src, dst, dog, dogmax, nx, ny, zr, t, ef, ntx, nty, cz, prio, hf.d, hf.nx, hf.ny, hf.nz);
 }
 
 // r04: the 64 x 32 tiles of the big levels (MCfg<HW, 64>): eight waves, two workgroups per CU, planned for 512 slots.
-#ifndef S3D_MARCH_WIDE_MIN_TILES
-#define S3D_MARCH_WIDE_MIN_TILES 100  /* 64 x 32 tiles per plane from which a level takes them (512 x 512: 128; 256 x 256 would march 16 chunks of 16 planes + ramp) */
-#endif
 static bool march_wide_ok(int nx, int ny, int nzo, int hw, int plan_slots) {
 	const int mode = hook(SIFT3D_HOOK_MARCH_TILES);  // 0 product rule, 1 wherever the geometry allows (parity tests on small volumes), 2 never
 	if (mode == 2 || plan_slots > 0 || hw < 2 || hw > 6) return false;  // (a planned launch shares the machine with another octave: 32 x 32 tiles, three per CU)
 	if (!(nx == 64 || nx >= 64 + ((hw + 3) / 4) * 4)) return false;  // the shifted last tile column starts at nx - 64: 0 or beyond the left halo (march_applicable)
 	const int ntiles = ((nx + 63) / 64) * ((ny + 31) / 32);
 	// (short columns: four chunks of a few planes + the ramp cost what three chunks of the 32 x 32 form do -- 512 x 512 x 32: 0.384 vs 0.376 ms)
-	return mode == 1 || (ntiles >= S3D_MARCH_WIDE_MIN_TILES && nzo / std::max(1, 512 / ntiles) >= 24);  // planes per chunk
+	return mode == 1 || (ntiles >= kMarchWideMinTiles && nzo / std::max(1, 512 / ntiles) >= 24);  // planes per chunk
 }
 template <int HW>
 static void launch_march_wide(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &tg,
@@ -665,7 +595,7 @@ static void launch_march_wide(const float *src, float *dst, float *dog, unsigned
 	if (nzo <= 0) return;
 	const int ntx = (nx + C::TX - 1) / C::TX, nty = (ny + C::TY - 1) / C::TY, ntiles = ntx * nty;
 	// z chunking as in launch_march_hw: residency rounds of at most 512 workgroups, a round costs its planes + the ramp
-	const int ramp = 2 * HW + 1, cap = (!dog && HW <= S3D_MARCH_WIDE_OCC6_MAXHW) ? 768 : 512;
+	const int ramp = 2 * HW + 1, cap = 512;
 	int cz = nzo;
 	{
 		double best = 1e300;
@@ -709,8 +639,8 @@ bool march_applicable(int nx, int ny, int nzg, const Taps &t) {
 	const int hx = ((t.hw + 3) / 4) * 4;
 	if (!(nx == 32 || nx >= 32 + hx) || !(ny == 32 || ny >= 32 + t.hw) || nzg < 2 * t.hw + 2) return false;
 	if (!(t.hw == 2 || t.hw == 3 || t.hw == 4 || t.hw == 5 || t.hw == 6 || t.hw == 8)) return false;
-	if (S3D_MARCH_ZSYM)  // the symmetric form of the z-scatter needs what GaussianSmooth_3D's generator gives: tap[hw + d] == tap[hw - d] bit for bit
-		for (int d = 1; d <= t.hw; d++) if (memcmp(&t.w[t.hw + d], &t.w[t.hw - d], sizeof(float)) != 0) return false;
+	// the symmetric form of the z-scatter needs what GaussianSmooth_3D's generator gives: tap[hw + d] == tap[hw - d] bit for bit
+	for (int d = 1; d <= t.hw; d++) if (memcmp(&t.w[t.hw + d], &t.w[t.hw - d], sizeof(float)) != 0) return false;
 	return true;
 }
 

@@ -7,6 +7,9 @@ TAG=${1:-rXX}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
+# compile-time gate first (no GPU time is spent on sources whose hot kernels spill): resource report + the ring contract of k_describe
+python3 $REPO/scripts/kernel_resources.py --check --out $OUT/${TAG}_kernel_resources.txt > /dev/null
+python3 $REPO/scripts/check_desc_ring.py > $OUT/${TAG}_desc_ring_check.txt
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
 # PMC passes FIRST (separate --pmc runs, no trace options): bench.py reports roofline.traffic / descriptor.roofline only from files
