@@ -897,12 +897,14 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 				if (a != 0) atomicAdd(&sp.gacc[(size_t)kpos * kDesc + e], a);
 			}
 			if (tid == 0) __hip_atomic_store(&sp.gmass[kpos * 8 + part], mass_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			// arrival: the payload is device-scope atomics and one write-through store, so there is nothing in a cache to write back or to
-			// invalidate -- every wave waits for its own operations to be acknowledged, then ONE lane counts the part in.  (__threadfence()
-			// by 256 threads here and once more in the finisher cost 40-100 us per part: the split ran 2.3x slower than no split.)
+			// arrival: the payload is device-scope atomics and one device-scope store (performed at the memory side, not in this XCD's L2);
+			// every wave waits for its own operations to be acknowledged, then ONE lane counts the part in with an acquire-release
+			// read-modify-write at agent scope (the relaxed counter relied on that payload never sitting in a cache; the
+			// one-lane form is formally ordered and costs a few microseconds per part.  __threadfence() by all 256 threads here and once
+			// more in the finisher cost 40-100 us per part: the split ran 2.3x slower than no split.)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 			__syncthreads();
-			if (tid == 0) s_last = atomicAdd(&sp.gdone[kpos], 1u);
+			if (tid == 0) s_last = __hip_atomic_fetch_add(&sp.gdone[kpos], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 			__syncthreads();
 			if (s_last != (unsigned)(S - 1)) break;  // block-uniform: another part finishes the keypoint (leaves the attempt loop; see below)
 			mass_sum = 0.0f;

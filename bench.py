@@ -331,6 +331,24 @@ def main():
                      "traffic": traffic, "traffic_note": traffic_note,
                      "frac_survey": 68.0 * pv / t_pyr / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_survey": 68.0 * pv},
     }
+    # ... and SURVEY 8d's work AS DEFINED, timed ("work moved out of the timed region earns no credit" -- the default
+    # build leaves G[nd], DoG[0] and DoG[nd-1] to the detection stage): the same extractor with every Gaussian and DoG level built and
+    # written (hooks glast_eager + dog_eager), its pyramid stage against the 68 B per pyramid voxel of that accounting.
+    try:
+        if not (rank == 0 and world == 1):
+            raise RuntimeError("measured at N = 1 only")
+        with capi.hook("glast_eager", 1), capi.hook("dog_eager", 1):
+            exe = capi.CSIFT3D(None, device=local, device_ptr=vol.data_ptr(), shape=(n, n, n))
+            te = []
+            for _ in range(2 + 5):
+                exe.run_stages(1)
+                te.append(exe.m_timer["d_BuildGSS"] + exe.m_timer["d_BuildDOG"])
+            exe.close()
+        t_eager = float(np.median(te[2:]))
+        out["roofline"]["every_level_built"] = {"seconds": t_eager, "bytes": 68.0 * pv, "frac": 68.0 * pv / t_eager / 1e9 / HBM_PEAK_GBS,
+                                                "note": "all 6 Gaussian + 5 DoG levels of every octave built and written (hooks glast_eager, dog_eager): SURVEY 8d's 68 B per pyramid voxel with nothing deferred to detection"}
+    except Exception as e:  # noqa: BLE001 -- a side measurement
+        out["roofline"]["every_level_built"] = {"error": f"{type(e).__name__}: {e}"}
     # ---- descriptor stage (keypoints/s and window-voxels/s, not an HBM fraction) + the VALU-issue roofline of k_describe
     if stage["d_Extraction"] > 0 and nkp:
         wv = descriptor_window_voxels(kp)
