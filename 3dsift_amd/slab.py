@@ -222,6 +222,11 @@ class DistComm:
         # rows) while the main thread exchanges the records / partial histograms of the sharded octaves' descriptor windows (r05):
         # operations of ONE communicator must be issued in the same order on every rank, so the tail gets its own
         self.tail_group = dist.new_group(ranks=list(range(self.world)))
+        # (its communicator is created by its first collective: here, on the constructing thread, not later inside the tail's thread
+        # beside the main thread's point-to-point traffic)
+        import torch
+        warm = torch.zeros(1, dtype=torch.int32, device="cuda" if self.stream_ordered else "cpu")
+        dist.all_reduce(warm, op=dist.ReduceOp.SUM, group=self.tail_group)
 
     def local_ranks(self):
         return [self.rank]

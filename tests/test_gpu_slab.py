@@ -228,3 +228,42 @@ def test_seeded_tail_equals_octaves_of_single_volume():
         h.close()
     assert np.array_equal(full, ds)
     t.close(); ref.close()
+
+
+def test_python_driver_over_rccl_world_of_one():
+    """The python driver over `DistComm` with the nccl (= RCCL) backend, one rank on the one GPU of the box: process-group and
+    communicator set-up (the tail's own group included), the count all-gather, the MAX / SUM all-reduces on device tensors, the empty
+    point-to-point groups and the whole partial-window path with the rank's own part -- everything of the N > 1 run that does not need a
+    second GPU.  Keypoints and descriptors equal the single volume bit for bit."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import importlib, os, sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        capi = importlib.import_module("3dsift_amd.capi"); slab = importlib.import_module("3dsift_amd.slab"); synth = importlib.import_module("3dsift_amd.synth")
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        vol = synth.blobs((96, 112, 128), seed=31, noise=0.01)
+        nz, ny, nx = vol.shape
+        ref = capi.CreateCSIFT3D(vol); ref.KpSiftAlgorithm(); kp_ref, ds_ref = ref.GetKeypoints()
+        ex = slab.SlabExtractor((nx, ny, nz), slab.DistComm(), device=0, sharded_octaves=2)
+        assert ex.desc_partial and ex.halo == 13
+        ex.load(volume=vol)
+        ex.KpSiftAlgorithm(); ex.KpSiftAlgorithm()
+        kp, ds = ex.GetKeypoints()
+        assert len(kp) == len(kp_ref) > 50, (len(kp), len(kp_ref))
+        for f in kp_ref.dtype.names:
+            assert np.array_equal(kp[f], kp_ref[f]), f
+        assert np.array_equal(ds, ds_ref)
+        ex.close(); ref.close()
+        dist.destroy_process_group()
+        print("rccl world of one ok", len(kp))
+    """) % root
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl world of one ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
