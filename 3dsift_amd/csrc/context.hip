@@ -1829,8 +1829,25 @@ extern "C" int sift3d_slab_detect(sift3d_handle c) {
 	return SIFT3D_ERR_CAPACITY;
 }
 
+// planes per side the level buffers must carry for the keypoint windows of this context: whole descriptor windows, or (partial) the
+// orientation windows only
+static int slab_window_halo(const sift3d_ctx *c, bool whole_descriptor_windows) {
+	int need = 0;
+	for (int i = 1; i <= c->p.num_kp_levels; i++) {
+		const float sc = c->dog[(size_t)i].scale, u = c->dog[(size_t)i].unit;
+		const int desc_reach = (int)ceilf(2.0f * (sc * 7.071067812f) / u) + 2, ori_reach = (int)floorf(4.5f * sc / u) + 1;
+		need = std::max(need, whole_descriptor_windows ? desc_reach : ori_reach);
+	}
+	return need;
+}
+
 extern "C" int sift3d_slab_describe(sift3d_handle c) {
 	if (!c || !c->slab || c->stage < 3) return SIFT3D_ERR_STATE;
+	if (c->desc_partial || c->halo < slab_window_halo(c, true)) {
+		// (sift3d_slab_halo_planes caps its answers at the buffers' halo: whole windows on a smaller halo would read planes nobody exchanged)
+		set_last_error("sift3d_slab_describe marches whole descriptor windows: the level buffers' halo is too small for them (or the context is in partial-window mode) -- use sift3d_slab_orient / describe_partial / describe_finish");
+		return SIFT3D_ERR_STATE;
+	}
 	int rc = set_device(c->device);
 	if (rc) return rc;
 	hipStream_t st = c->stream;
@@ -1989,6 +2006,7 @@ extern "C" int sift3d_slab_describe_finish(sift3d_handle c, const void *d_record
 // every rank's orientation before it waits for the first count
 extern "C" int sift3d_slab_orient_launch(sift3d_handle c) {
 	if (!c || !c->slab || c->stage < 3) return SIFT3D_ERR_STATE;
+	if (c->halo < slab_window_halo(c, false)) { set_last_error("the level buffers' halo is smaller than the orientation windows' reach"); return SIFT3D_ERR_STATE; }
 	int rc = set_device(c->device);
 	if (rc) return rc;
 	hipStream_t st = c->stream;

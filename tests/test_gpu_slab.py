@@ -267,3 +267,17 @@ def test_python_driver_over_rccl_world_of_one():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl world of one ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_whole_window_describe_is_refused_on_a_partial_window_halo():
+    """sift3d_slab_describe marches whole descriptor windows (38 planes of halo); on the 13-plane halo of the partial-window mode it
+    would read planes nobody exchanged: refused loudly (ERR_STATE), the partial-window calls are the way."""
+    vol = _volume((64, 64, 64), seed=3)
+    ex = slab.SlabExtractor((64, 64, 64), slab.SimComm(2), sharded_octaves=1)   # desc_partial: the driver's default
+    ex.load(volume=vol)
+    ex.KpSiftAlgorithm()
+    st = ex._wl()[0].stages[0]
+    st.ctx.detect()
+    with pytest.raises(capi.Sift3dError, match="whole descriptor windows"):
+        st.ctx.describe()
+    ex.close()
