@@ -331,7 +331,8 @@ __global__ void __launch_bounds__(64 * kLwWaves) k_lazy_wave(DetectLevels L, Tap
 		const int zg = zl + zr.zoff;  // global plane
 		if (!(x >= H && x <= nx - 2 - H && y >= H && y <= ny - 2 - H && zg >= H && zg <= nzg - 2 - H)) continue;  // k_lazy_next's
 		// the 20 floats of a row start at x - 8 - shift: shift = how far x + 11 would reach beyond the row's last sample
-		const int shift = max(0, x + 11 - (nx - 1));
+		// (never further than the row's first sample: rows shorter than 20 floats let the piece run into the NEXT row instead)
+		const int shift = min(max(0, x + 11 - (nx - 1)), x - H);
 		const float *base = src + ic - (size_t)H * sz - (size_t)H * sy - (size_t)(H + shift);
 #pragma unroll
 		for (int j = 0; j < kLwInstr; j++) {
@@ -704,7 +705,8 @@ void launch_detect_mark(const DetectLevels &L, int nlevels, int nx, int ny, cons
 	if (lazy) {
 		// interior candidates of the default half width: one wave each (k_lazy_wave: 768 workgroups of two waves are resident); the rest
 		// (next to a border, other half widths): one workgroup each
-		const bool wave_form = lazy_taps->hw == 8 && !hook(SIFT3D_HOOK_LAZY_GENERIC);
+		// (the wave form keeps its 23 piece offsets as 32-bit byte offsets from the block's first sample: 17 planes must span < 4 GB)
+		const bool wave_form = lazy_taps->hw == 8 && !hook(SIFT3D_HOOK_LAZY_GENERIC) && (size_t)nx * (size_t)ny * 17u * sizeof(float) < ((size_t)1 << 32);
 		if (wave_form)
 			hipLaunchKernelGGL(k_lazy_wave, dim3(256 * 3), dim3(64 * kLwWaves), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
 			                   b.masks, b.block_counts);

@@ -380,7 +380,9 @@ def test_lazy_last_level_wave_form_matches_the_workgroup_form(capi, orc, synth):
     border one workgroup each (k_lazy_next); the hook lazy_generic sends all of them down the workgroup form.  Same extrema either way,
     and equal to the oracle's; shapes with rows shorter than x + 11 (the staged row is shifted) and a noise volume dense in candidates."""
     rng = np.random.default_rng(9)
-    for vol in (synth.blobs((96, 80, 72), seed=5, noise=0.02), rng.random((64, 56, 120), dtype=np.float32), synth.blobs((40, 128, 44), seed=6, noise=0.01)):
+    # (x = 72, 76, 80: octaves with rows of 18 .. 20 voxels, shorter than or equal to the 20 floats staged per row)
+    for vol in (synth.blobs((96, 80, 72), seed=5, noise=0.02), rng.random((64, 56, 120), dtype=np.float32), synth.blobs((40, 128, 44), seed=6, noise=0.01),
+                rng.random((80, 72, 76), dtype=np.float32), rng.random((72, 80, 80), dtype=np.float32)):
         g = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
         with capi.hook("lazy_generic", 1):
             h = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
