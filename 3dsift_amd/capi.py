@@ -50,7 +50,7 @@ SYMBOLS = [
     "sift3d_slab_orient_count",
     # test hooks / debug accessors / matcher timing
     # native driver of the z-slab sharding
-    "sift3d_sharded_create", "sift3d_sharded_run", "sift3d_sharded_num_keypoints", "sift3d_sharded_get_keypoints", "sift3d_sharded_info",
+    "sift3d_sharded_create", "sift3d_sharded_create_ex", "sift3d_sharded_run", "sift3d_sharded_num_keypoints", "sift3d_sharded_get_keypoints", "sift3d_sharded_info",
     "sift3d_sharded_error", "sift3d_sharded_destroy",
     "sift3d_test_hook", "sift3d_debug_counters", "sift3d_debug_face_lookup", "sift3d_match_times", "sift3d_debug_copy_bandwidth",
     "sift3d_match_warmup",
@@ -58,6 +58,7 @@ SYMBOLS = [
 HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "desc_nocache": 4, "match_nodma": 5, "one_stream": 6,
          "desc_mass_shift": 7, "list_cap": 8, "peer_copy": 9, "desc_nosplit": 10, "march_tiles": 11, "desc_exact_cells": 12, "lazy_generic": 13}
 ORIENT_WORDS = 34
+SHARDED_PARTIAL_WINDOWS = 1   # sift3d_sharded_create_ex flag
 
 
 class Params(C.Structure):
@@ -161,6 +162,7 @@ def lib():
         L.sift3d_run_describe.argtypes = [C.c_void_p]
         L.sift3d_import_descriptors_device.argtypes = [C.c_void_p, C.c_void_p]
         L.sift3d_sharded_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Params), _ip, C.c_int, C.c_int, C.c_int]
+        L.sift3d_sharded_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(Params), _ip, C.c_int, C.c_int, C.c_int, C.c_uint]
         L.sift3d_sharded_run.argtypes = [C.c_void_p]
         L.sift3d_sharded_num_keypoints.argtypes = [C.c_void_p, _ip]
         L.sift3d_sharded_get_keypoints.argtypes = [C.c_void_p, C.c_void_p, _fp]
@@ -592,16 +594,17 @@ class SlabCSIFT3D(CSIFT3D):
 
 class ShardedCSIFT3D:
     """One host volume [z, y, x] sharded as z-slabs by the library's native driver (csrc/sharded.hip): `devices` = one rank per GPU
-    over RCCL, or sim_ranks = n ranks simulated on devices[0]."""
+    over RCCL, or sim_ranks = n ranks simulated on devices[0].  partial_windows: descriptor windows split along z over the ranks
+    (sift3d_sharded_create_ex, SIFT3D_SHARDED_PARTIAL_WINDOWS) instead of whole windows on wide halos."""
 
-    def __init__(self, volume, devices=(0,), sim_ranks=0, sharded_octaves=0, **kw):
+    def __init__(self, volume, devices=(0,), sim_ranks=0, sharded_octaves=0, partial_windows=False, **kw):
         vol = np.ascontiguousarray(volume, dtype=np.float32)
         nz, ny, nx = vol.shape
         self._h = C.c_void_p()
         p = _params(kw)
         devs = (C.c_int * len(devices))(*devices)
-        _check(lib().sift3d_sharded_create(C.byref(self._h), vol.ctypes.data_as(C.c_void_p), nx, ny, nz, C.byref(p), devs, len(devices),
-                                           int(sim_ranks), int(sharded_octaves)))
+        _check(lib().sift3d_sharded_create_ex(C.byref(self._h), vol.ctypes.data_as(C.c_void_p), nx, ny, nz, C.byref(p), devs, len(devices),
+                                              int(sim_ranks), int(sharded_octaves), SHARDED_PARTIAL_WINDOWS if partial_windows else 0))
 
     def KpSiftAlgorithm(self):
         rc = lib().sift3d_sharded_run(self._h)

@@ -10,6 +10,9 @@
 //                       G[1..3]           : up to `halo` planes (orientation / descriptor windows)   deferred: own stream + communicator
 //                       DoG[1..3]         : 1 plane (the extremum test reads z +- 1)                  deferred
 //                     The normalisation maximum and the DoG maxima are all-reduced (MAX); x / y blurs need no communication.
+//   windows (r05,     sift3d_sharded_create_ex(..., SIFT3D_SHARDED_PARTIAL_WINDOWS)): the descriptor windows are split along z over the ranks --
+//   opt-in)           records to the z-neighbours, every rank marches its part, 768 int32 + the mass back, the owner finishes (3dsift_amd/slab.py does
+//                     the same and is where the protocol is tested over gloo): the halos of G[1..3] shrink from 24 / 30 / 38 planes to 8 / 10 / 12.
 //   tail              level 0 of the first replicated octave is all-gathered (1 / 8^S of a level); the remaining octaves run
 //                     replicated in a seeded context per rank; their orientation work is dealt by extremum index (an integer
 //                     all-reduce(SUM) of zero-padded rows restores it exactly), their descriptor work by keypoint.
@@ -35,6 +38,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <shared_mutex>
@@ -101,6 +105,18 @@ std::vector<Transfer> halo_transfers(const Bounds &bounds, int nz, int kind, int
 	return out;
 }
 
+// neigh[r] = the ranks q != r whose owned planes a descriptor window of a keypoint of rank r can reach into (windows cover at most `reach`
+// planes either side of the keypoint's plane); symmetric, ascending
+std::vector<std::vector<int>> window_neighbours(const Bounds &bounds, int reach) {
+	std::vector<std::vector<int>> out(bounds.size());
+	for (size_t r = 0; r < bounds.size(); r++) {
+		const int z0 = bounds[r].first, z1 = bounds[r].second, lo = z0 - reach, hi = z1 - 1 + reach;
+		for (size_t q = 0; q < bounds.size(); q++)
+			if (q != r && z1 > z0 && bounds[q].second > bounds[q].first && bounds[q].first <= hi && bounds[q].second - 1 >= lo) out[r].push_back((int)q);
+	}
+	return out;
+}
+
 // ---- librccl through dlopen ---------------------------------------------------------------------------------------------
 struct Rccl {
 	void *lib = nullptr;
@@ -160,6 +176,7 @@ struct Worker {  // the sharded octaves + the seeded, replicated tail context of
 	sift3d_handle tail = nullptr;
 	float *seed = nullptr, *seed_mine = nullptr;
 	ncclComm_t c_urgent = nullptr, c_deferred = nullptr, c_tail = nullptr;
+	char *pscratch = nullptr; size_t pscratch_bytes = 0;  // partial descriptor windows: records / histograms / masses of a stage (grow-only, device)
 	std::vector<sift3d_keypoint> kp;      // results of this rank's sharded octaves, reference order per stage
 	std::vector<float> desc;
 	std::vector<int> kp_stage_end;        // prefix ends per stage in kp
@@ -187,6 +204,14 @@ struct sift3d_sharded {
 	// failure protocol of the RCCL transport: `failed` is set once, by the first rank whose step failed, which then aborts every
 	// communicator.  Ranks hold comm_mu shared while they ISSUE RCCL calls (short, host side) and the aborter takes it exclusively,
 	// so that no thread is inside a call on a communicator while it is torn down.
+	// r05, partial descriptor windows (opt-in): accepted keypoints / flagged records per sharded octave and rank, written by the rank
+	// threads and read by all of them behind a rendezvous
+	bool partial = false;
+	std::vector<std::vector<int>> kp_count, redo_count;
+	std::mutex rv_mu;
+	std::condition_variable rv_cv;
+	int rv_arrived = 0;
+	unsigned rv_gen = 0;
 	std::atomic<bool> failed{false};
 	std::atomic<bool> comms_aborted{false};  // abort_all ran: the communicators are gone (their pointers are left alone)
 	std::shared_timed_mutex comm_mu;
@@ -303,6 +328,223 @@ int allgather_seed(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	}
 	SH_NCCL(w, g_rccl.GroupEnd());
 	return SIFT3D_OK;
+}
+
+// ---- partial descriptor windows (r05, opt-in; the protocol of 3dsift_amd/slab.py _describe_partial) ---------------------
+// every rank thread of the RCCL transport arrives; values written before are visible to all after.  A dead handle lets the waiters go.
+int rendezvous(sift3d_sharded *H, Worker &w) {
+	if (H->sim) return SIFT3D_OK;
+	std::unique_lock<std::mutex> lk(H->rv_mu);
+	const unsigned gen = H->rv_gen;
+	if (++H->rv_arrived == H->world) { H->rv_arrived = 0; H->rv_gen++; H->rv_cv.notify_all(); return SIFT3D_OK; }
+	while (H->rv_gen == gen) {
+		if (H->failed.load()) { set_err(w, "aborted: another rank failed"); return SIFT3D_ERR_STATE; }
+		H->rv_cv.wait_for(lk, std::chrono::milliseconds(20));
+	}
+	return SIFT3D_OK;
+}
+
+struct RawXfer { int src, dst; const void *sp; void *dp; size_t bytes; };  // sp valid where src is local, dp where dst is local
+
+int exchange_raw(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<RawXfer> &ts) {
+	if (ts.empty()) return SIFT3D_OK;
+	if (H->sim) {
+		Worker &w0 = *ws[0];
+		for (const RawXfer &t : ts) SH_HIP(w0, hipMemcpyAsync(t.dp, t.sp, t.bytes, hipMemcpyDeviceToDevice, w0.stream));
+		return SIFT3D_OK;
+	}
+	Worker &w = *ws[0];
+	std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
+	SH_LIVE(H, w);
+	SH_NCCL(w, g_rccl.GroupStart());
+	for (const RawXfer &t : ts) {
+		if (t.src == w.rank) SH_NCCL(w, g_rccl.Send(t.sp, t.bytes, ncclInt8, t.dst, w.c_urgent, w.stream));
+		else if (t.dst == w.rank) SH_NCCL(w, g_rccl.Recv(t.dp, t.bytes, ncclInt8, t.src, w.c_urgent, w.stream));
+	}
+	SH_NCCL(w, g_rccl.GroupEnd());
+	return SIFT3D_OK;
+}
+
+// device scratch of one rank for one round of one stage: pointers into Worker::pscratch
+struct PartLayout {
+	char *recs = nullptr;                      // this rank's records, processing order (round 2: the flagged subset)
+	float *units = nullptr;                    // round 2: their exact units
+	int *redo = nullptr; float *units_next = nullptr;
+	std::map<int, char *> recs_in;             // neighbour r's records
+	std::map<int, float *> units_in;
+	std::map<int, int *> part_h;               // this rank's part of the windows of r's records (r = itself or a neighbour)
+	std::map<int, float *> part_m;
+	std::map<int, int *> got_h;                // neighbour q's part of this rank's records
+	std::map<int, float *> got_m;
+};
+
+int lay_out(Worker &w, const std::vector<int> &counts, const std::vector<int> &nb, size_t rb, PartLayout &L) {
+	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+	const size_t me = (size_t)counts[(size_t)w.rank];
+	size_t need = al(me * rb) + 3 * al(me * 4) + al(me * 768 * 4) + al(me * 4);
+	for (int r : nb) {
+		const size_t n = (size_t)counts[(size_t)r];
+		need += al(n * rb) + al(n * 4) + al(n * 768 * 4) + al(n * 4);  // r's records + units here, this rank's part of them
+		need += al(me * 768 * 4) + al(me * 4);                        // r's part of this rank's records
+	}
+	need = std::max<size_t>(need, 256);
+	if (need > w.pscratch_bytes) {
+		SH_HIP(w, hipStreamSynchronize(w.stream));
+		if (w.pscratch) SH_HIP(w, hipFree(w.pscratch));
+		w.pscratch = nullptr; w.pscratch_bytes = 0;
+		const size_t cap = need + need / 4;
+		SH_HIP(w, hipMalloc(reinterpret_cast<void **>(&w.pscratch), cap));
+		w.pscratch_bytes = cap;
+	}
+	char *p = w.pscratch;
+	auto take = [&](size_t b) { char *q = p; p += al(b); return q; };
+	L = PartLayout();
+	L.recs = take(me * rb);
+	L.units = reinterpret_cast<float *>(take(me * 4));
+	L.redo = reinterpret_cast<int *>(take(me * 4));
+	L.units_next = reinterpret_cast<float *>(take(me * 4));
+	L.part_h[w.rank] = reinterpret_cast<int *>(take(me * 768 * 4));
+	L.part_m[w.rank] = reinterpret_cast<float *>(take(me * 4));
+	for (int r : nb) {
+		const size_t n = (size_t)counts[(size_t)r];
+		L.recs_in[r] = take(n * rb);
+		L.units_in[r] = reinterpret_cast<float *>(take(n * 4));
+		L.part_h[r] = reinterpret_cast<int *>(take(n * 768 * 4));
+		L.part_m[r] = reinterpret_cast<float *>(take(n * 4));
+		L.got_h[r] = reinterpret_cast<int *>(take(me * 768 * 4));
+		L.got_m[r] = reinterpret_cast<float *>(take(me * 4));
+	}
+	return SIFT3D_OK;
+}
+
+// one round: records (round 2: + units) to the neighbours, every rank's part in one launch, the parts back, the owner's finish.
+// counts[r]: records of rank r in this round (known to every rank); L[i] belongs to ws[i] and already holds its records (and units).
+int partial_round(sift3d_sharded *H, std::vector<Worker *> &ws, int s, const std::vector<std::vector<int>> &neigh, const std::vector<int> &counts,
+                  std::vector<PartLayout> &L, size_t rb, bool second, std::vector<int> &n_redo) {
+	std::map<int, size_t> local;
+	for (size_t i = 0; i < ws.size(); i++) local[ws[i]->rank] = i;
+	auto is_local = [&](int r) { return local.count(r) != 0; };
+	const Bounds &bounds = ws[0]->stages[(size_t)s].bounds;
+	std::vector<RawXfer> ts;
+	for (int r = 0; r < H->world; r++)
+		for (int q : neigh[(size_t)r]) {
+			const size_t n = (size_t)counts[(size_t)r];
+			if (!n || (!is_local(r) && !is_local(q))) continue;
+			const PartLayout *Lr = is_local(r) ? &L[local[r]] : nullptr;
+			PartLayout *Lq = is_local(q) ? &L[local[q]] : nullptr;
+			ts.push_back(RawXfer{r, q, Lr ? Lr->recs : nullptr, Lq ? Lq->recs_in[r] : nullptr, n * rb});
+			if (second) ts.push_back(RawXfer{r, q, Lr ? Lr->units : nullptr, Lq ? Lq->units_in[r] : nullptr, n * 4});
+		}
+	int rc = exchange_raw(H, ws, ts);
+	if (rc) return rc;
+	for (size_t i = 0; i < ws.size(); i++) {
+		Worker &w = *ws[i];
+		const int q = w.rank;
+		std::vector<int> owners{q};
+		owners.insert(owners.end(), neigh[(size_t)q].begin(), neigh[(size_t)q].end());
+		std::vector<const void *> recs; std::vector<int> n, o0, o1; std::vector<const float *> un; std::vector<int *> hh; std::vector<float *> mm;
+		for (int r : owners) {
+			if (!counts[(size_t)r]) continue;
+			recs.push_back(r == q ? L[i].recs : L[i].recs_in[r]);
+			un.push_back(!second ? nullptr : r == q ? L[i].units : L[i].units_in[r]);
+			n.push_back(counts[(size_t)r]); hh.push_back(L[i].part_h[r]); mm.push_back(L[i].part_m[r]);
+			o0.push_back(bounds[(size_t)r].first); o1.push_back(bounds[(size_t)r].second);
+		}
+		SH_HIP(w, hipSetDevice(w.device));
+		SH_ABI(w, sift3d_slab_describe_partial(w.stages[(size_t)s].ctx, (int)recs.size(), recs.data(), n.data(), second ? un.data() : nullptr, hh.data(),
+		                                       mm.data(), o0.data(), o1.data()));
+	}
+	ts.clear();
+	for (int q = 0; q < H->world; q++)
+		for (int r : neigh[(size_t)q]) {
+			const size_t n = (size_t)counts[(size_t)r];
+			if (!n || (!is_local(r) && !is_local(q))) continue;
+			PartLayout *Lq = is_local(q) ? &L[local[q]] : nullptr, *Lr = is_local(r) ? &L[local[r]] : nullptr;
+			ts.push_back(RawXfer{q, r, Lq ? Lq->part_h[r] : nullptr, Lr ? Lr->got_h[q] : nullptr, n * 768 * 4});
+			ts.push_back(RawXfer{q, r, Lq ? Lq->part_m[r] : nullptr, Lr ? Lr->got_m[q] : nullptr, n * 4});
+		}
+	rc = exchange_raw(H, ws, ts);
+	if (rc) return rc;
+	for (size_t i = 0; i < ws.size(); i++) {
+		Worker &w = *ws[i];
+		const int r = w.rank, n = counts[(size_t)r];
+		std::vector<int> from = neigh[(size_t)r];
+		from.push_back(r);
+		std::sort(from.begin(), from.end());  // the masses are added in ascending rank order, as the python driver does
+		std::vector<const int *> hh; std::vector<const float *> mm;
+		if (n) for (int q : from) { hh.push_back(q == r ? L[i].part_h[r] : L[i].got_h[q]); mm.push_back(q == r ? L[i].part_m[r] : L[i].got_m[q]); }
+		SH_HIP(w, hipSetDevice(w.device));
+		int nr = 0;
+		SH_ABI(w, sift3d_slab_describe_finish(w.stages[(size_t)s].ctx, n ? L[i].recs : nullptr, n, (int)hh.size(), hh.data(), mm.data(), second && n ? L[i].units : nullptr,
+		                                      second ? 1 : 0, n ? L[i].redo : nullptr, n ? L[i].units_next : nullptr, &nr));
+		n_redo[i] = nr;
+	}
+	return SIFT3D_OK;
+}
+
+// orientation of the owned extrema, then the descriptors of sharded octave s from partial integer histograms
+int describe_partial_stage(sift3d_sharded *H, std::vector<Worker *> &ws, int s) {
+	Worker &w0 = *ws[0];
+	int rbi = 0, reach = 0;
+	SH_ABI(w0, sift3d_slab_record_bytes(&rbi));
+	const size_t rb = (size_t)rbi;
+	for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_ABI(*w, sift3d_slab_orient_launch(w->stages[(size_t)s].ctx)); }
+	for (Worker *w : ws) {
+		int n = 0;
+		SH_HIP(*w, hipSetDevice(w->device));
+		SH_ABI(*w, sift3d_slab_orient_count(w->stages[(size_t)s].ctx, &n));
+		H->kp_count[(size_t)s][(size_t)w->rank] = n;
+	}
+	int rc = rendezvous(H, w0);
+	if (rc) return rc;
+	const std::vector<int> counts = H->kp_count[(size_t)s];
+	SH_ABI(w0, sift3d_slab_desc_reach(w0.stages[(size_t)s].ctx, &reach));
+	const std::vector<std::vector<int>> neigh = window_neighbours(w0.stages[(size_t)s].bounds, reach);
+	std::vector<PartLayout> L(ws.size());
+	std::vector<int> n_redo(ws.size(), 0);
+	for (size_t i = 0; i < ws.size(); i++) {
+		Worker &w = *ws[i];
+		SH_HIP(w, hipSetDevice(w.device));
+		if ((rc = lay_out(w, counts, neigh[(size_t)w.rank], rb, L[i])) != SIFT3D_OK) return rc;
+		if (counts[(size_t)w.rank]) SH_ABI(w, sift3d_slab_export_records(w.stages[(size_t)s].ctx, L[i].recs));
+	}
+	if ((rc = partial_round(H, ws, s, neigh, counts, L, rb, false, n_redo)) != SIFT3D_OK) return rc;
+	for (size_t i = 0; i < ws.size(); i++) H->redo_count[(size_t)s][(size_t)ws[i]->rank] = n_redo[i];
+	if ((rc = rendezvous(H, w0)) != SIFT3D_OK) return rc;
+	const std::vector<int> tot = H->redo_count[(size_t)s];
+	if (!std::any_of(tot.begin(), tot.end(), [](int v) { return v > 0; })) return SIFT3D_OK;
+	// rare: records whose first fixed-point unit failed are repeated, by every part, with the exact unit.  The flagged subset is compacted
+	// through the host (a few records), then the scratch is laid out again for the second round's counts.
+	std::vector<std::vector<char>> recs2(ws.size());
+	std::vector<std::vector<float>> units2(ws.size());
+	for (size_t i = 0; i < ws.size(); i++) {
+		Worker &w = *ws[i];
+		const size_t n = (size_t)counts[(size_t)w.rank];
+		if (!tot[(size_t)w.rank]) continue;
+		std::vector<char> recs(n * rb);
+		std::vector<int> redo(n);
+		std::vector<float> un(n);
+		SH_HIP(w, hipSetDevice(w.device));
+		SH_HIP(w, hipMemcpyAsync(recs.data(), L[i].recs, n * rb, hipMemcpyDeviceToHost, w.stream));
+		SH_HIP(w, hipMemcpyAsync(redo.data(), L[i].redo, n * 4, hipMemcpyDeviceToHost, w.stream));
+		SH_HIP(w, hipMemcpyAsync(un.data(), L[i].units_next, n * 4, hipMemcpyDeviceToHost, w.stream));
+		SH_HIP(w, hipStreamSynchronize(w.stream));
+		for (size_t k = 0; k < n; k++)
+			if (redo[k]) { recs2[i].insert(recs2[i].end(), recs.begin() + (ptrdiff_t)(k * rb), recs.begin() + (ptrdiff_t)((k + 1) * rb)); units2[i].push_back(un[k]); }
+		if ((int)units2[i].size() != tot[(size_t)w.rank]) { set_err(w, "flagged records and their count disagree"); return SIFT3D_ERR_STATE; }
+	}
+	for (size_t i = 0; i < ws.size(); i++) {
+		Worker &w = *ws[i];
+		SH_HIP(w, hipSetDevice(w.device));
+		SH_HIP(w, hipStreamSynchronize(w.stream));  // (simulated ranks share the stream: every rank's first round has drained before a scratch moves)
+		if ((rc = lay_out(w, tot, neigh[(size_t)w.rank], rb, L[i])) != SIFT3D_OK) return rc;
+		if (tot[(size_t)w.rank]) {
+			SH_HIP(w, hipMemcpyAsync(L[i].recs, recs2[i].data(), recs2[i].size(), hipMemcpyHostToDevice, w.stream));
+			SH_HIP(w, hipMemcpyAsync(L[i].units, units2[i].data(), units2[i].size() * 4, hipMemcpyHostToDevice, w.stream));
+			SH_HIP(w, hipStreamSynchronize(w.stream));  // (the host vectors are pageable and go out of scope)
+		}
+	}
+	return partial_round(H, ws, s, neigh, tot, L, rb, true, n_redo);
 }
 
 // the replicated tail of the local workers: pyramid + extrema of the remaining octaves on every rank, orientation dealt by extremum
@@ -438,9 +680,10 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		for (Worker *w : ws) {
 			if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
 			rc = sift3d_slab_detect(w->stages[(size_t)s].ctx);
-			if (rc == SIFT3D_OK) rc = sift3d_slab_describe(w->stages[(size_t)s].ctx);
-			if (rc != SIFT3D_OK) { w->err = std::string("sharded keypoints: ") + sift3d_error_string(rc) + " (" + sift3d_last_error() + ")"; break; }
+			if (rc == SIFT3D_OK && !H->partial) rc = sift3d_slab_describe(w->stages[(size_t)s].ctx);
+			if (rc != SIFT3D_OK) { set_err(*w, std::string("sharded keypoints: ") + sift3d_error_string(rc) + " (" + sift3d_last_error() + ")"); break; }
 		}
+		if (rc == SIFT3D_OK && H->partial) rc = describe_partial_stage(H, ws, s);
 	}
 	if (rc != SIFT3D_OK) abort_all(H);               // (the tail thread may sit in its all-reduce waiting for ranks that will not come)
 	if (tail_thread.joinable()) tail_thread.join();  // joined whatever happened above: it calls into contexts destroy would free
@@ -486,6 +729,8 @@ void destroy_worker(Worker &w, int phase, bool comms_aborted) {
 			s.arena = nullptr;
 		}
 		for (float *&d : w.dogmax) { if (d) (void)hipFree(d); d = nullptr; }
+		if (w.pscratch) (void)hipFree(w.pscratch);
+		w.pscratch = nullptr; w.pscratch_bytes = 0;
 		if (w.seed) (void)hipFree(w.seed);
 		if (w.seed_mine) (void)hipFree(w.seed_mine);
 		w.seed = w.seed_mine = nullptr;
@@ -532,6 +777,11 @@ extern "C" const char *sift3d_sharded_error(sift3d_sharded_handle H) { return H 
 
 extern "C" int sift3d_sharded_create(sift3d_sharded_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
                                      const int *devices, int ndev, int sim_ranks, int sharded_octaves) {
+	return sift3d_sharded_create_ex(out, volume, nx, ny, nz, params, devices, ndev, sim_ranks, sharded_octaves, 0u);
+}
+
+extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
+                                        const int *devices, int ndev, int sim_ranks, int sharded_octaves, unsigned flags) {
 	if (!out) return SIFT3D_ERR_ARG;
 	*out = nullptr;
 	if (!volume || nx <= 0 || ny <= 0 || nz <= 0 || !devices || ndev < 1 || sim_ranks < 0 || (sim_ranks > 0 && ndev != 1)) {
@@ -549,7 +799,8 @@ extern "C" int sift3d_sharded_create(sift3d_sharded_handle *out, const float *vo
 	H->world = H->sim ? sim_ranks : ndev;
 	H->devices.assign(devices, devices + ndev);
 	H->levels = H->p.num_kp_levels; H->ng = H->levels + 3;
-	if (sift3d_slab_min_halo(&H->p, &H->halo) != SIFT3D_OK) return fail(SIFT3D_ERR_ARG, "bad parameters");
+	H->partial = (flags & SIFT3D_SHARDED_PARTIAL_WINDOWS) != 0;
+	if ((H->partial ? sift3d_slab_min_halo_partial(&H->p, &H->halo) : sift3d_slab_min_halo(&H->p, &H->halo)) != SIFT3D_OK) return fail(SIFT3D_ERR_ARG, "bad parameters");
 	H->noct = octaves_total(nx, ny, nz);
 	if (H->noct < 1) return fail(SIFT3D_ERR_ARG, "volume too small for one octave");
 	// sharded octaves: as asked, but none whose planes are smaller than the level kernel's tile (+ widest half width) or thinner than the ranks
@@ -591,6 +842,7 @@ extern "C" int sift3d_sharded_create(sift3d_sharded_handle *out, const float *vo
 				CR_HIP(hipMalloc(&st.arena, sizeof(float) * st.arena_floats));
 				CR_ABI(sift3d_slab_create(&st.ctx, &d, &H->p, w.device, st.arena, st.arena_floats));
 				CR_ABI(sift3d_set_stream(st.ctx, w.stream));
+				if (H->partial) CR_ABI(sift3d_slab_set_desc_partial(st.ctx, 1));
 			} else {
 				return fail(SIFT3D_ERR_ARG, "a rank would own no planes of a sharded octave");
 			}
@@ -614,6 +866,19 @@ extern "C" int sift3d_sharded_create(sift3d_sharded_handle *out, const float *vo
 			CR_HIP(hipMalloc(&w.seed, sizeof(float) * (size_t)dx * dy * std::max(dz, 1)));
 			const int mine = *std::max_element(H->counts2.begin(), H->counts2.end());
 			CR_HIP(hipMalloc(&w.seed_mine, sizeof(float) * (size_t)dx * dy * std::max(mine, 1)));
+		}
+	}
+	if (H->partial) {
+		// one finish launch adds at most kDescSegs parts: the owner's and those of five z-neighbours (slabs thinner than that take the whole-window path)
+		H->kp_count.assign((size_t)S, std::vector<int>((size_t)H->world, 0));
+		H->redo_count = H->kp_count;
+		for (const Stage &st : H->workers[0].stages) {
+			int reach = 0;
+			CR_ABI(sift3d_slab_desc_reach(st.ctx, &reach));
+			for (const std::vector<int> &nb : window_neighbours(st.bounds, reach))
+				if ((int)nb.size() + 1 > kDescSegs)
+					return fail(SIFT3D_ERR_ARG, "partial descriptor windows: a slab of octave " + std::to_string(st.octave) + " is so thin that a window spans more than " +
+					                                std::to_string(kDescSegs) + " ranks; use fewer sharded octaves or whole windows");
 		}
 	}
 	if (!H->sim) {

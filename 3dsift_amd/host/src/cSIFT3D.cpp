@@ -93,6 +93,11 @@ static int sim_ranks() {
 	const char *e = getenv("SIFT3D_SIM_RANKS");
 	return e ? atoi(e) : 0;
 }
+// SIFT3D_PARTIAL_WINDOWS=1: the sharded driver splits the descriptor windows along z over the ranks (sift3d_sharded_create_ex)
+static unsigned shard_flags() {
+	const char *e = getenv("SIFT3D_PARTIAL_WINDOWS");
+	return e && atoi(e) > 0 ? SIFT3D_SHARDED_PARTIAL_WINDOWS : 0u;
+}
 
 struct CSIFT3D::Impl {
 	sift3d_handle h = nullptr;
@@ -154,8 +159,8 @@ CSIFT3D::CSIFT3D(float *volume, int x_dim, int y_dim, int z_dim, int num_kp_leve
 	const int sim = sim_ranks();
 	if (devs.size() > 1 || sim > 1) {
 		const int one = impl->device;
-		const int rc = sift3d_sharded_create(&impl->sh, volume, x_dim, y_dim, z_dim, &p, sim > 1 ? &one : devs.data(), sim > 1 ? 1 : (int)devs.size(),
-		                                     sim > 1 ? sim : 0, 0);
+		const int rc = sift3d_sharded_create_ex(&impl->sh, volume, x_dim, y_dim, z_dim, &p, sim > 1 ? &one : devs.data(), sim > 1 ? 1 : (int)devs.size(),
+		                                        sim > 1 ? sim : 0, 0, shard_flags());
 		complain("CSIFT3D (sharded upload + normalise)", rc);
 		return;
 	}

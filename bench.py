@@ -79,7 +79,7 @@ def parse_dims(txt):
     return nx, ny, nz
 
 
-def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321):
+def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partial_windows=False):
     """The same workload through the library's NATIVE driver (csrc/sharded.hip: one process, one host thread per GPU, RCCL halo
     exchange; or sim_ranks simulated on devices[0]).  The volume starts on the host, like CreateCSIFT3D(float*) gets it."""
     import torch
@@ -88,7 +88,7 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321):
     nx, ny, nz = dims
     vol = synth.blobs_torch((nz, ny, nx), torch.device("cuda", devices[0]), seed=seed).cpu().numpy()
     t0 = time.perf_counter()
-    sh = capi.ShardedCSIFT3D(vol, devices=tuple(devices), sim_ranks=sim_ranks)
+    sh = capi.ShardedCSIFT3D(vol, devices=tuple(devices), sim_ranks=sim_ranks, partial_windows=partial_windows)
     t_ctor = time.perf_counter() - t0
     del vol
     for _ in range(warmup):
@@ -104,7 +104,8 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321):
     return {"workload": f"{nx}x{ny}x{nz} fp32 synthetic blob volume, z-slabs over {info['world']} rank(s), native C++ driver"
                         + (" SIMULATED on one GPU" if sim_ranks else " (RCCL)"),
             "value": nx * ny * nz / dt / 1e6, "unit": "Mvoxels/s", "ms_per_step": dt * 1e3, "keypoints": int(len(kp)),
-            "sharded_octaves": info["sharded_octaves"], "halo_planes": info["halo"], "ctor_s_incl_H2D_of_the_slabs": round(t_ctor, 3),
+            "sharded_octaves": info["sharded_octaves"], "halo_planes": info["halo"],
+            "descriptor_windows": "partial integer histograms" if partial_windows else "whole windows on plane halos", "ctor_s_incl_H2D_of_the_slabs": round(t_ctor, 3),
             "note": "ms_per_step = host wall time of sift3d_sharded_run up to the results of every rank on the host (keypoint and descriptor D2H included)"}
 
 
@@ -219,6 +220,7 @@ def main():
     ap.add_argument("--no-slab-leg", action="store_true", help="do not append the configs[3] measurement (N=1: the single-GPU run of the 1024x1024x512 volume; N>1: z-slabs over the ranks)")
     ap.add_argument("--strict-legs", action="store_true", help="exit non-zero when a side leg (slab / slab_native) failed; the JSON line is printed either way")
     ap.add_argument("--native", action="store_true", help="slab workload on one process: the library's native C++ driver (RCCL over --gpus devices, or --sim-ranks)")
+    ap.add_argument("--partial-windows", action="store_true", help="with --native: descriptor windows split along z over the ranks (sift3d_sharded_create_ex)")
     args = ap.parse_args()
 
     import torch
@@ -235,7 +237,8 @@ def main():
 
     if args.workload == "slab" and args.native and world == 1:
         dims = parse_dims(args.slab_dims)
-        r = run_slab_native(dims, list(range(max(1, args.gpus))) if not args.sim_ranks else [local], args.steps, args.warmup, sim_ranks=args.sim_ranks)
+        r = run_slab_native(dims, list(range(max(1, args.gpus))) if not args.sim_ranks else [local], args.steps, args.warmup, sim_ranks=args.sim_ranks,
+                            partial_windows=args.partial_windows)
         print(json.dumps({"metric": "Mvoxels/s end-to-end KpSiftAlgorithm, one volume sharded as z-slabs (native driver)", "value": r["value"],
                           "unit": "Mvoxels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -642,6 +645,11 @@ def main():
                 torch.cuda.empty_cache()
                 nres, nat_err = guarded(lambda: run_slab_native(parse_dims(args.slab_dims), list(range(world)), SLAB_STEPS, SLAB_WARMUP), 180)
                 out["slab_native"] = nres if nat_err is None else {"error": nat_err}
+                if nat_err is None:
+                    # r05, opt-in form of the native driver: descriptor windows split along z (13-plane level halos, records out, integer
+                    # histograms back).  Simulated ranks only in development; reported beside the default form, never instead of it.
+                    pres, p_err = guarded(lambda: run_slab_native(parse_dims(args.slab_dims), list(range(world)), SLAB_STEPS, SLAB_WARMUP, partial_windows=True), 120)
+                    out["slab_native_partial_windows"] = pres if p_err is None else {"error": p_err}
                 if store is not None:
                     try:
                         store.set("s3d_native_done", "1")
@@ -651,7 +659,7 @@ def main():
                 torch.cuda.empty_cache()
                 try:
                     import datetime
-                    store.wait(["s3d_native_done"], datetime.timedelta(seconds=200))
+                    store.wait(["s3d_native_done"], datetime.timedelta(seconds=330))
                 except Exception:
                     pass
     failed = []

@@ -272,6 +272,12 @@ int sift3d_import_descriptors_device(sift3d_handle h, const float *d_desc_src);
 typedef struct sift3d_sharded *sift3d_sharded_handle;
 int sift3d_sharded_create(sift3d_sharded_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
                           const int *devices, int ndev, int sim_ranks, int sharded_octaves);
+/* the same with option bits.  SIFT3D_SHARDED_PARTIAL_WINDOWS (r05, opt-in): the descriptor windows are split along z over the ranks
+ * (records to the z-neighbours, partial integer histograms back: the sift3d_slab_describe_partial / _finish protocol above) instead of
+ * carrying whole windows on 38-plane halos; same results bit for bit.  Refused when a slab is so thin that a window spans more than 6 ranks. */
+#define SIFT3D_SHARDED_PARTIAL_WINDOWS 1u
+int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
+                             const int *devices, int ndev, int sim_ranks, int sharded_octaves, unsigned flags);
 int sift3d_sharded_run(sift3d_sharded_handle h);
 int sift3d_sharded_num_keypoints(sift3d_sharded_handle h, int *n);
 int sift3d_sharded_get_keypoints(sift3d_sharded_handle h, sift3d_keypoint *out, float *desc /* n*768, may be NULL */);

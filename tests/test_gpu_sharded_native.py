@@ -45,8 +45,39 @@ def test_simulated_ranks_equal_the_single_volume(vol_and_single, ranks, octs):
     sh.close()
 
 
+@pytest.mark.parametrize("ranks,octs", [(2, 1), (2, 2), (3, 2), (4, 2), (5, 1)])
+def test_simulated_ranks_with_partial_descriptor_windows_equal_the_single_volume(vol_and_single, ranks, octs):
+    """sift3d_sharded_create_ex(SIFT3D_SHARDED_PARTIAL_WINDOWS): records to the z-neighbours, partial integer histograms back, 13-plane
+    level halos instead of 39 -- the same keypoints and descriptors, bit for bit, run after run on the same scratch."""
+    vol, kp, ds = vol_and_single
+    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=True)
+    info = sh.info()
+    assert info["world"] == ranks and info["halo"] == capi.slab_min_halo_partial()
+    for _ in range(2):
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        assert np.array_equal(k2, kp), (ranks, octs)
+        assert np.array_equal(d2, ds), (ranks, octs)
+    sh.close()
+
+
+def test_native_partial_windows_second_round_and_thin_slabs(vol_and_single):
+    """(a) desc_mass_shift flags every record in the first round: the native driver compacts the flagged subset and repeats it with the exact
+    unit over the same exchange; (b) 8 ranks x 2 octaves of the 160-plane volume would make a window span more than six ranks: refused."""
+    vol, _, _ = vol_and_single
+    with capi.hook("desc_mass_shift", 9):
+        ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+        kp, ds = ex.GetKeypoints()
+        assert ex.debug_counters()["desc_second_passes"] > len(kp) // 4
+        sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=3, sharded_octaves=2, partial_windows=True)
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        sh.close(); ex.close()
+    assert np.array_equal(k2, kp) and np.array_equal(d2, ds)
+    with pytest.raises(capi.Sift3dError, match="partial descriptor windows"):
+        capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=8, sharded_octaves=2, partial_windows=True)
+
+
 def test_random_native_plans_equal_the_single_volume():
-    """Six random (shape, simulated ranks, sharded octaves) draws through the native driver: keypoints and descriptors bit-identical
+    """Six random (shape, simulated ranks, sharded octaves, whole / partial descriptor windows) draws through the native driver: keypoints and descriptors bit-identical
     to the single-volume extractor (uneven slabs, odd depths, slabs thinner than the halo)."""
     rng = np.random.default_rng(808)
     done = 0
@@ -56,15 +87,15 @@ def test_random_native_plans_equal_the_single_volume():
         nz = int(rng.integers(48, 150)); ny = int(rng.choice([48, 64, 70, 96])); nx = int(rng.choice([48, 64, 72, 96, 130]))
         ranks = int(rng.integers(2, 7)); octs = int(rng.integers(1, 3))
         vol = synth.blobs((nz, ny, nx), seed=900 + case, noise=0.01)
-        try:
-            sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs)
+        try:   # every other case with the descriptor windows split along z
+            sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=bool(case & 1))
         except capi.Sift3dError:
-            continue   # (too few planes for that many slabs)
+            continue   # (too few planes for that many slabs, or slabs too thin for partial windows)
         ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
         kp, ds = ex.GetKeypoints()
         with capi.hook("march_tiles", done & 1):   # every second plan with the 64 x 32 tiles wherever a slab's levels fit them
             k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
-        tag = ((nz, ny, nx), ranks, octs, sh.info())
+        tag = ((nz, ny, nx), ranks, octs, case & 1, sh.info())
         sh.close(); ex.close()
         assert np.array_equal(k2, kp), tag
         assert np.array_equal(d2, ds), tag
@@ -72,9 +103,10 @@ def test_random_native_plans_equal_the_single_volume():
     assert done == 6
 
 
-def test_rccl_transport_world_of_one(vol_and_single):
+@pytest.mark.parametrize("partial", [False, True])
+def test_rccl_transport_world_of_one(vol_and_single, partial):
     vol, kp, ds = vol_and_single
-    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=0, sharded_octaves=2)   # one real rank: every collective goes through librccl
+    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=0, sharded_octaves=2, partial_windows=partial)   # one real rank: every collective goes through librccl
     assert sh.info()["world"] == 1
     k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
     sh.close()
@@ -107,9 +139,9 @@ def test_cpp_shell_shards_for_the_unchanged_user():
         subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(PKG, "host"), "-o", os.path.join(t, "m"), os.path.join(t, "m.cpp"),
                                "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-Wl,-rpath," + PKG])
         outs = []
-        for env in ({}, {"SIFT3D_SIM_RANKS": "4"}, {"SIFT3D_DEVICES": "0"}):
+        for env in ({}, {"SIFT3D_SIM_RANKS": "4"}, {"SIFT3D_DEVICES": "0"}, {"SIFT3D_SIM_RANKS": "3", "SIFT3D_PARTIAL_WINDOWS": "1"}):
             e = dict(os.environ, **env)
             o = subprocess.check_output([os.path.join(t, "m"), os.path.join(t, "v.bin"), os.path.join(t, "k.bin")], env=e, stderr=subprocess.STDOUT).decode()
             outs.append((o.strip().splitlines()[-1].split()[1], open(os.path.join(t, "k.bin"), "rb").read()))
     assert int(outs[0][0]) > 30
-    assert outs[1] == outs[0] and outs[2] == outs[0]
+    assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0]
