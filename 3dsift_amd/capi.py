@@ -33,7 +33,8 @@ SYMBOLS = [
     "sift3d_default_params", "sift3d_create", "sift3d_destroy", "sift3d_run", "sift3d_run_async", "sift3d_wait", "sift3d_run_stages",
     "sift3d_stage_times", "sift3d_num_keypoints", "sift3d_get_keypoints", "sift3d_device_results",
     "sift3d_num_octaves", "sift3d_level_info", "sift3d_copy_level", "sift3d_copy_input", "sift3d_num_extrema",
-    "sift3d_get_extrema", "sift3d_get_orientation_codes", "sift3d_gaussian_smooth", "sift3d_downsample", "sift3d_dog_sub", "sift3d_match",
+    "sift3d_get_extrema", "sift3d_get_orientation_codes", "sift3d_gaussian_smooth", "sift3d_downsample", "sift3d_dog_sub", "sift3d_conv_axis",
+    "sift3d_orient_keypoint", "sift3d_describe_keypoint", "sift3d_match",
     "sift3d_match_handles",
     "sift3d_device_count", "sift3d_error_string", "sift3d_last_error",
     # multi-GPU sharding (z-slabs of octave 0 + seeded replicated tail)
@@ -115,6 +116,9 @@ def lib():
         L.sift3d_gaussian_smooth.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, C.c_int]
         L.sift3d_downsample.argtypes = [_fp, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.sift3d_dog_sub.argtypes = [_fp, _fp, C.c_size_t, _fp, C.c_int]
+        L.sift3d_conv_axis.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, _fp, C.c_int]
+        L.sift3d_orient_keypoint.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, _ip]
+        L.sift3d_describe_keypoint.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, _fp, C.c_int]
         L.sift3d_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int,
                                    C.c_int, C.c_int, _ip, _ip, _fp, _fp, _fp, _ip, C.POINTER(C.c_double)]
         L.sift3d_match_handles.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, _ip, _ip, _fp, _fp, _fp, _ip, C.POINTER(C.c_double)]
@@ -667,6 +671,37 @@ def dog_sub(prev, cur, device=0):
     out = np.empty_like(prev)
     _check(lib().sift3d_dog_sub(_f(prev), _f(cur), prev.size, _f(out), device))
     return out
+
+
+def conv_axis(vol, dim, weight, device=0):
+    """GaussianSmooth_3D_Imp (Include/cSIFT3D.h:214): one pass along dim (0 x, 1 y, 2 z) with the caller's taps."""
+    vol = np.ascontiguousarray(vol, dtype=np.float32); w = np.ascontiguousarray(weight, dtype=np.float32)
+    nz, ny, nx = vol.shape
+    out = np.empty_like(vol)
+    _check(lib().sift3d_conv_axis(_f(vol), nx, ny, nz, int(dim), _f(w), int(w.size), _f(out), device))
+    return out
+
+
+def orient_keypoint(level, unit, kp, sigma, max_eig_ratio=0.9, corner_thresh=0.4, device=0):
+    """Assign_Orientation_Imp (Include/cSIFT3D.h:224) for ONE keypoint record (a KP_DTYPE scalar array of shape (1,), updated in place)
+    on a host level [z, y, x]; returns the reference's code."""
+    level = np.ascontiguousarray(level, dtype=np.float32)
+    nz, ny, nx = level.shape
+    assert kp.dtype == KP_DTYPE and kp.shape == (1,) and kp.flags.c_contiguous
+    code = C.c_int(0)
+    _check(lib().sift3d_orient_keypoint(_f(level), nx, ny, nz, float(unit), kp.ctypes.data_as(C.c_void_p), float(sigma), float(max_eig_ratio),
+                                        float(corner_thresh), device, C.byref(code)))
+    return code.value
+
+
+def describe_keypoint(level, unit, kp, device=0):
+    """Extract_Descriptor_Imp (Include/cSIFT3D.h:228) for ONE keypoint record (shape (1,), Rotation transposed in place); returns desc[768]."""
+    level = np.ascontiguousarray(level, dtype=np.float32)
+    nz, ny, nx = level.shape
+    assert kp.dtype == KP_DTYPE and kp.shape == (1,) and kp.flags.c_contiguous
+    desc = np.zeros(DESC, np.float32)
+    _check(lib().sift3d_describe_keypoint(_f(level), nx, ny, nz, float(unit), kp.ctypes.data_as(C.c_void_p), _f(desc), device))
+    return desc
 
 
 class muBruteMatcher:

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <thread>
 
 #include "sift3d_internal.h"
@@ -429,10 +430,80 @@ static void plan_pyramid(sift3d_ctx *c, int noct_total) {
 
 // Gaussian window tables (see WinLut): orientation (Src/cSIFT3D.cc:915, 968-971) and descriptor
 // (Src/cSIFT3D.cc:1155-1156, 1270, 1312) windows of every (octave, keypoint level).
-static int build_luts(sift3d_ctx *c) {
+// one table: which = 0 the orientation window (sigma, radius = 3 sigma), 1 the descriptor window of a keypoint of scale `scale`
+// (sigma = 7.0711 scale, radius = 2 sigma) on a level of unit u; appended to `pool`.  Returns false when a descriptor table is too long for the LDS.
+static bool append_lut(std::vector<float> &pool, WinLut &L, int which, float sigma, float radius, float u, float scale) {
+	bool fits_lds = true;
+	const float r2 = radius * radius, uu = u * u;
+	const int len = (int)floor((double)r2 / (double)uu) + 2;
+	L.off = (int)pool.size(); L.len = len; L.nin = -1; L.radius = radius; L.sigma = sigma; L.fix_scale = 1.0f; L.list_off = -1; L.list_R = 0;
+	if (which == 1) {
+		// 32-bit histogram bins: a bin (cell, vertex) collects wgt * |g| * bary over the voxels within one cell of its centre;
+		// the trilinear weights of those voxels sum to at most (cw + 2)^3 (cw = cell width in voxels = desc_width / (4u) =
+		// 5 scale / u), |g| <= sqrt(3) (normalised data, |0.5 (a - b) / u| <= 1 per axis, weight <= 1), bary <= 1 + 2e-6
+		const double cw = 5.0 * (double)scale / (double)u, bound = (cw + 2.0) * (cw + 2.0) * (cw + 2.0) * 1.7321 * 1.001;
+		int k = (int)floor(log2(2147483647.0 / bound));
+		k = std::max(0, std::min(k, 29));
+		L.fix_scale = (float)ldexp(1.0, k);
+	}
+	if (which == 1 && len > kMaxDescLut) fits_lds = false;  // k_describe<false>: table read from global memory
+	for (int n = 0; n < len; n++) {
+		const float sq = (float)n * uu;  // exact: equals the reference's fp32 sum of squares
+		float w;
+		if (!(sq > r2)) L.nin = n;
+		if (sq > r2) w = -1.0f;
+		else if (which == 0) w = expf((float)(-0.5 * (double)sq / (double)(sigma * sigma)));
+		else w = expf(-0.5f * sq / (sigma * sigma)) * (0.5f / u);  // exact scaling (u = 2^octave), see WinLut
+		pool.push_back(w);
+	}
+	// sum of the weights over the lattice points of the sphere (k_describe's first guess of the gradient mass)
+	const int R = (int)floor(sqrt((double)std::max(L.nin, 0)));
+	double ws = 0.0;
+	for (int dz = -R; dz <= R; dz++)
+		for (int dy = -R; dy <= R; dy++)
+			for (int dx = -R; dx <= R; dx++) {
+				const int n = dx * dx + dy * dy + dz * dz;
+				if (n <= L.nin) ws += (double)pool[(size_t)L.off + n] * (which == 1 ? (double)u / 0.5 : 1.0);
+			}
+	L.wsum = (float)std::max(ws, 1.0);
+	if (which == 0 && R <= 127 && L.nin < 65536) {  // lattice points of the orientation sphere (WinLut::list_off)
+		std::vector<unsigned> words((size_t)2 * R + 2);
+		for (int dz = -R; dz <= R; dz++) {
+			words[(size_t)(dz + R)] = (unsigned)(words.size() - ((size_t)2 * R + 2));
+			for (int dy = -R; dy <= R; dy++)
+				for (int dx = -R; dx <= R; dx++) {
+					const int n = dx * dx + dy * dy + dz * dz;
+					if (n <= L.nin) words.push_back((unsigned)(dx + 128) | (unsigned)(dy + 128) << 8 | (unsigned)n << 16);
+				}
+		}
+		words[(size_t)2 * R + 1] = (unsigned)(words.size() - ((size_t)2 * R + 2));
+		L.list_off = (int)pool.size(); L.list_R = R;
+		pool.resize(pool.size() + words.size());
+		memcpy(pool.data() + L.list_off, words.data(), words.size() * sizeof(unsigned));
+	}
+	return fits_lds;
+}
+
+static int upload_luts(sift3d_ctx *c, const std::vector<WinLut> &luts, std::vector<float> &pool) {
+	if (pool.empty()) pool.push_back(-1.0f);
+	if (c->d_luts) { S3D_HIP(hipFree(c->d_luts)); c->d_luts = nullptr; }
+	if (c->d_lutpool) { S3D_HIP(hipFree(c->d_lutpool)); c->d_lutpool = nullptr; }
+	S3D_HIP(hipMalloc(&c->d_luts, sizeof(WinLut) * luts.size()));
+	S3D_HIP(hipMalloc(&c->d_lutpool, sizeof(float) * pool.size()));
+	S3D_HIP(hipMemcpy(c->d_luts, luts.data(), sizeof(WinLut) * luts.size(), hipMemcpyHostToDevice));
+	S3D_HIP(hipMemcpy(c->d_lutpool, pool.data(), sizeof(float) * pool.size(), hipMemcpyHostToDevice));
+	return SIFT3D_OK;
+}
+
+static std::vector<WinLut> blank_luts(const sift3d_ctx *c) {
 	std::vector<WinLut> luts((size_t)std::max(1, c->noct + c->octave_base) * 8 * 2);
-	std::vector<float> pool;
 	for (auto &l : luts) { l.off = 0; l.len = 0; l.nin = -1; l.radius = 0; l.sigma = 0; l.fix_scale = 1.0f; l.wsum = 1.0f; l.list_off = -1; l.list_R = 0; }
+	return luts;
+}
+
+static int build_luts(sift3d_ctx *c) {
+	std::vector<WinLut> luts = blank_luts(c);
+	std::vector<float> pool;
 	for (int o = 0; o < c->noct; o++)
 		for (int lv = 1; lv <= c->p.num_kp_levels && lv < 8; lv++) {
 			const Level &D = c->dog[(size_t)o * c->nd + lv];  // keypoint scale = DoG level scale (Src/cSIFT3D.cc:407)
@@ -441,64 +512,10 @@ static int build_luts(sift3d_ctx *c) {
 				float sigma, radius;
 				if (which == 0) { sigma = 1.5f * scale; radius = sigma * 3.0f; }
 				else { sigma = scale * 7.071067812f; radius = 2.0f * sigma; }
-				const float r2 = radius * radius, uu = u * u;
-				const int len = (int)floor((double)r2 / (double)uu) + 2;
-				WinLut &L = luts[((size_t)(o + c->octave_base) * 8 + lv) * 2 + which];
-				L.off = (int)pool.size(); L.len = len; L.nin = -1; L.radius = radius; L.sigma = sigma; L.fix_scale = 1.0f;
-				if (which == 1) {
-					// 32-bit histogram bins: a bin (cell, vertex) collects wgt * |g| * bary over the voxels within one cell of its centre;
-					// the trilinear weights of those voxels sum to at most (cw + 2)^3 (cw = cell width in voxels = desc_width / (4u) =
-					// 5 scale / u), |g| <= sqrt(3) (normalised data, |0.5 (a - b) / u| <= 1 per axis, weight <= 1), bary <= 1 + 2e-6
-					const double cw = 5.0 * (double)scale / (double)u, bound = (cw + 2.0) * (cw + 2.0) * (cw + 2.0) * 1.7321 * 1.001;
-					int k = (int)floor(log2(2147483647.0 / bound));
-					k = std::max(0, std::min(k, 29));
-					L.fix_scale = (float)ldexp(1.0, k);
-				}
-				if (which == 1 && len > kMaxDescLut) c->desc_lut_lds = false;  // k_describe<false>: table read from global memory
-				for (int n = 0; n < len; n++) {
-					const float sq = (float)n * uu;  // exact: equals the reference's fp32 sum of squares
-					float w;
-					if (!(sq > r2)) L.nin = n;
-					if (sq > r2) w = -1.0f;
-					else if (which == 0) w = expf((float)(-0.5 * (double)sq / (double)(sigma * sigma)));
-					else w = expf(-0.5f * sq / (sigma * sigma)) * (0.5f / u);  // exact scaling (u = 2^octave), see WinLut
-					pool.push_back(w);
-				}
-				{
-					// sum of the weights over the lattice points of the sphere (k_describe's first guess of the gradient mass)
-					const int R = (int)floor(sqrt((double)std::max(L.nin, 0)));
-					double ws = 0.0;
-					for (int dz = -R; dz <= R; dz++)
-						for (int dy = -R; dy <= R; dy++)
-							for (int dx = -R; dx <= R; dx++) {
-								const int n = dx * dx + dy * dy + dz * dz;
-								if (n <= L.nin) ws += (double)pool[(size_t)L.off + n] * (which == 1 ? (double)u / 0.5 : 1.0);
-							}
-					L.wsum = (float)std::max(ws, 1.0);
-					if (which == 0 && R <= 127 && L.nin < 65536) {  // lattice points of the orientation sphere (WinLut::list_off)
-						std::vector<unsigned> words((size_t)2 * R + 2);
-						for (int dz = -R; dz <= R; dz++) {
-							words[(size_t)(dz + R)] = (unsigned)(words.size() - ((size_t)2 * R + 2));
-							for (int dy = -R; dy <= R; dy++)
-								for (int dx = -R; dx <= R; dx++) {
-									const int n = dx * dx + dy * dy + dz * dz;
-									if (n <= L.nin) words.push_back((unsigned)(dx + 128) | (unsigned)(dy + 128) << 8 | (unsigned)n << 16);
-								}
-						}
-						words[(size_t)2 * R + 1] = (unsigned)(words.size() - ((size_t)2 * R + 2));
-						L.list_off = (int)pool.size(); L.list_R = R;
-						pool.resize(pool.size() + words.size());
-						memcpy(pool.data() + L.list_off, words.data(), words.size() * sizeof(unsigned));
-					}
-				}
+				if (!append_lut(pool, luts[((size_t)(o + c->octave_base) * 8 + lv) * 2 + which], which, sigma, radius, u, scale)) c->desc_lut_lds = false;
 			}
 		}
-	if (pool.empty()) pool.push_back(-1.0f);
-	S3D_HIP(hipMalloc(&c->d_luts, sizeof(WinLut) * luts.size()));
-	S3D_HIP(hipMalloc(&c->d_lutpool, sizeof(float) * pool.size()));
-	S3D_HIP(hipMemcpy(c->d_luts, luts.data(), sizeof(WinLut) * luts.size(), hipMemcpyHostToDevice));
-	S3D_HIP(hipMemcpy(c->d_lutpool, pool.data(), sizeof(float) * pool.size(), hipMemcpyHostToDevice));
-	return SIFT3D_OK;
+	return upload_luts(c, luts, pool);
 }
 
 // how a context is built: the classic whole-volume extractor, a SEEDED tail (octaves >= octave_base starting from a
@@ -1338,6 +1355,199 @@ extern "C" int sift3d_gaussian_smooth(const float *src, int nx, int ny, int nz, 
 	return SIFT3D_OK;
 }
 
+
+// GaussianSmooth_3D_Imp (Src/cSIFT3D.cc:624-788): ONE pass along `dim` with the caller's taps (width odd: the reference reads
+// weight[0 .. 2 (width / 2)]), interior and boundary rule of the pipeline's generic pass (k_conv_axis)
+extern "C" int sift3d_conv_axis(const float *src, int nx, int ny, int nz, int dim, const float *weight, int width, float *dst, int device) {
+	if (!src || !dst || !weight || nx <= 0 || ny <= 0 || nz <= 0 || dim < 0 || dim > 2) return SIFT3D_ERR_ARG;
+	if (width < 1 || !(width & 1) || width / 2 > kMaxHW) { set_last_error("sift3d_conv_axis: the kernel width must be odd and at most 2 * 64 + 1"); return SIFT3D_ERR_ARG; }
+	int rc = set_device(device);
+	if (rc) return rc;
+	Taps t;
+	t.hw = width / 2;
+	for (int i = 0; i < kMaxTaps; i++) t.w[i] = i < width ? weight[i] : 0.f;
+	const size_t n = (size_t)nx * ny * nz;
+	float *d = nullptr;
+	S3D_HIP(hipMalloc(&d, sizeof(float) * n * 2));
+	hipError_t e = hipMemcpy(d, src, sizeof(float) * n, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		launch_conv_axis(dim, d, d + n, nx, ny, nz, t, nullptr, nullptr, nullptr, nullptr);
+		e = hipDeviceSynchronize();
+	}
+	if (e == hipSuccess) e = hipMemcpy(dst, d + n, sizeof(float) * n, hipMemcpyDeviceToHost);
+	hipFree(d);
+	if (e != hipSuccess) { set_last_error(hipGetErrorString(e)); return SIFT3D_ERR_HIP; }
+	return SIFT3D_OK;
+}
+
+// ---- one keypoint on a caller-provided level: Assign_Orientation_Imp / Extract_Descriptor_Imp (Src/cSIFT3D.cc:913-1138, 1152-1381) as
+// free functions (Include/cSIFT3D.h:224, 228).  The pipeline's own kernels run on the BOX of the level the window reaches -- the clipped
+// window bounds of Src/cSIFT3D.cc:939-955 / 1184-1200 plus the plane either side the central differences read -- with the keypoint's
+// coordinates shifted into it: the kernels' own clipping of a window to [1, n - 2] of that box gives the same voxel set as the
+// reference's on the whole level, and nothing else of the level is read.  The box lives in level slot 1 of a small one-octave context that
+// is kept for the next call (a loop over keypoints, as the reference's callers run, pays for it once); its tables are rebuilt when sigma / scale /
+// unit change.  The keypoint must sit on a voxel and the level's unit must be a power of two, as in the pipeline: anything else is refused.
+namespace {
+struct OneKp {
+	sift3d_ctx *c = nullptr;
+	int device = -1, octave_base = -1, edge = 0;
+	float ori_sigma = -1.f, scale = -1.f;
+};
+std::mutex g_onekp_mu;
+OneKp g_onekp;  // (never destroyed at exit: the HIP runtime may be gone by then)
+
+struct Box { int lo[3], n[3]; };  // first voxel of the box in the level, box dimensions
+
+// window bounds like win_bounds (kernels_orient.hip / kernels_desc.hip), then one voxel either side
+bool window_box(const int c[3], const int dims[3], float radius, float unit, Box &b) {
+	for (int a = 0; a < 3; a++) {
+		if (dims[a] < 3) return false;
+		const int s = (int)floorf((float)c[a] - radius / unit), e = (int)ceilf((float)c[a] + radius / unit);
+		const int lo = s > 1 ? s : 1, hi = e < dims[a] - 2 ? e : dims[a] - 2;
+		if (hi < lo) return false;
+		b.lo[a] = lo - 1; b.n[a] = hi - lo + 3;
+	}
+	return true;
+}
+
+int onekp_prepare(OneKp &K, int device, float unit, int edge, float ori_sigma, float scale) {
+	int ex = 0;
+	const float m = frexpf(unit, &ex);
+	if (!(unit >= 1.0f) || m != 0.5f || ex - 1 > 20) { set_last_error("the level's unit must be a power of two >= 1 (2^octave)"); return SIFT3D_ERR_ARG; }
+	const int ob = ex - 1;
+	if (!K.c || K.device != device || K.octave_base != ob || K.edge < edge) {
+		if (K.c) { sift3d_destroy(K.c); K = OneKp(); }
+		CreateCfg cfg;
+		const int e = std::max(96, (edge + 31) & ~31);
+		cfg.nx = cfg.ny = cfg.nz = e; cfg.octave_base = ob; cfg.noct_total = ob + 1; cfg.seeded = true;
+		sift3d_ctx *c = nullptr;
+		int rc = create_common(&c, cfg, nullptr, device);
+		if (rc) return rc;
+		K.c = c; K.device = device; K.octave_base = ob; K.edge = e;
+	}
+	if (K.ori_sigma != ori_sigma || K.scale != scale) {
+		sift3d_ctx *c = K.c;
+		std::vector<WinLut> luts = blank_luts(c);
+		std::vector<float> pool;
+		c->desc_lut_lds = true;
+		const size_t at = ((size_t)K.octave_base * 8 + 1) * 2;
+		(void)append_lut(pool, luts[at], 0, ori_sigma, ori_sigma * 3.0f, unit, scale);
+		const float dsig = scale * 7.071067812f;
+		if (!append_lut(pool, luts[at + 1], 1, dsig, 2.0f * dsig, unit, scale)) c->desc_lut_lds = false;
+		S3D_HIP(hipStreamSynchronize(c->stream));
+		int rc = upload_luts(c, luts, pool);
+		if (rc) return rc;
+		K.ori_sigma = ori_sigma; K.scale = scale;
+	}
+	return SIFT3D_OK;
+}
+
+// the box -> level slot 1, its dimensions -> the level table, the record -> extremum 0
+int onekp_load(OneKp &K, const float *level, int nx, int ny, float unit, const Box &b, const DevKp &rec) {
+	sift3d_ctx *c = K.c;
+	hipStream_t st = c->stream;
+	std::vector<float> box((size_t)b.n[0] * b.n[1] * b.n[2]);
+	for (int z = 0; z < b.n[2]; z++)
+		for (int y = 0; y < b.n[1]; y++)
+			memcpy(&box[((size_t)z * b.n[1] + y) * b.n[0]], level + ((size_t)(b.lo[2] + z) * ny + (size_t)(b.lo[1] + y)) * nx + b.lo[0], sizeof(float) * b.n[0]);
+	Level &L = c->gss[1];
+	const LevelRef ref{L.d, b.n[0], b.n[1], b.n[2], unit, 0};
+	const unsigned words[3] = {1u, 0u, 0u};  // extrema, overflow flag, keypoints
+	const int code = rec.code;
+	S3D_HIP(hipMemcpyAsync(L.d, box.data(), sizeof(float) * box.size(), hipMemcpyHostToDevice, st));
+	S3D_HIP(hipMemcpyAsync(c->d_levels + ((size_t)K.octave_base * 8 + 1), &ref, sizeof(ref), hipMemcpyHostToDevice, st));
+	S3D_HIP(hipMemcpyAsync(c->d_ext, &rec, sizeof(rec), hipMemcpyHostToDevice, st));
+	S3D_HIP(hipMemcpyAsync(c->d_codes, &code, sizeof(int), hipMemcpyHostToDevice, st));
+	S3D_HIP(hipMemcpyAsync(c->d_total, words, sizeof(words), hipMemcpyHostToDevice, st));
+	S3D_HIP(hipStreamSynchronize(st));  // (the sources are pageable host memory of this frame)
+	return SIFT3D_OK;
+}
+
+int onekp_check(const float *level, int nx, int ny, int nz, const sift3d_keypoint *kp, int c[3]) {
+	if (!level || !kp || nx < 3 || ny < 3 || nz < 3) { set_last_error("bad level / keypoint"); return SIFT3D_ERR_ARG; }
+	const float f[3] = {kp->x, kp->y, kp->z};
+	const int dims[3] = {nx, ny, nz};
+	for (int a = 0; a < 3; a++) {
+		c[a] = (int)f[a];
+		if ((float)c[a] != f[a] || c[a] < 0 || c[a] >= dims[a]) { set_last_error("the keypoint must sit on a voxel of the level (integral x, y, z inside it)"); return SIFT3D_ERR_ARG; }
+	}
+	if (!(kp->scale > 0.0f)) { set_last_error("keypoint scale must be positive"); return SIFT3D_ERR_ARG; }
+	return SIFT3D_OK;
+}
+}  // namespace
+
+// kp in: x, y, z (voxel of the level), scale; out: win, eigvalue, eigvector, Rotation (as Assign_Orientation_Imp leaves it: not
+// transposed), str_tensor (computed from zero: the reference accumulates into what Initialize_Keypoint zeroed).  *code: the reference's
+// return value (1 accepted, -1 weak gradient, -2 eigenvalue ratio / not distinct, -3 corner).
+extern "C" int sift3d_orient_keypoint(const float *level, int nx, int ny, int nz, float unit, sift3d_keypoint *kp, float sigma, float max_eig_ratio,
+                                      float corner_thresh, int device, int *code) {
+	int ctr[3];
+	int rc = onekp_check(level, nx, ny, nz, kp, ctr);
+	if (rc) return rc;
+	if (!code || !(sigma > 0.0f)) { set_last_error("sift3d_orient_keypoint: bad argument"); return SIFT3D_ERR_ARG; }
+	if ((rc = set_device(device)) != SIFT3D_OK) return rc;
+	const int dims[3] = {nx, ny, nz};
+	Box b;
+	if (!window_box(ctr, dims, sigma * 3.0f, unit, b)) { set_last_error("the orientation window is empty"); return SIFT3D_ERR_ARG; }
+	std::lock_guard<std::mutex> lk(g_onekp_mu);
+	OneKp &K = g_onekp;
+	if ((rc = onekp_prepare(K, device, unit, std::max(b.n[0], std::max(b.n[1], b.n[2])), sigma, kp->scale)) != SIFT3D_OK) return rc;
+	sift3d_ctx *c = K.c;
+	DevKp rec;
+	memset(&rec, 0, sizeof(rec));
+	rec.x = ctr[0] - b.lo[0]; rec.y = ctr[1] - b.lo[1]; rec.z = ctr[2] - b.lo[2];
+	rec.octave = K.octave_base; rec.level = 1; rec.scale = kp->scale; rec.slot = -1;
+	if ((rc = onekp_load(K, level, nx, ny, unit, b, rec)) != SIFT3D_OK) return rc;
+	hipStream_t st = c->stream;
+	launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, max_eig_ratio, corner_thresh, 0, 1, c->d_order,
+	              c->d_nkp + 3, st);
+	S3D_HIP(hipMemcpyAsync(&rec, c->d_ext, sizeof(rec), hipMemcpyDeviceToHost, st));
+	S3D_HIP(hipStreamSynchronize(st));
+	S3D_HIP(hipGetLastError());
+	*code = rec.code;
+	for (int i = 0; i < 3; i++) { kp->win[i] = rec.win[i]; kp->eigvalue[i] = rec.eigvalue[i]; }
+	for (int i = 0; i < 9; i++) { kp->eigvector[i] = rec.eigvector[i]; kp->Rotation[i] = rec.rot[i]; kp->str_tensor[i] = rec.st[i]; }
+	return SIFT3D_OK;
+}
+
+// kp in: x, y, z, scale, Rotation (as the orientation stage leaves it), str_tensor (first guess of the histogram's fixed-point unit only);
+// out: Rotation TRANSPOSED (Src/cSIFT3D.cc:1214 inverts it in place), desc768 = the normalised descriptor (cc:1350-1358)
+extern "C" int sift3d_describe_keypoint(const float *level, int nx, int ny, int nz, float unit, sift3d_keypoint *kp, float *desc768, int device) {
+	int ctr[3];
+	int rc = onekp_check(level, nx, ny, nz, kp, ctr);
+	if (rc) return rc;
+	if (!desc768) return SIFT3D_ERR_ARG;
+	if ((rc = set_device(device)) != SIFT3D_OK) return rc;
+	const int dims[3] = {nx, ny, nz};
+	const float dsig = kp->scale * 7.071067812f;
+	Box b;
+	if (!window_box(ctr, dims, 2.0f * dsig, unit, b)) { set_last_error("the descriptor window is empty"); return SIFT3D_ERR_ARG; }
+	std::lock_guard<std::mutex> lk(g_onekp_mu);
+	OneKp &K = g_onekp;
+	// (the orientation table of the pair is the pipeline's for this scale: its weight sum enters the first guess of the fixed-point unit)
+	if ((rc = onekp_prepare(K, device, unit, std::max(b.n[0], std::max(b.n[1], b.n[2])), K.c && K.scale == kp->scale ? K.ori_sigma : 1.5f * kp->scale, kp->scale)) != SIFT3D_OK)
+		return rc;
+	sift3d_ctx *c = K.c;
+	DevKp rec;
+	memset(&rec, 0, sizeof(rec));
+	rec.x = ctr[0] - b.lo[0]; rec.y = ctr[1] - b.lo[1]; rec.z = ctr[2] - b.lo[2];
+	rec.octave = K.octave_base; rec.level = 1; rec.scale = kp->scale; rec.code = 1; rec.slot = -1;
+	for (int i = 0; i < 3; i++) { rec.win[i] = kp->win[i]; rec.eigvalue[i] = kp->eigvalue[i]; }
+	for (int i = 0; i < 9; i++) { rec.eigvector[i] = kp->eigvector[i]; rec.rot[i] = kp->Rotation[i]; rec.st[i] = kp->str_tensor[i]; }
+	if ((rc = onekp_load(K, level, nx, ny, unit, b, rec)) != SIFT3D_OK) return rc;
+	hipStream_t st = c->stream;
+	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, c->d_slots_part, st);
+	launch_describe(c->d_ext, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->d_desc, c->kp_cap, 0, 1, c->d_order, c->d_nkp, c->d_nkp + 1, st,
+	                c->desc_lut_lds, &c->dsplit);
+	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
+	sift3d_keypoint out;
+	S3D_HIP(hipMemcpyAsync(desc768, c->d_desc, sizeof(float) * kDesc, hipMemcpyDeviceToHost, st));
+	S3D_HIP(hipMemcpyAsync(&out, c->d_kpout, sizeof(out), hipMemcpyDeviceToHost, st));
+	S3D_HIP(hipStreamSynchronize(st));
+	S3D_HIP(hipGetLastError());
+	for (int i = 0; i < 9; i++) kp->Rotation[i] = out.Rotation[i];
+	return SIFT3D_OK;
+}
 
 extern "C" int sift3d_downsample(const float *src, int snx, int sny, int snz, float *dst, int nx, int ny, int nz, int device) {
 	if (!src || !dst || nx <= 0 || ny <= 0 || nz <= 0 || snx <= 0 || sny <= 0 || snz <= 0 || 2 * (nx - 1) >= snx || 2 * (ny - 1) >= sny ||

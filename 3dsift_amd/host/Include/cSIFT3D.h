@@ -170,6 +170,13 @@ public:
 SIFT_LIBRARY_API void DownSample_3D(TexImage *src, TexImage *dst);
 SIFT_LIBRARY_API void GaussianSmooth_3D(TexImage *src, TexImage *dst, float sigma);
 SIFT_LIBRARY_API void Sub(TexImage *prev, TexImage *cur, TexImage *dog);
+// the per-axis pass and the per-keypoint stages (Include/cSIFT3D.h:214, 224, 228 of the reference) on HOST data, run by the pipeline's
+// device kernels: GaussianSmooth_3D_Imp one pass along `dim` with the caller's taps (odd width; `unit` is unused, as in the reference);
+// Assign_Orientation_Imp / Extract_Descriptor_Imp one keypoint on a caller-held level (kp.x, y, z integral, one power-of-two unit, kp.desc
+// -> DESC_NUMEL floats; the mesh argument is not read: the kernels carry the icosahedron of Initialize_geometry)
+SIFT_LIBRARY_API void GaussianSmooth_3D_Imp(TexImage *src, TexImage *dst, int dim, float unit, float *weight, int width);
+SIFT_LIBRARY_API int Assign_Orientation_Imp(Keypoint &kp, TexImage *gaussian, const float sigma, const float max_eig_ratio, const float corner_thresh);
+SIFT_LIBRARY_API void Extract_Descriptor_Imp(Keypoint &kp, TexImage *gaussian, Mesh *mesh);
 
 // The small per-voxel / per-vector helpers of the same header (Include/cSIFT3D.h:216-238), as HOST utilities on HOST data
 // (host/src/helpers.cpp).  They are not part of the extraction path -- KpSiftAlgorithm never calls them, its kernels carry their own
@@ -182,6 +189,10 @@ SIFT_LIBRARY_API void Transpose_Matrix(float *Rot);                             
 SIFT_LIBRARY_API void Swap_Element(float &a, float &b);                                                                // :1584-1590
 SIFT_LIBRARY_API int cart2bary(Cvec *cart, const Tri *const tri, Cvec *const bary, float *const k);                    // :1592-1637
 SIFT_LIBRARY_API void normailize_desc(float *desc);                                                                    // :1639-1656
+SIFT_LIBRARY_API void Trilinear_interpolation_over_desc(Mesh *mesh, Keypoint &kp, Cvec &vbins, Cvec &grad, int loop_idx);              // :1383-1448
+SIFT_LIBRARY_API void Trilinear_interpolation_over_desc_debug(Mesh *mesh, Keypoint &kp, Cvec &vbins, Cvec &grad, int loop_idx,        // :1450-1540
+                                                              float *host_dvbins, int *host_intersect_id, float *host_bary, int *host_offset,
+                                                              float *host_desc_accum, int debug);
 // the icosahedron the descriptor histograms are binned on (Include/cUtil.h:60, Src/cUtil.cc:113-175; winding quirk included).
 // mesh->tri is malloc()ed (20 triangles); the caller free()s it.  Returns 0.
 SIFT_LIBRARY_API int Initialize_geometry(Mesh *mesh);

@@ -5,7 +5,9 @@
 // reference it reports problems on stderr and carries on with an empty result (no exceptions).
 #include "../Include/cSIFT3D.h"
 
+#include <cstddef>
 #include <cstdio>
+#include <iostream>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -57,6 +59,41 @@ void Sub(TexImage *prev, TexImage *cur, TexImage *dog) {  // Src/cSIFT3D.cc:849-
 	shape_like(dog, prev);
 	const int rc = sift3d_dog_sub(prev->_Data, cur->_Data, (size_t)prev->GetDimX() * prev->GetDimY() * prev->GetDimZ(), dog->_Data, GetDevice());
 	if (rc) std::cerr << "Sub: " << sift3d_last_error() << std::endl;
+}
+void GaussianSmooth_3D_Imp(TexImage *src, TexImage *dst, int dim, float /*unit: the reference blurs in voxel coordinates, cc:645*/, float *weight,
+                           int width) {  // Src/cSIFT3D.cc:624-788
+	if (!contiguous(src) || !dst || !weight) { std::cerr << "GaussianSmooth_3D_Imp: bad image" << std::endl; return; }
+	shape_like(dst, src);
+	const int rc = sift3d_conv_axis(src->_Data, src->GetDimX(), src->GetDimY(), src->GetDimZ(), dim, weight, width, dst->_Data, GetDevice());
+	if (rc) std::cerr << "GaussianSmooth_3D_Imp: " << sift3d_last_error() << std::endl;
+}
+
+// One keypoint on a caller-held level (Include/cSIFT3D.h:224, 228 of the reference): the device kernels of the pipeline on the box of the
+// level the window reaches (sift3d_orient_keypoint / sift3d_describe_keypoint).  As in the pipeline the keypoint sits on a voxel and the
+// level has one power-of-two unit; other inputs are reported on stderr and rejected (orientation: return 0, "not run").
+static bool kp_level_ok(const char *who, TexImage *g) {
+	if (!contiguous(g) || g->GetUnitX() != g->GetUnitY() || g->GetUnitX() != g->GetUnitZ()) {
+		std::cerr << who << ": the level must be contiguous with one unit on all axes" << std::endl;
+		return false;
+	}
+	return true;
+}
+static_assert(sizeof(sift3d_keypoint) == offsetof(Keypoint, desc), "Keypoint = sift3d_keypoint + desc pointer");
+int Assign_Orientation_Imp(Keypoint &kp, TexImage *gaussian, const float sigma, const float max_eig_ratio, const float corner_thresh) {  // cc:913-1138
+	if (!kp_level_ok("Assign_Orientation_Imp", gaussian)) return 0;
+	int code = 0;
+	const int rc = sift3d_orient_keypoint(gaussian->_Data, gaussian->GetDimX(), gaussian->GetDimY(), gaussian->GetDimZ(), gaussian->GetUnitX(),
+	                                      reinterpret_cast<sift3d_keypoint *>(&kp), sigma, max_eig_ratio, corner_thresh, GetDevice(), &code);
+	if (rc) { std::cerr << "Assign_Orientation_Imp: " << sift3d_last_error() << std::endl; return 0; }
+	return code;
+}
+void Extract_Descriptor_Imp(Keypoint &kp, TexImage *gaussian, Mesh *mesh) {  // cc:1152-1381; the mesh is the library's own icosahedron (Initialize_geometry)
+	(void)mesh;
+	if (!kp.desc) { std::cerr << "Extract_Descriptor_Imp: kp.desc must point to DESC_NUMEL floats" << std::endl; return; }
+	if (!kp_level_ok("Extract_Descriptor_Imp", gaussian)) return;
+	const int rc = sift3d_describe_keypoint(gaussian->_Data, gaussian->GetDimX(), gaussian->GetDimY(), gaussian->GetDimZ(), gaussian->GetUnitX(),
+	                                        reinterpret_cast<sift3d_keypoint *>(&kp), kp.desc, GetDevice());
+	if (rc) std::cerr << "Extract_Descriptor_Imp: " << sift3d_last_error() << std::endl;
 }
 int GetDevice() {
 	if (g_device < 0) {

@@ -90,6 +90,58 @@ int Check_intersect_faces(Mesh *mesh, Cvec *grad, Cvec *bary) {
 	return -1;
 }
 
+// One window voxel into the 4 x 4 x 4 x 12 histogram (Src/cSIFT3D.cc:1383-1540): the face the gradient passes through, its barycentric
+// weights, and the eight cells around the bin coordinates (base cell by TRUNCATION, fractions by floor -- the reference's pairing).  Host
+// helper like the others of this file; the extraction path scatters inside k_describe.  trace (the _debug form with debug > 0): the
+// fractions, barycentrics and face of voxel loop_idx, and per visited cell the three bin offsets and contributions.
+namespace {
+struct ScatterTrace { float *dvbins; int *face; float *bary; int *offset; float *accum; };
+void scatter_voxel(Mesh *mesh, Keypoint &kp, const Cvec &vbins, Cvec &grad, int loop_idx, const ScatterTrace *trace) {
+	const float frac[3] = {vbins.x - floorf(vbins.x), vbins.y - floorf(vbins.y), vbins.z - floorf(vbins.z)};
+	const int cell[3] = {(int)vbins.x, (int)vbins.y, (int)vbins.z};
+	Cvec bary;
+	const int face = Check_intersect_faces(mesh, &grad, &bary);
+	if (trace) {
+		for (int a = 0; a < 3; a++) trace->dvbins[loop_idx * 3 + a] = frac[a];
+		trace->bary[loop_idx * 3 + 0] = bary.x; trace->bary[loop_idx * 3 + 1] = bary.y; trace->bary[loop_idx * 3 + 2] = bary.z;
+		trace->face[loop_idx] = face;
+	}
+	if (face < 0) return;
+	const float mag = std::sqrt(dot(grad, grad));
+	const float w3[3] = {bary.x, bary.y, bary.z};
+	const Tri &T = mesh->tri[face];
+	int visited = 0;
+	for (int corner = 0; corner < 8; corner++) {  // x slowest, z fastest: the order the reference adds in
+		const int up[3] = {corner >> 2, (corner >> 1) & 1, corner & 1};
+		const int c[3] = {cell[0] + up[0], cell[1] + up[1], cell[2] + up[2]};
+		bool inside = true;
+		for (int a = 0; a < 3; a++) inside = inside && c[a] >= 0 && c[a] < NHIST_PER_DIM;
+		if (!inside) continue;
+		// the spatial weight is a double product (1.0 - f is a double expression in the reference), rounded once
+		double wd = 1.0;
+		for (int a = 0; a < 3; a++) wd *= up[a] ? (double)frac[a] : 1.0 - (double)frac[a];
+		const float wgt = (float)wd;
+		const int bin0 = (c[0] + NHIST_PER_DIM * c[1] + NHIST_PER_DIM * NHIST_PER_DIM * c[2]) * ICOS_NVERT;
+		for (int v = 0; v < 3; v++) {
+			const float add = mag * wgt * w3[v];
+			kp.desc[bin0 + T.idx[v]] += add;
+			if (trace) { trace->offset[(loop_idx * 8 + visited) * 3 + v] = bin0 + T.idx[v]; trace->accum[(loop_idx * 8 + visited) * 3 + v] = add; }
+		}
+		visited++;
+	}
+}
+}  // namespace
+
+void Trilinear_interpolation_over_desc(Mesh *mesh, Keypoint &kp, Cvec &vbins, Cvec &grad, int loop_idx) {
+	scatter_voxel(mesh, kp, vbins, grad, loop_idx, nullptr);
+}
+
+void Trilinear_interpolation_over_desc_debug(Mesh *mesh, Keypoint &kp, Cvec &vbins, Cvec &grad, int loop_idx, float *host_dvbins,
+                                             int *host_intersect_id, float *host_bary, int *host_offset, float *host_desc_accum, int debug) {
+	const ScatterTrace t{host_dvbins, host_intersect_id, host_bary, host_offset, host_desc_accum};
+	scatter_voxel(mesh, kp, vbins, grad, loop_idx, debug > 0 ? &t : nullptr);
+}
+
 void normailize_desc(float *desc) {
 	float norm = 0.0f;
 	for (int i = 0; i < DESC_NUMEL; i++) norm += desc[i] * desc[i];

@@ -132,6 +132,18 @@ int sift3d_gaussian_smooth(const float *src, int nx, int ny, int nz, float sigma
 int sift3d_downsample(const float *src, int snx, int sny, int snz, float *dst, int nx, int ny, int nz, int device);
 /* Replaces the free function Sub (Include/cSIFT3D.h:218; Src/cSIFT3D.cc:849-882): dog = (cur - prev) * (-1), n voxels, host volumes. */
 int sift3d_dog_sub(const float *prev, const float *cur, size_t n, float *dog, int device);
+/* Replaces the free function GaussianSmooth_3D_Imp (Include/cSIFT3D.h:214; Src/cSIFT3D.cc:624-788): ONE pass along `dim` (0 x, 1 y, 2 z)
+ * with the caller's taps weight[0 .. width) (width odd, <= 129), interior and mirror-boundary rule as in the pipeline; host volumes. */
+int sift3d_conv_axis(const float *src, int nx, int ny, int nz, int dim, const float *weight, int width, float *dst, int device);
+/* Replace the free functions Assign_Orientation_Imp / Extract_Descriptor_Imp (Include/cSIFT3D.h:224, 228; Src/cSIFT3D.cc:913-1138,
+ * 1152-1381) for ONE keypoint on a caller-provided HOST level (nx x ny x nz, isotropic unit = 2^octave): the pipeline's own kernels run on
+ * the box of the level the window reaches.  The keypoint sits on a voxel (integral x, y, z), as every keypoint of the pipeline does;
+ * anything else is refused.  orient: in x, y, z, scale; out win, eigvalue, eigvector, Rotation (not transposed), str_tensor and *code =
+ * the reference's return value (1 / -1 / -2 / -3).  describe: in x, y, z, scale, Rotation as orientation left it (+ str_tensor: first
+ * guess of the fixed-point unit only); out desc768 (normalised) and Rotation TRANSPOSED, like Src/cSIFT3D.cc:1214 leaves it. */
+int sift3d_orient_keypoint(const float *level, int nx, int ny, int nz, float unit, sift3d_keypoint *kp, float sigma, float max_eig_ratio,
+                           float corner_thresh, int device, int *code);
+int sift3d_describe_keypoint(const float *level, int nx, int ny, int nz, float unit, sift3d_keypoint *kp, float *desc768, int device);
 
 /* Replaces muBruteMatcher::injectMatch / bijectMatch / enhancedMatch (Src/cMatcher.cc:146-228).
  * mode 1 inject, 2 biject, 3 enhanced.  desc: n*768 / m*768, xyz: n*3 / m*3 (rx,ry,rz).
