@@ -1,7 +1,7 @@
 // asan_check.cpp -- driver of the ASan + UBSan build of the host-side code (make -C 3dsift_amd/host asan; tests/test_sanitizers_cpu.py).
 //
 //   asan_check <dir>
-// <dir> holds files written by the test: good_*.nii[.gz] (every supported datatype / byte order / gzip), bad_*.nii (malformed
+// <dir> holds files written by the test: good_*.nii[.gz] / .hdr + .img (every supported datatype / byte order / gzip / header version), bad_* (malformed
 // headers, truncated payloads, random bytes), m.bin (raw matrix).  Every reader is run on every file; results are printed so the
 // test can compare them; the sanitizers abort the process on any out-of-bounds access, use-after-free or undefined behaviour.
 // Also walks the no-device error paths of the shell classes (on a box without a GPU the constructor fails loudly and every later
@@ -37,7 +37,7 @@ int main(int argc, char **argv) {
 		closedir(d);
 	}
 	for (const std::string &n : names) {
-		if (n.find(".nii") == std::string::npos) continue;
+		if (n.find(".nii") == std::string::npos && n.find(".hdr") == std::string::npos && n.find(".img") == std::string::npos) continue;
 		int nx = -1, ny = -1, nz = -1;
 		float *v = readNiiFile((dir + "/" + n).c_str(), nx, ny, nz);
 		if (v) {

@@ -82,6 +82,26 @@ def nifti1_bytes(vol, dtype, code, big_endian=False, slope=2.0, inter=5.0, vox_o
     return bytes(h[:hdr_bytes]) + vol.astype(np.dtype(dtype).newbyteorder(e)).tobytes()
 
 
+def nifti2_header(vol, dtype, code, big_endian=False, magic=b"n+2\0\r\n\032\n", vox_offset=544, slope=2.0, inter=5.0):
+    """the 540-byte NIfTI-2 header (+ 4 extension bytes) written by hand"""
+    import struct
+    nz, ny, nx = vol.shape
+    e = ">" if big_endian else "<"
+    h = bytearray(544)
+    struct.pack_into(e + "i", h, 0, 540)
+    h[4:12] = magic
+    struct.pack_into(e + "2h", h, 12, code, np.dtype(dtype).itemsize * 8)
+    struct.pack_into(e + "8q", h, 16, 3, nx, ny, nz, 1, 1, 1, 1)
+    struct.pack_into(e + "8d", h, 104, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0)  # pixdim
+    struct.pack_into(e + "q", h, 168, vox_offset)
+    struct.pack_into(e + "2d", h, 176, slope, inter)
+    return bytes(h)
+
+
+def payload(vol, dtype, big_endian=False):
+    return vol.astype(np.dtype(dtype).newbyteorder(">" if big_endian else "<")).tobytes()
+
+
 def make_g1(ref):
     """The reference builds its taps inline (no accessor), so G1 pins them through the impulse response of GaussianSmooth_3D: for a unit
     impulse the x pass leaves tap[d] exactly, the y and z passes multiply by the centre tap: line[d] = rn(tc * rn(tc * tap[d]))."""
@@ -117,7 +137,41 @@ def make_g9():
              ("f4_off0_tight", "f4", 16, False, False), ("i2_off348_tight", "i2", 4, False, False), ("i2_off100", "i2", 4, False, False)]
     lax = {"f4_off0_tight": dict(vox_offset=0.0, hdr_bytes=348), "i2_off348_tight": dict(vox_offset=348.0, hdr_bytes=348),
            "i2_off100": dict(vox_offset=100.0)}
-    g9 = {"names": np.array([c[0] for c in cases])}
+    # r05: NIfTI-2 single files, and two-file images (.hdr + .img: NIfTI-1 "ni1", NIfTI-2 "ni2", ANALYZE 7.5 without a magic), named by
+    # either file.  (name, dtype, code, big endian, gz, kind)
+    more = [("f4_nii2", "f4", 16, False, False, "n+2"), ("i2_nii2_be", "i2", 4, True, False, "n+2"), ("f8_nii2_gz", "f8", 64, False, True, "n+2"),
+            ("i2_pair", "i2", 4, False, False, "ni1"), ("f4_pair_be_gz", "f4", 16, True, True, "ni1"), ("u2_pair_nii2", "u2", 512, False, False, "ni2"),
+            ("u1_analyze", "u1", 2, False, False, "analyze"), ("f4_pair_by_img", "f4", 16, False, False, "ni1")]
+    g9 = {"names": np.array([c[0] for c in cases] + [c[0] for c in more])}
+    with tempfile.TemporaryDirectory() as t:
+        for name, dt, code, be, gz, kind in more:
+            info = np.iinfo(dt) if np.dtype(dt).kind in "iu" else None
+            vol = np.clip(base, info.min, info.max).astype(dt) if info else base.astype(dt)
+            z = (lambda b: gzip.compress(b, mtime=0)) if gz else (lambda b: b)
+            sfx = ".gz" if gz else ""
+            if kind == "n+2":
+                files = {name + ".nii" + sfx: z(nifti2_header(vol, dt, code, be) + payload(vol, dt, be))}
+                arg = name + ".nii" + sfx
+            else:
+                if kind == "ni2":
+                    hdr = nifti2_header(vol, dt, code, be, magic=b"ni2\0\r\n\032\n", vox_offset=0)[:540]
+                else:
+                    hb = bytearray(nifti1_bytes(vol, dt, code, big_endian=be, vox_offset=0.0, hdr_bytes=348))
+                    hb[344:348] = b"ni1\0" if kind == "ni1" else b"\0\0\0\0"
+                    hdr = bytes(hb)
+                files = {name + ".hdr" + sfx: z(hdr), name + ".img" + sfx: z(payload(vol, dt, be))}
+                arg = name + (".img" if name.endswith("by_img") else ".hdr") + sfx
+            for fn_, blob in files.items():
+                open(os.path.join(t, fn_), "wb").write(blob)
+            nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
+            ptr = fn(os.path.join(t, arg).encode(), C.byref(nx), C.byref(ny), C.byref(nz))
+            assert ptr and (nx.value, ny.value, nz.value) == (7, 6, 5), name
+            g9[name + "_files"] = np.array(sorted(files))
+            for fn_, blob in files.items():
+                g9[name + "_blob_" + fn_] = np.frombuffer(blob, np.uint8)
+            g9[name + "_arg"] = np.array(arg)
+            g9[name + "_data"] = np.ctypeslib.as_array(ptr, shape=(5, 6, 7)).copy()
+            g9[name + "_plain"] = vol.astype(np.float32)
     with tempfile.TemporaryDirectory() as t:
         for name, dt, code, be, gz in cases:
             info = np.iinfo(dt) if np.dtype(dt).kind in "iu" else None

@@ -77,16 +77,24 @@ def test_read_nii_matches_reference_reader(shell):
     fn.restype = C.POINTER(C.c_float)
     fn.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     with tempfile.TemporaryDirectory() as t:
+        seen = set()
         for name in g["names"]:
             name = str(name)
-            p = os.path.join(t, name + (".nii.gz" if bool(g[name + "_gz"]) else ".nii"))
-            open(p, "wb").write(g[name + "_file"].tobytes())
+            if name + "_files" in g.files:   # r05: NIfTI-2 single files and .hdr + .img pairs (NIfTI-1 / NIfTI-2 / ANALYZE), named by either file
+                for fn_ in g[name + "_files"]:
+                    open(os.path.join(t, str(fn_)), "wb").write(g[name + "_blob_" + str(fn_)].tobytes())
+                p = os.path.join(t, str(g[name + "_arg"]))
+                seen.add("pair" if len(g[name + "_files"]) == 2 else "nii2")
+            else:
+                p = os.path.join(t, name + (".nii.gz" if bool(g[name + "_gz"]) else ".nii"))
+                open(p, "wb").write(g[name + "_file"].tobytes())
             nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
             ptr = fn(p.encode(), C.byref(nx), C.byref(ny), C.byref(nz))
             want = g[name + "_data"]
             assert ptr and (nz.value, ny.value, nx.value) == want.shape, name
             got = np.ctypeslib.as_array(ptr, shape=want.shape).copy()
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), name
+        assert seen == {"pair", "nii2"}
 
 
 def test_read_nii_rejects_malformed_headers(shell):
@@ -102,6 +110,10 @@ def test_read_nii_rejects_malformed_headers(shell):
     b = bytearray(good); struct.pack_into("<f", b, 108, 3.0e9); bad["vox_offset absurd"] = b
     b = bytearray(good); struct.pack_into("<h", b, 70, 1536); bad["unsupported datatype"] = b
     bad["truncated payload"] = good[:-10]
+    b = bytearray(good); b[344:348] = b"ni1\0"; bad["header of a pair in a file that is not *.hdr"] = b
+    b = bytearray(good); b[344:348] = b"xyz\0"; bad["unknown magic"] = b
+    b = bytearray(544); struct.pack_into("<i", b, 0, 540); b[4:12] = b"n+2\0\r\n\032\n"; struct.pack_into("<2h", b, 12, 4, 16)
+    struct.pack_into("<8q", b, 16, 3, 7, 6, 1 << 40, 1, 1, 1, 1); bad["NIfTI-2 with an absurd dimension"] = b + good[352:]
     with tempfile.TemporaryDirectory() as t:
         for why, blob in bad.items():
             p = os.path.join(t, "x.nii")

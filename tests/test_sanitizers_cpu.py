@@ -87,6 +87,23 @@ def test_host_readers_and_shell_under_asan_ubsan():
         b = bytearray(rng.integers(0, 256, 4096, dtype=np.uint8).tobytes()); struct.pack_into("<i", b, 0, 348); b[344:348] = b"n+1\0"; bad["random348"] = b
         for k, v in bad.items():
             open(os.path.join(t, f"bad_{k}.nii"), "wb").write(bytes(v))
+        # r05: NIfTI-2 and two-file images
+        vol2 = base.astype("f4")
+        h2 = bytearray(544); struct.pack_into("<i", h2, 0, 540); h2[4:12] = b"n+2\0\r\n\032\n"; struct.pack_into("<2h", h2, 12, 16, 32)
+        struct.pack_into("<8q", h2, 16, 3, 7, 6, 5, 1, 1, 1, 1); struct.pack_into("<q", h2, 168, 544)
+        open(os.path.join(t, "good_v2.nii"), "wb").write(bytes(h2) + vol2.tobytes())
+        hp = bytearray(_nifti1(vol2, "f4", 16)[:348]); hp[344:348] = b"ni1\0"; struct.pack_into("<f", hp, 108, 0.0)
+        open(os.path.join(t, "good_pair.hdr"), "wb").write(bytes(hp)); open(os.path.join(t, "good_pair.img"), "wb").write(vol2.tobytes())
+        v2 = vol2.ravel().astype(np.float64)
+        for fn in ("good_v2.nii", "good_pair.hdr", "good_pair.img"):
+            want[fn] = float((v2 * ((np.arange(v2.size) % 97) + 1)).sum())
+        open(os.path.join(t, "bad_noimg.hdr"), "wb").write(bytes(hp))                                   # the .img is missing
+        open(os.path.join(t, "bad_shortimg.hdr"), "wb").write(bytes(hp)); open(os.path.join(t, "bad_shortimg.img"), "wb").write(vol2.tobytes()[:100])
+        b = bytearray(rng.integers(0, 256, 4096, dtype=np.uint8).tobytes()); struct.pack_into("<i", b, 0, 540); b[4:12] = b"n+2\0\r\n\032\n"
+        open(os.path.join(t, "bad_random540.nii"), "wb").write(bytes(b))
+        b = bytearray(rng.integers(0, 256, 4096, dtype=np.uint8).tobytes()); struct.pack_into(">i", b, 0, 540); b[4:12] = b"ni2\0\r\n\032\n"
+        open(os.path.join(t, "bad_random540be.hdr"), "wb").write(bytes(b))
+        more_bad = ["bad_noimg.hdr", "bad_shortimg.hdr", "bad_shortimg.img", "bad_random540.nii", "bad_random540be.hdr"]
         open(os.path.join(t, "bad_notgz.nii.gz"), "wb").write(b"\x1f\x8b" + rng.integers(0, 256, 200, dtype=np.uint8).tobytes())
         m = rng.random((4, 5, 6)).astype(np.float32)
         open(os.path.join(t, "m.bin"), "wb").write(struct.pack("<3i", 6, 5, 4) + m.tobytes())
@@ -105,6 +122,8 @@ def test_host_readers_and_shell_under_asan_ubsan():
         if k in ("faroff",):
             continue
         assert lines[f"bad_{k}.nii"] == ["rejected"], (k, lines[f"bad_{k}.nii"])
+    for fn in more_bad:
+        assert lines[fn] == ["rejected"], (fn, lines[fn])
     out = r.stdout
     want_m = float((m.ravel().astype(np.float64) * ((np.arange(m.size) % 97) + 1)).sum())
     ml = [ln.split() for ln in out.splitlines() if ln.startswith("matrix ") or ln.startswith("matrix2 ")]
