@@ -77,6 +77,42 @@ int main(int argc, char **argv) {
 		printf("csv_garbage %zu\n", c.size());
 		read_sift_kp((dir + "/nope.csv").c_str(), c);
 	}
+	// per-voxel / per-keypoint free functions (r05): the host scatter on cell coordinates at and beyond the block's faces, vanishing
+	// gradients; the device-backed ones report "no device" here (or refuse bad inputs) and must leave their outputs defined
+	{
+		Mesh mesh;
+		Initialize_geometry(&mesh);
+		std::vector<float> d(DESC_NUMEL, 0.f), dv(3 * 64), br(3 * 64), acc(24 * 64, 0.f);
+		std::vector<int> face(64), off(24 * 64, -1);
+		Keypoint k;
+		k.desc = d.data();
+		int i = 0;
+		for (float bx : {-0.5f, -0.25f, 0.f, 2.75f, 3.f, 3.49f, 4.f, -1.f})
+			for (float gz : {0.f, 1.f, -2.f, 1e-9f}) {
+				Cvec vb(bx, 3.25f - bx, 0.5f * bx), g(0.3f * gz, -gz, 0.5f * gz);
+				Trilinear_interpolation_over_desc(&mesh, k, vb, g, i);
+				Trilinear_interpolation_over_desc_debug(&mesh, k, vb, g, i, dv.data(), face.data(), br.data(), off.data(), acc.data(), 1);
+				i++;
+			}
+		double sum = 0;
+		for (float v : d) sum += v;
+		printf("scatter %d voxels sum %.6f\n", i, sum);
+		free(mesh.tri);
+		TexImage lvl, out;
+		lvl.SetImageSize(12, 10, 9);
+		lvl.MallocArrayMemory();
+		for (int j = 0; j < 12 * 10 * 9; j++) lvl._Data[j] = (float)(j % 17) * 0.01f;
+		lvl.SetImageUnit(1.f, 1.f, 1.f);
+		float w[4] = {0.25f, 0.5f, 0.25f, 0.f};
+		GaussianSmooth_3D_Imp(&lvl, &out, 1, 1.f, w, 3);
+		GaussianSmooth_3D_Imp(&lvl, &out, 1, 1.f, w, 4);  // even width: refused
+		Keypoint q;
+		q.x = 5; q.y = 4; q.z = 4; q.scale = 1.6f; q.desc = d.data();
+		printf("orient code %d\n", Assign_Orientation_Imp(q, &lvl, 2.4f, 0.9f, 0.4f));
+		Extract_Descriptor_Imp(q, &lvl, nullptr);
+		q.x = 5.5f;
+		printf("orient off-voxel code %d\n", Assign_Orientation_Imp(q, &lvl, 2.4f, 0.9f, 0.4f));
+	}
 	// shell classes: with a GPU this is a tiny real run; without one every call reports the error and returns empty results
 	{
 		std::vector<float> vol(24 * 20 * 28);

@@ -130,3 +130,4 @@ def test_host_readers_and_shell_under_asan_ubsan():
     assert len(ml) == 2 and all(x[1:4] == ["6", "5", "4"] and abs(float(x[4]) - want_m) < 1e-6 * want_m for x in ml), ml
     assert "matrix_trunc 1" in out and "matrix_bad 1" in out and "matrix_missing 1" in out  # the reference's convention: 0 ok, 1 failure
     assert "csv 3 10.12346 0.00000 -4.50000" in out and "asan_check done" in out
+    assert "scatter 32 voxels sum" in out and "orient off-voxel code 0" in out   # r05: the per-voxel / per-keypoint free functions ran under the sanitizers
