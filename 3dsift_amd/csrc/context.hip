@@ -1029,9 +1029,16 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 				// 1's: they used to queue behind octave 1's candidate pass (0.35 ms beside octave 0's masks) and ended the stage 0.13 ms
 				// after octave 0's emit (profiles/r04e_timeline_full.txt); every octave has its own scratch
 				hipStream_t sc = (c->noct > 2 && c->ostream.size() > 2 && c->ostream[2] != st && c->ostream[2] != sb) ? c->ostream[2] : sb;
-				if (sc != sb) { S3D_HIP(hipEventRecord(c->ev_det_fork2, sb)); S3D_HIP(hipStreamWaitEvent(sc, c->ev_det_fork2, 0)); }  // every pyramid is complete
+				// r05: with the early start the masks of an octave >= 2 follow ITS pyramid (the event its last level recorded), not every
+				// octave's: the chains of these octaves -- three launches of a few microseconds each per octave, the last thing the stage waited
+				// for whenever HIP dealt sb and sc onto one hardware queue -- start beside the tail of the pyramid.  Measured (scripts/ab_full.py,
+				// three pairs): extrema 0.75 -> 0.69 ms, pyramid 2.02 -> 2.02; octave 1's masks behind octave 1's pyramid as well: extrema 0.67
+				// but pyramid 2.06 (its 0.2 ms of k_mark beside octave 0's widest level) -- not taken
+				const bool own = early && sc != sb;
+				if (sc != sb && !own) { S3D_HIP(hipEventRecord(c->ev_det_fork2, sb)); S3D_HIP(hipStreamWaitEvent(sc, c->ev_det_fork2, 0)); }  // every pyramid is complete
 				for (int o = 1; o < c->noct; o++) {
 					const Level &C = c->dog[(size_t)o * c->nd + 1];
+					if (own && o >= 2) S3D_HIP(hipStreamWaitEvent(sc, c->ev_done[o], 0));
 					launch_detect_mark(DLs[(size_t)o], nl, C.nx, C.ny, C.zr_all(), c->p.peak_thresh, o + c->octave_base, c->det_o[(size_t)o], o == 1 ? sb : sc, lt);
 				}
 				S3D_HIP(hipEventRecord(c->ev_det_join, sb));
