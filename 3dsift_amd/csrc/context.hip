@@ -2231,7 +2231,7 @@ extern "C" int sift3d_slab_describe_finish(sift3d_handle c, const void *d_record
 	hipStream_t st = c->stream;
 	unsigned *counter = c->d_nkp + 4;  // (d_total + 6: a spare word behind the orientation's redo counter)
 	S3D_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
-	launch_describe_finish(static_cast<const DevKp *>(d_records), (unsigned)n, c->d_luts, nparts, d_hist, d_mass, d_units, final_round != 0, c->d_desc,
+	launch_describe_finish(static_cast<const DevKp *>(d_records), (unsigned)n, c->d_levels, c->d_luts, nparts, d_hist, d_mass, d_units, final_round != 0, c->d_desc,
 	                       d_redo, d_units_next, counter, st);
 	unsigned host = 0;
 	if (!final_round) {  // (a final round flags nothing)

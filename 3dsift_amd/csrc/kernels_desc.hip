@@ -381,19 +381,33 @@ __device__ __forceinline__ float pick_scale_d(float mass, float provable) {
 // ... of the FIRST pass: from an estimate of the gradient mass (rms gradient of the orientation window, from the structure tensor, times
 // the descriptor window's weight sum, with 4x head room) -- a function of the keypoint's record and the level's tables alone, so every
 // GPU that marches a part of the window (PARTIAL) uses the same unit.  dev_flags bits 8..: the hook SIFT3D_HOOK_DESC_MASS_SHIFT (estimate / 2^s)
-__device__ __forceinline__ float first_pass_unit(const DevKp &kp, const WinLut &lut_o, const WinLut &lut, int dev_flags) {
+// r05: ... times the share of the window's bounding box that lies inside the level: a window cut off by the volume's border collects that
+// much less (scripts/soak_random.py: a radius-55 window in a 64 x 128 x 80 volume got a unit 16x coarser than its mass allowed and lost
+// 2.9e-5 RMS to rounding).  Whole windows: the factor is exactly 1.
+// (wx, wy, wz: the window's clipped box, Src/cSIFT3D.cc:1184-1200, of the WHOLE window -- the same on every rank that marches a part)
+__device__ __forceinline__ float first_pass_unit(const DevKp &kp, const WinLut &lut_o, const WinLut &lut, int wx, int wy, int wz, int dev_flags) {
 	const float st_tr = fmaxf(kp.st[0] + kp.st[4] + kp.st[8], 0.0f);
-	const float m_est = __fsqrt_rn(__fdiv_rn(st_tr, lut_o.wsum)) * lut.wsum;
+	const float side = (float)(2 * (int)__fsqrt_rn((float)max(lut.nin, 0)) + 1);  // lattice points across the sphere
+	const float inside = fminf(__fdiv_rn((float)max(wx, 0) * (float)max(wy, 0) * (float)max(wz, 0), side * side * side), 1.0f);
+	const float m_est = __fsqrt_rn(__fdiv_rn(st_tr, lut_o.wsum)) * lut.wsum * inside;
 	return pick_scale_d(m_est * 4.0f * __uint_as_float((unsigned)(127 - ((dev_flags >> 8) & 63)) << 23), lut.fix_scale);
 }
 // does a pass whose unit was fix_scale have to be repeated with the exact unit?  mass = the window's gradient mass * 1.001.  Every bin
 // (and replica) sum is <= mass * fix_scale + half a unit per contribution (< 2^20 contributions): overflow.  And a first guess far ABOVE
 // the mass (a sharp structure inside the orientation window, a flat descriptor window: the zero background of CT / MR volumes) leaves a
 // unit that much coarser than necessary: below 1/64 of the range the keypoint is redone as well, whenever the exact bound gives a finer
-// unit (rounding noise per bin stays < 1e-5 of the descriptor norm)
-__device__ __forceinline__ bool unit_fails(float mass, float fix_scale, float provable) {
+// unit (rounding noise per bin stays < 1e-5 of the descriptor norm).
+// r05 (scripts/soak_random.py, sigma_default 2.47: a window of radius 55 voxels, 7e5 lattice points in its sphere): what counts is the
+// size of the AVERAGE contribution in units -- products below half a unit round to zero, and the products of a voxel (trilinear x
+// barycentric weights) crowd towards zero, so coarse units lose a share of every bin that normalisation only cancels where it is the
+// same in all bins: 13 M contributions of 2.5 units left 2.9e-5 RMS in that keypoint (5e-7 with the exact unit).  A window with more
+// lattice points in its sphere than 2^18 (the default parameters' largest: 2.1e5) must therefore use a share of the range larger by
+// that ratio, at most 1/4 -- the average contribution stays what it is for the default windows at 1/64.
+__device__ __forceinline__ bool unit_fails(float mass, float fix_scale, float provable, int nin) {
 	const bool overflow = !(mass * fix_scale + 1048576.0f < 2147483648.0f);
-	const bool coarse = mass * fix_scale < 2147483648.0f / 64.0f && pick_scale_d(mass, provable) > fix_scale;
+	const float nsphere = 4.18879f * (float)nin * __fsqrt_rn((float)nin);  // lattice points within radius sqrt(nin)
+	const float share = fminf(fmaxf(nsphere * (1.0f / 262144.0f), 1.0f) * (1.0f / 64.0f), 0.25f);
+	const bool coarse = mass * fix_scale < 2147483648.0f * share && pick_scale_d(mass, provable) > fix_scale;
 	return overflow || coarse;
 }
 // normalise -> clamp -> normalise (Src/cSIFT3D.cc:1350-1358, 1639-1656) of the 768 values the first 256 threads of a workgroup hold
@@ -514,7 +528,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		float *const p_mass = PARTIAL ? pp.seg[sg].mass + k : nullptr;
 		const int slot = kpb[k].slot;                        // row of the keypoint in the results (reference order)
 		const int cxi = kpb[k].x, cyi = kpb[k].y, czi = kpb[k].z;
-		const int li = kpb[k].octave * 8 + kpb[k].level;
+		const int li = __builtin_amdgcn_readfirstlane(kpb[k].octave * 8 + kpb[k].level);  // (block-uniform: a scalar, like the loop-carried cur_lut it is compared with)
 		const float scale = kpb[k].scale;
 		const LevelRef L = levels[li];
 		const WinLut lut = luts[li * 2 + 1];
@@ -534,12 +548,12 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		// gradient of the orientation window, from the structure tensor, times the descriptor window's weight sum, with 4x head
 		// room), sums the true M on the way and, should the estimate have been too small, the keypoint is redone once with the
 		// exact bound.  WinLut::fix_scale (provable for ANY data of this window size) is the coarsest unit ever used.
-		float fix_scale = first_pass_unit(kpb[k], luts[li * 2], lut, dev_flags);
-		if (PARTIAL && pp.seg[sg].units != nullptr && pp.seg[sg].units[k] > 0.0f) fix_scale = pp.seg[sg].units[k];  // second round: the exact unit, from the owner
 		int x0, x1, y0, y1, z0, z1;
 		win_bounds_d((float)cxi, win_radius, u, L.nx, x0, x1);
 		win_bounds_d((float)cyi, win_radius, u, L.ny, y0, y1);
 		win_bounds_d((float)czi, win_radius, u, L.nz, z0, z1);
+		float fix_scale = first_pass_unit(kpb[k], luts[li * 2], lut, x1 - x0 + 1, y1 - y0 + 1, z1 - z0 + 1, dev_flags);
+		if (PARTIAL && pp.seg[sg].units != nullptr && pp.seg[sg].units[k] > 0.0f) fix_scale = pp.seg[sg].units[k];  // second round: the exact unit, from the owner
 		if (PARTIAL) {
 			// this rank's z part of the window (the chords below are clipped to it; the planes z0 - 1 and z1 + 1 the gradient reads lie in
 			// the buffer's halo).  Nothing of the window here: zeros, and on to the next record (block-uniform).
@@ -637,7 +651,9 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		for (int i = tid; i < kLenBins; i += NT) s_cnt[i] = 0u;
 		if (tid == 0) s_tile = 0u;
 		__syncthreads();
-		for (int ps = tid; ps < nch * kUL; ps += NT) {  // pair slot = unit * kUL + position in the unit: kUL consecutive lanes per unit
+		int tc = tid;  // (opaque: the first pair slot's unit / position constants are not values to carry through the keypoint loop and the march)
+		asm volatile("" : "+v"(tc));
+		for (int ps = tc; ps < nch * kUL; ps += NT) {  // pair slot = unit * kUL + position in the unit: kUL consecutive lanes per unit
 			const int uu = ps / kUL, spos = ps % kUL;
 			const int uyi = (u0 + uu) / nux, uxi = (u0 + uu) - uyi * nux;
 			int rr[2], za[2], zb[2];
@@ -670,7 +686,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			if (lane == 63) s_nnz = incl - cb;  // key 0 comes last: everything before it is non-empty
 		}
 		__syncthreads();
-		for (int uu = tid; uu < nch; uu += NT) {
+		for (int uu = tc; uu < nch; uu += NT) {
 			int len;
 			if (chord_cached) {
 				int lo = 255, hi = 0;
@@ -862,7 +878,11 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) msum = msum + __shfl_xor(msum, o, 64);
 		__syncthreads();
-		if (lane == 0) red[wid] = msum;
+		{
+			int tm = tid;  // (opaque: the address of this wave's slot is not a value to carry through the march)
+			asm volatile("" : "+v"(tm));
+			if ((tm & 63) == 0) red[tm >> 6] = msum;
+		}
 		__syncthreads();
 		float mass_sum = (red[0] + red[1]) + (red[2] + red[3]);
 		if (NW == 8) mass_sum = mass_sum + ((red[4] + red[5]) + (red[6] + red[7]));
@@ -911,7 +931,7 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			for (int q = 0; q < S; q++) mass_sum = mass_sum + __hip_atomic_load(&sp.gmass[kpos * 8 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // part order: deterministic
 		}
 		const float mass = mass_sum * 1.001f;
-		if (attempt == 1 || !unit_fails(mass, fix_scale, lut.fix_scale)) {
+		if (attempt == 1 || !unit_fails(mass, fix_scale, lut.fix_scale, lut.nin)) {
 			finished = true;
 			break;
 		}
@@ -1031,7 +1051,7 @@ struct FinishParts {
 	const int *hist[kDescSegs] = {};
 	const float *mass[kDescSegs] = {};
 };
-__global__ void __launch_bounds__(256) k_describe_finish(const DevKp *__restrict__ recs, unsigned n, const WinLut *__restrict__ luts, FinishParts fp,
+__global__ void __launch_bounds__(256) k_describe_finish(const DevKp *__restrict__ recs, unsigned n, const LevelRef *__restrict__ levels, const WinLut *__restrict__ luts, FinishParts fp,
                                                           const float *__restrict__ units, int final_round, int dev_flags,
                                                           float *__restrict__ d_desc, int *__restrict__ redo, float *__restrict__ units_next,
                                                           unsigned *__restrict__ d_counters) {
@@ -1040,12 +1060,17 @@ __global__ void __launch_bounds__(256) k_describe_finish(const DevKp *__restrict
 	for (unsigned k = blockIdx.x; k < n; k += gridDim.x) {  // block-uniform
 		const int li = recs[k].octave * 8 + recs[k].level;
 		const WinLut lut = luts[li * 2 + 1];
-		float fix_scale = first_pass_unit(recs[k], luts[li * 2], lut, dev_flags);
+		const LevelRef L = levels[li];
+		int wx0, wx1, wy0, wy1, wz0, wz1;
+		win_bounds_d((float)recs[k].x, lut.radius, L.unit, L.nx, wx0, wx1);
+		win_bounds_d((float)recs[k].y, lut.radius, L.unit, L.ny, wy0, wy1);
+		win_bounds_d((float)recs[k].z, lut.radius, L.unit, L.nz, wz0, wz1);
+		float fix_scale = first_pass_unit(recs[k], luts[li * 2], lut, wx1 - wx0 + 1, wy1 - wy0 + 1, wz1 - wz0 + 1, dev_flags);
 		if (units != nullptr && units[k] > 0.0f) fix_scale = units[k];
 		float msum = 0.0f;
 		for (int p = 0; p < fp.nparts; p++) msum = msum + fp.mass[p][k];
 		const float m = msum * 1.001f;
-		if (!final_round && unit_fails(m, fix_scale, lut.fix_scale)) {
+		if (!final_round && unit_fails(m, fix_scale, lut.fix_scale, lut.nin)) {
 			if (tid == 0) { redo[k] = 1; units_next[k] = pick_scale_d(m, lut.fix_scale); atomicAdd(d_counters, 1u); }
 			continue;
 		}
@@ -1094,7 +1119,7 @@ void launch_describe_partial(const LevelRef *d_levels, const WinLut *d_luts, con
 		                   d_lutpool, (float *)nullptr, n, 0, 1, (const int *)nullptr, (const unsigned *)nullptr, d_work, dev_flags, 0u, 0u, DescSplit{}, pp);
 }
 
-void launch_describe_finish(const DevKp *recs, unsigned n, const WinLut *d_luts, int nparts, const int *const *d_hist, const float *const *d_mass,
+void launch_describe_finish(const DevKp *recs, unsigned n, const LevelRef *d_levels, const WinLut *d_luts, int nparts, const int *const *d_hist, const float *const *d_mass,
                             const float *d_units, bool final_round, float *d_desc, int *d_redo, float *d_units_next, unsigned *d_counters,
                             hipStream_t st) {
 	if (n == 0) return;
@@ -1102,7 +1127,7 @@ void launch_describe_finish(const DevKp *recs, unsigned n, const WinLut *d_luts,
 	fp.nparts = nparts;
 	for (int p = 0; p < nparts; p++) { fp.hist[p] = d_hist[p]; fp.mass[p] = d_mass[p]; }
 	const int dev_flags = (hook(SIFT3D_HOOK_DESC_MASS_SHIFT) & 63) << 8;
-	hipLaunchKernelGGL(k_describe_finish, dim3((int)std::min(n, 4096u)), dim3(256), 0, st, recs, n, d_luts, fp, d_units, final_round ? 1 : 0, dev_flags,
+	hipLaunchKernelGGL(k_describe_finish, dim3((int)std::min(n, 4096u)), dim3(256), 0, st, recs, n, d_levels, d_luts, fp, d_units, final_round ? 1 : 0, dev_flags,
 	                   d_desc, d_redo, d_units_next, d_counters);
 }
 

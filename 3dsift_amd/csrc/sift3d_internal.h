@@ -264,7 +264,7 @@ void launch_describe_partial(const LevelRef *d_levels, const WinLut *d_luts, con
 // the owner's finish: nparts <= kDescSegs partial results of its n records (its own part and its neighbours', ascending rank: the masses
 // are added in that order); rows go to d_desc[recs[k].slot]; records whose unit failed get redo[k] = 1, units_next[k] = the exact unit,
 // and are counted in d_counters[0] (unless final_round)
-void launch_describe_finish(const DevKp *recs, unsigned n, const WinLut *d_luts, int nparts, const int *const *d_hist, const float *const *d_mass,
+void launch_describe_finish(const DevKp *recs, unsigned n, const LevelRef *d_levels, const WinLut *d_luts, int nparts, const int *const *d_hist, const float *const *d_mass,
                             const float *d_units, bool final_round, float *d_desc, int *d_redo, float *d_units_next, unsigned *d_counters,
                             hipStream_t st);
 void launch_describe(const DevKp *kps, const unsigned *d_count, unsigned cap, const LevelRef *d_levels,

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Soak run (GPU box, not part of the test suite): N random draws of (shape, parameters, hooks) through the whole pipeline against the
+oracle -- every level, extrema, keypoints, descriptors -- plus the native z-slab driver (whole / partial windows) on the same volume
+against the single-volume result.   python3 scripts/soak_random.py [N=40] [seed=1]
+Prints one line per draw and a summary; exits non-zero on the first mismatch (the draw is printed so that it can be replayed)."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+capi = importlib.import_module("3dsift_amd.capi")
+synth = importlib.import_module("3dsift_amd.synth")
+import oracle_lib as ol
+from hipcheck import bits, compare_keypoints, extrema_table
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+orc = ol.load("orc")
+rng = np.random.default_rng(seed)
+pool = [24, 32, 33, 40, 47, 48, 56, 64, 65, 70, 72, 80, 96, 100, 128, 130]
+t0 = time.time()
+nkp = 0
+for case in range(N):
+    shape = tuple(int(rng.choice(pool)) for _ in range(3))
+    levels = int(rng.integers(1, 5))
+    sd = float(np.round(rng.uniform(1.2, 2.6), 2))
+    params = dict(num_kp_levels=levels, sigma_default=sd, sigma_n_default=float(np.round(rng.uniform(0.5, min(1.15, sd - 0.2)), 2)),
+                  peak_thresh=float(np.round(rng.uniform(0.03, 0.25), 3)), max_eig_thres=float(np.round(rng.uniform(0.7, 0.95), 2)),
+                  corner_thresh=float(np.round(rng.uniform(0.2, 0.6), 2)))
+    hooks = {}
+    for name, p in (("march_tiles", 0.4), ("dog_eager", 0.15), ("glast_eager", 0.15), ("lazy_generic", 0.15), ("desc_nosplit", 0.15), ("det_serial", 0.1), ("one_stream", 0.1)):
+        if rng.random() < p:
+            hooks[name] = 1
+    if rng.random() < 0.1:
+        hooks["desc_mass_shift"] = int(rng.integers(3, 10))
+    if rng.random() < 0.1:
+        hooks["list_cap"] = int(rng.integers(64, 600))
+    vol = synth.blobs(shape, seed=5000 + seed * 1000 + case, noise=float(rng.choice([0.0, 0.01, 0.03])))
+    tag = (case, shape, params, hooks)
+    import contextlib
+    with contextlib.ExitStack() as st:
+        for k, v in hooks.items():
+            st.enter_context(capi.hook(k, v))
+        try:
+            g = capi.CreateCSIFT3D(vol, **params).KpSiftAlgorithm()
+        except capi.Sift3dError as e:
+            if "129 taps" in str(e):
+                print("draw", tag, "refused (kernel wider than 129 taps)")
+                continue
+            raise
+        o = orc.extractor(vol, **params).run(5)
+        try:
+            assert g.num_octaves == o.num_octaves
+            for oc in range(g.num_octaves):
+                for i in range(levels + 3):
+                    assert np.array_equal(bits(g.gss(oc, i)), bits(o.gss(oc, i))), ("gss", oc, i)
+                for i in range(levels + 2):
+                    assert np.array_equal(bits(g.dog(oc, i)), bits(o.dog(oc, i))), ("dog", oc, i)
+            assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema())), "extrema"
+            kp, desc = g.GetKeypoints()
+            okp, odesc = o.keypoints()
+            compare_keypoints(kp, desc, okp, odesc)
+            # the native z-slab driver on the same volume (default parameters only take the hooks' paths; its own parameters: the draw's)
+            ranks = int(rng.integers(2, 6)); octs = int(rng.integers(1, 3)); partial = bool(rng.integers(0, 2))
+            try:
+                sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=partial, **params)
+            except capi.Sift3dError:
+                sh = None
+            if sh is not None:
+                k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+                sh.close()
+                assert np.array_equal(k2, kp), ("sharded keypoints", ranks, octs, partial)
+                assert np.array_equal(d2, desc), ("sharded descriptors", ranks, octs, partial)
+        except AssertionError as e:
+            print("MISMATCH", tag, e, flush=True)
+            sys.exit(1)
+        nkp += len(kp)
+        print("draw %3d ok  %-16s levels %d sigma %.2f hooks %s  kp %d%s" % (case, shape, levels, sd, hooks, len(kp), "" if sh is None else "  slabs %d/%d%s" % (ranks, octs, " partial" if partial else "")), flush=True)
+        g.close()
+print("soak: %d draws, %d keypoints, %.0f s, all equal" % (N, nkp, time.time() - t0))
