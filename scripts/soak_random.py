@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak run (GPU box, not part of the test suite): N random draws of (shape, parameters, hooks) through the whole pipeline against the
 oracle -- every level, extrema, keypoints, descriptors -- plus the native z-slab driver (whole / partial windows) on the same volume
-against the single-volume result.   python3 scripts/soak_random.py [N=40] [seed=1]
+against the single-volume result, and every third draw the matcher (three modes) on the keypoints of the volume and of a perturbed copy.   python3 scripts/soak_random.py [N=40] [seed=1]
 Prints one line per draw and a summary; exits non-zero on the first mismatch (the draw is printed so that it can be replayed)."""
 import importlib, os, sys, time
 import numpy as np
@@ -16,7 +16,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 orc = ol.load("orc")
 rng = np.random.default_rng(seed)
-pool = [24, 32, 33, 40, 47, 48, 56, 64, 65, 70, 72, 80, 96, 100, 128, 130]
+pool = [24, 32, 33, 40, 47, 48, 56, 64, 65, 70, 72, 80, 96, 100, 128, 130, 160, 192]
 t0 = time.time()
 nkp = 0
 for case in range(N):
@@ -70,6 +70,21 @@ for case in range(N):
                 sh.close()
                 assert np.array_equal(k2, kp), ("sharded keypoints", ranks, octs, partial)
                 assert np.array_equal(d2, desc), ("sharded descriptors", ranks, octs, partial)
+            # every third draw: the matcher on this volume's keypoints against those of a perturbed copy (all three modes, every output)
+            if case % 3 == 0 and len(kp) >= 2:
+                vol2 = (vol + synth.blobs(shape, seed=9000 + case, noise=0.0) * np.float32(0.05)).astype(np.float32)
+                g2 = capi.CreateCSIFT3D(vol2, **params).KpSiftAlgorithm()
+                kpb, descb = g2.GetKeypoints()
+                g2.close()
+                if len(kpb) >= 1:
+                    ax = np.stack([kp["rx"], kp["ry"], kp["rz"]], 1); bx = np.stack([kpb["rx"], kpb["ry"], kpb["rz"]], 1)
+                    mt = capi.muBruteMatcher()
+                    thr = float(rng.choice([0.7, 0.85, 0.95]))
+                    for mode in (1, 2, 3):
+                        got = mt._match(desc, ax, descb, bx, thr, mode)
+                        want = orc.match(desc, ax, descb, bx, thr, mode)
+                        for key in want:
+                            assert np.array_equal(got[key], want[key]), ("matcher", mode, key, thr)
         except AssertionError as e:
             print("MISMATCH", tag, e, flush=True)
             sys.exit(1)
