@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak run (GPU box, not part of the test suite): N random draws of (shape, parameters, hooks) through the whole pipeline against the
 oracle -- every level, extrema, keypoints, descriptors -- plus the native z-slab driver (whole / partial windows) on the same volume
-against the single-volume result, and every third draw the matcher (three modes) on the keypoints of the volume and of a perturbed copy.   python3 scripts/soak_random.py [N=40] [seed=1]
+against the single-volume result, and every third draw the matcher (three modes) on the keypoints of the volume and of a perturbed copy.   python3 scripts/soak_random.py [N=40] [seed=1] [kinds]
 Prints one line per draw and a summary; exits non-zero on the first mismatch (the draw is printed so that it can be replayed)."""
 import importlib, os, sys, time
 import numpy as np
@@ -14,6 +14,7 @@ from hipcheck import bits, compare_keypoints, extrema_table
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+KINDS = len(sys.argv) > 3 and sys.argv[3] == "kinds"   # other data than the synthetic blobs: a masked body, white noise, piecewise constant boxes
 orc = ol.load("orc")
 rng = np.random.default_rng(seed)
 pool = [24, 32, 33, 40, 47, 48, 56, 64, 65, 70, 72, 80, 96, 100, 128, 130, 160, 192]
@@ -35,11 +36,25 @@ for case in range(N):
     if rng.random() < 0.1:
         hooks["list_cap"] = int(rng.integers(64, 600))
     vol = synth.blobs(shape, seed=5000 + seed * 1000 + case, noise=float(rng.choice([0.0, 0.01, 0.03])))
+    kind = str(rng.choice(["blobs", "blobs", "masked", "noise", "steps"])) if KINDS else "blobs"
+    if kind == "masked":      # a zero background around a body, like CT / MR volumes: flat descriptor windows, exact zeros
+        zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n) for n in shape], indexing="ij")
+        vol = np.where(zz * zz + 0.8 * yy * yy + 1.2 * xx * xx < float(rng.uniform(0.3, 0.9)), vol, 0).astype(np.float32)
+    elif kind == "noise":     # white noise: extrema everywhere (list regrow), tiny windows' worth of structure
+        vol = np.random.default_rng(7000 + case).random(shape).astype(np.float32)
+    elif kind == "steps":     # piecewise constant boxes: sharp edges, plateaus with zero gradient, ties between neighbours
+        r2 = np.random.default_rng(8000 + case)
+        vol = np.zeros(shape, np.float32)
+        for _ in range(int(r2.integers(5, 40))):
+            lo = [int(r2.integers(0, n - 2)) for n in shape]; hi = [int(r2.integers(l + 1, n)) for l, n in zip(lo, shape)]
+            vol[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] += np.float32(r2.uniform(-1, 1))
+    hooks["_kind"] = kind
     tag = (case, shape, params, hooks)
     import contextlib
     with contextlib.ExitStack() as st:
         for k, v in hooks.items():
-            st.enter_context(capi.hook(k, v))
+            if not k.startswith("_"):
+                st.enter_context(capi.hook(k, v))
         try:
             g = capi.CreateCSIFT3D(vol, **params).KpSiftAlgorithm()
         except capi.Sift3dError as e:
