@@ -760,3 +760,35 @@ def test_split_descriptor_windows_match_unsplit(capi, synth):
             assert split == plain and split[1] > 20, (shape, shift)
             assert n_split == n_plain and (shift == 0 or n_split > 0), (shape, shift, n_split, n_plain)
             assert again == split, (shape, shift)
+
+
+def test_rows_wider_than_4096_voxels(capi, orc):
+    """k_mark / k_emit walk a row's ballot words in segments of 64: rows of 4 200 and 9 000 voxels (found nowhere else in the suite; the
+    soak run scripts/soak_shapes.py has more such shapes), white noise so that extrema sit in every segment"""
+    for shape in ((16, 16, 4200), (8, 8, 9000)):
+        vol = np.random.default_rng(shape[2]).random(shape).astype(np.float32)
+        g = capi.CreateCSIFT3D(vol, peak_thresh=0.05).KpSiftAlgorithm()
+        o = orc.extractor(vol, peak_thresh=0.05).run(5)
+        assert np.array_equal(extrema_table(g.extrema()), extrema_table(o.extrema())), shape
+        assert (g.extrema()["x"] > 4096).sum() > 5
+        kp, desc = g.GetKeypoints()
+        okp, odesc = o.keypoints()
+        assert len(kp) > 100
+        compare_keypoints(kp, desc, okp, odesc)
+        g.close()
+
+
+def test_large_window_cut_off_by_the_volume_border(capi, orc, synth):
+    """The draw of scripts/soak_random.py that fell outside the descriptor bar in round 5: sigma_default 2.47 gives windows of radius 55 voxels,
+    cut off by the border of a 64 x 128 x 80 volume; the first fixed-point unit assumed the whole sphere, was 16x coarser than the window's mass
+    allowed and 340 000 contributions of 12 units each lost 2.9e-5 RMS to rounding.  With the estimate scaled by the share of the window inside
+    the level: 3.6e-6."""
+    vol = synth.blobs((80, 128, 64), seed=6010, noise=0.0)
+    params = dict(num_kp_levels=3, sigma_default=2.47, sigma_n_default=0.51, peak_thresh=0.097, max_eig_thres=0.95, corner_thresh=0.3)
+    g = capi.CreateCSIFT3D(vol, **params).KpSiftAlgorithm()
+    o = orc.extractor(vol, **params).run(5)
+    kp, desc = g.GetKeypoints()
+    okp, odesc = o.keypoints()
+    assert len(kp) > 100 and kp["scale"].max() > 3.9
+    compare_keypoints(kp, desc, okp, odesc, rms_tol=8e-6)
+    g.close()
