@@ -85,6 +85,22 @@ for case in range(N):
                 sh.close()
                 assert np.array_equal(k2, kp), ("sharded keypoints", ranks, octs, partial)
                 assert np.array_equal(d2, desc), ("sharded descriptors", ranks, octs, partial)
+            # every other draw: the python z-slab driver (3dsift_amd/slab.py, ranks simulated on this GPU) with the draw's parameters
+            if case % 2 == 1:
+                slab = importlib.import_module("3dsift_amd.slab")
+                w2 = int(rng.integers(2, 5)); o2 = int(rng.integers(1, 3)); p2 = bool(rng.integers(0, 2))
+                try:
+                    ex = slab.SlabExtractor((shape[2], shape[1], shape[0]), slab.SimComm(w2), sharded_octaves=o2, desc_partial=p2, **params)
+                except (ValueError, capi.Sift3dError, AssertionError):
+                    ex = None
+                if ex is not None:
+                    ex.load(volume=vol)
+                    ex.KpSiftAlgorithm()
+                    k3, d3 = ex.GetKeypoints()
+                    ex.close()
+                    for f in kp.dtype.names:
+                        assert np.array_equal(k3[f], kp[f]), ("python slab driver", f, w2, o2, p2)
+                    assert np.array_equal(d3, desc), ("python slab driver descriptors", w2, o2, p2)
             # every third draw: the matcher on this volume's keypoints against those of a perturbed copy (all three modes, every output)
             if case % 3 == 0 and len(kp) >= 2:
                 vol2 = (vol + synth.blobs(shape, seed=9000 + case, noise=0.0) * np.float32(0.05)).astype(np.float32)
@@ -104,6 +120,7 @@ for case in range(N):
             print("MISMATCH", tag, e, flush=True)
             sys.exit(1)
         nkp += len(kp)
-        print("draw %3d ok  %-16s levels %d sigma %.2f hooks %s  kp %d%s" % (case, shape, levels, sd, hooks, len(kp), "" if sh is None else "  slabs %d/%d%s" % (ranks, octs, " partial" if partial else "")), flush=True)
+        pys = "  py-slabs %d/%d%s" % (w2, o2, " partial" if p2 else "") if (case % 2 == 1 and ex is not None) else ""
+        print("draw %3d ok  %-16s levels %d sigma %.2f hooks %s  kp %d%s%s" % (case, shape, levels, sd, hooks, len(kp), "" if sh is None else "  slabs %d/%d%s" % (ranks, octs, " partial" if partial else ""), pys), flush=True)
         g.close()
 print("soak: %d draws, %d keypoints, %.0f s, all equal" % (N, nkp, time.time() - t0))
