@@ -182,20 +182,31 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 				unsigned off[kBatch];
 #pragma unroll
 				for (int bb = 0; bb < kBatch; bb++) off[bb] = min((unsigned)(min(w0 + bb, nws - 1) * 64 + lane), omax);
-				float up[kBatch], mid[kBatch];
+				// r05: the x neighbours of a row come from the LANES beside (DPP wave shifts of the row's own registers) instead of two more
+				// loads of the row shifted by one voxel: the kernel's vector-memory pipe was busy for the whole launch (TA_BUSY = kernel time,
+				// profiles/r05f_pmc_k_mark.json: 28.6 M load instructions per step, three per word and row) while its VALU idled at 30 %.  Only the
+				// batch's two outer voxels -- x - 1 of its first word, x + 1 of its last -- are loaded, by lanes 0 and 1 of one more load per row.
+				const int eoff = (lane & 1) ? (int)min((unsigned)((w0 + kBatch) * 64), omax) : w0 * 64 - 1;
+				float up[kBatch], mid[kBatch], emid;
 				{
 					const float *ra = pl + sy * (size_t)(y0 + ry_a - 1), *rb = ra + sy;
 #pragma unroll
 					for (int bb = 0; bb < kBatch; bb++) { up[bb] = ra[off[bb]]; mid[bb] = rb[off[bb]]; }
+					emid = rb[eoff];  // (x - 1 of the row's first voxel: the row above's last element, in bounds; evaluate() drops that voxel)
 				}
 				for (int ry = ry_a; ry < ry_b; ry++) {
-					const float *rm = pl + sy * (size_t)(y0 + ry), *rd = rm + sy;
+					const float *rd = pl + sy * (size_t)(y0 + ry + 1);
 					float dn[kBatch], xl[kBatch], xr[kBatch];
 #pragma unroll
+					for (int bb = 0; bb < kBatch; bb++) dn[bb] = rd[off[bb]];
+					const float edn = rd[eoff];
+#pragma unroll
 					for (int bb = 0; bb < kBatch; bb++) {
-						dn[bb] = rd[off[bb]];
-						// (x - 1 of the row's first voxel / x + 1 of its last: the neighbouring rows' ends, in bounds, and evaluate() drops both voxels)
-						xl[bb] = (rm - 1)[off[bb]]; xr[bb] = (rm + 1)[off[bb]];
+						// lane l <- lane l - 1 (lane 0: the last voxel of the word before) and lane l <- lane l + 1 (lane 63: the first voxel of the word behind)
+						const int le = __builtin_amdgcn_readlane(__float_as_int(bb == 0 ? emid : mid[bb > 0 ? bb - 1 : 0]), bb == 0 ? 0 : 63);
+						const int re = __builtin_amdgcn_readlane(__float_as_int(bb == kBatch - 1 ? emid : mid[bb < kBatch - 1 ? bb + 1 : 0]), bb == kBatch - 1 ? 1 : 0);
+						xl[bb] = __int_as_float(__builtin_amdgcn_update_dpp(le, __float_as_int(mid[bb]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+						xr[bb] = __int_as_float(__builtin_amdgcn_update_dpp(re, __float_as_int(mid[bb]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
 					}
 					const unsigned idrow = (unsigned)((ry - r_lo) << 12);
 #pragma unroll
@@ -207,6 +218,7 @@ __global__ void __launch_bounds__(kThreads) k_mark(DetectLevels L, int nx, int n
 					}
 #pragma unroll
 					for (int bb = 0; bb < kBatch; bb++) { up[bb] = mid[bb]; mid[bb] = dn[bb]; }
+					emid = edn;
 				}
 			}
 		}
