@@ -109,6 +109,28 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partia
             "note": "ms_per_step = host wall time of sift3d_sharded_run up to the results of every rank on the host (keypoint and descriptor D2H included)"}
 
 
+def run_slab_native_child(dims_txt, gpus, steps, warmup, partial_windows, timeout):
+    """run_slab_native in a CHILD process (N > 1: rank 0's process starts it while the other ranks idle).  The native driver's RCCL
+    point-to-point transport meets its first second GPU in the driver's run: a hard fault there (one host thread per GPU inside librccl)
+    must not take the process that holds the headline measurement with it.  Returns (slab dict, None) or (None, reason)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "slab", "--native", "--gpus", str(gpus), "--slab-dims", dims_txt,
+           "--steps", str(steps), "--warmup", str(warmup)] + (["--partial-windows"] if partial_windows else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                                              "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    except subprocess.TimeoutExpired:
+        return None, "timed out after %d s" % timeout
+    for line in reversed(r.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)["slab"], None
+            except Exception:
+                break
+    return None, "exit code %d: %s" % (r.returncode, (r.stderr.strip().splitlines() or ["no output"])[-1][:300])
+
+
 def run_slab(dims, world, rank, local, dev, steps, warmup, sim_ranks=0, seed=4321):
     """Strong-scaling workload: one nx x ny x nz volume, z-slabs over the ranks.  Returns a dict (same on all ranks)."""
     import torch
@@ -643,12 +665,13 @@ def main():
                 store = None
             if rank == 0:
                 torch.cuda.empty_cache()
-                nres, nat_err = guarded(lambda: run_slab_native(parse_dims(args.slab_dims), list(range(world)), SLAB_STEPS, SLAB_WARMUP), 180)
+                # (each in a child process of rank 0: a hard fault of the native transport's first multi-GPU run must not cost the headline line)
+                nres, nat_err = run_slab_native_child(args.slab_dims, world, SLAB_STEPS, SLAB_WARMUP, False, 180)
                 out["slab_native"] = nres if nat_err is None else {"error": nat_err}
                 if nat_err is None:
                     # r05, opt-in form of the native driver: descriptor windows split along z (13-plane level halos, records out, integer
                     # histograms back).  Simulated ranks only in development; reported beside the default form, never instead of it.
-                    pres, p_err = guarded(lambda: run_slab_native(parse_dims(args.slab_dims), list(range(world)), SLAB_STEPS, SLAB_WARMUP, partial_windows=True), 120)
+                    pres, p_err = run_slab_native_child(args.slab_dims, world, SLAB_STEPS, SLAB_WARMUP, True, 120)
                     out["slab_native_partial_windows"] = pres if p_err is None else {"error": p_err}
                 if store is not None:
                     try:

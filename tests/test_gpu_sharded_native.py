@@ -145,3 +145,20 @@ def test_cpp_shell_shards_for_the_unchanged_user():
             outs.append((o.strip().splitlines()[-1].split()[1], open(os.path.join(t, "k.bin"), "rb").read()))
     assert int(outs[0][0]) > 30
     assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0]
+
+
+def test_bench_runs_the_native_legs_in_a_child_process():
+    """bench.py at N > 1 starts the native driver's legs as CHILD processes of rank 0 (a hard fault of the transport's first multi-GPU run must
+    not cost the headline line).  Here: the helper itself on the one GPU (an RCCL world of one), both window forms; a child that fails
+    (a volume too small to shard) comes back as a reason, not as an exception."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    for partial in (False, True):
+        res, err = bench.run_slab_native_child("256x192x128", 1, 2, 1, partial, 240)
+        assert err is None, err
+        assert res["keypoints"] > 100 and res["ms_per_step"] > 0
+        assert res["descriptor_windows"] == ("partial integer histograms" if partial else "whole windows on plane halos")
+    res, err = bench.run_slab_native_child("8x8x4", 1, 1, 0, False, 120)
+    assert res is None and err
