@@ -28,7 +28,7 @@ KP_DTYPE = np.dtype(
 )
 assert KP_DTYPE.itemsize == 168
 
-# every symbol include/sift3d_hip.h declares (tests check that the library exports all of them)
+# every symbol include/sift3d_hip.h and include/sift3d_hip_test.h declare (tests check that the library exports all of them)
 SYMBOLS = [
     "sift3d_default_params", "sift3d_create", "sift3d_destroy", "sift3d_run", "sift3d_run_async", "sift3d_wait", "sift3d_run_stages",
     "sift3d_stage_times", "sift3d_num_keypoints", "sift3d_get_keypoints", "sift3d_device_results",
@@ -54,7 +54,7 @@ SYMBOLS = [
     "sift3d_sharded_create", "sift3d_sharded_create_ex", "sift3d_sharded_run", "sift3d_sharded_num_keypoints", "sift3d_sharded_get_keypoints", "sift3d_sharded_info",
     "sift3d_sharded_error", "sift3d_sharded_destroy",
     "sift3d_test_hook", "sift3d_debug_counters", "sift3d_debug_face_lookup", "sift3d_match_times", "sift3d_debug_copy_bandwidth",
-    "sift3d_match_warmup",
+    "sift3d_match_warmup", "sift3d_test_staging_slice",
 ]
 HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "desc_nocache": 4, "match_nodma": 5, "one_stream": 6,
          "desc_mass_shift": 7, "list_cap": 8, "peer_copy": 9, "desc_nosplit": 10, "march_tiles": 11, "desc_exact_cells": 12, "lazy_generic": 13}
@@ -305,11 +305,17 @@ class CSIFT3D:
         _check(lib().sift3d_run_stages(self._h, int(upto)))
         return self
 
-    def GetKeypoints(self, with_desc=True):
+    def GetKeypoints(self, with_desc=True, out=None):
+        """out = (kp, desc): arrays of the result's size to fill instead of new ones (the C++ caller's vectors)"""
         n = C.c_int(0)
         _check(lib().sift3d_num_keypoints(self._h, C.byref(n)))
-        kp = np.zeros(n.value, KP_DTYPE)
-        desc = np.zeros((n.value, DESC), np.float32)
+        if out is not None:
+            kp, desc = out
+            assert kp.dtype == KP_DTYPE and kp.shape == (n.value,) and desc.dtype == np.float32 and desc.shape == (n.value, DESC)
+            assert kp.flags.c_contiguous and desc.flags.c_contiguous
+        else:
+            kp = np.zeros(n.value, KP_DTYPE)
+            desc = np.zeros((n.value, DESC), np.float32)
         if n.value:
             _check(lib().sift3d_get_keypoints(self._h, kp.ctypes.data, _f(desc) if with_desc else None))
         return kp, desc

@@ -1531,8 +1531,10 @@ extern "C" int sift3d_describe_keypoint(const float *level, int nx, int ny, int 
 	if (!window_box(ctr, dims, 2.0f * dsig, unit, b)) { set_last_error("the descriptor window is empty"); return SIFT3D_ERR_ARG; }
 	std::lock_guard<std::mutex> lk(g_onekp_mu);
 	OneKp &K = g_onekp;
-	// (the orientation table of the pair is the pipeline's for this scale: its weight sum enters the first guess of the fixed-point unit)
-	if ((rc = onekp_prepare(K, device, unit, std::max(b.n[0], std::max(b.n[1], b.n[2])), K.c && K.scale == kp->scale ? K.ori_sigma : 1.5f * kp->scale, kp->scale)) != SIFT3D_OK)
+	// the orientation table of the pair is ALWAYS the pipeline's for this scale (sigma = 1.5 scale): its weight sum enters the first guess of the
+	// fixed-point unit, so a table left behind by an earlier sift3d_orient_keypoint with another sigma would make the descriptor's low bits
+	// depend on the call history; onekp_prepare rebuilds the pair when it differs
+	if ((rc = onekp_prepare(K, device, unit, std::max(b.n[0], std::max(b.n[1], b.n[2])), 1.5f * kp->scale, kp->scale)) != SIFT3D_OK)
 		return rc;
 	sift3d_ctx *c = K.c;
 	DevKp rec;

@@ -338,7 +338,14 @@ int rendezvous(sift3d_sharded *H, Worker &w) {
 	const unsigned gen = H->rv_gen;
 	if (++H->rv_arrived == H->world) { H->rv_arrived = 0; H->rv_gen++; H->rv_cv.notify_all(); return SIFT3D_OK; }
 	while (H->rv_gen == gen) {
-		if (H->failed.load()) { set_err(w, "aborted: another rank failed"); return SIFT3D_ERR_STATE; }
+		if (H->failed.load()) {
+			// a waiter that leaves takes its arrival with it and wakes the others, so that the count is right whatever the caller does next
+			// (today a failed handle is dead; the invariant is local to this function all the same)
+			H->rv_arrived = std::max(0, H->rv_arrived - 1);
+			H->rv_cv.notify_all();
+			set_err(w, "aborted: another rank failed");
+			return SIFT3D_ERR_STATE;
+		}
 		H->rv_cv.wait_for(lk, std::chrono::milliseconds(20));
 	}
 	return SIFT3D_OK;

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/sift3d_hip.h"
+#include "../../include/sift3d_hip_test.h"
 
 // All arithmetic that must reproduce the reference bit-for-bit is written as separate IEEE
 // multiplies and adds.  The library is compiled with -ffp-contract=off; the pragma makes the

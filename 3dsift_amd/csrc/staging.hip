@@ -20,6 +20,7 @@ namespace s3d {
 namespace {
 constexpr size_t kChunk = (size_t)16 << 20;  // bytes per pinned buffer
 constexpr int kBufs = 4;
+constexpr int kSub = 4;  // the device -> host direction deals every buffer as kSub pieces (staged_d2h)
 // One pool per device (r04; before: one process-wide pool behind one mutex whose events were re-created whenever the calling device
 // changed -- the rank threads of the sharded driver took turns through it inside the timed region): 4 x 16 MB of pinned memory and
 // four events per device that is ever used, created on first use by a thread whose current device is that device.
@@ -27,6 +28,7 @@ struct Pool {
 	std::mutex mu;
 	char *buf[kBufs] = {};
 	hipEvent_t ev[kBufs] = {};
+	hipEvent_t ev2[kBufs * kSub] = {};  // one per piece of the device -> host direction
 };
 constexpr int kMaxDev = 64;
 Pool g_pools[kMaxDev];
@@ -37,24 +39,23 @@ int pool_ready(Pool &P) {  // the caller holds P.mu and has made the pool's devi
 		if (!P.buf[i]) S3D_HIP(hipHostMalloc(reinterpret_cast<void **>(&P.buf[i]), kChunk, hipHostMallocPortable));
 		if (!P.ev[i]) S3D_HIP(hipEventCreateWithFlags(&P.ev[i], hipEventDisableTiming));
 	}
+	for (int i = 0; i < kBufs * kSub; i++)
+		if (!P.ev2[i]) S3D_HIP(hipEventCreateWithFlags(&P.ev2[i], hipEventDisableTiming));
 	return SIFT3D_OK;
 }
 
-// memcpy with a few helper threads (a single core moves 8-12 GB/s; PCIe 5 x16 wants ~50) -- the device -> host direction
-void par_memcpy(char *dst, const char *src, size_t bytes) {
-	const unsigned hc = std::thread::hardware_concurrency();
-	const int nt = (int)std::min<size_t>(std::max(1u, std::min(4u, hc ? hc / 2 : 1u)), std::max<size_t>(1, bytes >> 20));
-	if (nt <= 1) { memcpy(dst, src, bytes); return; }
-	const size_t part = ((bytes / nt) + 4095) & ~(size_t)4095;
-	std::vector<std::thread> th;
-	for (int t = 1; t < nt; t++) {
-		const size_t o = std::min(bytes, part * (size_t)t), e = std::min(bytes, o + part);
-		if (e > o) th.emplace_back([=] { memcpy(dst + o, src + o, e - o); });
-	}
-	memcpy(dst, src, std::min(bytes, part));
-	for (auto &t : th) t.join();
-}
 }  // namespace
+
+// Thread t of nt copies bytes [*o, *e) of an n-byte chunk: page-aligned parts of CEIL(n / nt) bytes, so that nt parts always cover
+// the chunk (r05 took the floor: with n / nt a multiple of 4096 and n % nt != 0 the last n % nt bytes of a chunk were never copied --
+// a 195 x 273 x 315 volume lost its last voxel to whatever an earlier upload had left in the pinned buffer).  tests/test_cabi_cpu.py
+// walks the coverage through sift3d_test_staging_slice.
+void staging_slice(size_t n, int nt, int t, size_t *o, size_t *e) {
+	if (nt < 1) nt = 1;
+	const size_t part = (((n + (size_t)nt - 1) / (size_t)nt) + 4095) & ~(size_t)4095;
+	*o = std::min(n, part * (size_t)t);
+	*e = std::min(n, *o + part);
+}
 
 // host (pageable) -> device; returns after every byte has been handed to the stream (the copies are still in flight: stream-ordered).
 // r05: the copy INTO the pinned chunks was the bound (r04: four helper threads spawned per 16 MB chunk, 33.7 GB/s for the 512 MB of a
@@ -82,7 +83,8 @@ int staged_h2d(void *d_dst, const void *h_src, size_t bytes, int device, hipStre
 				std::this_thread::yield();
 			}
 			const size_t off = i * kChunk, n = std::min(kChunk, bytes - off);
-			const size_t part = ((n / (size_t)nt) + 4095) & ~(size_t)4095, o = std::min(n, part * (size_t)t), e = std::min(n, o + part);
+			size_t o, e;
+			staging_slice(n, nt, t, &o, &e);
 			if (e > o) memcpy(g_pool.buf[i % kBufs] + o, static_cast<const char *>(h_src) + off + o, e - o);
 			filled[i].fetch_add(1, std::memory_order_release);
 		}
@@ -102,7 +104,8 @@ int staged_h2d(void *d_dst, const void *h_src, size_t bytes, int device, hipStre
 		while (i >= drained + (size_t)kBufs && err == hipSuccess) err = drain_one();
 		if (err != hipSuccess) break;
 		const size_t off = i * kChunk, n = std::min(kChunk, bytes - off);
-		const size_t part = ((n / (size_t)nt) + 4095) & ~(size_t)4095, e0 = std::min(n, part);
+		size_t o0, e0;
+		staging_slice(n, nt, 0, &o0, &e0);
 		memcpy(g_pool.buf[i % kBufs], static_cast<const char *>(h_src) + off, e0);
 		filled[i].fetch_add(1, std::memory_order_release);
 		while (filled[i].load(std::memory_order_acquire) < nt) std::this_thread::yield();
@@ -120,7 +123,11 @@ int staged_h2d(void *d_dst, const void *h_src, size_t bytes, int device, hipStre
 	return SIFT3D_OK;
 }
 
-// device -> host (pageable); synchronous: the data is in h_dst on return
+// device -> host (pageable); synchronous: the data is in h_dst on return.
+// r06: the mirror image of staged_h2d (r05's form spawned four threads per 16 MB chunk and waited for a whole chunk's DMA before the
+// first byte moved on: GetKeypoints brought the 36.6 MB of a 512^3 run back at 11 GB/s).  The 64 MB of pinned memory are dealt as
+// 16 slots of 4 MB -- a result of a few tens of MB is many pieces in flight -- the calling thread only issues DMAs and frees slots, the copy threads
+// live for the whole call and each moves its slice of piece after piece out of the pinned slot into the caller's (pageable) memory.
 int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStream_t st) {
 	if (bytes == 0) return SIFT3D_OK;
 	if (bytes < ((size_t)1 << 20)) {
@@ -132,21 +139,67 @@ int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStre
 	std::lock_guard<std::mutex> lock(g_pool.mu);
 	int rc = pool_ready(g_pool);
 	if (rc) return rc;
-	const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+	constexpr size_t kPiece = kChunk / kSub;
+	constexpr size_t kSlots = (size_t)kBufs * kSub;
+	const size_t npieces = (bytes + kPiece - 1) / kPiece;
+	const unsigned hc = std::thread::hardware_concurrency();
+	const int nt = (int)std::min<size_t>(std::max(1u, std::min(8u, hc ? hc / 2 : 1u)), std::max<size_t>(1, bytes >> 22));
+	auto slot = [&](size_t i) { return g_pool.buf[(i % kSlots) / kSub] + ((i % kSlots) % kSub) * kPiece; };
+	// landed: pieces whose DMA has completed (the calling thread's event wait); copied[i]: copy threads done with piece i
+	std::atomic<size_t> landed{0};
+	std::atomic<bool> stop{false};
+	std::vector<std::atomic<int>> copied(npieces);
+	for (auto &f : copied) f.store(0);
+	auto copy_piece = [&](size_t i, int t) {
+		const size_t off = i * kPiece, n = std::min(kPiece, bytes - off);
+		size_t o, e;
+		staging_slice(n, nt, t, &o, &e);
+		if (e > o) memcpy(static_cast<char *>(h_dst) + off + o, slot(i) + o, e - o);
+		copied[i].fetch_add(1, std::memory_order_release);
+	};
+	auto worker = [&](int t) {
+		for (size_t i = 0; i < npieces; i++) {
+			while (i >= landed.load(std::memory_order_acquire)) {
+				if (stop.load(std::memory_order_relaxed)) return;
+				std::this_thread::yield();
+			}
+			copy_piece(i, t);
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
+	hipError_t err = hipSuccess;
+	size_t issued = 0;
 	auto issue = [&](size_t i) -> hipError_t {
-		const size_t off = i * kChunk, n = std::min(kChunk, bytes - off);
-		hipError_t e = hipMemcpyAsync(g_pool.buf[i % kBufs], static_cast<const char *>(d_src) + off, n, hipMemcpyDeviceToHost, st);
-		if (e == hipSuccess) e = hipEventRecord(g_pool.ev[i % kBufs], st);
+		const size_t off = i * kPiece, n = std::min(kPiece, bytes - off);
+		hipError_t e = hipMemcpyAsync(slot(i), static_cast<const char *>(d_src) + off, n, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipEventRecord(g_pool.ev2[i % kSlots], st);
 		return e;
 	};
-	for (size_t i = 0; i < std::min<size_t>(kBufs, nchunks); i++) S3D_HIP(issue(i));
-	for (size_t i = 0; i < nchunks; i++) {
-		const size_t off = i * kChunk, n = std::min(kChunk, bytes - off);
-		S3D_HIP(hipEventSynchronize(g_pool.ev[i % kBufs]));
-		par_memcpy(static_cast<char *>(h_dst) + off, g_pool.buf[i % kBufs], n);
-		if (i + kBufs < nchunks) S3D_HIP(issue(i + kBufs));  // the buffer is free again
+	while (issued < std::min(kSlots, npieces) && err == hipSuccess)
+		if ((err = issue(issued)) == hipSuccess) issued++;
+	for (size_t i = 0; i < npieces && err == hipSuccess; i++) {
+		if ((err = hipEventSynchronize(g_pool.ev2[i % kSlots])) != hipSuccess) break;
+		landed.store(i + 1, std::memory_order_release);
+		copy_piece(i, 0);  // the calling thread is copy thread 0
+		// the slot of piece i is free for piece i + kSlots once every thread has copied its slice out
+		if (issued < npieces) {
+			while (copied[i].load(std::memory_order_acquire) < nt) std::this_thread::yield();
+			if ((err = issue(issued)) == hipSuccess) issued++;
+		}
 	}
+	if (err != hipSuccess) stop.store(true);
+	for (auto &t : th) t.join();
+	// (on an error the DMAs already handed to the stream still target the pool: drained before the next caller may use it)
+	if (err != hipSuccess) { (void)hipStreamSynchronize(st); set_last_error(std::string("staged download: ") + hipGetErrorString(err)); return SIFT3D_ERR_HIP; }
 	return SIFT3D_OK;
 }
 
 }  // namespace s3d
+
+// test-only symbol (include/sift3d_hip_test.h): the slice of copy thread t
+extern "C" int sift3d_test_staging_slice(size_t n, int nt, int t, size_t *o, size_t *e) {
+	if (!o || !e || nt < 1 || t < 0 || t >= nt) return SIFT3D_ERR_ARG;
+	s3d::staging_slice(n, nt, t, o, e);
+	return SIFT3D_OK;
+}

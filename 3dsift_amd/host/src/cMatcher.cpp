@@ -2,6 +2,7 @@
 // Reference: 3DSIFT/Src/cMatcher.cc:146-228 (bijectMatchBase and its three public wrappers).
 #include "../Include/cMatcher.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 
@@ -9,7 +10,10 @@
 
 namespace CPUSIFT {
 
-muBruteMatcher::muBruteMatcher() { (void)sift3d_match_warmup(0); }  // the matcher's kernels, stream and scratch exist before the first call
+// The matcher's kernels, stream and scratch exist before the first call -- on the device the calls will use (SetDevice / SIFT3D_DEVICE), not
+// on GPU 0 whatever was selected.  A matcher constructed as a static object warms nothing up (the HIP runtime may not be initialised yet, and
+// SetDevice has not been called): warmed stays false and the first run() does it.
+muBruteMatcher::muBruteMatcher() {}
 float muBruteMatcher::getCalculationTime() { return totalTime; }
 std::vector<float> muBruteMatcher::getGlodenDistSquare() { return glodenDistSquare; }
 std::vector<float> muBruteMatcher::getSilverDistSquare() { return silverDistSquare; }
@@ -25,6 +29,11 @@ void muBruteMatcher::run(std::vector<Cvec> &refMatch, std::vector<Cvec> &tarMatc
 	int np = 0, rc;
 	double sec = 0;
 	usedDeviceResults = false;
+	{
+		static std::atomic<int> warmed_device{-1};  // (one warm-up per device and process is enough: the matcher's stream and scratch are the library's)
+		const int dev = GetDevice();
+		if (warmed_device.load() != dev) { (void)sift3d_match_warmup(dev); warmed_device.store(dev); }
+	}
 	// Keypoint vectors that still alias their extractors (the Example flow: GetKeypoints() straight into the matcher) are matched
 	// from the descriptors and coordinates already resident on the device: no gather, no host round trip of N x 768 floats
 	CSIFT3D *oa = CSIFT3D::OwnerOf(ref_kp), *ob = CSIFT3D::OwnerOf(tar_kp);

@@ -298,43 +298,8 @@ int sift3d_sharded_info(sift3d_sharded_handle h, int *world, int *sharded_octave
 const char *sift3d_sharded_error(sift3d_sharded_handle h);
 int sift3d_sharded_destroy(sift3d_sharded_handle h);
 
-/* ------------------------------------------------------------------------------------------------------------
- * Test hooks (no reference counterpart).  The product has branches that ordinary inputs rarely reach (list
- * overflow -> regrow -> rerun, the second descriptor pass with the exact fixed-point unit, the register-staged
- * matcher of >= 4 GB matrices, ...).  A hook forces such a branch so that the parity tests execute it; results must
- * not change.  Process-wide, read by the next create / run / match; returns the previous value (-1: unknown hook).
- * The library never reads the environment.
- * ------------------------------------------------------------------------------------------------------------ */
-enum {
-	SIFT3D_HOOK_DOG_EAGER = 0,      /* 1: write every DoG level (default: first / last level of an octave formed on request) */
-	SIFT3D_HOOK_GLAST_EAGER = 1,    /* 1: build the last Gaussian level of every octave (default: evaluated at parked candidates) */
-	SIFT3D_HOOK_DET_SERIAL = 2,     /* 1: extremum masks of all octaves on one stream with one scratch */
-	SIFT3D_HOOK_SEPARABLE = 3,      /* 1: every Gaussian level by the generic three-pass kernels */
-	SIFT3D_HOOK_DESC_NOCACHE = 4,   /* 1: k_describe recomputes the column chords (the path of windows > 255 planes) */
-	SIFT3D_HOOK_MATCH_NODMA = 5,    /* 1: matcher tiles staged through registers (the path of matrices >= 4 GB) */
-	SIFT3D_HOOK_ONE_STREAM = 6,     /* 1: all octaves on the handle's stream (isolated kernel durations in a trace) */
-	SIFT3D_HOOK_DESC_MASS_SHIFT = 7,/* s: k_describe's first gradient-mass estimate is divided by 2^s -> the exact-unit second pass runs */
-	SIFT3D_HOOK_LIST_CAP = 8,       /* n > 0: initial capacity of the extrema / keypoint lists -> overflow, regrow, rerun */
-	SIFT3D_HOOK_PEER_COPY = 9,      /* 1: sift3d_match_handles stages the target's results through its peer-copy scratch even on one device */
-	SIFT3D_HOOK_DESC_NOSPLIT = 10,  /* 1: a descriptor window is never split over several workgroups (the form of runs with many keypoints) */
-	SIFT3D_HOOK_MARCH_TILES = 11,   /* 1: the 64 x 32 tiles of the pyramid kernel wherever a level's geometry allows them (default: big levels only); 2: never */
-	SIFT3D_HOOK_DESC_EXACT_CELLS = 12, /* 1: k_describe forms the cell coordinates of EVERY voxel with the reference's arithmetic (default: only next to a discontinuity) */
-	SIFT3D_HOOK_LAZY_GENERIC = 13,  /* 1: every parked candidate of the lazy last level takes the one-workgroup form (default: interior ones one wave each) */
-	SIFT3D_HOOK_COUNT = 14
-};
-int sift3d_test_hook(int which, int value);
-/* how often the rare paths ran: c[0] list regrows of the last run, c[1] keypoints whose descriptor took the second pass in
- * the last run, c[2] rows the calling thread's last sift3d_match re-scored exactly (near-tie guard), c[3] reserved */
-int sift3d_debug_counters(sift3d_handle h, int c[4]);
-/* Check_intersect_faces + cart2bary (Src/cSIFT3D.cc:1542-1573, 1592-1637) of k_describe on n gradient vectors (host, n*3):
- * face index (-1: none) and the three barycentric weights as the kernel forms them, through both of its routes:
- * route 0 = predicted face verified with the margin (falls back to route 1 when the margin fails), route 1 = the literal
- * ordered 20-face scan.  Unit-level parity against golden g7. */
-/* GB/s (read + write, best of `iters`) of a float4 device-to-device copy of `bytes` bytes on `device`: the measured copy ceiling
- * reported beside the 8 TB/s spec peak */
-int sift3d_debug_copy_bandwidth(size_t bytes, int iters, int device, double *gbs);
-int sift3d_debug_face_lookup(const float *grad3, int n, int route, int *face, float *bary3, int device);
-
+/* Test hooks, rare-path counters and the unit-level debug entry points live in include/sift3d_hip_test.h: this header is the
+ * product boundary only. */
 const char *sift3d_error_string(int code);
 const char *sift3d_last_error(void); /* thread-local detail of the last failure */
 

@@ -22,7 +22,7 @@ print("traffic stamp", d["kernel_source_sha"], "sources", capi.kernel_source_sha
 print("reads %.2f GB writes %.2f GB" % (d["total_read_bytes"] / 1e9, d["total_write_bytes"] / 1e9))
 print("value %.1f Mvoxel/s  %.2f ms/step  stages %s" % (b["value"], b["ms_per_step"], b["stage_ms"]))
 r = b["roofline"]
-print("roofline frac (52 B moved) %.3f  survey (68 B) %.3f  of copy ceiling %.3f (%.0f GB/s)  traffic %s" % (r["frac"], r["frac_survey"], r["frac_of_copy_ceiling"], r["copy_ceiling_GBs"], r["traffic"]))
+print("roofline frac (52 B moved) %.3f  every level built (68 B, timed) %s  of copy ceiling %.3f (%.0f GB/s)  traffic %s" % (r["frac"], r.get("frac_every_level_built"), r["frac_of_copy_ceiling"], r["copy_ceiling_GBs"], r["traffic"]))
 print("descriptor", {k: v for k, v in b.get("descriptor", {}).items()})
 print("nonaligned", b.get("nonaligned"))
 print("ctor_ms", b.get("ctor_ms"), "get_keypoints_ms", b.get("get_keypoints_ms"))

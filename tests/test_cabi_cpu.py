@@ -20,10 +20,13 @@ def capi():
     return m
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "sift3d_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(sift3d_[a-z_0-9]+)\s*\(", src)))
+def header_functions(which=("sift3d_hip.h", "sift3d_hip_test.h")):
+    names = set()
+    for h in which:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(sift3d_[a-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_exports_every_declared_symbol(capi):
@@ -33,6 +36,28 @@ def test_exports_every_declared_symbol(capi):
     for n in names:
         assert hasattr(L, n), f"libsift3d_hip.so does not export {n}"
     assert sorted(capi.SYMBOLS) == names
+    # the product header carries no test hook / debug entry point (they live in include/sift3d_hip_test.h)
+    assert not [n for n in header_functions(("sift3d_hip.h",)) if "_test_" in n or "_debug_" in n]
+
+
+def test_staging_slices_tile_every_chunk(capi):
+    """csrc/staging.hip: the nt copy threads' byte ranges of a pinned chunk must tile it (floor division left the last
+    n % nt bytes of a chunk uncopied whenever n / nt was a multiple of 4096 -- a 195 x 273 x 315 volume's last voxel)."""
+    import ctypes as C
+    L = capi.lib()
+    L.sift3d_test_staging_slice.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    rng = np.random.default_rng(7)
+    chunk = 16 << 20
+    sizes = [195 * 273 * 315 * 4 % chunk, 67076100 % chunk, chunk, 1, 4095, 4096, 4097, 8 * 4096 + 4, 8 * 4096 * 3 + 7] + [int(v) for v in rng.integers(1, chunk, 300)]
+    for n in sizes:
+        for nt in (1, 2, 3, 4, 5, 7, 8):
+            pos = 0
+            for t in range(nt):
+                o, e = C.c_size_t(0), C.c_size_t(0)
+                assert L.sift3d_test_staging_slice(n, nt, t, C.byref(o), C.byref(e)) == 0
+                assert o.value == min(pos, n) and e.value >= o.value, (n, nt, t, o.value, e.value)
+                pos = e.value
+            assert pos == n, (n, nt, pos)
 
 
 def test_struct_layouts(capi):
