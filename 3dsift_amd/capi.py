@@ -30,7 +30,7 @@ assert KP_DTYPE.itemsize == 168
 
 # every symbol include/sift3d_hip.h and include/sift3d_hip_test.h declare (tests check that the library exports all of them)
 SYMBOLS = [
-    "sift3d_default_params", "sift3d_create", "sift3d_destroy", "sift3d_run", "sift3d_run_async", "sift3d_wait", "sift3d_run_stages",
+    "sift3d_default_params", "sift3d_create", "sift3d_destroy", "sift3d_run", "sift3d_run_async", "sift3d_run_async_after", "sift3d_wait", "sift3d_run_stages",
     "sift3d_stage_times", "sift3d_num_keypoints", "sift3d_get_keypoints", "sift3d_device_results",
     "sift3d_num_octaves", "sift3d_level_info", "sift3d_copy_level", "sift3d_copy_input", "sift3d_num_extrema",
     "sift3d_get_extrema", "sift3d_get_orientation_codes", "sift3d_gaussian_smooth", "sift3d_downsample", "sift3d_dog_sub", "sift3d_conv_axis",
@@ -49,6 +49,9 @@ SYMBOLS = [
     "sift3d_slab_set_desc_partial", "sift3d_slab_min_halo_partial", "sift3d_slab_record_bytes", "sift3d_slab_desc_reach", "sift3d_slab_orient",
     "sift3d_slab_export_records", "sift3d_slab_describe_partial", "sift3d_slab_describe_finish", "sift3d_slab_orient_launch",
     "sift3d_slab_orient_count",
+    # r06: the same stages without host read-backs, the tail's seed level in place, the native driver's plan
+    "sift3d_slab_keypoints_launch", "sift3d_slab_keypoints_count", "sift3d_slab_describe_finish_launch", "sift3d_slab_describe_finish_count",
+    "sift3d_seed_buffer", "sift3d_sharded_plan",
     # test hooks / debug accessors / matcher timing
     # native driver of the z-slab sharding
     "sift3d_sharded_create", "sift3d_sharded_create_ex", "sift3d_sharded_run", "sift3d_sharded_num_keypoints", "sift3d_sharded_get_keypoints", "sift3d_sharded_info",
@@ -59,7 +62,8 @@ SYMBOLS = [
 HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "desc_nocache": 4, "match_nodma": 5, "one_stream": 6,
          "desc_mass_shift": 7, "list_cap": 8, "peer_copy": 9, "desc_nosplit": 10, "march_tiles": 11, "desc_exact_cells": 12, "lazy_generic": 13}
 ORIENT_WORDS = 34
-SHARDED_PARTIAL_WINDOWS = 1   # sift3d_sharded_create_ex flag
+SHARDED_PARTIAL_WINDOWS = 1   # sift3d_sharded_create_ex flags
+SHARDED_WHOLE_WINDOWS = 2
 
 
 class Params(C.Structure):
@@ -174,6 +178,7 @@ def lib():
         L.sift3d_sharded_error.argtypes = [C.c_void_p]
         L.sift3d_sharded_error.restype = C.c_char_p
         L.sift3d_sharded_destroy.argtypes = [C.c_void_p]
+        L.sift3d_sharded_plan.argtypes = [C.c_void_p, _ip, _ip, _ip]
         L.sift3d_test_hook.argtypes = [C.c_int, C.c_int]
         L.sift3d_debug_counters.argtypes = [C.c_void_p, _ip]
         L.sift3d_debug_face_lookup.argtypes = [_fp, C.c_int, C.c_int, _ip, _fp, C.c_int]
@@ -292,9 +297,13 @@ class CSIFT3D:
         _check(lib().sift3d_run(self._h))
         return self
 
-    def KpSiftAlgorithmAsync(self):
-        """enqueue the whole pipeline and return (sift3d_run_async); Wait() -- or any accessor -- completes it"""
-        _check(lib().sift3d_run_async(self._h))
+    def KpSiftAlgorithmAsync(self, after=None):
+        """enqueue the whole pipeline and return (sift3d_run_async); Wait() -- or any accessor -- completes it.  after = another extractor
+        with a run in flight on the same GPU: this pipeline starts when that one's orientation stage has ended (sift3d_run_async_after)"""
+        if after is not None:
+            _check(lib().sift3d_run_async_after(self._h, after._h))
+        else:
+            _check(lib().sift3d_run_async(self._h))
         return self
 
     def Wait(self):
@@ -607,14 +616,18 @@ class ShardedCSIFT3D:
     over RCCL, or sim_ranks = n ranks simulated on devices[0].  partial_windows: descriptor windows split along z over the ranks
     (sift3d_sharded_create_ex, SIFT3D_SHARDED_PARTIAL_WINDOWS) instead of whole windows on wide halos."""
 
-    def __init__(self, volume, devices=(0,), sim_ranks=0, sharded_octaves=0, partial_windows=False, **kw):
-        vol = np.ascontiguousarray(volume, dtype=np.float32)
+    def __init__(self, volume, devices=(0,), sim_ranks=0, sharded_octaves=0, partial_windows=None, **kw):
+        """partial_windows: None = the driver's rule (descriptor windows split along z unless a slab is too thin for that), True = split or
+        refuse, False = whole windows on the wide halos"""
+        vol = np.ascontiguousarray(volume, np.float32)
+        assert vol.ndim == 3
         nz, ny, nx = vol.shape
         self._h = C.c_void_p()
         p = _params(kw)
         devs = (C.c_int * len(devices))(*devices)
+        flags = 0 if partial_windows is None else (SHARDED_PARTIAL_WINDOWS if partial_windows else SHARDED_WHOLE_WINDOWS)
         _check(lib().sift3d_sharded_create_ex(C.byref(self._h), vol.ctypes.data_as(C.c_void_p), nx, ny, nz, C.byref(p), devs, len(devices),
-                                              int(sim_ranks), int(sharded_octaves), SHARDED_PARTIAL_WINDOWS if partial_windows else 0))
+                                              int(sim_ranks), int(sharded_octaves), flags))
 
     def KpSiftAlgorithm(self):
         rc = lib().sift3d_sharded_run(self._h)
@@ -633,7 +646,10 @@ class ShardedCSIFT3D:
     def info(self):
         w = C.c_int(0); s = C.c_int(0); h = C.c_int(0); t = (C.c_double * 2)()
         _check(lib().sift3d_sharded_info(self._h, C.byref(w), C.byref(s), C.byref(h), t))
-        return {"world": w.value, "sharded_octaves": s.value, "halo": h.value, "seconds": t[0], "seconds_incl_merge": t[1]}
+        pw = C.c_int(0); tr = C.c_int(0); pl = (C.c_int * max(1, w.value))()
+        _check(lib().sift3d_sharded_plan(self._h, C.byref(pw), C.byref(tr), pl))
+        return {"world": w.value, "sharded_octaves": s.value, "halo": h.value, "seconds": t[0], "seconds_incl_merge": t[1],
+                "partial_windows": bool(pw.value), "tail_rank": tr.value, "planes": [int(v) for v in pl][:w.value]}
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -250,6 +250,7 @@ struct sift3d_ctx {
 	// results / state
 	int stage = 0;  // highest stage run
 	bool pending = false;  // sift3d_run_async enqueued a run that sift3d_wait has not completed yet
+	hipEvent_t gate = nullptr;  // sift3d_run_async_after: the next enqueue starts behind this event (another handle's orientation stage); one shot
 	unsigned n_ext = 0, n_kp = 0;
 	hipEvent_t ev[8] = {};
 	double times[8] = {};
@@ -838,6 +839,7 @@ static int run_enqueue(sift3d_ctx *c, int upto, bool part_orient) {
 		c->dsplit_dirty = false;
 	}
 	{
+		if (c->gate) { S3D_HIP(hipStreamWaitEvent(st, c->gate, 0)); c->gate = nullptr; }
 		S3D_HIP(hipMemsetAsync(c->d_dogmax, 0, sizeof(unsigned) * (size_t)(std::max(1, c->noct * c->nd) + 6), st));
 		S3D_HIP(hipEventRecord(c->ev[0], st));
 		// ---- Build_Gaussian_Scale_Space (Src/cSIFT3D.cc:268-319) with the DoG (346-360) fused into the z pass ----
@@ -1147,6 +1149,18 @@ extern "C" int sift3d_run_async(sift3d_handle c) {
 	return SIFT3D_OK;
 }
 
+// Two volumes back to back on one GPU (Example.cpp:21-44 extracts a reference and a target volume one after the other): the second
+// volume's pipeline starts when the FIRST volume's orientation stage has ended, i.e. its memory-bound front (pyramid, extrema, orientation)
+// runs beside the first volume's descriptor stage, which is bound by instruction issue and the LDS.  `after` must have a run in flight
+// (sift3d_run_async) on the same device; otherwise this is sift3d_run_async.
+extern "C" int sift3d_run_async_after(sift3d_handle c, sift3d_handle after) {
+	if (!c) return SIFT3D_ERR_ARG;
+	if (after && after != c && after->pending && after->device == c->device) c->gate = after->ev[4];
+	const int rc = sift3d_run_async(c);
+	c->gate = nullptr;
+	return rc;
+}
+
 extern "C" int sift3d_wait(sift3d_handle c) {
 	if (!c) return SIFT3D_ERR_ARG;
 	if (!c->pending) return SIFT3D_OK;  // nothing in flight (a blocking run has completed already)
@@ -1184,9 +1198,11 @@ extern "C" int sift3d_get_keypoints(sift3d_handle c, sift3d_keypoint *out, float
 	if (rc) return rc;
 	if (desc && c->stage < 5) return SIFT3D_ERR_STATE;
 	// results were complete when the run returned; the copies go through the pinned staging pool on the handle's own stream
-	if (out && (rc = staged_d2h(out, c->d_kpout, sizeof(sift3d_keypoint) * (size_t)c->n_kp, c->device, c->own_stream))) return rc;
-	if (desc && (rc = staged_d2h(desc, c->d_desc, sizeof(float) * kDesc * (size_t)c->n_kp, c->device, c->own_stream))) return rc;
-	return SIFT3D_OK;
+	D2HSeg sg[2];
+	int ns = 0;
+	if (out) sg[ns++] = D2HSeg{out, c->d_kpout, sizeof(sift3d_keypoint) * (size_t)c->n_kp};
+	if (desc) sg[ns++] = D2HSeg{desc, c->d_desc, sizeof(float) * kDesc * (size_t)c->n_kp};
+	return staged_d2h_v(sg, ns, c->device, c->own_stream);
 }
 
 extern "C" int sift3d_device_results(sift3d_handle c, const float **d_desc, const float **d_xyz, int *n) {
@@ -2274,6 +2290,113 @@ extern "C" int sift3d_slab_orient_count(sift3d_handle c, int *n_kp) {
 	if (rc) return rc;
 	c->stage = 4;
 	*n_kp = (int)c->n_kp;
+	return SIFT3D_OK;
+}
+
+// ---- r06: the same stages without a host read-back between them.  A driver enqueues detection + orientation of every sharded octave (and of
+// every simulated rank), then asks for the counts; the GPU works on the later launches while the host learns the earlier counts.  Rare events
+// (a list that overflowed, a record whose fixed-point unit failed) are found when the counts are read and take the blocking forms above.
+static int slab_keypoints_enqueue(sift3d_ctx *c) {
+	hipStream_t st = c->stream;
+	S3D_HIP(hipMemsetAsync(c->d_total, 0, sizeof(unsigned) * 3, st));
+	DetectLevels DL;
+	memset(&DL, 0, sizeof(DL));
+	const int nl = c->nd - 2;
+	for (int i = 1; i <= nl; i++) {
+		DL.cur[i - 1] = c->dog[i].d; DL.prev[i - 1] = c->dog[i - 1].d; DL.next[i - 1] = c->dog[i + 1].d;
+		DL.absmax_bits[i - 1] = c->d_dogmax + i;
+		DL.level_id[i - 1] = i;
+		DL.scale[i - 1] = c->dog[i].scale;
+	}
+	if (c->dog_elide) {
+		DL.prev0_hi = c->gss[1].d; DL.prev0_lo = c->gss[0].d;
+		DL.nextl_hi = c->gss[c->nd].d; DL.nextl_lo = c->gss[c->nd - 1].d;
+		DL.nextl_slot = nl - 1;
+		if (c->g_last_elide) { DL.nextl_hi = nullptr; DL.lazy_src = DL.nextl_lo; }
+	}
+	const Level &C = c->dog[1];
+	launch_detect_octave(DL, nl, C.nx, C.ny, C.zr(c->own0 - C.zoff, c->own1 - C.zoff), c->p.peak_thresh, c->octave_base, c->det,
+	                     c->d_ext, c->ext_cap, st, c->g_last_elide ? &c->taps[c->ng - 1] : nullptr);
+	launch_orient(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_levels, c->d_luts, c->d_lutpool, c->p.max_eig_thres,
+	              c->p.corner_thresh, 0, 1, c->d_order, c->d_nkp + 3, st);
+	launch_slots(c->d_ext, c->d_codes, c->d_total, c->ext_cap, c->d_nkp, c->d_order, c->kp_cap, c->d_slots_part, st);
+	S3D_HIP(hipMemcpyAsync(c->h_words, c->d_total, sizeof(unsigned) * 3, hipMemcpyDeviceToHost, st));
+	S3D_HIP(hipEventRecord(c->ev[6], st));
+	return SIFT3D_OK;
+}
+
+// Detect_KeyPoints + Assign_Orientation (Src/cSIFT3D.cc:362-482) of the slab's owned planes, enqueued; the counts travel to pinned memory behind them
+extern "C" int sift3d_slab_keypoints_launch(sift3d_handle c) {
+	if (!c || !c->slab) return SIFT3D_ERR_ARG;
+	if (c->stage < 1) return SIFT3D_ERR_STATE;
+	if (c->halo < slab_window_halo(c, false)) { set_last_error("the level buffers' halo is smaller than the orientation windows' reach"); return SIFT3D_ERR_STATE; }
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	return slab_keypoints_enqueue(c);
+}
+
+// waits for the counts of sift3d_slab_keypoints_launch; a list that overflowed is regrown and the two stages run again (blocking: rare)
+extern "C" int sift3d_slab_keypoints_count(sift3d_handle c, int *n_kp) {
+	if (!c || !c->slab || !n_kp) return SIFT3D_ERR_ARG;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	for (int attempt = 0; attempt < 4; attempt++) {
+		S3D_HIP(hipEventSynchronize(c->ev[6]));
+		S3D_HIP(hipGetLastError());
+		const unsigned n_ext = c->h_words[0], over = c->h_words[1], n_acc = c->h_words[2];
+		if (over == 0 && n_ext <= c->ext_cap) {
+			c->n_ext = n_ext; c->n_kp = n_acc; c->stage = 4;
+			*n_kp = (int)n_acc;
+			return SIFT3D_OK;
+		}
+		S3D_HIP(hipStreamSynchronize(c->stream));  // (nothing of this handle may still use the lists that are about to be replaced)
+		if ((rc = alloc_lists(c, std::max(n_ext, c->ext_cap) * 2u)) != SIFT3D_OK) return rc;
+		c->n_regrow++;
+		if ((rc = slab_keypoints_enqueue(c)) != SIFT3D_OK) return rc;
+	}
+	set_last_error("extrema list kept overflowing");
+	return SIFT3D_ERR_CAPACITY;
+}
+
+// sift3d_slab_describe_finish of the FIRST round without its read-back: the finish, the final records and the count of flagged records
+// (to pinned memory) are enqueued; sift3d_slab_describe_finish_count waits for that count.  Nothing flagged (the rule): the results are complete.
+extern "C" int sift3d_slab_describe_finish_launch(sift3d_handle c, const void *d_records, int n, int nparts, const int *const *d_hist,
+                                                  const float *const *d_mass, int *d_redo, float *d_units_next) {
+	if (!c || !c->slab || n < 0 || nparts < 0 || nparts > kDescSegs || (n > 0 && (!d_records || !d_hist || !d_mass || nparts < 1 || !d_redo || !d_units_next)))
+		return SIFT3D_ERR_ARG;
+	if (c->stage < 4) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	hipStream_t st = c->stream;
+	unsigned *counter = c->d_nkp + 4;
+	S3D_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), st));
+	launch_describe_finish(static_cast<const DevKp *>(d_records), (unsigned)n, c->d_levels, c->d_luts, nparts, d_hist, d_mass, nullptr, false, c->d_desc,
+	                       d_redo, d_units_next, counter, st);
+	launch_finalize(c->d_ext, c->d_total, c->ext_cap, 1, c->d_kpout, c->d_xyz, c->kp_cap, st);
+	S3D_HIP(hipMemcpyAsync(c->h_words + 5, counter, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+	S3D_HIP(hipEventRecord(c->ev[7], st));
+	c->n_desc_redo = 0;
+	return SIFT3D_OK;
+}
+extern "C" int sift3d_slab_describe_finish_count(sift3d_handle c, int *n_redo) {
+	if (!c || !c->slab || !n_redo) return SIFT3D_ERR_ARG;
+	if (c->stage < 4) return SIFT3D_ERR_STATE;
+	int rc = set_device(c->device);
+	if (rc) return rc;
+	S3D_HIP(hipEventSynchronize(c->ev[7]));
+	S3D_HIP(hipGetLastError());
+	*n_redo = (int)c->h_words[5];
+	if (c->h_words[5] == 0) c->stage = 5;
+	return SIFT3D_OK;
+}
+
+// level 0 of a seeded context's first octave in device memory (nx * ny * nz floats): a driver that gathers the seed level writes it in
+// place, on the stream it gave the handle (sift3d_set_stream), and follows with sift3d_run_async -- no staging copy, no host synchronisation
+extern "C" int sift3d_seed_buffer(sift3d_handle c, float **d_level0, size_t *floats) {
+	if (!c || !c->seeded || c->slab || !d_level0) return SIFT3D_ERR_ARG;
+	if (c->noct <= 0) { *d_level0 = nullptr; if (floats) *floats = 0; return SIFT3D_OK; }
+	*d_level0 = c->gss[0].d;
+	if (floats) *floats = c->gss[0].n();
 	return SIFT3D_OK;
 }
 

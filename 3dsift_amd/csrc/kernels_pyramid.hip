@@ -8,6 +8,8 @@
 //   * interior term = src[p-d]; boundary term = (1-frac)*src[lo] + frac*src[hi] with the mirror /
 //     "2*dim_end - c - 0.1f" coordinate rule of Src/cSIFT3D.cc:722-788 evaluated in fp32
 //   * DoG = (cur - prev) * (-1)  (Src/cSIFT3D.cc:875)
+#include <algorithm>
+
 #include "sift3d_internal.h"
 
 namespace s3d {
@@ -56,6 +58,43 @@ __global__ void __launch_bounds__(256) k_copy16(const float4 *__restrict__ src, 
 void launch_copy16(const float *src, float *dst, size_t nfloats, hipStream_t st) {
 	const size_t n4 = nfloats / 4;
 	hipLaunchKernelGGL(k_copy16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst), n4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The simulated transport of the z-slab driver (csrc/sharded.hip, all ranks on one GPU): the "sends" of one exchange step -- up to
+// kCopySegs plane ranges -- as ONE launch instead of one hipMemcpyAsync each (a level of eight simulated ranks posted 42 copies of a few
+// planes: ~500 copy launches per step on the one stream the ranks share), and the MAX "all-reduce" of the DoG maxima on the device.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_copy_segments(CopySegs a) {
+	const int sg = blockIdx.y;
+	if (sg >= a.n) return;
+	const float *__restrict__ src = a.src[sg];
+	float *__restrict__ dst = a.dst[sg];
+	const size_t nf = a.floats[sg];
+	// (plane ranges of one level: both ends share the alignment of plane * nx * ny floats; a 16-byte body where both are aligned)
+	const bool al = ((((size_t)src) | ((size_t)dst)) & 15) == 0;
+	const size_t n4 = al ? nf / 4 : 0;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+		reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i];
+	for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void launch_copy_segments(const CopySegs &a, hipStream_t st) {
+	if (a.n <= 0) return;
+	size_t mx = 0;
+	for (int i = 0; i < a.n; i++) mx = std::max(mx, a.floats[i]);
+	if (mx == 0) return;
+	const unsigned gx = (unsigned)std::min<size_t>(std::max<size_t>(1, (mx / 4 + 255) / 256), 256);
+	hipLaunchKernelGGL(k_copy_segments, dim3(gx, (unsigned)a.n), dim3(256), 0, st, a);
+}
+__global__ void __launch_bounds__(64) k_max_merge(MaxMerge a) {
+	const int i = threadIdx.x;
+	if (i >= a.n) return;
+	float m = 0.0f;
+	for (int r = 0; r < a.np; r++) m = fmaxf(m, a.p[r][i]);
+	for (int r = 0; r < a.np; r++) a.p[r][i] = m;
+}
+void launch_max_merge(const MaxMerge &a, hipStream_t st) {
+	if (a.np > 0 && a.n > 0) hipLaunchKernelGGL(k_max_merge, dim3(1), dim3(64), 0, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -10,24 +10,29 @@
 //                       G[1..3]           : up to `halo` planes (orientation / descriptor windows)   deferred: own stream + communicator
 //                       DoG[1..3]         : 1 plane (the extremum test reads z +- 1)                  deferred
 //                     The normalisation maximum and the DoG maxima are all-reduced (MAX); x / y blurs need no communication.
-//   windows (r05,     sift3d_sharded_create_ex(..., SIFT3D_SHARDED_PARTIAL_WINDOWS)): the descriptor windows are split along z over the ranks --
-//   opt-in)           records to the z-neighbours, every rank marches its part, 768 int32 + the mass back, the owner finishes (3dsift_amd/slab.py does
-//                     the same and is where the protocol is tested over gloo): the halos of G[1..3] shrink from 24 / 30 / 38 planes to 8 / 10 / 12.
-//   tail              level 0 of the first replicated octave is all-gathered (1 / 8^S of a level); the remaining octaves run
-//                     replicated in a seeded context per rank; their orientation work is dealt by extremum index (an integer
-//                     all-reduce(SUM) of zero-padded rows restores it exactly), their descriptor work by keypoint.
-//
+//   windows           the descriptor windows are split along z over the ranks (r05; the default since r06): records to the z-neighbours, every
+//                     rank marches its part, 768 int32 + the mass back, the owner finishes (3dsift_amd/slab.py does the same and is where the
+//                     protocol is tested over gloo): the halos of G[1..3] are 8 / 10 / 12 planes instead of 24 / 30 / 38.  Whole windows on the
+//                     wide halos remain for slabs so thin that a window would span more than six ranks (and behind SIFT3D_SHARDED_WHOLE_WINDOWS).
+//   tail              (r06) the remaining octaves run ONCE, on the last rank: every rank sends its planes of their seed level (1 / 8^S of a
+//                     level) to that rank, which runs them as an ordinary seeded extractor on streams of its own beside its slab; that rank
+//                     owns fewer planes of the sharded octaves in exchange (slab_bounds).  r05 ran the tail on every rank (all-gather, orientation
+//                     and descriptors dealt and all-reduced): eight times the pyramid and the extrema of the tail for an eighth of its descriptors.
+//   no read-backs     (r06) detection and orientation of every sharded octave are enqueued before the first count is read; the first round's
+//                     finish leaves its count of flagged records in pinned memory and is only looked at when everything else is enqueued.
 // Transport:
 //   RCCL   one host thread per GPU, three communicators per rank (urgent / deferred / tail: operations of one communicator must be
-//          issued in the same order on every rank, and the three flows run concurrently), point-to-point ncclSend / ncclRecv between
+//          issued in the same order on every rank, and the three flows run concurrently; the tail's carries the gather of the seed level
+//          alone), point-to-point ncclSend / ncclRecv between
 //          z-neighbours over xGMI inside ncclGroupStart / End, on the rank's own streams: no host synchronisation between the
 //          levels.  librccl is opened at run time (dlopen), so the library loads on hosts without it.
 //          Failure protocol (r04): the first rank (or tail thread) whose step fails aborts EVERY communicator of the handle
 //          (ncclCommAbort), so that z-neighbours blocked in a receive / reduction kernel return instead of wedging the process; the
 //          handle is then dead -- sift3d_sharded_run returns an error from now on, the caller destroys it and, if it wants to go on,
 //          starts a fresh process (nothing is restarted in place).
-//   SIM    all ranks in this process on ONE GPU and one stream: sends are device copies, reductions go through the host.  This is
-//          how the 1-GPU test boxes check the driver (same code, same plan) against the single-volume result.
+//   SIM    all ranks in this process on ONE GPU and one stream: the sends of an exchange step are one copy launch (kernels_pyramid.hip
+//          k_copy_segments), the MAX reduction a device kernel.  This is how the 1-GPU test boxes check the driver (same code, same
+//          plan) against the single-volume result, and how the work of eight ranks is added up on one GPU (bench.py --sim-ranks).
 //
 // 3dsift_amd/slab.py drives the same C-ABI slab contexts from python over torch.distributed; this file is what the C++ user gets:
 // CSIFT3DFactory::CreateCSIFT3D with SIFT3D_DEVICES=0,1,...,7 (3dsift_amd/host/src/cSIFT3D.cpp).
@@ -63,17 +68,33 @@ int octaves_total(int nx, int ny, int nz) {  // Src/cSIFT3D.cc:254-255
 	return std::max(0, (int)log2f((float)mn) - 2);
 }
 
-// owned plane ranges per rank: contiguous, starts on multiples of `align`, as equal as possible, remainder to the last rank
-bool slab_bounds(int nz, int world, int align, Bounds &out) {
+// owned plane ranges per rank: contiguous, starts on multiples of `align`, as equal as possible, remainder to the last rank.
+// tail_planes (r06): the last rank also runs the replicated tail, which costs about as much as that many planes of the first sharded
+// octave: it owns that many planes fewer than the others (never less than half an even share)
+bool slab_bounds(int nz, int world, int align, Bounds &out, int tail_planes = 0) {
 	const int units = nz / align;
 	if (units < world) return false;
-	const int base = units / world, rem = units % world;
+	std::vector<int> n((size_t)world, 0);
+	const int tu = world > 1 ? std::max(0, tail_planes / align) : 0;
+	if (tu == 0) {  // the even deal: remainders to the first ranks
+		const int base = units / world, rem = units % world;
+		for (int r = 0; r < world; r++) n[(size_t)r] = base + (r < rem ? 1 : 0);
+	} else {
+		// every rank carries (units + tu) / world units of work, the last rank tu of them as the tail: it owns that many units fewer (at
+		// least half an even share, at least one unit); the others deal the rest evenly
+		const double target = (double)(units + tu) / (double)world;
+		int last = (int)lround(target - (double)tu);
+		last = std::max(last, std::max(1, units / world / 2));
+		last = std::min(last, units / world);
+		const int rest = units - last, base = rest / (world - 1), rem = rest % (world - 1);
+		for (int r = 0; r < world - 1; r++) n[(size_t)r] = base + (r < rem ? 1 : 0);
+		n[(size_t)world - 1] = last;
+	}
 	out.clear();
 	int z = 0;
 	for (int r = 0; r < world; r++) {
-		const int n = align * (base + (r < rem ? 1 : 0));
-		out.push_back({z, z + n});
-		z += n;
+		out.push_back({z, z + align * n[(size_t)r]});
+		z += align * n[(size_t)r];
 	}
 	out.back().second = nz;
 	return true;
@@ -166,22 +187,20 @@ struct Stage {  // one sharded octave of one rank
 	}
 };
 
-struct Worker {  // the sharded octaves + the seeded, replicated tail context of one rank
+struct Worker {  // the sharded octaves of one rank (+ the tail's extractor on the last rank)
 	int rank = 0, device = 0;
 	hipStream_t stream = nullptr, dstream = nullptr;  // the rank's stream; the stream of its deferred halos (RCCL)
+	hipStream_t tstream = nullptr;                    // tail rank: the stream of the tail's extractor (the seed level is gathered on it)
 	bool own_stream = false;
 	hipEvent_t ev_level = nullptr, ev_def = nullptr, ev_seed = nullptr;
 	std::vector<Stage> stages;
 	std::vector<float *> dogmax;  // per stage: 8 floats (device)
-	sift3d_handle tail = nullptr;
-	float *seed = nullptr, *seed_mine = nullptr;
+	sift3d_handle tail = nullptr; // tail rank only: the seeded extractor of the octaves >= S
+	float *seed_dst = nullptr;    // tail rank: level 0 of the tail's first octave (inside the tail's arena)
+	float *seed_mine = nullptr;   // this rank's planes of that level (other ranks: a buffer of their own; tail rank: a pointer into seed_dst)
+	bool seed_mine_owned = false;
 	ncclComm_t c_urgent = nullptr, c_deferred = nullptr, c_tail = nullptr;
-	char *pscratch = nullptr; size_t pscratch_bytes = 0;  // partial descriptor windows: records / histograms / masses of a stage (grow-only, device)
-	std::vector<sift3d_keypoint> kp;      // results of this rank's sharded octaves, reference order per stage
-	std::vector<float> desc;
-	std::vector<int> kp_stage_end;        // prefix ends per stage in kp
-	std::vector<sift3d_keypoint> tkp;     // tail records (complete on every rank)
-	std::vector<float> tdesc;             // tail descriptors: only this rank's rows are filled
+	std::vector<char *> pscratch; std::vector<size_t> pscratch_bytes;  // partial descriptor windows: records / histograms / masses, per stage (grow-only, device)
 	std::string err;
 };
 
@@ -196,15 +215,11 @@ struct sift3d_sharded {
 	std::vector<int> need, hws;
 	std::vector<int> counts2;   // planes of the tail's seed level owned per rank
 	int sx = 0, sy = 0, sz = 0; // dims of the tail's seed level
+	int tail_rank = -1;         // the rank that runs the octaves >= S (-1: none)
 	bool ran = false;
-	std::vector<sift3d_keypoint> kp;
-	std::vector<float> desc;
 	double times[4] = {0, 0, 0, 0};
 	std::string err;
-	// failure protocol of the RCCL transport: `failed` is set once, by the first rank whose step failed, which then aborts every
-	// communicator.  Ranks hold comm_mu shared while they ISSUE RCCL calls (short, host side) and the aborter takes it exclusively,
-	// so that no thread is inside a call on a communicator while it is torn down.
-	// r05, partial descriptor windows (opt-in): accepted keypoints / flagged records per sharded octave and rank, written by the rank
+	// descriptor windows split along z (the default): accepted keypoints / flagged records per sharded octave and rank, written by the rank
 	// threads and read by all of them behind a rendezvous
 	bool partial = false;
 	std::vector<std::vector<int>> kp_count, redo_count;
@@ -212,6 +227,9 @@ struct sift3d_sharded {
 	std::condition_variable rv_cv;
 	int rv_arrived = 0;
 	unsigned rv_gen = 0;
+	// failure protocol of the RCCL transport: `failed` is set once, by the first rank whose step failed, which then aborts every
+	// communicator.  Ranks hold comm_mu shared while they ISSUE RCCL calls (short, host side) and the aborter takes it exclusively,
+	// so that no thread is inside a call on a communicator while it is torn down.
 	std::atomic<bool> failed{false};
 	std::atomic<bool> comms_aborted{false};  // abort_all ran: the communicators are gone (their pointers are left alone)
 	std::shared_timed_mutex comm_mu;
@@ -252,12 +270,16 @@ int exchange(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<Tra
 	if (ts.empty()) return SIFT3D_OK;
 	if (H->sim) {
 		Worker &w0 = *ws[0];
+		CopySegs cs;
 		for (const Transfer &t : ts) {
 			Stage &s = H->workers[(size_t)t.src].stages[(size_t)t.stage], &d = H->workers[(size_t)t.dst].stages[(size_t)t.stage];
 			float *sp = s.view(t.kind, t.idx, t.zg0, t.zg1), *dp = d.view(t.kind, t.idx, t.zg0, t.zg1);
 			if (!sp || !dp) { set_err(w0, "halo transfer outside a level buffer"); return SIFT3D_ERR_STATE; }
-			SH_HIP(w0, hipMemcpyAsync(dp, sp, sizeof(float) * s.plane * (size_t)(t.zg1 - t.zg0), hipMemcpyDeviceToDevice, w0.stream));
+			cs.src[cs.n] = sp; cs.dst[cs.n] = dp; cs.floats[cs.n] = s.plane * (size_t)(t.zg1 - t.zg0); cs.n++;
+			if (cs.n == kCopySegs) { launch_copy_segments(cs, w0.stream); cs.n = 0; }
 		}
+		launch_copy_segments(cs, w0.stream);
+		SH_HIP(w0, hipGetLastError());
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
@@ -286,6 +308,14 @@ int exchange(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<Tra
 int allreduce_max_dev(sift3d_sharded *H, std::vector<Worker *> &ws, int stage, int n) {
 	if (H->sim) {
 		Worker &w0 = *ws[0];
+		if ((int)ws.size() <= kMaxMergePtrs && n <= 64) {  // on the device, in the shared stream's order (no host round trip)
+			MaxMerge mm;
+			for (Worker *w : ws) mm.p[mm.np++] = w->dogmax[(size_t)stage];
+			mm.n = n;
+			launch_max_merge(mm, w0.stream);
+			SH_HIP(w0, hipGetLastError());
+			return SIFT3D_OK;
+		}
 		std::vector<float> m((size_t)n, 0.f), t((size_t)n);
 		SH_HIP(w0, hipStreamSynchronize(w0.stream));
 		for (Worker *w : ws) {
@@ -302,31 +332,50 @@ int allreduce_max_dev(sift3d_sharded *H, std::vector<Worker *> &ws, int stage, i
 	return SIFT3D_OK;
 }
 
-// every worker's seed level = the owned planes of all ranks, in rank order (uneven counts: one broadcast per rank in a group)
-int allgather_seed(sift3d_sharded *H, std::vector<Worker *> &ws) {
+// The tail's seed level = the owned planes of all ranks, in rank order, gathered ON THE TAIL RANK straight into level 0 of its seeded
+// extractor, on that extractor's stream; then the tail's whole KpSiftAlgorithm is enqueued behind it (sift3d_run_async: the tail's own
+// streams, beside the rank's slab work; sift3d_wait at the end of the run).  The tail rank's own planes were decimated in place.
+int gather_seed_and_start_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	const size_t pl = (size_t)H->sx * H->sy;
+	std::vector<size_t> off((size_t)H->world + 1, 0);
+	for (int r = 0; r < H->world; r++) off[(size_t)r + 1] = off[(size_t)r] + pl * (size_t)H->counts2[(size_t)r];
+	Worker *tw = nullptr;
+	for (Worker *w : ws) if (w->rank == H->tail_rank) tw = w;
 	if (H->sim) {
 		Worker &w0 = *ws[0];
-		size_t off = 0;
-		for (int r = 0; r < H->world; r++) {
-			const size_t cnt = pl * (size_t)H->counts2[(size_t)r];
-			for (Worker *w : ws)
-				if (cnt) SH_HIP(w0, hipMemcpyAsync(w->seed + off, H->workers[(size_t)r].seed_mine, sizeof(float) * cnt, hipMemcpyDeviceToDevice, w0.stream));
-			off += cnt;
+		if (!tw) { set_err(w0, "no tail rank among the simulated ranks"); return SIFT3D_ERR_STATE; }
+		CopySegs cs;
+		for (Worker *w : ws) {
+			const size_t cnt = off[(size_t)w->rank + 1] - off[(size_t)w->rank];
+			if (w == tw || !cnt) continue;
+			cs.src[cs.n] = w->seed_mine; cs.dst[cs.n] = tw->seed_dst + off[(size_t)w->rank]; cs.floats[cs.n] = cnt; cs.n++;
+			if (cs.n == kCopySegs) { launch_copy_segments(cs, w0.stream); cs.n = 0; }
 		}
+		launch_copy_segments(cs, w0.stream);
+		SH_HIP(w0, hipEventRecord(tw->ev_seed, w0.stream));
+		SH_HIP(w0, hipStreamWaitEvent(tw->tstream, tw->ev_seed, 0));
+		SH_ABI(*tw, sift3d_run_async(tw->tail));
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
-	std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
-	SH_LIVE(H, w);
-	SH_NCCL(w, g_rccl.GroupStart());
-	size_t off = 0;
-	for (int r = 0; r < H->world; r++) {
-		const size_t cnt = pl * (size_t)H->counts2[(size_t)r];
-		if (cnt) SH_NCCL(w, g_rccl.Broadcast(w.seed_mine, w.seed + off, cnt, ncclFloat, r, w.c_urgent, w.stream));
-		off += cnt;
+	{
+		std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
+		SH_LIVE(H, w);
+		if (&w != tw) {
+			const size_t cnt = off[(size_t)w.rank + 1] - off[(size_t)w.rank];
+			if (cnt) SH_NCCL(w, g_rccl.Send(w.seed_mine, cnt, ncclFloat, H->tail_rank, w.c_tail, w.stream));  // behind the decimation on the rank's stream
+			return SIFT3D_OK;
+		}
+		SH_NCCL(w, g_rccl.GroupStart());
+		for (int r = 0; r < H->world; r++) {
+			const size_t cnt = off[(size_t)r + 1] - off[(size_t)r];
+			if (r != w.rank && cnt) SH_NCCL(w, g_rccl.Recv(w.seed_dst + off[(size_t)r], cnt, ncclFloat, r, w.c_tail, w.tstream));
+		}
+		SH_NCCL(w, g_rccl.GroupEnd());
 	}
-	SH_NCCL(w, g_rccl.GroupEnd());
+	SH_HIP(w, hipEventRecord(w.ev_seed, w.stream));            // the tail rank's own planes (decimated in place on its stream)
+	SH_HIP(w, hipStreamWaitEvent(w.tstream, w.ev_seed, 0));
+	SH_ABI(w, sift3d_run_async(w.tail));
 	return SIFT3D_OK;
 }
 
@@ -357,7 +406,15 @@ int exchange_raw(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector
 	if (ts.empty()) return SIFT3D_OK;
 	if (H->sim) {
 		Worker &w0 = *ws[0];
-		for (const RawXfer &t : ts) SH_HIP(w0, hipMemcpyAsync(t.dp, t.sp, t.bytes, hipMemcpyDeviceToDevice, w0.stream));
+		CopySegs cs;
+		for (const RawXfer &t : ts) {
+			if (!t.bytes) continue;
+			if (t.bytes & 3) { SH_HIP(w0, hipMemcpyAsync(t.dp, t.sp, t.bytes, hipMemcpyDeviceToDevice, w0.stream)); continue; }  // (never: records, histograms and masses are words)
+			cs.src[cs.n] = static_cast<const float *>(t.sp); cs.dst[cs.n] = static_cast<float *>(t.dp); cs.floats[cs.n] = t.bytes / 4; cs.n++;
+			if (cs.n == kCopySegs) { launch_copy_segments(cs, w0.stream); cs.n = 0; }
+		}
+		launch_copy_segments(cs, w0.stream);
+		SH_HIP(w0, hipGetLastError());
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
@@ -385,7 +442,7 @@ struct PartLayout {
 	std::map<int, float *> got_m;
 };
 
-int lay_out(Worker &w, const std::vector<int> &counts, const std::vector<int> &nb, size_t rb, PartLayout &L) {
+int lay_out(Worker &w, int s, const std::vector<int> &counts, const std::vector<int> &nb, size_t rb, PartLayout &L) {
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
 	const size_t me = (size_t)counts[(size_t)w.rank];
 	size_t need = al(me * rb) + 3 * al(me * 4) + al(me * 768 * 4) + al(me * 4);
@@ -395,15 +452,17 @@ int lay_out(Worker &w, const std::vector<int> &counts, const std::vector<int> &n
 		need += al(me * 768 * 4) + al(me * 4);                        // r's part of this rank's records
 	}
 	need = std::max<size_t>(need, 256);
-	if (need > w.pscratch_bytes) {
+	if (w.pscratch.size() <= (size_t)s) { w.pscratch.resize((size_t)s + 1, nullptr); w.pscratch_bytes.resize((size_t)s + 1, 0); }
+	if (need > w.pscratch_bytes[(size_t)s]) {
+		// (a stage's scratch is only in use between the enqueue of its windows and the end of the run; the run before has drained)
 		SH_HIP(w, hipStreamSynchronize(w.stream));
-		if (w.pscratch) SH_HIP(w, hipFree(w.pscratch));
-		w.pscratch = nullptr; w.pscratch_bytes = 0;
+		if (w.pscratch[(size_t)s]) SH_HIP(w, hipFree(w.pscratch[(size_t)s]));
+		w.pscratch[(size_t)s] = nullptr; w.pscratch_bytes[(size_t)s] = 0;
 		const size_t cap = need + need / 4;
-		SH_HIP(w, hipMalloc(reinterpret_cast<void **>(&w.pscratch), cap));
-		w.pscratch_bytes = cap;
+		SH_HIP(w, hipMalloc(reinterpret_cast<void **>(&w.pscratch[(size_t)s]), cap));
+		w.pscratch_bytes[(size_t)s] = cap;
 	}
-	char *p = w.pscratch;
+	char *p = w.pscratch[(size_t)s];
 	auto take = [&](size_t b) { char *q = p; p += al(b); return q; };
 	L = PartLayout();
 	L.recs = take(me * rb);
@@ -426,6 +485,8 @@ int lay_out(Worker &w, const std::vector<int> &counts, const std::vector<int> &n
 
 // one round: records (round 2: + units) to the neighbours, every rank's part in one launch, the parts back, the owner's finish.
 // counts[r]: records of rank r in this round (known to every rank); L[i] belongs to ws[i] and already holds its records (and units).
+// first round: the finish is only enqueued (sift3d_slab_describe_finish_launch; its count of flagged records is read when the whole step has been
+// enqueued); second round: the blocking finish of the flagged subset.
 int partial_round(sift3d_sharded *H, std::vector<Worker *> &ws, int s, const std::vector<std::vector<int>> &neigh, const std::vector<int> &counts,
                   std::vector<PartLayout> &L, size_t rb, bool second, std::vector<int> &n_redo) {
 	std::map<int, size_t> local;
@@ -482,46 +543,53 @@ int partial_round(sift3d_sharded *H, std::vector<Worker *> &ws, int s, const std
 		if (n) for (int q : from) { hh.push_back(q == r ? L[i].part_h[r] : L[i].got_h[q]); mm.push_back(q == r ? L[i].part_m[r] : L[i].got_m[q]); }
 		SH_HIP(w, hipSetDevice(w.device));
 		int nr = 0;
-		SH_ABI(w, sift3d_slab_describe_finish(w.stages[(size_t)s].ctx, n ? L[i].recs : nullptr, n, (int)hh.size(), hh.data(), mm.data(), second && n ? L[i].units : nullptr,
-		                                      second ? 1 : 0, n ? L[i].redo : nullptr, n ? L[i].units_next : nullptr, &nr));
+		if (second)
+			SH_ABI(w, sift3d_slab_describe_finish(w.stages[(size_t)s].ctx, n ? L[i].recs : nullptr, n, (int)hh.size(), hh.data(), mm.data(), n ? L[i].units : nullptr,
+			                                      1, n ? L[i].redo : nullptr, n ? L[i].units_next : nullptr, &nr));
+		else
+			SH_ABI(w, sift3d_slab_describe_finish_launch(w.stages[(size_t)s].ctx, n ? L[i].recs : nullptr, n, (int)hh.size(), hh.data(), mm.data(), n ? L[i].redo : nullptr,
+			                                             n ? L[i].units_next : nullptr));
 		n_redo[i] = nr;
 	}
 	return SIFT3D_OK;
 }
 
-// orientation of the owned extrema, then the descriptors of sharded octave s from partial integer histograms
-int describe_partial_stage(sift3d_sharded *H, std::vector<Worker *> &ws, int s) {
+// the descriptors of sharded octave s from partial integer histograms, first round, ENQUEUED (the keypoint counts of every rank are known:
+// H->kp_count[s]); the state the rare second round needs stays in PS
+struct PartStage {
+	std::vector<std::vector<int>> neigh;
+	std::vector<int> counts;
+	std::vector<PartLayout> L;
+	size_t rb = 0;
+};
+int partial_stage_enqueue(sift3d_sharded *H, std::vector<Worker *> &ws, int s, PartStage &PS) {
 	Worker &w0 = *ws[0];
 	int rbi = 0, reach = 0;
 	SH_ABI(w0, sift3d_slab_record_bytes(&rbi));
-	const size_t rb = (size_t)rbi;
-	for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_ABI(*w, sift3d_slab_orient_launch(w->stages[(size_t)s].ctx)); }
-	for (Worker *w : ws) {
-		int n = 0;
-		SH_HIP(*w, hipSetDevice(w->device));
-		SH_ABI(*w, sift3d_slab_orient_count(w->stages[(size_t)s].ctx, &n));
-		H->kp_count[(size_t)s][(size_t)w->rank] = n;
-	}
-	int rc = rendezvous(H, w0);
-	if (rc) return rc;
-	const std::vector<int> counts = H->kp_count[(size_t)s];
+	PS.rb = (size_t)rbi;
+	PS.counts = H->kp_count[(size_t)s];
 	SH_ABI(w0, sift3d_slab_desc_reach(w0.stages[(size_t)s].ctx, &reach));
-	const std::vector<std::vector<int>> neigh = window_neighbours(w0.stages[(size_t)s].bounds, reach);
-	std::vector<PartLayout> L(ws.size());
+	PS.neigh = window_neighbours(w0.stages[(size_t)s].bounds, reach);
+	PS.L.assign(ws.size(), PartLayout());
 	std::vector<int> n_redo(ws.size(), 0);
+	int rc;
 	for (size_t i = 0; i < ws.size(); i++) {
 		Worker &w = *ws[i];
 		SH_HIP(w, hipSetDevice(w.device));
-		if ((rc = lay_out(w, counts, neigh[(size_t)w.rank], rb, L[i])) != SIFT3D_OK) return rc;
-		if (counts[(size_t)w.rank]) SH_ABI(w, sift3d_slab_export_records(w.stages[(size_t)s].ctx, L[i].recs));
+		if ((rc = lay_out(w, s, PS.counts, PS.neigh[(size_t)w.rank], PS.rb, PS.L[i])) != SIFT3D_OK) return rc;
+		if (PS.counts[(size_t)w.rank]) SH_ABI(w, sift3d_slab_export_records(w.stages[(size_t)s].ctx, PS.L[i].recs));
 	}
-	if ((rc = partial_round(H, ws, s, neigh, counts, L, rb, false, n_redo)) != SIFT3D_OK) return rc;
-	for (size_t i = 0; i < ws.size(); i++) H->redo_count[(size_t)s][(size_t)ws[i]->rank] = n_redo[i];
-	if ((rc = rendezvous(H, w0)) != SIFT3D_OK) return rc;
+	return partial_round(H, ws, s, PS.neigh, PS.counts, PS.L, PS.rb, false, n_redo);
+}
+
+// rare: records whose first fixed-point unit failed (H->redo_count[s], known to every rank) are repeated, by every part, with the exact unit.
+// The flagged subset is compacted through the host (a few records), then the scratch is laid out again for the second round's counts.
+int partial_stage_second(sift3d_sharded *H, std::vector<Worker *> &ws, int s, PartStage &PS) {
 	const std::vector<int> tot = H->redo_count[(size_t)s];
-	if (!std::any_of(tot.begin(), tot.end(), [](int v) { return v > 0; })) return SIFT3D_OK;
-	// rare: records whose first fixed-point unit failed are repeated, by every part, with the exact unit.  The flagged subset is compacted
-	// through the host (a few records), then the scratch is laid out again for the second round's counts.
+	const std::vector<int> &counts = PS.counts;
+	const size_t rb = PS.rb;
+	std::vector<PartLayout> &L = PS.L;
+	int rc;
 	std::vector<std::vector<char>> recs2(ws.size());
 	std::vector<std::vector<float>> units2(ws.size());
 	for (size_t i = 0; i < ws.size(); i++) {
@@ -540,83 +608,28 @@ int describe_partial_stage(sift3d_sharded *H, std::vector<Worker *> &ws, int s) 
 			if (redo[k]) { recs2[i].insert(recs2[i].end(), recs.begin() + (ptrdiff_t)(k * rb), recs.begin() + (ptrdiff_t)((k + 1) * rb)); units2[i].push_back(un[k]); }
 		if ((int)units2[i].size() != tot[(size_t)w.rank]) { set_err(w, "flagged records and their count disagree"); return SIFT3D_ERR_STATE; }
 	}
+	std::vector<int> n_redo(ws.size(), 0);
 	for (size_t i = 0; i < ws.size(); i++) {
 		Worker &w = *ws[i];
 		SH_HIP(w, hipSetDevice(w.device));
 		SH_HIP(w, hipStreamSynchronize(w.stream));  // (simulated ranks share the stream: every rank's first round has drained before a scratch moves)
-		if ((rc = lay_out(w, tot, neigh[(size_t)w.rank], rb, L[i])) != SIFT3D_OK) return rc;
+		if ((rc = lay_out(w, s, tot, PS.neigh[(size_t)w.rank], rb, L[i])) != SIFT3D_OK) return rc;
 		if (tot[(size_t)w.rank]) {
 			SH_HIP(w, hipMemcpyAsync(L[i].recs, recs2[i].data(), recs2[i].size(), hipMemcpyHostToDevice, w.stream));
 			SH_HIP(w, hipMemcpyAsync(L[i].units, units2[i].data(), units2[i].size() * 4, hipMemcpyHostToDevice, w.stream));
 			SH_HIP(w, hipStreamSynchronize(w.stream));  // (the host vectors are pageable and go out of scope)
 		}
 	}
-	return partial_round(H, ws, s, neigh, tot, L, rb, true, n_redo);
+	return partial_round(H, ws, s, PS.neigh, tot, L, rb, true, n_redo);
 }
 
-// the replicated tail of the local workers: pyramid + extrema of the remaining octaves on every rank, orientation dealt by extremum
-// index and restored everywhere by an integer all-reduce(SUM) of zero-padded rows (exact), descriptors dealt by keypoint
-int run_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
-	Worker &w0 = *ws[0];
-	for (Worker *w : ws) {
-		SH_HIP(*w, hipSetDevice(w->device));
-		SH_HIP(*w, hipEventSynchronize(w->ev_seed));  // the all-gathered seed level exists
-		SH_ABI(*w, sift3d_seed_upload(w->tail, w->seed, 1));
-		SH_ABI(*w, sift3d_run_partial_orientation(w->tail));
-	}
-	std::vector<int *> rows(ws.size(), nullptr);
-	std::vector<int> next(ws.size(), 0);
-	for (size_t i = 0; i < ws.size(); i++) {
-		Worker *w = ws[i];
-		SH_HIP(*w, hipSetDevice(w->device));
-		SH_ABI(*w, sift3d_num_extrema(w->tail, &next[i]));
-		if (next[i] > 0) {
-			SH_HIP(*w, hipMalloc(&rows[i], sizeof(int) * (size_t)next[i] * SIFT3D_ORIENT_WORDS));
-			SH_ABI(*w, sift3d_export_orientation_device(w->tail, rows[i]));
-		}
-	}
-	int rc = SIFT3D_OK;
-	if (H->sim) {
-		const size_t n = (size_t)next[0] * SIFT3D_ORIENT_WORDS;
-		std::vector<int> sum(n, 0), t(n);
-		for (size_t i = 0; i < ws.size() && n; i++) {
-			if (next[i] != next[0]) { set_err(w0, "replicated tails disagree on the number of extrema"); rc = SIFT3D_ERR_STATE; break; }
-			if (hipMemcpy(t.data(), rows[i], sizeof(int) * n, hipMemcpyDeviceToHost) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
-			for (size_t k = 0; k < n; k++) sum[k] += t[k];
-		}
-		for (size_t i = 0; i < ws.size() && n && rc == SIFT3D_OK; i++)
-			if (hipMemcpy(rows[i], sum.data(), sizeof(int) * n, hipMemcpyHostToDevice) != hipSuccess) rc = SIFT3D_ERR_HIP;
-	} else if (next[0] > 0) {
-		Worker &w = *ws[0];
-		hipStream_t ts = nullptr;  // the tail's collective runs on the null stream of the rank's device, ordered behind the export above
-		ncclResult_t r = ncclSuccess;
-		{
-			std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
-			if (H->failed.load() || !w.c_tail) { set_err(w, "aborted: another rank failed"); rc = SIFT3D_ERR_STATE; }
-			else r = g_rccl.AllReduce(rows[0], rows[0], (size_t)next[0] * SIFT3D_ORIENT_WORDS, ncclInt32, ncclSum, w.c_tail, ts);
-		}
-		if (rc != SIFT3D_OK) {}
-		else if (r != ncclSuccess) { set_err(w, std::string("ncclAllReduce (tail): ") + g_rccl.GetErrorString(r)); rc = SIFT3D_ERR_HIP; }
-		else if (hipStreamSynchronize(ts) != hipSuccess) { set_err(w, "tail all-reduce did not complete"); rc = SIFT3D_ERR_HIP; }
-		if (rc == SIFT3D_OK && H->failed.load()) { set_err(w, "aborted: another rank failed"); rc = SIFT3D_ERR_STATE; }  // an aborted collective leaves garbage rows
-	}
-	for (size_t i = 0; i < ws.size(); i++) {
-		Worker *w = ws[i];
-		if (rc == SIFT3D_OK) {
-			(void)hipSetDevice(w->device);
-			if (next[i] > 0) rc = sift3d_import_orientation_device(w->tail, rows[i]);
-			if (rc == SIFT3D_OK) rc = sift3d_run_describe(w->tail);
-			if (rc != SIFT3D_OK) w->err = std::string("tail: ") + sift3d_error_string(rc) + " (" + sift3d_last_error() + ")";
-		}
-		if (rows[i]) (void)hipFree(rows[i]);
-	}
-	return rc;
-}
-
-// CSIFT3D::KpSiftAlgorithm (Src/cSIFT3D.cc:165-235) over the slabs of the local workers
+// CSIFT3D::KpSiftAlgorithm (Src/cSIFT3D.cc:165-235) over the slabs of the local workers.  Host synchronisations of a step: the keypoint
+// counts of the sharded octaves (read once everything up to the orientation of the LAST sharded octave has been enqueued), the counts of
+// flagged records (read once every window has been enqueued), the tail's wait and the final drain.
 int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	Worker &w0 = *ws[0];
 	const int ng = H->ng;
+	const bool has_tail = H->noct > H->S;
 	for (Worker *w : ws) SH_HIP(*w, hipSetDevice(w->device));
 	for (int s = 0; s < H->S; s++) {
 		const Stage &st0 = w0.stages[(size_t)s];
@@ -659,6 +672,8 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 						SH_ABI(*w, sift3d_slab_decimate_async(w->stages[(size_t)s].ctx, w->seed_mine));
 					}
 				}
+				// the tail starts as soon as its seed level exists: beside the last levels of the last sharded octave
+				if (s + 1 == H->S && has_tail && (rc = gather_seed_and_start_tail(H, ws)) != SIFT3D_OK) return rc;
 			}
 		}
 		// DoG maxima -> global (threshold of Detect_KeyPoints, Src/cSIFT3D.cc:379-384)
@@ -672,52 +687,62 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 			SH_HIP(*w, hipEventRecord(w->ev_def, w->dstream));
 			SH_HIP(*w, hipStreamWaitEvent(w->stream, w->ev_def, 0));
 		}
-	const bool has_tail = H->noct > H->S;
-	if (has_tail) {
-		int rc = allgather_seed(H, ws);
-		if (rc) return rc;
-		for (Worker *w : ws) SH_HIP(*w, hipEventRecord(w->ev_seed, w->stream));
-	}
-	// replicated tail on its own host thread (RCCL), beside the sharded detection and descriptors; inline for simulated ranks
-	int tail_rc = SIFT3D_OK;
-	std::thread tail_thread;
-	if (has_tail && !H->sim) tail_thread = std::thread([&] { tail_rc = run_tail(H, ws); if (tail_rc != SIFT3D_OK) abort_all(H); });
 	int rc = SIFT3D_OK;
-	for (int s = 0; s < H->S && rc == SIFT3D_OK; s++) {
-		for (Worker *w : ws) {
-			if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
-			rc = sift3d_slab_detect(w->stages[(size_t)s].ctx);
-			if (rc == SIFT3D_OK && !H->partial) rc = sift3d_slab_describe(w->stages[(size_t)s].ctx);
-			if (rc != SIFT3D_OK) { set_err(*w, std::string("sharded keypoints: ") + sift3d_error_string(rc) + " (" + sift3d_last_error() + ")"); break; }
+	auto say = [&](Worker &w, const char *what, int r) { set_err(w, std::string(what) + ": " + sift3d_error_string(r) + " (" + sift3d_last_error() + ")"); };
+	if (H->partial) {
+		// extrema + orientation of EVERY sharded octave enqueued, then the counts (the GPU is busy with the later octaves while the host waits
+		// for the first), shared with the other ranks' threads behind one rendezvous
+		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++)
+			for (Worker *w : ws) {
+				if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
+				if ((rc = sift3d_slab_keypoints_launch(w->stages[(size_t)s].ctx)) != SIFT3D_OK) { say(*w, "sharded keypoints", rc); break; }
+			}
+		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++)
+			for (Worker *w : ws) {
+				int n = 0;
+				if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
+				if ((rc = sift3d_slab_keypoints_count(w->stages[(size_t)s].ctx, &n)) != SIFT3D_OK) { say(*w, "sharded keypoint counts", rc); break; }
+				H->kp_count[(size_t)s][(size_t)w->rank] = n;
+			}
+		if (rc == SIFT3D_OK) rc = rendezvous(H, w0);
+		std::vector<PartStage> PS((size_t)H->S);
+		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++) rc = partial_stage_enqueue(H, ws, s, PS[(size_t)s]);
+		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++)
+			for (Worker *w : ws) {
+				int nr = 0;
+				if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
+				if ((rc = sift3d_slab_describe_finish_count(w->stages[(size_t)s].ctx, &nr)) != SIFT3D_OK) { say(*w, "sharded descriptors", rc); break; }
+				H->redo_count[(size_t)s][(size_t)w->rank] = nr;
+			}
+		if (rc == SIFT3D_OK) rc = rendezvous(H, w0);
+		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++) {
+			const std::vector<int> &tot = H->redo_count[(size_t)s];
+			if (std::any_of(tot.begin(), tot.end(), [](int v) { return v > 0; })) rc = partial_stage_second(H, ws, s, PS[(size_t)s]);
 		}
-		if (rc == SIFT3D_OK && H->partial) rc = describe_partial_stage(H, ws, s);
+	} else {
+		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++)
+			for (Worker *w : ws) {
+				if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
+				rc = sift3d_slab_detect(w->stages[(size_t)s].ctx);
+				if (rc == SIFT3D_OK) rc = sift3d_slab_describe(w->stages[(size_t)s].ctx);
+				if (rc != SIFT3D_OK) { say(*w, "sharded keypoints", rc); break; }
+			}
 	}
-	if (rc != SIFT3D_OK) abort_all(H);               // (the tail thread may sit in its all-reduce waiting for ranks that will not come)
-	if (tail_thread.joinable()) tail_thread.join();  // joined whatever happened above: it calls into contexts destroy would free
-	if (rc == SIFT3D_OK && H->failed.load()) { set_err(w0, "aborted: another rank failed"); rc = SIFT3D_ERR_STATE; }  // halos of an aborted exchange are garbage
-	if (has_tail && H->sim && rc == SIFT3D_OK) tail_rc = run_tail(H, ws);
-	if (rc == SIFT3D_OK) rc = tail_rc;
-	if (rc != SIFT3D_OK) return rc;
-	// results of the local ranks to the host
+	if (rc != SIFT3D_OK) abort_all(H);  // (peers may sit in a receive waiting for this rank)
+	// the tail's run is completed whatever happened above (an extractor with a run in flight must not be destroyed under it)
+	for (Worker *w : ws)
+		if (w->tail && has_tail) {
+			(void)hipSetDevice(w->device);
+			const int trc = sift3d_wait(w->tail);
+			if (trc != SIFT3D_OK && rc == SIFT3D_OK) { say(*w, "tail", trc); rc = trc; abort_all(H); }
+		}
 	for (Worker *w : ws) {
-		SH_HIP(*w, hipSetDevice(w->device));
-		w->kp.clear(); w->desc.clear(); w->kp_stage_end.clear();
-		for (int s = 0; s < H->S; s++) {
-			int n = 0;
-			SH_ABI(*w, sift3d_num_keypoints(w->stages[(size_t)s].ctx, &n));
-			const size_t o = w->kp.size();
-			w->kp.resize(o + (size_t)n); w->desc.resize((o + (size_t)n) * kDesc);
-			if (n) SH_ABI(*w, sift3d_get_keypoints(w->stages[(size_t)s].ctx, w->kp.data() + o, w->desc.data() + o * kDesc));
-			w->kp_stage_end.push_back((int)w->kp.size());
-		}
-		if (has_tail) {
-			int n = 0;
-			SH_ABI(*w, sift3d_num_keypoints(w->tail, &n));
-			w->tkp.resize((size_t)n); w->tdesc.resize((size_t)n * kDesc);
-			if (n) SH_ABI(*w, sift3d_get_keypoints(w->tail, w->tkp.data(), w->tdesc.data()));
-		}
+		(void)hipSetDevice(w->device);
+		const hipError_t e = hipStreamSynchronize(w->stream);
+		if (e != hipSuccess && rc == SIFT3D_OK) { set_err(*w, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); rc = SIFT3D_ERR_HIP; }
 	}
-	return SIFT3D_OK;
+	if (rc == SIFT3D_OK && H->failed.load()) { set_err(w0, "aborted: another rank failed"); rc = SIFT3D_ERR_STATE; }  // halos of an aborted exchange are garbage
+	return rc;
 }
 
 // phase 0: everything that may still enqueue on or wait for a stream; phase 1: the streams (simulated ranks SHARE rank 0's stream: it
@@ -728,19 +753,19 @@ void destroy_worker(Worker &w, int phase, bool comms_aborted) {
 	if (phase == 0) {
 		if (w.stream) (void)hipStreamSynchronize(w.stream);
 		if (w.dstream) (void)hipStreamSynchronize(w.dstream);
-		if (w.tail) sift3d_destroy(w.tail);
-		w.tail = nullptr;
+		if (w.tstream) (void)hipStreamSynchronize(w.tstream);
+		if (w.tail) { (void)sift3d_set_stream(w.tail, nullptr); sift3d_destroy(w.tail); }
+		w.tail = nullptr; w.seed_dst = nullptr;
 		for (Stage &s : w.stages) {
 			if (s.ctx) { (void)sift3d_set_stream(s.ctx, nullptr); sift3d_destroy(s.ctx); s.ctx = nullptr; }
 			if (s.arena) (void)hipFree(s.arena);
 			s.arena = nullptr;
 		}
 		for (float *&d : w.dogmax) { if (d) (void)hipFree(d); d = nullptr; }
-		if (w.pscratch) (void)hipFree(w.pscratch);
-		w.pscratch = nullptr; w.pscratch_bytes = 0;
-		if (w.seed) (void)hipFree(w.seed);
-		if (w.seed_mine) (void)hipFree(w.seed_mine);
-		w.seed = w.seed_mine = nullptr;
+		for (char *&ps : w.pscratch) { if (ps) (void)hipFree(ps); ps = nullptr; }
+		w.pscratch.clear(); w.pscratch_bytes.clear();
+		if (w.seed_mine && w.seed_mine_owned) (void)hipFree(w.seed_mine);
+		w.seed_mine = nullptr; w.seed_mine_owned = false;
 		if (w.ev_level) (void)hipEventDestroy(w.ev_level);
 		if (w.ev_def) (void)hipEventDestroy(w.ev_def);
 		if (w.ev_seed) (void)hipEventDestroy(w.ev_seed);
@@ -753,21 +778,10 @@ void destroy_worker(Worker &w, int phase, bool comms_aborted) {
 		w.c_urgent = w.c_deferred = w.c_tail = nullptr;
 	} else {
 		if (w.dstream) (void)hipStreamDestroy(w.dstream);
+		if (w.tstream) (void)hipStreamDestroy(w.tstream);
 		if (w.own_stream && w.stream) (void)hipStreamDestroy(w.stream);
-		w.dstream = w.stream = nullptr;
+		w.dstream = w.tstream = w.stream = nullptr;
 	}
-}
-
-// rows (keypoint slots, reference order) whose descriptor a partitioned handle computes: the library deals the accepted keypoints in
-// its processing order -- keypoint level descending, stable (kernels_orient.hip k_slots) -- position p goes to rank p % world
-std::vector<int> described_rows(const std::vector<sift3d_keypoint> &kp, int rank, int world) {
-	std::vector<int> order(kp.size());
-	for (size_t i = 0; i < kp.size(); i++) order[i] = (int)i;
-	std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kp[(size_t)a].level > kp[(size_t)b].level; });
-	std::vector<int> rows;
-	for (size_t p = (size_t)rank; p < order.size(); p += (size_t)world) rows.push_back(order[p]);
-	std::sort(rows.begin(), rows.end());
-	return rows;
 }
 
 }  // namespace
@@ -806,8 +820,8 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	H->world = H->sim ? sim_ranks : ndev;
 	H->devices.assign(devices, devices + ndev);
 	H->levels = H->p.num_kp_levels; H->ng = H->levels + 3;
-	H->partial = (flags & SIFT3D_SHARDED_PARTIAL_WINDOWS) != 0;
-	if ((H->partial ? sift3d_slab_min_halo_partial(&H->p, &H->halo) : sift3d_slab_min_halo(&H->p, &H->halo)) != SIFT3D_OK) return fail(SIFT3D_ERR_ARG, "bad parameters");
+	int halo_whole = 0, halo_partial = 0;
+	if (sift3d_slab_min_halo(&H->p, &halo_whole) != SIFT3D_OK || sift3d_slab_min_halo_partial(&H->p, &halo_partial) != SIFT3D_OK) return fail(SIFT3D_ERR_ARG, "bad parameters");
 	H->noct = octaves_total(nx, ny, nz);
 	if (H->noct < 1) return fail(SIFT3D_ERR_ARG, "volume too small for one octave");
 	// sharded octaves: as asked, but none whose planes are smaller than the level kernel's tile (+ widest half width) or thinner than the ranks
@@ -815,8 +829,35 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	auto fits = [](int n) { return n == 32 || n >= 40; };  // one 32 x 32 tile, or room for a shifted last tile behind the widest mirror zone
 	while (S > 1 && (!fits(nx >> (S - 1)) || !fits(ny >> (S - 1)) || (nz >> S) < H->world)) S--;
 	H->S = S;
+	// the tail (octaves >= S) runs once, on the last rank, which owns fewer planes in exchange: the tail is a volume of nz / 2^S planes of
+	// 1 / 4^S the size, i.e. nz / 8^S planes of the first octave (x 8/7 for its own octaves), and small volumes cost ~2.3x as much per voxel as
+	// the big levels (256^3: 1.7 ms against 24 ms for 32 times the voxels)
+	H->tail_rank = H->noct > S ? H->world - 1 : -1;
+	const int tail_planes = H->tail_rank >= 0 ? (int)lround(2.6 * (double)nz / (double)(1 << (3 * S))) : 0;
 	Bounds b;
-	if (!slab_bounds(nz, H->world, 1 << S, b)) return fail(SIFT3D_ERR_ARG, "too few planes for this many slabs");
+	if (!slab_bounds(nz, H->world, 1 << S, b, tail_planes)) return fail(SIFT3D_ERR_ARG, "too few planes for this many slabs");
+	// descriptor windows: split along z over the ranks (partial integer histograms) unless the caller asks for whole windows -- or a slab is so
+	// thin that a window would span more ranks than one finish launch adds parts (the owner's and five z-neighbours'): then whole windows too,
+	// unless partial windows were asked for by name (refused, as in r05)
+	{
+		H->partial = (flags & SIFT3D_SHARDED_WHOLE_WINDOWS) == 0;
+		const int reach = halo_whole - 1;  // planes a window reaches beyond its keypoint, in voxels of ITS octave: the same in every octave (scale / unit)
+		Bounds bo = b;
+		int dz = nz;
+		for (int o = 0; o < S && H->partial; o++) {
+			for (const std::vector<int> &nb : window_neighbours(bo, reach))
+				if ((int)nb.size() + 1 > kDescSegs) {
+					if (flags & SIFT3D_SHARDED_PARTIAL_WINDOWS)
+						return fail(SIFT3D_ERR_ARG, "partial descriptor windows: a slab of octave " + std::to_string(o) + " is so thin that a window spans more than " +
+						                                std::to_string(kDescSegs) + " ranks; use fewer sharded octaves or whole windows");
+					H->partial = false;
+					break;
+				}
+			bo = halve_bounds(bo, dz);
+			dz /= 2;
+		}
+	}
+	H->halo = H->partial ? halo_partial : halo_whole;
 	if (!H->sim) {
 		std::lock_guard<std::mutex> lk(g_rccl_mu);
 		std::string e;
@@ -867,29 +908,29 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 			sift3d_handle c0 = w.stages[0].ctx;
 			for (int i = 0; i < H->ng; i++) { int v = 0; CR_ABI(sift3d_slab_halo_planes(c0, i, &v)); H->need.push_back(v); CR_ABI(sift3d_slab_level_hw(c0, i, &v)); H->hws.push_back(v); }
 		}
-		if (H->noct > S) {
-			CR_ABI(sift3d_create_seeded(&w.tail, dx, dy, dz, S, H->noct, &H->p, w.device));
-			CR_ABI(sift3d_set_describe_partition(w.tail, r, H->world));
-			CR_HIP(hipMalloc(&w.seed, sizeof(float) * (size_t)dx * dy * std::max(dz, 1)));
-			const int mine = *std::max_element(H->counts2.begin(), H->counts2.end());
-			CR_HIP(hipMalloc(&w.seed_mine, sizeof(float) * (size_t)dx * dy * std::max(mine, 1)));
+		if (H->tail_rank >= 0) {
+			const size_t pl2 = (size_t)dx * dy;
+			if (r == H->tail_rank) {
+				// the tail: an ordinary seeded extractor of the octaves >= S on a stream of its own; its level 0 is where the seed level is gathered
+				CR_ABI(sift3d_create_seeded(&w.tail, dx, dy, dz, S, H->noct, &H->p, w.device));
+				CR_HIP(hipStreamCreateWithFlags(&w.tstream, hipStreamNonBlocking));
+				CR_ABI(sift3d_set_stream(w.tail, w.tstream));
+				size_t nf = 0;
+				CR_ABI(sift3d_seed_buffer(w.tail, &w.seed_dst, &nf));
+				size_t off = 0;
+				for (int q = 0; q < r; q++) off += pl2 * (size_t)H->counts2[(size_t)q];
+				if (!w.seed_dst || off + pl2 * (size_t)H->counts2[(size_t)r] > nf) return fail(SIFT3D_ERR_STATE, "the tail's seed level is smaller than the ranks' pieces");
+				w.seed_mine = w.seed_dst + off;  // the tail rank decimates its own planes in place
+			} else {
+				CR_HIP(hipMalloc(&w.seed_mine, sizeof(float) * pl2 * (size_t)std::max(H->counts2[(size_t)r], 1)));
+				w.seed_mine_owned = true;
+			}
 		}
 	}
-	if (H->partial) {
-		// one finish launch adds at most kDescSegs parts: the owner's and those of five z-neighbours (slabs thinner than that take the whole-window path)
-		H->kp_count.assign((size_t)S, std::vector<int>((size_t)H->world, 0));
-		H->redo_count = H->kp_count;
-		for (const Stage &st : H->workers[0].stages) {
-			int reach = 0;
-			CR_ABI(sift3d_slab_desc_reach(st.ctx, &reach));
-			for (const std::vector<int> &nb : window_neighbours(st.bounds, reach))
-				if ((int)nb.size() + 1 > kDescSegs)
-					return fail(SIFT3D_ERR_ARG, "partial descriptor windows: a slab of octave " + std::to_string(st.octave) + " is so thin that a window spans more than " +
-					                                std::to_string(kDescSegs) + " ranks; use fewer sharded octaves or whole windows");
-		}
-	}
+	H->kp_count.assign((size_t)S, std::vector<int>((size_t)H->world, 0));
+	H->redo_count = H->kp_count;
 	if (!H->sim) {
-		// three communicators over the same devices: urgent halos + reductions, deferred halos, the tail's reduction
+		// three communicators over the same devices: urgent halos + reductions, deferred halos, the gather of the tail's seed level
 		std::vector<ncclComm_t> c((size_t)H->world);
 		for (int k = 0; k < 3; k++) {
 			ncclResult_t r = g_rccl.CommInitAll(c.data(), H->world, H->devices.data());
@@ -970,6 +1011,7 @@ extern "C" int sift3d_sharded_run(sift3d_sharded_handle H) {
 	}
 	const auto t0 = std::chrono::steady_clock::now();
 	int rc = SIFT3D_OK;
+	H->ran = false;
 	if (H->sim) {
 		std::vector<Worker *> ws;
 		for (Worker &w : H->workers) ws.push_back(&w);
@@ -993,50 +1035,107 @@ extern "C" int sift3d_sharded_run(sift3d_sharded_handle H) {
 			}
 	}
 	if (rc) { set_last_error(H->err); return rc; }
-	H->times[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-	// ---- merge: reference order (octave, level, z, y, x) (Src/cSIFT3D.cc:373-416): per sharded octave the ranks' lists concatenated and
-	// sorted by (level, z, y, x); then the tail, whose records are complete on every rank and whose descriptor rows are dealt
-	H->kp.clear(); H->desc.clear();
-	for (int s = 0; s < H->S; s++) {
-		std::vector<std::pair<const sift3d_keypoint *, const float *>> items;
-		for (Worker &w : H->workers) {
-			const int a = s ? w.kp_stage_end[(size_t)s - 1] : 0, e = w.kp_stage_end[(size_t)s];
-			for (int i = a; i < e; i++) items.push_back({&w.kp[(size_t)i], &w.desc[(size_t)i * kDesc]});
-		}
-		std::stable_sort(items.begin(), items.end(), [](const std::pair<const sift3d_keypoint *, const float *> &A, const std::pair<const sift3d_keypoint *, const float *> &B) {
-			const sift3d_keypoint &a = *A.first, &b = *B.first;
-			if (a.level != b.level) return a.level < b.level;
-			if (a.z != b.z) return a.z < b.z;
-			if (a.y != b.y) return a.y < b.y;
-			return a.x < b.x;
-		});
-		for (auto &it : items) { H->kp.push_back(*it.first); H->desc.insert(H->desc.end(), it.second, it.second + kDesc); }
-	}
-	if (H->noct > H->S) {
-		const Worker &w0 = H->workers[0];
-		const size_t o = H->kp.size();
-		H->kp.insert(H->kp.end(), w0.tkp.begin(), w0.tkp.end());
-		H->desc.resize((o + w0.tkp.size()) * kDesc, 0.0f);
-		for (const Worker &w : H->workers)
-			for (int row : described_rows(w0.tkp, w.rank, H->world))
-				memcpy(&H->desc[(o + (size_t)row) * kDesc], &w.tdesc[(size_t)row * kDesc], sizeof(float) * kDesc);
-	}
-	H->times[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	// like the single-GPU extractor's, the results stay on the devices until they are asked for (sift3d_sharded_get_keypoints)
+	H->times[0] = H->times[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	H->ran = true;
 	return SIFT3D_OK;
 }
 
 extern "C" int sift3d_sharded_num_keypoints(sift3d_sharded_handle H, int *n) {
 	if (!H || !n) return SIFT3D_ERR_ARG;
-	*n = H->ran ? (int)H->kp.size() : 0;
+	*n = 0;
+	if (!H->ran) return SIFT3D_OK;
+	int tot = 0;
+	for (Worker &w : H->workers) {
+		for (Stage &st : w.stages) { int k = 0; int rc = sift3d_num_keypoints(st.ctx, &k); if (rc) return rc; tot += k; }
+		if (w.tail) { int k = 0; int rc = sift3d_num_keypoints(w.tail, &k); if (rc) return rc; tot += k; }
+	}
+	*n = tot;
 	return SIFT3D_OK;
 }
 
+// GetKeypoints (Src/cSIFT3D.cc:1686-1688) in reference order (octave, level, z, y, x) (Src/cSIFT3D.cc:373-416).  A rank's list of a sharded
+// octave is in that order for the planes it owns, and the ranks own ascending, disjoint plane ranges: the merged list of an octave is, level
+// by level, the ranks' runs of that level one after the other -- no sort, and every run's descriptors travel from their GPU straight to
+// their place in the caller's array (r05 copied every rank's results into vectors of the handle, sorted pointers and copied twice more).
+// The tail's list, complete on the tail rank, follows the sharded octaves'.
 extern "C" int sift3d_sharded_get_keypoints(sift3d_sharded_handle H, sift3d_keypoint *out, float *desc) {
 	if (!H) return SIFT3D_ERR_ARG;
-	if (!H->ran) return SIFT3D_OK;
-	if (out && !H->kp.empty()) memcpy(out, H->kp.data(), sizeof(sift3d_keypoint) * H->kp.size());
-	if (desc && !H->desc.empty()) memcpy(desc, H->desc.data(), sizeof(float) * H->desc.size());
+	if (!H->ran || (!out && !desc)) return SIFT3D_OK;
+	const auto t0 = std::chrono::steady_clock::now();
+	const int W = H->world, S = H->S;
+	auto bad = [&](Worker &w, int rc, const char *what) { H->err = std::string(what) + ": " + sift3d_error_string(rc) + " (" + sift3d_last_error() + ")"; (void)w; set_last_error(H->err); return rc; };
+	// 1. the records of every (rank, stage): small (168 bytes each)
+	std::vector<std::vector<std::vector<sift3d_keypoint>>> recs((size_t)W, std::vector<std::vector<sift3d_keypoint>>((size_t)S));
+	for (Worker &w : H->workers) {
+		if (hipSetDevice(w.device) != hipSuccess) return SIFT3D_ERR_HIP;
+		for (int s = 0; s < S; s++) {
+			int n = 0, rc = sift3d_num_keypoints(w.stages[(size_t)s].ctx, &n);
+			if (rc) return bad(w, rc, "sift3d_num_keypoints");
+			recs[(size_t)w.rank][(size_t)s].resize((size_t)n);
+			if (n && (rc = sift3d_get_keypoints(w.stages[(size_t)s].ctx, recs[(size_t)w.rank][(size_t)s].data(), nullptr)) != SIFT3D_OK) return bad(w, rc, "sift3d_get_keypoints");
+		}
+	}
+	// 2. the runs: (stage, level, rank) -> [a, b) of that rank's list, and where the run starts in the merged list
+	std::vector<std::vector<D2HSeg>> segs((size_t)W);
+	size_t pos = 0;
+	for (int s = 0; s < S; s++) {
+		std::vector<size_t> at((size_t)W, 0);
+		for (int lv = 0; lv < 16; lv++)
+			for (int r = 0; r < W; r++) {
+				const std::vector<sift3d_keypoint> &L = recs[(size_t)r][(size_t)s];
+				size_t a = at[(size_t)r], b = a;
+				while (b < L.size() && L[b].level == lv) b++;
+				if (b == a) continue;
+				at[(size_t)r] = b;
+				if (out) memcpy(out + pos, L.data() + a, sizeof(sift3d_keypoint) * (b - a));
+				if (desc) {
+					const float *dd = nullptr;
+					int n = 0;
+					Worker &w = H->workers[(size_t)r];
+					const int rc = sift3d_device_results(w.stages[(size_t)s].ctx, &dd, nullptr, &n);
+					if (rc) return bad(w, rc, "sift3d_device_results");
+					segs[(size_t)r].push_back(D2HSeg{desc + pos * kDesc, dd + a * kDesc, sizeof(float) * kDesc * (b - a)});
+				}
+				pos += b - a;
+			}
+		for (int r = 0; r < W; r++)
+			if (at[(size_t)r] != recs[(size_t)r][(size_t)s].size()) { H->err = "a rank's keypoint list is not ordered by level"; set_last_error(H->err); return SIFT3D_ERR_STATE; }
+	}
+	// 3. the tail's results behind them
+	if (H->tail_rank >= 0) {
+		Worker &w = H->workers[(size_t)H->tail_rank];
+		if (hipSetDevice(w.device) != hipSuccess) return SIFT3D_ERR_HIP;
+		int n = 0, rc = sift3d_num_keypoints(w.tail, &n);
+		if (rc) return bad(w, rc, "sift3d_num_keypoints (tail)");
+		if (n && out && (rc = sift3d_get_keypoints(w.tail, out + pos, nullptr)) != SIFT3D_OK) return bad(w, rc, "sift3d_get_keypoints (tail)");
+		if (n && desc) {
+			const float *dd = nullptr;
+			if ((rc = sift3d_device_results(w.tail, &dd, nullptr, nullptr)) != SIFT3D_OK) return bad(w, rc, "sift3d_device_results (tail)");
+			segs[(size_t)w.rank].push_back(D2HSeg{desc + pos * kDesc, dd, sizeof(float) * kDesc * (size_t)n});
+		}
+		pos += (size_t)n;
+	}
+	// 4. the descriptors: one staged pipeline per GPU (its own pinned pool), the GPUs side by side
+	if (desc) {
+		std::vector<int> rcs((size_t)W, SIFT3D_OK);
+		std::vector<std::string> errs((size_t)W);
+		auto pull = [&](int r) {
+			Worker &w = H->workers[(size_t)r];
+			if (segs[(size_t)r].empty()) return;
+			if (hipSetDevice(w.device) != hipSuccess) { rcs[(size_t)r] = SIFT3D_ERR_HIP; return; }
+			rcs[(size_t)r] = staged_d2h_v(segs[(size_t)r].data(), (int)segs[(size_t)r].size(), w.device, w.stream);
+			if (rcs[(size_t)r]) errs[(size_t)r] = sift3d_last_error();
+		};
+		if (H->sim || W == 1) for (int r = 0; r < W; r++) pull(r);
+		else {
+			std::vector<std::thread> th;
+			for (int r = 0; r < W; r++) th.emplace_back(pull, r);
+			for (auto &t : th) t.join();
+		}
+		for (int r = 0; r < W; r++) if (rcs[(size_t)r]) { H->err = "rank " + std::to_string(r) + ": " + errs[(size_t)r]; set_last_error(H->err); return rcs[(size_t)r]; }
+	}
+	H->times[1] = H->times[0] + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	return SIFT3D_OK;
 }
 
@@ -1046,5 +1145,14 @@ extern "C" int sift3d_sharded_info(sift3d_sharded_handle H, int *world, int *sha
 	if (sharded_octaves) *sharded_octaves = H->S;
 	if (halo) *halo = H->halo;
 	if (seconds) { seconds[0] = H->times[0]; seconds[1] = H->times[1]; }
+	return SIFT3D_OK;
+}
+
+extern "C" int sift3d_sharded_plan(sift3d_sharded_handle H, int *partial_windows, int *tail_rank, int *planes /* [world] or NULL */) {
+	if (!H) return SIFT3D_ERR_ARG;
+	if (partial_windows) *partial_windows = H->partial ? 1 : 0;
+	if (tail_rank) *tail_rank = H->tail_rank;
+	if (planes && !H->workers.empty())
+		for (int r = 0; r < H->world; r++) planes[r] = H->workers[(size_t)r].stages[0].z1 - H->workers[(size_t)r].stages[0].z0;
 	return SIFT3D_OK;
 }

@@ -136,6 +136,12 @@ bool march_applicable(int nx, int ny, int nzg, const Taps &t);
 bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogmax, int nx, int ny, const ZRange &zr, const Taps &t,
                         hipStream_t st, int plan_slots = 0, int prio = 0, const MarchHalf *half = nullptr);
 void launch_copy16(const float *src, float *dst, size_t nfloats, hipStream_t st);  // float4 copy (bandwidth ceiling probe)
+// simulated transport of the z-slab driver (sharded.hip): one exchange step's plane ranges in one launch; MAX over np arrays of n <= 64 floats, in place in all of them
+constexpr int kCopySegs = 32, kMaxMergePtrs = 16;
+struct CopySegs { const float *src[kCopySegs]; float *dst[kCopySegs]; size_t floats[kCopySegs]; int n = 0; };
+struct MaxMerge { float *p[kMaxMergePtrs]; int np = 0, n = 0; };
+void launch_copy_segments(const CopySegs &a, hipStream_t st);
+void launch_max_merge(const MaxMerge &a, hipStream_t st);
 // ---- kernels_small.hip: every level of the SMALL octaves (16^3-class and below) in one launch of one workgroup ----
 constexpr int kSmallMaxOct = 4, kSmallMaxLv = 8;
 struct SmallOct { float *g[kSmallMaxLv]; float *dog[kSmallMaxLv]; int nx, ny, nz; };  // Gaussian / DoG level buffers of one octave
@@ -310,6 +316,8 @@ double dev_tune_d(const char *env_name, double dflt);
 // ---- staging.hip: pageable host memory <-> device through pinned, double-buffered chunks --------
 int staged_h2d(void *d_dst, const void *h_src, size_t bytes, int device, hipStream_t st);  // stream-ordered on return
 int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStream_t st);  // complete on return
+struct D2HSeg { void *h_dst; const void *d_src; size_t bytes; };
+int staged_d2h_v(const D2HSeg *segs, int nseg, int device, hipStream_t st);                   // several pairs through one pipeline
 
 // error plumbing
 void set_last_error(const std::string &s);

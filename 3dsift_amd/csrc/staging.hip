@@ -21,6 +21,10 @@ namespace {
 constexpr size_t kChunk = (size_t)16 << 20;  // bytes per pinned buffer
 constexpr int kBufs = 4;
 constexpr int kSub = 4;  // the device -> host direction deals every buffer as kSub pieces (staged_d2h)
+#ifndef S3D_D2H_THREADS
+#define S3D_D2H_THREADS 12
+#endif
+constexpr int kD2HThreads = S3D_D2H_THREADS;
 // One pool per device (r04; before: one process-wide pool behind one mutex whose events were re-created whenever the calling device
 // changed -- the rank threads of the sharded driver took turns through it inside the timed region): 4 x 16 MB of pinned memory and
 // four events per device that is ever used, created on first use by a thread whose current device is that device.
@@ -123,15 +127,19 @@ int staged_h2d(void *d_dst, const void *h_src, size_t bytes, int device, hipStre
 	return SIFT3D_OK;
 }
 
-// device -> host (pageable); synchronous: the data is in h_dst on return.
+// device -> host (pageable); synchronous: the data is in the destinations on return.
 // r06: the mirror image of staged_h2d (r05's form spawned four threads per 16 MB chunk and waited for a whole chunk's DMA before the
 // first byte moved on: GetKeypoints brought the 36.6 MB of a 512^3 run back at 11 GB/s).  The 64 MB of pinned memory are dealt as
-// 16 slots of 4 MB -- a result of a few tens of MB is many pieces in flight -- the calling thread only issues DMAs and frees slots, the copy threads
-// live for the whole call and each moves its slice of piece after piece out of the pinned slot into the caller's (pageable) memory.
-int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStream_t st) {
-	if (bytes == 0) return SIFT3D_OK;
-	if (bytes < ((size_t)1 << 20)) {
-		S3D_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+// 16 slots of 4 MB -- a result of a few tens of MB is many pieces in flight -- the calling thread only issues DMAs and frees slots, the copy
+// threads live for the whole call and each moves its slice of piece after piece out of the pinned slot into the caller's (pageable) memory.
+// Several (destination, source) pairs travel in ONE call (GetKeypoints: the records and the descriptors): one set of threads, one pipeline.
+int staged_d2h_v(const D2HSeg *segs, int nseg, int device, hipStream_t st) {
+	size_t total = 0;
+	for (int k = 0; k < nseg; k++) total += segs[k].bytes;
+	if (total == 0) return SIFT3D_OK;
+	if (total < ((size_t)1 << 20)) {
+		for (int k = 0; k < nseg; k++)
+			if (segs[k].bytes) S3D_HIP(hipMemcpyAsync(segs[k].h_dst, segs[k].d_src, segs[k].bytes, hipMemcpyDeviceToHost, st));
 		S3D_HIP(hipStreamSynchronize(st));
 		return SIFT3D_OK;
 	}
@@ -141,9 +149,15 @@ int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStre
 	if (rc) return rc;
 	constexpr size_t kPiece = kChunk / kSub;
 	constexpr size_t kSlots = (size_t)kBufs * kSub;
-	const size_t npieces = (bytes + kPiece - 1) / kPiece;
+	// pieces never straddle two pairs
+	struct Piece { char *dst; const char *src; size_t n; };
+	std::vector<Piece> pieces;
+	for (int k = 0; k < nseg; k++)
+		for (size_t off = 0; off < segs[k].bytes; off += kPiece)
+			pieces.push_back(Piece{static_cast<char *>(segs[k].h_dst) + off, static_cast<const char *>(segs[k].d_src) + off, std::min(kPiece, segs[k].bytes - off)});
+	const size_t npieces = pieces.size();
 	const unsigned hc = std::thread::hardware_concurrency();
-	const int nt = (int)std::min<size_t>(std::max(1u, std::min(8u, hc ? hc / 2 : 1u)), std::max<size_t>(1, bytes >> 22));
+	const int nt = (int)std::min<size_t>(std::max(1u, std::min((unsigned)kD2HThreads, hc ? hc / 2 : 1u)), std::max<size_t>(1, total >> 21));
 	auto slot = [&](size_t i) { return g_pool.buf[(i % kSlots) / kSub] + ((i % kSlots) % kSub) * kPiece; };
 	// landed: pieces whose DMA has completed (the calling thread's event wait); copied[i]: copy threads done with piece i
 	std::atomic<size_t> landed{0};
@@ -151,10 +165,9 @@ int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStre
 	std::vector<std::atomic<int>> copied(npieces);
 	for (auto &f : copied) f.store(0);
 	auto copy_piece = [&](size_t i, int t) {
-		const size_t off = i * kPiece, n = std::min(kPiece, bytes - off);
 		size_t o, e;
-		staging_slice(n, nt, t, &o, &e);
-		if (e > o) memcpy(static_cast<char *>(h_dst) + off + o, slot(i) + o, e - o);
+		staging_slice(pieces[i].n, nt, t, &o, &e);
+		if (e > o) memcpy(pieces[i].dst + o, slot(i) + o, e - o);
 		copied[i].fetch_add(1, std::memory_order_release);
 	};
 	auto worker = [&](int t) {
@@ -166,18 +179,18 @@ int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStre
 			copy_piece(i, t);
 		}
 	};
-	std::vector<std::thread> th;
-	for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
 	hipError_t err = hipSuccess;
 	size_t issued = 0;
 	auto issue = [&](size_t i) -> hipError_t {
-		const size_t off = i * kPiece, n = std::min(kPiece, bytes - off);
-		hipError_t e = hipMemcpyAsync(slot(i), static_cast<const char *>(d_src) + off, n, hipMemcpyDeviceToHost, st);
+		hipError_t e = hipMemcpyAsync(slot(i), pieces[i].src, pieces[i].n, hipMemcpyDeviceToHost, st);
 		if (e == hipSuccess) e = hipEventRecord(g_pool.ev2[i % kSlots], st);
 		return e;
 	};
+	// (the DMAs are on their way before the threads exist: spawning them costs as much as the first pieces take to land)
 	while (issued < std::min(kSlots, npieces) && err == hipSuccess)
 		if ((err = issue(issued)) == hipSuccess) issued++;
+	std::vector<std::thread> th;
+	for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
 	for (size_t i = 0; i < npieces && err == hipSuccess; i++) {
 		if ((err = hipEventSynchronize(g_pool.ev2[i % kSlots])) != hipSuccess) break;
 		landed.store(i + 1, std::memory_order_release);
@@ -193,6 +206,10 @@ int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStre
 	// (on an error the DMAs already handed to the stream still target the pool: drained before the next caller may use it)
 	if (err != hipSuccess) { (void)hipStreamSynchronize(st); set_last_error(std::string("staged download: ") + hipGetErrorString(err)); return SIFT3D_ERR_HIP; }
 	return SIFT3D_OK;
+}
+int staged_d2h(void *h_dst, const void *d_src, size_t bytes, int device, hipStream_t st) {
+	const D2HSeg sg{h_dst, d_src, bytes};
+	return staged_d2h_v(&sg, 1, device, st);
 }
 
 }  // namespace s3d

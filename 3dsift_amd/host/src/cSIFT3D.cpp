@@ -130,10 +130,12 @@ static int sim_ranks() {
 	const char *e = getenv("SIFT3D_SIM_RANKS");
 	return e ? atoi(e) : 0;
 }
-// SIFT3D_PARTIAL_WINDOWS=1: the sharded driver splits the descriptor windows along z over the ranks (sift3d_sharded_create_ex)
+// SIFT3D_PARTIAL_WINDOWS: unset = the driver's rule (descriptor windows split along z over the ranks unless a slab is too thin for it),
+// 1 = split or refuse, 0 = whole windows on the wide halos (sift3d_sharded_create_ex)
 static unsigned shard_flags() {
 	const char *e = getenv("SIFT3D_PARTIAL_WINDOWS");
-	return e && atoi(e) > 0 ? SIFT3D_SHARDED_PARTIAL_WINDOWS : 0u;
+	if (!e) return 0u;
+	return atoi(e) > 0 ? SIFT3D_SHARDED_PARTIAL_WINDOWS : SIFT3D_SHARDED_WHOLE_WINDOWS;
 }
 
 struct CSIFT3D::Impl {

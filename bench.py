@@ -14,7 +14,8 @@ data-path collective); value = N * 512^3 * K / max-over-ranks time.
 times BASELINE.json configs[3] instead: ONE volume sharded as z-slabs over the N ranks (3dsift_amd/slab.py: halo
 exchange + all-reduce over RCCL; strong scaling, N=1 is the plain single-GPU extractor on the whole volume).
 --sim-ranks R runs R simulated ranks on one GPU (functional check / redundancy accounting, not a speed claim).
-A default N>1 run appends the slab measurement as "slab": {...} to its JSON line, behind a watchdog.
+A default N>1 run appends the slab measurement as "slab": {...} to its JSON line: "native" (the library's C++ driver, first class),
+"python" (3dsift_amd/slab.py over torch.distributed), each behind a watchdog and with speedup_vs_n1 against the committed N = 1 record.
 
 The JSON line also carries
   roofline      pyramid build (the HBM-bound part north_star sets a target for): the bytes its kernels MOVE
@@ -81,9 +82,10 @@ def parse_dims(txt):
     return nx, ny, nz
 
 
-def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partial_windows=False):
+def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partial_windows=None):
     """The same workload through the library's NATIVE driver (csrc/sharded.hip: one process, one host thread per GPU, RCCL halo
-    exchange; or sim_ranks simulated on devices[0]).  The volume starts on the host, like CreateCSIFT3D(float*) gets it."""
+    exchange; or sim_ranks simulated on devices[0]).  The volume starts on the host, like CreateCSIFT3D(float*) gets it.
+    partial_windows: None = the driver's rule (descriptor windows split along z), False = whole windows on the wide halos."""
     import torch
     capi = importlib.import_module("3dsift_amd.capi")
     synth = importlib.import_module("3dsift_amd.synth")
@@ -99,16 +101,20 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partia
     for _ in range(steps):
         sh.KpSiftAlgorithm()
         ts.append(sh.info()["seconds"])
+    t0 = time.perf_counter()
     kp, _ = sh.GetKeypoints()
+    t_get = time.perf_counter() - t0
     info = sh.info()
     sh.close()
     dt = float(np.median(ts))
     return {"workload": f"{nx}x{ny}x{nz} fp32 synthetic blob volume, z-slabs over {info['world']} rank(s), native C++ driver"
                         + (" SIMULATED on one GPU" if sim_ranks else " (RCCL)"),
-            "value": nx * ny * nz / dt / 1e6, "unit": "Mvoxels/s", "ms_per_step": dt * 1e3, "keypoints": int(len(kp)),
-            "sharded_octaves": info["sharded_octaves"], "halo_planes": info["halo"],
-            "descriptor_windows": "partial integer histograms" if partial_windows else "whole windows on plane halos", "ctor_s_incl_H2D_of_the_slabs": round(t_ctor, 3),
-            "note": "ms_per_step = host wall time of sift3d_sharded_run up to the results of every rank on the host (keypoint and descriptor D2H included)"}
+            "value": nx * ny * nz / dt / 1e6, "unit": "Mvoxels/s", "ms_per_step": dt * 1e3, "ms_per_step_all": [round(t * 1e3, 3) for t in ts], "keypoints": int(len(kp)),
+            "sharded_octaves": info["sharded_octaves"], "halo_planes": info["halo"], "slab_planes": info["planes"], "tail_rank": info["tail_rank"],
+            "descriptor_windows": "partial integer histograms" if info["partial_windows"] else "whole windows on plane halos", "ctor_s_incl_H2D_of_the_slabs": round(t_ctor, 3),
+            "get_keypoints_ms_D2H_of_every_rank_and_merge": round(t_get * 1e3, 3),
+            "note": "ms_per_step = host wall time of sift3d_sharded_run: KpSiftAlgorithm, results complete on the devices (like the single-GPU extractor's step; "
+                    "r05 counted the D2H of every rank's results and the merge in it: now get_keypoints_ms)"}
 
 
 def run_slab_native_child(dims_txt, gpus, steps, warmup, partial_windows, timeout):
@@ -117,7 +123,7 @@ def run_slab_native_child(dims_txt, gpus, steps, warmup, partial_windows, timeou
     must not take the process that holds the headline measurement with it.  Returns (slab dict, None) or (None, reason)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "slab", "--native", "--gpus", str(gpus), "--slab-dims", dims_txt,
-           "--steps", str(steps), "--warmup", str(warmup)] + (["--partial-windows"] if partial_windows else [])
+           "--steps", str(steps), "--warmup", str(warmup)] + ([] if partial_windows is None else ["--partial-windows"] if partial_windows else ["--whole-windows"])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
                                                               "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
     try:
@@ -244,7 +250,8 @@ def main():
     ap.add_argument("--no-slab-leg", action="store_true", help="do not append the configs[3] measurement (N=1: the single-GPU run of the 1024x1024x512 volume; N>1: z-slabs over the ranks)")
     ap.add_argument("--strict-legs", action="store_true", help="exit non-zero when a side leg (slab / slab_native) failed; the JSON line is printed either way")
     ap.add_argument("--native", action="store_true", help="slab workload on one process: the library's native C++ driver (RCCL over --gpus devices, or --sim-ranks)")
-    ap.add_argument("--partial-windows", action="store_true", help="with --native: descriptor windows split along z over the ranks (sift3d_sharded_create_ex)")
+    ap.add_argument("--partial-windows", action="store_true", help="with --native: descriptor windows split along z over the ranks or a refusal (the default is the driver's rule: split unless a slab is too thin)")
+    ap.add_argument("--whole-windows", action="store_true", help="with --native: whole descriptor windows on the wide plane halos (r05's default)")
     args = ap.parse_args()
 
     import torch
@@ -262,7 +269,7 @@ def main():
     if args.workload == "slab" and args.native and world == 1:
         dims = parse_dims(args.slab_dims)
         r = run_slab_native(dims, list(range(max(1, args.gpus))) if not args.sim_ranks else [local], args.steps, args.warmup, sim_ranks=args.sim_ranks,
-                            partial_windows=args.partial_windows)
+                            partial_windows=True if args.partial_windows else (False if args.whole_windows else None))
         print(json.dumps({"metric": "Mvoxels/s end-to-end KpSiftAlgorithm, one volume sharded as z-slabs (native driver)", "value": r["value"],
                           "unit": "Mvoxels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -644,64 +651,81 @@ def main():
         res, slab_err = guarded(lambda: run_slab(parse_dims(args.slab_dims), 1, 0, local, dev, SLAB_STEPS, SLAB_WARMUP), 240)
         out["slab"] = dict(res, n=1, steps=SLAB_STEPS, warmup=SLAB_WARMUP) if slab_err is None else {"error": slab_err}
     if world > 1 and not args.no_slab_leg:
-        # BASELINE configs[3] next to the headline number: one 1024x1024x512 volume over the same ranks.  The RCCL halo
-        # path cannot be exercised on the 1-GPU development boxes, so it runs behind a watchdog: whatever happens, the
-        # headline line is printed.
+        # BASELINE configs[3] next to the headline number: one 1024x1024x512 volume over the same GPUs.  No multi-GPU box exists in development:
+        # every leg runs behind a watchdog and, whatever happens, the headline line is printed.
+        #   slab.native (first class since r06)  the library's own driver (csrc/sharded.hip): one process, one host thread per GPU, RCCL
+        #                         point-to-point halos, descriptor windows split along z, the tail once on the last rank -- what a C++ user
+        #                         of SIFT3D_DEVICES=0-7 gets.  Runs in a CHILD process of rank 0 while the other ranks wait on the host-side store.
+        #   slab.python           3dsift_amd/slab.py over torch.distributed (one process per GPU): the driver the protocol is tested with over gloo
+        #   slab.native_whole_windows   the native driver with whole descriptor windows on 39-plane halos (r05's default)
         slab_attempted = True
         ex.close(); del vol
-        res, slab_err = guarded(lambda: run_slab(parse_dims(args.slab_dims), world, rank, local, dev, SLAB_STEPS, SLAB_WARMUP), 240)
-        out["slab"] = dict(res, n=world, steps=SLAB_STEPS, warmup=SLAB_WARMUP) if slab_err is None else {"error": slab_err}
-        if slab_err is None:
-            # speed-up against the single-GPU run of the SAME volume: the N = 1 figure is a committed record of a `--gpus 1` run
-            # (profiles/slab_1gpu.json, written by scripts/collect_profile.sh), valid only for the kernel sources it was measured on
+        torch.cuda.empty_cache()
+
+        def speedup(block):
+            # against the single-GPU run of the SAME volume: a committed record of a `--gpus 1` run (profiles/slab_1gpu.json, written by
+            # scripts/collect_profile.sh), valid only for the kernel sources it was measured on
             try:
                 one = json.load(open(os.path.join(ROOT, "profiles", "slab_1gpu.json")))
                 if one.get("kernel_source_sha") == capi.kernel_source_sha() and one.get("dims") == args.slab_dims:
-                    out["slab"]["ms_per_step_1gpu"] = one["ms_per_step"]
-                    out["slab"]["speedup_vs_1gpu"] = one["ms_per_step"] / out["slab"]["ms_per_step"]
+                    block["ms_per_step_n1"] = one["ms_per_step"]
+                    block["speedup_vs_n1"] = one["ms_per_step"] / block["ms_per_step"]
                 else:
-                    out["slab"]["speedup_note"] = "profiles/slab_1gpu.json was measured on other kernel sources / dims: no speed-up reported"
+                    block["speedup_note"] = "profiles/slab_1gpu.json was measured on other kernel sources / dims: no speed-up reported"
             except Exception:
-                out["slab"]["speedup_note"] = "no profiles/slab_1gpu.json: no speed-up reported"
-        if slab_err is None:
-            # the same volume through the NATIVE driver: rank 0's process drives all the node's GPUs (one host thread each, RCCL), the
-            # other ranks idle at a barrier.  Its failure is reported, not fatal: this transport has never met a second GPU in development.
-            # The other ranks wait on the rendezvous STORE (host side): a NCCL barrier would park a spinning kernel on their GPUs
-            # while rank 0's threads use them.
+                block["speedup_note"] = "no profiles/slab_1gpu.json: no speed-up reported"
+
+        store = None
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
             store = None
-            try:
-                store = dist.distributed_c10d._get_default_store()
-            except Exception:
-                store = None
-            if rank == 0:
-                torch.cuda.empty_cache()
-                # (each in a child process of rank 0: a hard fault of the native transport's first multi-GPU run must not cost the headline line)
-                nres, nat_err = run_slab_native_child(args.slab_dims, world, SLAB_STEPS, SLAB_WARMUP, False, 180)
-                out["slab_native"] = nres if nat_err is None else {"error": nat_err}
-                if nat_err is None:
-                    # r05, opt-in form of the native driver: descriptor windows split along z (13-plane level halos, records out, integer
-                    # histograms back).  Simulated ranks only in development; reported beside the default form, never instead of it.
-                    pres, p_err = run_slab_native_child(args.slab_dims, world, SLAB_STEPS, SLAB_WARMUP, True, 120)
-                    out["slab_native_partial_windows"] = pres if p_err is None else {"error": p_err}
-                if store is not None:
-                    try:
-                        store.set("s3d_native_done", "1")
-                    except Exception:
-                        pass
-            elif store is not None:
-                torch.cuda.empty_cache()
+        slab = {"n": world, "steps": SLAB_STEPS, "warmup": SLAB_WARMUP,
+                "development_note": "the RCCL transports of both drivers have only met simulated ranks (one GPU) and gloo (CPU) in development"}
+        if rank == 0:
+            nres, nat_err = run_slab_native_child(args.slab_dims, world, SLAB_STEPS, SLAB_WARMUP, None, 180)
+            slab["native"] = nres if nat_err is None else {"error": nat_err}
+            if nat_err is None:
+                speedup(slab["native"])
+                wres, w_err = run_slab_native_child(args.slab_dims, world, SLAB_STEPS, SLAB_WARMUP, False, 120)
+                slab["native_whole_windows"] = wres if w_err is None else {"error": w_err}
+            if store is not None:
                 try:
-                    import datetime
-                    store.wait(["s3d_native_done"], datetime.timedelta(seconds=330))
+                    store.set("s3d_native_done", "1")
                 except Exception:
                     pass
+        elif store is not None:
+            # (the other ranks wait on the rendezvous STORE, host side: a NCCL barrier would park a spinning kernel on their GPUs while the
+            # child's threads use them)
+            try:
+                import datetime
+                store.wait(["s3d_native_done"], datetime.timedelta(seconds=330))
+            except Exception:
+                pass
+        res, slab_err = guarded(lambda: run_slab(parse_dims(args.slab_dims), world, rank, local, dev, SLAB_STEPS, SLAB_WARMUP), 240)
+        slab["python"] = res if slab_err is None else {"error": slab_err}
+        if slab_err is None:
+            speedup(slab["python"])
+        # the block's own headline: the native driver's figures where it ran
+        head = slab["native"] if rank == 0 and "error" not in slab.get("native", {"error": 1}) else (slab["python"] if slab_err is None else None)
+        if head is not None:
+            for k in ("value", "unit", "ms_per_step", "keypoints", "speedup_vs_n1", "ms_per_step_n1"):
+                if k in head:
+                    slab[k] = head[k]
+            slab["driver"] = "native" if head is slab.get("native") else "python"
+        else:
+            slab["error"] = "both drivers failed: native: %s; python: %s" % (slab.get("native", {}).get("error"), slab_err)
+        out["slab"] = slab
     failed = []
     if rank == 0:
         # the line's contract is the headline metric, measured above; a side leg that failed says so IN the line (and on stderr)
-        failed = [k for k in ("slab", "slab_native") if isinstance(out.get(k), dict) and "error" in out[k]]
+        legs = {"slab": out.get("slab")}
+        if isinstance(out.get("slab"), dict):
+            legs.update({"slab." + k: out["slab"].get(k) for k in ("native", "python", "native_whole_windows")})
+        failed = [k for k, v in legs.items() if isinstance(v, dict) and "error" in v]
         if failed:
             out["legs_failed"] = failed
-            print("bench.py: side leg(s) failed: %s" % ", ".join("%s (%s)" % (k, out[k]["error"]) for k in failed), file=sys.stderr, flush=True)
+            print("bench.py: side leg(s) failed: %s" % ", ".join("%s (%s)" % (k, legs[k]["error"]) for k in failed), file=sys.stderr, flush=True)
         print(json.dumps(out), flush=True)
     if slab_attempted:
         sys.stdout.flush()

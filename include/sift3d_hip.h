@@ -93,6 +93,11 @@ int sift3d_run(sift3d_handle h);
  * Every accessor of a handle with a run in flight completes it first; sift3d_wait without a run in flight returns SIFT3D_OK. */
 int sift3d_run_async(sift3d_handle h);
 int sift3d_wait(sift3d_handle h);
+/* sift3d_run_async whose pipeline starts when the orientation stage of `after` (a handle with a run in flight on the same GPU) has ended:
+ * the memory-bound front of this volume (pyramid, extrema, orientation) runs beside the descriptor stage of the volume before it, which is
+ * bound by instruction issue and the LDS (Example.cpp:21-44 extracts two volumes back to back).  after == NULL / nothing in flight: plain
+ * sift3d_run_async. */
+int sift3d_run_async_after(sift3d_handle h, sift3d_handle after);
 
 /* Replaces calling the public stage methods one by one (Include/cSIFT3D.h:157-165); `upto`:
  * 1 Initialize+Build_Gaussian_Scale_Space(+fused DoG), 2 Build_DOG_Scale_Space, 3 Detect_KeyPoints,
@@ -246,6 +251,15 @@ int sift3d_slab_describe_finish(sift3d_handle h, const void *d_records, int n, i
                                 float *d_units_next /* [n] out */, int *n_redo);
 int sift3d_slab_orient_launch(sift3d_handle h);                     /* sift3d_slab_orient as two calls (several ranks in one process) */
 int sift3d_slab_orient_count(sift3d_handle h, int *n_kp);
+/* r06 -- the same stages without a host read-back in between (the native driver's critical path): sift3d_slab_keypoints_launch enqueues
+ * Detect_KeyPoints + Assign_Orientation of the owned planes and the read-back of their counts; sift3d_slab_keypoints_count waits for it
+ * (a list that overflowed is regrown and both stages repeated, blocking).  sift3d_slab_describe_finish_launch is the first round's finish
+ * with the count of flagged records read back asynchronously; sift3d_slab_describe_finish_count waits for it (0: results complete). */
+int sift3d_slab_keypoints_launch(sift3d_handle h);
+int sift3d_slab_keypoints_count(sift3d_handle h, int *n_kp);
+int sift3d_slab_describe_finish_launch(sift3d_handle h, const void *d_records, int n, int nparts, const int *const *d_hist,
+                                       const float *const *d_mass, int *d_redo /* [n] out */, float *d_units_next /* [n] out */);
+int sift3d_slab_describe_finish_count(sift3d_handle h, int *n_redo);
 /* DownSample_3D of the owned planes of G[octave][num_kp_levels] -> d_dst = (nx/2) x (ny/2) x ((z1-z0)/2) floats (device):
  * the owned planes of level 0 of the next octave (a sharded slab context of octave+1, or the all-gather buffer of the tail) */
 int sift3d_slab_decimate(sift3d_handle h, float *d_dst);
@@ -254,6 +268,9 @@ int sift3d_slab_decimate(sift3d_handle h, float *d_dst);
 int sift3d_create_seeded(sift3d_handle *out, int nx, int ny, int nz, int octave_base, int noct_total,
                          const sift3d_params *params, int device);
 int sift3d_seed_upload(sift3d_handle h, const float *level0, int on_device);
+/* device address of that level 0 (nx*ny*nz floats): a driver that gathers the seed level writes it in place on the stream it gave the
+ * handle (sift3d_set_stream) and follows with sift3d_run_async -- no staging copy, no host synchronisation */
+int sift3d_seed_buffer(sift3d_handle h, float **d_level0, size_t *floats);
 /* only keypoints with slot % world == rank are described by this handle (rows of the others stay zero) */
 int sift3d_set_describe_partition(sift3d_handle h, int rank, int world);
 /* Partitioned orientation of a replicated context: sift3d_run_partial_orientation runs the pyramid, the extrema scan and
@@ -277,24 +294,30 @@ int sift3d_import_descriptors_device(sift3d_handle h, const float *d_desc_src);
  * back (GetKeypoints, :1686-1688; reference order).  devices[ndev]: one rank per listed GPU, halo exchange over RCCL (ncclSend /
  * ncclRecv between z-neighbours over xGMI, one host thread per GPU; librccl is opened at run time).  sim_ranks > 0 (ndev == 1):
  * that many ranks simulated on the one device -- device copies instead of sends -- which is how 1-GPU boxes test the driver.
- * sharded_octaves: octaves split into slabs (0 = default 2); the remaining octaves run replicated from an all-gathered seed level.
+ * sharded_octaves: octaves split into slabs (0 = default 2); the remaining octaves run ONCE, on the last rank, from a seed level gathered there.
  * Results equal the single-GPU results: pyramid / extrema / orientation bit for bit, descriptors bit for bit as well (integer
  * histograms).  The C++ shell reaches it through CreateCSIFT3D when SIFT3D_DEVICES lists several GPUs.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct sift3d_sharded *sift3d_sharded_handle;
 int sift3d_sharded_create(sift3d_sharded_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
                           const int *devices, int ndev, int sim_ranks, int sharded_octaves);
-/* the same with option bits.  SIFT3D_SHARDED_PARTIAL_WINDOWS (r05, opt-in): the descriptor windows are split along z over the ranks
- * (records to the z-neighbours, partial integer histograms back: the sift3d_slab_describe_partial / _finish protocol above) instead of
- * carrying whole windows on 38-plane halos; same results bit for bit.  Refused when a slab is so thin that a window spans more than 6 ranks. */
+/* the same with option bits.  By default (r06) the descriptor windows are split along z over the ranks (records to the z-neighbours, partial
+ * integer histograms back: the sift3d_slab_describe_partial / _finish protocol above; level halos of 13 planes), and whole windows on 39-plane
+ * halos are what remains for slabs so thin that a window would span more than 6 ranks.  SIFT3D_SHARDED_WHOLE_WINDOWS asks for whole windows
+ * always; SIFT3D_SHARDED_PARTIAL_WINDOWS for partial windows or a refusal (no silent change of form).  Same results bit for bit. */
 #define SIFT3D_SHARDED_PARTIAL_WINDOWS 1u
+#define SIFT3D_SHARDED_WHOLE_WINDOWS 2u
 int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
                              const int *devices, int ndev, int sim_ranks, int sharded_octaves, unsigned flags);
 int sift3d_sharded_run(sift3d_sharded_handle h);
 int sift3d_sharded_num_keypoints(sift3d_sharded_handle h, int *n);
 int sift3d_sharded_get_keypoints(sift3d_sharded_handle h, sift3d_keypoint *out, float *desc /* n*768, may be NULL */);
-/* ranks, sharded octaves, halo planes; seconds[0] = wall time of the last run up to the results on the host, [1] = incl. the merge */
+/* ranks, sharded octaves, halo planes; seconds[0] = wall time of the last run (KpSiftAlgorithm: the results are complete on the devices),
+ * [1] = the same + the read-back of every rank's results and their merge, once sift3d_sharded_get_keypoints has run (r05 counted both in [0]) */
 int sift3d_sharded_info(sift3d_sharded_handle h, int *world, int *sharded_octaves, int *halo, double seconds[2]);
+/* the plan: descriptor windows split along z (1) or whole (0); the rank that also runs the octaves behind the sharded ones, once for the
+ * node (-1: the volume has none), and the planes of octave 0 every rank owns (that rank owns fewer) */
+int sift3d_sharded_plan(sift3d_sharded_handle h, int *partial_windows, int *tail_rank, int *planes /* [world] or NULL */);
 const char *sift3d_sharded_error(sift3d_sharded_handle h);
 int sift3d_sharded_destroy(sift3d_sharded_handle h);
 

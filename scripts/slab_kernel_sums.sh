@@ -1,18 +1,21 @@
 #!/bin/bash
 # where the GPU time of the simulated 8-rank z-slab run goes: per-kernel sums of ONE step (rocprofv3 kernel trace of bench.py --workload slab --sim-ranks 8)
+#   slab_kernel_sums.sh [ranks] [native]      native: the C++ driver (csrc/sharded.hip) instead of 3dsift_amd/slab.py
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-rm -rf /tmp/p_ss; rocprofv3 --kernel-trace -d /tmp/p_ss --output-format csv -- python3 $R/bench.py --workload slab --sim-ranks ${1:-8} --steps 1 --warmup 1 > /tmp/p_ss.out 2>/dev/null
+NATIVE=""; export S3D_NSTEPS=3
+if [ "$2" = "native" ]; then NATIVE="--native"; export S3D_NSTEPS=2; fi
+rm -rf /tmp/p_ss; rocprofv3 --kernel-trace -d /tmp/p_ss --output-format csv -- python3 $R/bench.py --workload slab $NATIVE --sim-ranks ${1:-8} --steps 1 --warmup 1 > /tmp/p_ss.out 2>/dev/null
 f=$(find /tmp/p_ss -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
-import csv,sys,collections
+import csv,sys,collections,os
 rows=[r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 # bench.py runs the workload three times (first call, warm-up, timed step): a step begins with its ranks' level-0 launches
 # (k_march_level<2, ...), take everything from the first of the last step's on
 s3=[r for r in rows if 's3d::' in r['Kernel_Name']]
 l0=[i for i,r in enumerate(s3) if 'k_march_level<2' in r['Kernel_Name']]
-nsteps=3
+nsteps=int(os.environ.get("S3D_NSTEPS","3"))
 last=s3[l0[len(l0)-len(l0)//nsteps]:]
 t0=int(last[0]['Start_Timestamp']); t1=max(int(r['End_Timestamp']) for r in last)
 tot=collections.defaultdict(float); cnt=collections.Counter()
@@ -37,11 +40,11 @@ for q,d in sorted(perq.items(), key=lambda x:-sum(x[1].values())):
 PY
 python3 - "$f" <<'PY'
 # idle gaps of the busiest queue (the sharded stages' stream): what the GPU waits for between its kernels
-import csv,sys,collections
+import csv,sys,collections,os
 rows=[r for r in csv.DictReader(open(sys.argv[1])) if 's3d::' in r['Kernel_Name']]
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 l0=[i for i,r in enumerate(rows) if 'k_march_level<2' in r['Kernel_Name']]
-last=rows[l0[len(l0)-len(l0)//3]:]
+last=rows[l0[len(l0)-len(l0)//int(os.environ.get("S3D_NSTEPS","3"))]:]
 cnt=collections.Counter(r.get('Queue_Id','?') for r in last)
 q=cnt.most_common(1)[0][0]
 qs=[r for r in last if r.get('Queue_Id','?')==q]

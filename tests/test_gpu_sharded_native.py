@@ -2,11 +2,12 @@
 the C-ABI sift3d_sharded_* and through the C++ shell (CSIFT3DFactory::CreateCSIFT3D with SIFT3D_SIM_RANKS / SIFT3D_DEVICES).
 
 A 1-GPU box cannot run several RCCL ranks (one rank per device), so the driver is checked in two ways:
-  * simulated ranks (device copies instead of ncclSend / ncclRecv, same plan, same slab contexts, same merge): 2, 3 (uneven), 4 and
-    8 ranks, one and two sharded octaves -- keypoints AND descriptors bit-identical to the single-volume extractor;
-  * the RCCL transport itself with a world of ONE rank on the one GPU: librccl is opened, three communicators are created, the
-    MAX all-reduce of the DoG maxima, the broadcast group of the seed level and the integer SUM all-reduce of the tail's
-    orientation rows really run through RCCL on the device (the point-to-point halo sends need a second GPU)."""
+  * simulated ranks (device copies instead of ncclSend / ncclRecv, same plan, same slab contexts, same merge): 2 .. 8 ranks, one and
+    two sharded octaves, the default plan (descriptor windows split along z, the tail once on the last rank), forced partial and forced
+    whole windows -- keypoints AND descriptors bit-identical to the single-volume extractor;
+  * the RCCL transport itself with a world of ONE rank on the one GPU: librccl is opened, three communicators are created and the MAX
+    all-reduce of the DoG maxima really runs through RCCL on the device (the point-to-point halo sends and the gather of the tail's seed
+    level need a second GPU)."""
 import importlib
 import os
 import struct
@@ -34,10 +35,11 @@ def vol_and_single():
 
 @pytest.mark.parametrize("ranks,octs", [(2, 1), (2, 2), (3, 2), (4, 2), (8, 2), (5, 1)])
 def test_simulated_ranks_equal_the_single_volume(vol_and_single, ranks, octs):
+    """whole descriptor windows on the wide halos (SIFT3D_SHARDED_WHOLE_WINDOWS; r05's default, still what slabs too thin for the split get)"""
     vol, kp, ds = vol_and_single
-    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs)
+    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=False)
     info = sh.info()
-    assert info["world"] == ranks and 1 <= info["sharded_octaves"] <= octs
+    assert info["world"] == ranks and 1 <= info["sharded_octaves"] <= octs and not info["partial_windows"] and info["halo"] == capi.slab_min_halo()
     for _ in range(2):   # a second run on the same contexts gives the same result
         k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
         assert np.array_equal(k2, kp), (ranks, octs)
@@ -52,12 +54,40 @@ def test_simulated_ranks_with_partial_descriptor_windows_equal_the_single_volume
     vol, kp, ds = vol_and_single
     sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=True)
     info = sh.info()
-    assert info["world"] == ranks and info["halo"] == capi.slab_min_halo_partial()
+    assert info["world"] == ranks and info["halo"] == capi.slab_min_halo_partial() and info["partial_windows"]
     for _ in range(2):
         k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
         assert np.array_equal(k2, kp), (ranks, octs)
         assert np.array_equal(d2, ds), (ranks, octs)
     sh.close()
+
+
+@pytest.mark.parametrize("ranks,octs", [(2, 2), (4, 2), (8, 2), (6, 1)])
+def test_default_plan_splits_the_windows_and_runs_the_tail_once(vol_and_single, ranks, octs):
+    """r06 defaults of sift3d_sharded_create: descriptor windows split along z wherever a window spans at most six ranks (8 ranks x 2 octaves of
+    the 160-plane volume: whole windows instead), the octaves behind the sharded ones run ONCE, on the last rank, which owns fewer planes."""
+    vol, kp, ds = vol_and_single
+    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs)
+    info = sh.info()
+    assert info["partial_windows"] == (not (ranks == 8 and octs == 2)), info
+    assert info["tail_rank"] == ranks - 1 and sum(info["planes"]) == vol.shape[0] and info["planes"][-1] <= min(info["planes"][:-1]), info
+    for _ in range(2):
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        assert np.array_equal(k2, kp), info
+        assert np.array_equal(d2, ds), info
+    assert sh.info()["seconds_incl_merge"] > sh.info()["seconds"] > 0
+    sh.close()
+
+
+def test_native_list_regrow_without_readbacks(vol_and_single):
+    """the slab contexts' lists start tiny (hook list_cap): the overflow is found when the counts are read (sift3d_slab_keypoints_count), the lists
+    are regrown and detection + orientation repeated -- same results"""
+    vol, kp, ds = vol_and_single
+    with capi.hook("list_cap", 48):
+        sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=3, sharded_octaves=2)
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        sh.close()
+    assert np.array_equal(k2, kp) and np.array_equal(d2, ds)
 
 
 def test_native_partial_windows_second_round_and_thin_slabs(vol_and_single):
@@ -77,8 +107,8 @@ def test_native_partial_windows_second_round_and_thin_slabs(vol_and_single):
 
 
 def test_random_native_plans_equal_the_single_volume():
-    """Six random (shape, simulated ranks, sharded octaves, whole / partial descriptor windows) draws through the native driver: keypoints and descriptors bit-identical
-    to the single-volume extractor (uneven slabs, odd depths, slabs thinner than the halo)."""
+    """Six random (shape, simulated ranks, sharded octaves, default / partial / whole descriptor windows) draws through the native driver: keypoints and descriptors
+    bit-identical to the single-volume extractor (uneven slabs, odd depths, slabs thinner than the halo)."""
     rng = np.random.default_rng(808)
     done = 0
     for case in range(40):
@@ -88,14 +118,14 @@ def test_random_native_plans_equal_the_single_volume():
         ranks = int(rng.integers(2, 7)); octs = int(rng.integers(1, 3))
         vol = synth.blobs((nz, ny, nx), seed=900 + case, noise=0.01)
         try:   # every other case with the descriptor windows split along z
-            sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=bool(case & 1))
+            sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=(None, True, False)[case % 3])
         except capi.Sift3dError:
             continue   # (too few planes for that many slabs, or slabs too thin for partial windows)
         ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
         kp, ds = ex.GetKeypoints()
         with capi.hook("march_tiles", done & 1):   # every second plan with the 64 x 32 tiles wherever a slab's levels fit them
             k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
-        tag = ((nz, ny, nx), ranks, octs, case & 1, sh.info())
+        tag = ((nz, ny, nx), ranks, octs, case % 3, sh.info())
         sh.close(); ex.close()
         assert np.array_equal(k2, kp), tag
         assert np.array_equal(d2, ds), tag
@@ -103,7 +133,7 @@ def test_random_native_plans_equal_the_single_volume():
     assert done == 6
 
 
-@pytest.mark.parametrize("partial", [False, True])
+@pytest.mark.parametrize("partial", [False, True, None])
 def test_rccl_transport_world_of_one(vol_and_single, partial):
     vol, kp, ds = vol_and_single
     sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=0, sharded_octaves=2, partial_windows=partial)   # one real rank: every collective goes through librccl
@@ -139,12 +169,12 @@ def test_cpp_shell_shards_for_the_unchanged_user():
         subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(PKG, "host"), "-o", os.path.join(t, "m"), os.path.join(t, "m.cpp"),
                                "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-Wl,-rpath," + PKG])
         outs = []
-        for env in ({}, {"SIFT3D_SIM_RANKS": "4"}, {"SIFT3D_DEVICES": "0"}, {"SIFT3D_SIM_RANKS": "3", "SIFT3D_PARTIAL_WINDOWS": "1"}):
+        for env in ({}, {"SIFT3D_SIM_RANKS": "4"}, {"SIFT3D_DEVICES": "0"}, {"SIFT3D_SIM_RANKS": "3", "SIFT3D_PARTIAL_WINDOWS": "1"}, {"SIFT3D_SIM_RANKS": "3", "SIFT3D_PARTIAL_WINDOWS": "0"}):
             e = dict(os.environ, **env)
             o = subprocess.check_output([os.path.join(t, "m"), os.path.join(t, "v.bin"), os.path.join(t, "k.bin")], env=e, stderr=subprocess.STDOUT).decode()
             outs.append((o.strip().splitlines()[-1].split()[1], open(os.path.join(t, "k.bin"), "rb").read()))
     assert int(outs[0][0]) > 30
-    assert outs[1] == outs[0] and outs[2] == outs[0] and outs[3] == outs[0]
+    assert all(o == outs[0] for o in outs[1:])
 
 
 def test_bench_runs_the_native_legs_in_a_child_process():
@@ -155,10 +185,10 @@ def test_bench_runs_the_native_legs_in_a_child_process():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     bench = importlib.import_module("bench")
-    for partial in (False, True):
+    for partial in (None, False):
         res, err = bench.run_slab_native_child("256x192x128", 1, 2, 1, partial, 240)
         assert err is None, err
         assert res["keypoints"] > 100 and res["ms_per_step"] > 0
-        assert res["descriptor_windows"] == ("partial integer histograms" if partial else "whole windows on plane halos")
+        assert res["descriptor_windows"] == ("whole windows on plane halos" if partial is False else "partial integer histograms")
     res, err = bench.run_slab_native_child("8x8x4", 1, 1, 0, False, 120)
     assert res is None and err
