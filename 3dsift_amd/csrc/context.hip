@@ -1858,7 +1858,7 @@ extern "C" int sift3d_slab_create(sift3d_handle *out, const sift3d_slab_desc *d,
 	// the march kernel is the only slab-aware Gaussian: default half widths, planes of at least 32 x 32 voxels (and not 33 .. 31 + hw)
 	for (int i = c->seeded ? 1 : 0; i < c->ng; i++) {
 		const int hw = i == 0 ? c->base_taps.hw : c->taps[i].hw;
-		const bool inst = hw == 2 || hw == 3 || hw == 4 || hw == 5 || hw == 6 || hw == 8;
+		const bool inst = hw >= 2 && hw <= 8;
 		auto fits = [&](int n) { return n == 32 || n >= 32 + hw; };
 		if (!inst || !fits(c->nx) || !fits(c->ny) || hw + 1 > c->halo) {
 			sift3d_destroy(c); *out = nullptr;

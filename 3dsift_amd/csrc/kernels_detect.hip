@@ -299,9 +299,10 @@ __device__ __forceinline__ void lazy_tap_src(int p, int d, int n, int &lo, int &
 	lo = min(max(lo, 0), dim_end);  // same clamp as boundary_term (kernels_pyramid.hip)
 	hi = min(max(hi, 0), dim_end);
 }
-constexpr int kLT = kLazySlots / 2 - 1;   // taps at most (17)
-constexpr int kLR = kLT + 1;              // real samples an axis reads: one contiguous range of at most 2 hw + 2 indices
-constexpr int kLP = kLR + 1;              // x pitch of the staged block (odd: lanes = rows read conflict-free)
+// k_lazy_next<LT>: LT = taps at most.  17 (half width <= 8: the default parameters' last level; 24.6 KB of LDS, six workgroups per CU) and,
+// r06, 25 (half width <= 12: the last level of sigma_default up to 2.6 -- it used to be BUILT by three separable passes, the single most
+// expensive level of such a run, because the lazy form stopped at 8; 73 KB, two workgroups per CU, a few thousand candidates per volume)
+static_assert(kLazySlots / 2 - 1 == 25, "k_lazy_next's wide instantiation covers kLazySlots");
 // ---- r05: k_lazy_wave -- ONE WAVE per parked candidate that is interior along all three axes, default half width 8 ----
 // (r02-r04: one 256-thread workgroup per candidate, 189 registers, two workgroups per CU, five barriers, y-blur on 17 threads and z-blur
 // on one: ~15 us per candidate with 512 candidates in flight -- 1.3 ms of kernel time per 512^3 step over three queues, 0.29 ms of it on
@@ -398,12 +399,15 @@ __global__ void __launch_bounds__(64 * kLwWaves) k_lazy_wave(DetectLevels L, Tap
 }
 
 // the other parked candidates (next to a border of the level, or half widths other than 8): one WORKGROUP per candidate
+template <int kLT>
 __global__ void __launch_bounds__(256) k_lazy_next(DetectLevels L, Taps t, int nx, int ny, ZRange zr, int nyb,
                                                    const unsigned *__restrict__ prov, const unsigned *__restrict__ prov_count,
                                                    unsigned prov_cap, unsigned long long *__restrict__ masks,
                                                    unsigned *__restrict__ block_counts, int skip_interior) {
 	// the block of real samples the three passes reach (at most 18^3 voxels, rows contiguous in memory) is staged in LDS with
 	// coalesced loads, then x-blur per (row, plane), y-blur per plane, z-blur
+	constexpr int kLR = kLT + 1;              // real samples an axis reads: one contiguous range of at most 2 hw + 2 indices
+	constexpr int kLP = kLR + 1;              // x pitch of the staged block (odd: lanes = rows read conflict-free)
 	__shared__ float s_blk[kLR * kLR * kLP];
 	__shared__ float s_x[kLR * kLR];
 	__shared__ float s_y[kLR];
@@ -722,8 +726,12 @@ void launch_detect_mark(const DetectLevels &L, int nlevels, int nx, int ny, cons
 		if (wave_form)
 			hipLaunchKernelGGL(k_lazy_wave, dim3(256 * 3), dim3(64 * kLwWaves), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
 			                   b.masks, b.block_counts);
-		hipLaunchKernelGGL(k_lazy_next, dim3(wave_form ? 1536 : 1024), dim3(256), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
-		                   b.masks, b.block_counts, wave_form ? 1 : 0);
+		if (2 * lazy_taps->hw + 1 <= 17)
+			hipLaunchKernelGGL(k_lazy_next<17>, dim3(wave_form ? 1536 : 1024), dim3(256), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
+			                   b.masks, b.block_counts, wave_form ? 1 : 0);
+		else
+			hipLaunchKernelGGL(k_lazy_next<25>, dim3(512), dim3(256), 0, st, L, *lazy_taps, nx, ny, zr, nyb, b.prov, b.prov_count, b.prov_cap,
+			                   b.masks, b.block_counts, 0);
 	}
 }
 

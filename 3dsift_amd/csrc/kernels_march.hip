@@ -638,7 +638,7 @@ bool march_applicable(int nx, int ny, int nzg, const Taps &t) {
 	// for their first columns since r03; no test or bench shape had such a level)
 	const int hx = ((t.hw + 3) / 4) * 4;
 	if (!(nx == 32 || nx >= 32 + hx) || !(ny == 32 || ny >= 32 + t.hw) || nzg < 2 * t.hw + 2) return false;
-	if (!(t.hw == 2 || t.hw == 3 || t.hw == 4 || t.hw == 5 || t.hw == 6 || t.hw == 8)) return false;
+	if (!(t.hw >= 2 && t.hw <= kMarchMaxHW)) return false;  // (r06: hw 7 -- sigma_default 1.65 .. 1.75 -- has its instantiation too)
 	// the symmetric form of the z-scatter needs what GaussianSmooth_3D's generator gives: tap[hw + d] == tap[hw - d] bit for bit
 	for (int d = 1; d <= t.hw; d++) if (memcmp(&t.w[t.hw + d], &t.w[t.hw - d], sizeof(float)) != 0) return false;
 	return true;
@@ -666,6 +666,7 @@ bool launch_march_level(const float *src, float *dst, float *dog, unsigned *dogm
 	case 4: launch_march_hw<4>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
 	case 5: launch_march_hw<5>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
 	case 6: launch_march_hw<6>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
+	case 7: launch_march_hw<7>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
 	case 8: launch_march_hw<8>(src, dst, dog, dogmax, nx, ny, zr, t, st, plan_slots, prio, hf); return true;
 	default: return false;
 	}

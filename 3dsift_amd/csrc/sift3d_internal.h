@@ -192,7 +192,7 @@ struct DetectLevels {
 	int level_id[kMaxKpLevels];
 	float scale[kMaxKpLevels];
 };
-constexpr int kLazySlots = 36;  // k_lazy_next: 2 * (2 hw + 1) source slots per axis (boundary voxels) fit for hw <= 8
+constexpr int kLazySlots = 52;  // k_lazy_next: 2 * (2 hw + 1) source slots per axis (boundary voxels) fit for hw <= 12 (r06; 36 / hw <= 8 before)
 void launch_detect_mark(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, float peak_thresh, int octave,
                         const DetectBufs &b, hipStream_t st, const Taps *lazy_taps);
 void launch_detect_emit(const DetectLevels &L, int nlevels, int nx, int ny, const ZRange &zr, int octave, const DetectBufs &b, DevKp *out,

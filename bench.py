@@ -442,12 +442,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_nonaligned:
         # ---- a volume whose width and height are NOT multiples of the 32 x 32 tile of the level kernel (not part of `value`): the
         # pyramid stage priced like the headline's, per pyramid voxel
-        def leg(dims):
+        def leg(dims, **params):
             nx2, ny2, nz2 = dims
             shape2 = (nz2, ny2, nx2)
             v2 = synth.blobs_torch(shape2, dev, seed=4242)
             torch.cuda.synchronize()
-            e2 = capi.CSIFT3D(None, device=local, device_ptr=v2.data_ptr(), shape=shape2)
+            e2 = capi.CSIFT3D(None, device=local, device_ptr=v2.data_ptr(), shape=shape2, **params)
             e2.KpSiftAlgorithm()
             st2, t2 = {}, []
             for _ in range(5):
@@ -477,6 +477,17 @@ def main():
         cube = leg((ce, ce, ce))
         out["thin"]["equal_voxel_cube"] = {k: cube[k] for k in ("workload", "ms_per_step", "stage_ms", "pyramid_ns_per_pyramid_voxel")}
         out["thin"]["pyramid_ns_per_voxel_vs_equal_voxel_cube"] = out["thin"]["pyramid_ns_per_pyramid_voxel"] / cube["pyramid_ns_per_pyramid_voxel"]
+        # ---- other constructor arguments (Include/cSIFT3D.h:187-194 makes them ordinary arguments): the pyramid stage per pyramid
+        # voxel against the headline's.  sigma_default 2.0: half widths 4, 4, 5, 6, 8 fused and 10 for the last level (r06: evaluated at the
+        # parked candidates like the default's, it used to be BUILT by three separable passes); 1.7: half width 7 (r06: fused); two keypoint levels
+        out["other_parameters"] = {}
+        for tag, prm in (("sigma_default_2.0", dict(sigma_default=2.0)), ("sigma_default_1.7", dict(sigma_default=1.7)), ("num_kp_levels_2", dict(num_kp_levels=2))):
+            try:
+                lg = leg((n, n, n), **prm)
+                out["other_parameters"][tag] = {"ms_per_step": lg["ms_per_step"], "stage_ms": lg["stage_ms"], "pyramid_ns_per_pyramid_voxel": lg["pyramid_ns_per_pyramid_voxel"],
+                                                "pyramid_ns_per_voxel_vs_headline": lg["pyramid_ns_per_pyramid_voxel"] / (t_pyr / pv * 1e9)}
+            except Exception as e:  # noqa: BLE001 -- a side leg
+                out["other_parameters"][tag] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_sample > 0:
         # ---- CPU baseline + parity on a bounded sample: the [0:s]^3 crop of the same volume ----
         import oracle_lib as ol  # test infrastructure, used here ONLY as the timed baseline / checker

@@ -66,6 +66,65 @@ def test_config4_all_56_ordered_pairs_vs_oracle(orc):
     assert related == 8
 
 
+def test_config4_at_full_size_eight_512_cubed_volumes(orc):
+    """BASELINE configs[4] at its FULL size (the test above runs 8 x 256^3): eight 512^3 volumes extracted one after the other
+    (only the device-resident descriptors are kept), all 56 ordered pairs through enhancedMatch on the device.  The oracle's matcher takes
+    ~3 s per pair of 11 000-keypoint sets on the box's cores, so 16 of the 56 -- the 8 true correspondences and 8 unrelated pairs -- are
+    compared with it bit for bit; every pair is checked for the properties the reference's filter guarantees (Src/cMatcher.cc:81-144,
+    146-228) and against a second run through the host-input path of sift3d_match."""
+    import os
+    import torch
+
+    NF = 512
+    dev = torch.device("cuda", 0)
+    descs, xyzs, host = [], [], []
+    for k in range(WORLD):
+        vol = synth.blobs_torch((NF, NF, NF), dev, seed=1234 + k // 2, shift=(float(k % 2), 0.0, 0.0))
+        torch.cuda.synchronize()
+        ex = capi.CSIFT3D(None, device_ptr=vol.data_ptr(), shape=(NF, NF, NF)).KpSiftAlgorithm()
+        kp, ds = ex.GetKeypoints()
+        n = len(kp)
+        assert n > 5000
+        d_t = torch.empty((n, 768), dtype=torch.float32, device=dev)
+        x_t = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        ex.export_device(d_t.data_ptr(), x_t.data_ptr())
+        torch.cuda.synchronize()
+        descs.append(d_t); xyzs.append(x_t)
+        host.append((ds, np.stack([kp["rx"], kp["ry"], kp["rz"]], 1)))
+        ex.close()
+        del vol
+    mt = capi.muBruteMatcher()
+
+    def match_fn(da, xa, db, xb):
+        return mt.enhancedMatch(da.data_ptr(), xa.data_ptr(), db.data_ptr(), xb.data_ptr(), 0.85, on_device=True, n=da.shape[0], m=db.shape[0])
+
+    got = {}
+    for rank in range(WORLD):
+        got.update(dist.match_pairs(descs, xyzs, match_fn, rank, WORLD))
+    assert sorted(got) == sorted(dist.ordered_pairs(WORLD)) and len(got) == 56
+    for (i, j), res in sorted(got.items()):
+        n, m = len(host[i][0]), len(host[j][0])
+        g, sdx, gd, sd = res["gIdx"], res["sIdx"], res["gDist"], res["sDist"]
+        assert len(g) == n and ((g > -m) & (g < m)).all()                                 # a rejected match keeps its index, negated (Src/cMatcher.cc:93)
+        ok = g >= 0
+        assert (gd <= sd).all() and len(res["pairs"]) == int(ok.sum())                      # best <= second best; one pair per survivor (toCvec)
+        assert np.array_equal(res["pairs"][:, :3], host[i][1][ok]) and np.array_equal(res["pairs"][:, 3:], host[j][1][g[ok]])
+        if i // 2 == j // 2:
+            assert ok.sum() > 0.5 * n, (i, j, int(ok.sum()))                              # the shifted copy: most keypoints correspond
+    # the same 56 through the host-input path (H2D of both sets inside the call): the same answers
+    for (i, j) in [(0, 1), (2, 5), (7, 3)]:
+        again = mt.enhancedMatch(host[i][0], host[i][1], host[j][0], host[j][1], 0.85)
+        for key in again:
+            assert np.array_equal(again[key], got[(i, j)][key]), (i, j, key)
+    orc.set_threads(max(1, min(64, (os.cpu_count() or 2) // 2)))
+    checked = [(i, j) for (i, j) in sorted(got) if i // 2 == j // 2] + [(0, 2), (1, 4), (2, 7), (3, 0), (4, 6), (5, 1), (6, 3), (7, 5)]
+    assert len(checked) == 16
+    for (i, j) in checked:
+        want = orc.match(host[i][0], host[i][1], host[j][0], host[j][1], 0.85, 3)
+        for key in want:
+            assert np.array_equal(got[(i, j)][key], want[key]), (i, j, key)
+
+
 def test_match_handles_all_ordered_pairs_and_peer_copy_path(orc):
     """sift3d_match_handles (r04): the native building block of configs[4] -- the device-resident results of two extractors matched
     wherever they live.  Four live extractors, all twelve ordered pairs, every output equal to the oracle's matcher on the host copies;

@@ -264,7 +264,9 @@ def test_nondefault_num_kp_levels(capi, orc, synth, levels):
 
 
 @pytest.mark.parametrize("params", [
-    dict(sigma_default=2.0),                          # wider kernels: half widths without a fused instantiation
+    dict(sigma_default=2.0),                          # wider kernels: the last level (half width 10) evaluated at the parked candidates by k_lazy_next<25>
+    dict(sigma_default=1.7),                          # half width 7: fused since r06
+    dict(sigma_default=2.3),                          # half width 9 (separable) and 11 (lazy)
     dict(sigma_default=1.3, sigma_n_default=0.9),     # narrower base blur
     dict(peak_thresh=0.05),                           # many more extrema
     dict(peak_thresh=0.3, max_eig_thres=0.95, corner_thresh=0.2),
