@@ -51,13 +51,13 @@ SYMBOLS = [
     "sift3d_slab_orient_count",
     # r06: the same stages without host read-backs, the tail's seed level in place, the native driver's plan
     "sift3d_slab_keypoints_launch", "sift3d_slab_keypoints_count", "sift3d_slab_describe_finish_launch", "sift3d_slab_describe_finish_count",
-    "sift3d_seed_buffer", "sift3d_sharded_plan",
+    "sift3d_seed_buffer", "sift3d_sharded_plan", "sift3d_slab_describe_launch",
     # test hooks / debug accessors / matcher timing
     # native driver of the z-slab sharding
     "sift3d_sharded_create", "sift3d_sharded_create_ex", "sift3d_sharded_run", "sift3d_sharded_num_keypoints", "sift3d_sharded_get_keypoints", "sift3d_sharded_info",
     "sift3d_sharded_error", "sift3d_sharded_destroy",
     "sift3d_test_hook", "sift3d_debug_counters", "sift3d_debug_face_lookup", "sift3d_match_times", "sift3d_debug_copy_bandwidth",
-    "sift3d_match_warmup", "sift3d_test_staging_slice",
+    "sift3d_match_warmup", "sift3d_test_staging_slice", "sift3d_test_sharded_time_rank",
 ]
 HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "desc_nocache": 4, "match_nodma": 5, "one_stream": 6,
          "desc_mass_shift": 7, "list_cap": 8, "peer_copy": 9, "desc_nosplit": 10, "march_tiles": 11, "desc_exact_cells": 12, "lazy_generic": 13}
@@ -178,7 +178,7 @@ def lib():
         L.sift3d_sharded_error.argtypes = [C.c_void_p]
         L.sift3d_sharded_error.restype = C.c_char_p
         L.sift3d_sharded_destroy.argtypes = [C.c_void_p]
-        L.sift3d_sharded_plan.argtypes = [C.c_void_p, _ip, _ip, _ip]
+        L.sift3d_sharded_plan.argtypes = [C.c_void_p, _ip, _ip, _ip, _ip]
         L.sift3d_test_hook.argtypes = [C.c_int, C.c_int]
         L.sift3d_debug_counters.argtypes = [C.c_void_p, _ip]
         L.sift3d_debug_face_lookup.argtypes = [_fp, C.c_int, C.c_int, _ip, _fp, C.c_int]
@@ -646,10 +646,19 @@ class ShardedCSIFT3D:
     def info(self):
         w = C.c_int(0); s = C.c_int(0); h = C.c_int(0); t = (C.c_double * 2)()
         _check(lib().sift3d_sharded_info(self._h, C.byref(w), C.byref(s), C.byref(h), t))
-        pw = C.c_int(0); tr = C.c_int(0); pl = (C.c_int * max(1, w.value))()
-        _check(lib().sift3d_sharded_plan(self._h, C.byref(pw), C.byref(tr), pl))
+        pw = C.c_int(0); tr = C.c_int(0); pl = (C.c_int * max(1, w.value))(); sp = (C.c_int * max(1, s.value))()
+        _check(lib().sift3d_sharded_plan(self._h, C.byref(pw), C.byref(tr), pl, sp))
         return {"world": w.value, "sharded_octaves": s.value, "halo": h.value, "seconds": t[0], "seconds_incl_merge": t[1],
-                "partial_windows": bool(pw.value), "tail_rank": tr.value, "planes": [int(v) for v in pl][:w.value]}
+                "partial_windows": bool(pw.value), "stage_partial": [bool(v) for v in sp][:s.value], "tail_rank": tr.value, "planes": [int(v) for v in pl][:w.value]}
+
+    def time_rank(self, rank):
+        """simulated ranks, after a run: the GPU time (s) of one rank's whole step, re-run alone (sift3d_test_sharded_time_rank)"""
+        t = C.c_double(0)
+        lib().sift3d_test_sharded_time_rank.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        rc = lib().sift3d_test_sharded_time_rank(self._h, int(rank), C.byref(t))
+        if rc:
+            raise Sift3dError(f"{lib().sift3d_error_string(rc).decode()}: {lib().sift3d_last_error().decode()}")
+        return t.value
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

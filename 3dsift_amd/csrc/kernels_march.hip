@@ -579,7 +579,10 @@ static void launch_march_hw(const float *src, float *dst, float *dog, unsigned *
 // r04: the 64 x 32 tiles of the big levels (MCfg<HW, 64>): eight waves, two workgroups per CU, planned for 512 slots.
 static bool march_wide_ok(int nx, int ny, int nzo, int hw, int plan_slots) {
 	const int mode = hook(SIFT3D_HOOK_MARCH_TILES);  // 0 product rule, 1 wherever the geometry allows (parity tests on small volumes), 2 never
-	if (mode == 2 || plan_slots > 0 || hw < 2 || hw > 6) return false;  // (a planned launch shares the machine with another octave: 32 x 32 tiles, three per CU)
+	// (a planned launch shares the machine with another octave: 32 x 32 tiles, three per CU.  r06, measured again with the wide form for octave 0's
+	// widest level beside the chain of the smaller octaves -- S3D_WIDE_TAIL=1 in a -DS3D_DEV_SWITCHES build: see docs/experiments.md)
+	static const int wide_tail = dev_tune_i("S3D_WIDE_TAIL", 0);
+	if (mode == 2 || (plan_slots > 0 && !(wide_tail && plan_slots >= 512)) || hw < 2 || hw > 6) return false;
 	if (!(nx == 64 || nx >= 64 + ((hw + 3) / 4) * 4)) return false;  // the shifted last tile column starts at nx - 64: 0 or beyond the left halo (march_applicable)
 	const int ntiles = ((nx + 63) / 64) * ((ny + 31) / 32);
 	// (short columns: four chunks of a few planes + the ramp cost what three chunks of the 32 x 32 form do -- 512 x 512 x 32: 0.384 vs 0.376 ms)

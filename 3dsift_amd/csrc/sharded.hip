@@ -204,6 +204,27 @@ struct Worker {  // the sharded octaves of one rank (+ the tail's extractor on t
 	std::string err;
 };
 
+// device scratch of one rank for one round of one stage: pointers into Worker::pscratch
+struct PartLayout {
+	char *recs = nullptr;                      // this rank's records, processing order (round 2: the flagged subset)
+	float *units = nullptr;                    // round 2: their exact units
+	int *redo = nullptr; float *units_next = nullptr;
+	std::map<int, char *> recs_in;             // neighbour r's records
+	std::map<int, float *> units_in;
+	std::map<int, int *> part_h;               // this rank's part of the windows of r's records (r = itself or a neighbour)
+	std::map<int, float *> part_m;
+	std::map<int, int *> got_h;                // neighbour q's part of this rank's records
+	std::map<int, float *> got_m;
+};
+
+// a stage's first round of partial windows: who exchanges with whom, how many records, where every rank's lists live
+struct PartStage {
+	std::vector<std::vector<int>> neigh;
+	std::vector<int> counts;
+	std::vector<PartLayout> L;
+	size_t rb = 0;
+};
+
 }  // namespace
 
 struct sift3d_sharded {
@@ -212,7 +233,10 @@ struct sift3d_sharded {
 	sift3d_params p{};
 	std::vector<int> devices;
 	std::vector<Worker> workers;
-	std::vector<int> need, hws;
+	std::vector<std::vector<int>> need;  // per sharded octave: halo planes of every Gaussian level its consumers reach
+	std::vector<int> hws;
+	std::vector<char> stage_partial;     // per sharded octave: descriptor windows split along z (else whole windows on that octave's wide halos)
+	std::vector<int> stage_halo;         // ... and the halo planes its level buffers carry
 	std::vector<int> counts2;   // planes of the tail's seed level owned per rank
 	int sx = 0, sy = 0, sz = 0; // dims of the tail's seed level
 	int tail_rank = -1;         // the rank that runs the octaves >= S (-1: none)
@@ -223,6 +247,10 @@ struct sift3d_sharded {
 	// threads and read by all of them behind a rendezvous
 	bool partial = false;
 	std::vector<std::vector<int>> kp_count, redo_count;
+	// simulated ranks only: the layouts of the last full run (one PartStage per sharded octave, L indexed by rank), and the flag of a SOLO
+	// re-run of one rank on the buffers that run left behind (sift3d_test_sharded_time_rank: what ONE rank does in a step, timed alone)
+	std::vector<PartStage> ps_last;
+	bool solo = false;
 	std::mutex rv_mu;
 	std::condition_variable rv_cv;
 	int rv_arrived = 0;
@@ -272,6 +300,7 @@ int exchange(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<Tra
 		Worker &w0 = *ws[0];
 		CopySegs cs;
 		for (const Transfer &t : ts) {
+			if (H->solo && t.dst != w0.rank) continue;  // (solo: only what this rank RECEIVES; its neighbours' buffers hold the last full run's planes)
 			Stage &s = H->workers[(size_t)t.src].stages[(size_t)t.stage], &d = H->workers[(size_t)t.dst].stages[(size_t)t.stage];
 			float *sp = s.view(t.kind, t.idx, t.zg0, t.zg1), *dp = d.view(t.kind, t.idx, t.zg0, t.zg1);
 			if (!sp || !dp) { set_err(w0, "halo transfer outside a level buffer"); return SIFT3D_ERR_STATE; }
@@ -306,6 +335,7 @@ int exchange(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<Tra
 
 // in-place MAX over the ranks of n device floats per worker (non-negative values: the DoG maxima), stream ordered for RCCL
 int allreduce_max_dev(sift3d_sharded *H, std::vector<Worker *> &ws, int stage, int n) {
+	if (H->sim && H->solo) return SIFT3D_OK;  // (the rank's buffer still holds the global maxima of the last full run: run_local skips the export)
 	if (H->sim) {
 		Worker &w0 = *ws[0];
 		if ((int)ws.size() <= kMaxMergePtrs && n <= 64) {  // on the device, in the shared stream's order (no host round trip)
@@ -333,9 +363,8 @@ int allreduce_max_dev(sift3d_sharded *H, std::vector<Worker *> &ws, int stage, i
 }
 
 // The tail's seed level = the owned planes of all ranks, in rank order, gathered ON THE TAIL RANK straight into level 0 of its seeded
-// extractor, on that extractor's stream; then the tail's whole KpSiftAlgorithm is enqueued behind it (sift3d_run_async: the tail's own
-// streams, beside the rank's slab work; sift3d_wait at the end of the run).  The tail rank's own planes were decimated in place.
-int gather_seed_and_start_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
+// extractor, on that extractor's stream.  The tail rank's own planes were decimated in place.
+int gather_seed(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	const size_t pl = (size_t)H->sx * H->sy;
 	std::vector<size_t> off((size_t)H->world + 1, 0);
 	for (int r = 0; r < H->world; r++) off[(size_t)r + 1] = off[(size_t)r] + pl * (size_t)H->counts2[(size_t)r];
@@ -343,9 +372,12 @@ int gather_seed_and_start_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	for (Worker *w : ws) if (w->rank == H->tail_rank) tw = w;
 	if (H->sim) {
 		Worker &w0 = *ws[0];
+		if (!tw && H->solo) return SIFT3D_OK;  // (a solo rank that is not the tail rank: its piece was decimated, the send costs the GPU nothing)
 		if (!tw) { set_err(w0, "no tail rank among the simulated ranks"); return SIFT3D_ERR_STATE; }
 		CopySegs cs;
-		for (Worker *w : ws) {
+		std::vector<Worker *> srcs = ws;
+		if (H->solo) { srcs.clear(); for (Worker &w : H->workers) srcs.push_back(&w); }  // (the other ranks' pieces of the last full run)
+		for (Worker *w : srcs) {
 			const size_t cnt = off[(size_t)w->rank + 1] - off[(size_t)w->rank];
 			if (w == tw || !cnt) continue;
 			cs.src[cs.n] = w->seed_mine; cs.dst[cs.n] = tw->seed_dst + off[(size_t)w->rank]; cs.floats[cs.n] = cnt; cs.n++;
@@ -354,7 +386,6 @@ int gather_seed_and_start_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		launch_copy_segments(cs, w0.stream);
 		SH_HIP(w0, hipEventRecord(tw->ev_seed, w0.stream));
 		SH_HIP(w0, hipStreamWaitEvent(tw->tstream, tw->ev_seed, 0));
-		SH_ABI(*tw, sift3d_run_async(tw->tail));
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
@@ -375,7 +406,19 @@ int gather_seed_and_start_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	}
 	SH_HIP(w, hipEventRecord(w.ev_seed, w.stream));            // the tail rank's own planes (decimated in place on its stream)
 	SH_HIP(w, hipStreamWaitEvent(w.tstream, w.ev_seed, 0));
-	SH_ABI(w, sift3d_run_async(w.tail));
+	return SIFT3D_OK;
+}
+
+// the tail's whole KpSiftAlgorithm enqueued on its own streams (sift3d_run_async), behind the gathered seed level and behind what the tail
+// rank's stream holds at this point (see run_local for where that is)
+int start_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
+	for (Worker *w : ws) {
+		if (!w->tail || w->rank != H->tail_rank) continue;
+		SH_HIP(*w, hipSetDevice(w->device));
+		SH_HIP(*w, hipEventRecord(w->ev_seed, w->stream));
+		SH_HIP(*w, hipStreamWaitEvent(w->tstream, w->ev_seed, 0));
+		SH_ABI(*w, sift3d_run_async(w->tail));
+	}
 	return SIFT3D_OK;
 }
 
@@ -428,19 +471,6 @@ int exchange_raw(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector
 	SH_NCCL(w, g_rccl.GroupEnd());
 	return SIFT3D_OK;
 }
-
-// device scratch of one rank for one round of one stage: pointers into Worker::pscratch
-struct PartLayout {
-	char *recs = nullptr;                      // this rank's records, processing order (round 2: the flagged subset)
-	float *units = nullptr;                    // round 2: their exact units
-	int *redo = nullptr; float *units_next = nullptr;
-	std::map<int, char *> recs_in;             // neighbour r's records
-	std::map<int, float *> units_in;
-	std::map<int, int *> part_h;               // this rank's part of the windows of r's records (r = itself or a neighbour)
-	std::map<int, float *> part_m;
-	std::map<int, int *> got_h;                // neighbour q's part of this rank's records
-	std::map<int, float *> got_m;
-};
 
 int lay_out(Worker &w, int s, const std::vector<int> &counts, const std::vector<int> &nb, size_t rb, PartLayout &L) {
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -498,7 +528,8 @@ int partial_round(sift3d_sharded *H, std::vector<Worker *> &ws, int s, const std
 		for (int q : neigh[(size_t)r]) {
 			const size_t n = (size_t)counts[(size_t)r];
 			if (!n || (!is_local(r) && !is_local(q))) continue;
-			const PartLayout *Lr = is_local(r) ? &L[local[r]] : nullptr;
+			if (H->solo && !is_local(q)) continue;  // (solo: only what this rank receives, from the lists the last full run left in its neighbours' scratch)
+			const PartLayout *Lr = is_local(r) ? &L[local[r]] : (H->solo ? &H->ps_last[(size_t)s].L[(size_t)r] : nullptr);
 			PartLayout *Lq = is_local(q) ? &L[local[q]] : nullptr;
 			ts.push_back(RawXfer{r, q, Lr ? Lr->recs : nullptr, Lq ? Lq->recs_in[r] : nullptr, n * rb});
 			if (second) ts.push_back(RawXfer{r, q, Lr ? Lr->units : nullptr, Lq ? Lq->units_in[r] : nullptr, n * 4});
@@ -527,7 +558,8 @@ int partial_round(sift3d_sharded *H, std::vector<Worker *> &ws, int s, const std
 		for (int r : neigh[(size_t)q]) {
 			const size_t n = (size_t)counts[(size_t)r];
 			if (!n || (!is_local(r) && !is_local(q))) continue;
-			PartLayout *Lq = is_local(q) ? &L[local[q]] : nullptr, *Lr = is_local(r) ? &L[local[r]] : nullptr;
+			if (H->solo && !is_local(r)) continue;
+			PartLayout *Lq = is_local(q) ? &L[local[q]] : (H->solo ? &H->ps_last[(size_t)s].L[(size_t)q] : nullptr), *Lr = is_local(r) ? &L[local[r]] : nullptr;
 			ts.push_back(RawXfer{q, r, Lq ? Lq->part_h[r] : nullptr, Lr ? Lr->got_h[q] : nullptr, n * 768 * 4});
 			ts.push_back(RawXfer{q, r, Lq ? Lq->part_m[r] : nullptr, Lr ? Lr->got_m[q] : nullptr, n * 4});
 		}
@@ -556,12 +588,6 @@ int partial_round(sift3d_sharded *H, std::vector<Worker *> &ws, int s, const std
 
 // the descriptors of sharded octave s from partial integer histograms, first round, ENQUEUED (the keypoint counts of every rank are known:
 // H->kp_count[s]); the state the rare second round needs stays in PS
-struct PartStage {
-	std::vector<std::vector<int>> neigh;
-	std::vector<int> counts;
-	std::vector<PartLayout> L;
-	size_t rb = 0;
-};
 int partial_stage_enqueue(sift3d_sharded *H, std::vector<Worker *> &ws, int s, PartStage &PS) {
 	Worker &w0 = *ws[0];
 	int rbi = 0, reach = 0;
@@ -630,6 +656,9 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	Worker &w0 = *ws[0];
 	const int ng = H->ng;
 	const bool has_tail = H->noct > H->S;
+	// where the tail's pipeline is released on the tail rank's GPU: 0 as soon as its seed level has been gathered, 1 behind the rank's own
+	// pyramid, 2 behind its extrema + orientation, 3 behind its descriptor windows
+	static const int tail_start = dev_tune_i("S3D_TAIL_START", 0);
 	for (Worker *w : ws) SH_HIP(*w, hipSetDevice(w->device));
 	for (int s = 0; s < H->S; s++) {
 		const Stage &st0 = w0.stages[(size_t)s];
@@ -642,7 +671,7 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 			int rc = exchange(H, ws, halo_transfers(bounds, nzs, KIND_GSS, i, 0, urgent_h, s), 0);
 			if (rc) return rc;
 			// deferred: the wider keypoint-window halo of G[1..levels] and the DoG plane behind it, on the deferred flow
-			std::vector<Transfer> late = halo_transfers(bounds, nzs, KIND_GSS, i, urgent_h, H->need[(size_t)i], s);
+			std::vector<Transfer> late = halo_transfers(bounds, nzs, KIND_GSS, i, urgent_h, H->need[(size_t)s][(size_t)i], s);
 			if (i - 1 >= 1 && i - 1 <= H->levels) {
 				std::vector<Transfer> dg = halo_transfers(bounds, nzs, KIND_DOG, i - 1, 0, 1, s);
 				late.insert(late.end(), dg.begin(), dg.end());
@@ -672,12 +701,14 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 						SH_ABI(*w, sift3d_slab_decimate_async(w->stages[(size_t)s].ctx, w->seed_mine));
 					}
 				}
-				// the tail starts as soon as its seed level exists: beside the last levels of the last sharded octave
-				if (s + 1 == H->S && has_tail && (rc = gather_seed_and_start_tail(H, ws)) != SIFT3D_OK) return rc;
+				if (s + 1 == H->S && has_tail) {
+					if ((rc = gather_seed(H, ws)) != SIFT3D_OK) return rc;
+					if (tail_start == 0 && (rc = start_tail(H, ws)) != SIFT3D_OK) return rc;
+				}
 			}
 		}
 		// DoG maxima -> global (threshold of Detect_KeyPoints, Src/cSIFT3D.cc:379-384)
-		for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_ABI(*w, sift3d_slab_export_dogmax_device(w->stages[(size_t)s].ctx, w->dogmax[(size_t)s])); }
+		if (!H->solo) for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_ABI(*w, sift3d_slab_export_dogmax_device(w->stages[(size_t)s].ctx, w->dogmax[(size_t)s])); }
 		int rc = allreduce_max_dev(H, ws, s, 8);
 		if (rc) return rc;
 		for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_ABI(*w, sift3d_slab_import_dogmax_device(w->stages[(size_t)s].ctx, w->dogmax[(size_t)s])); }
@@ -687,9 +718,10 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 			SH_HIP(*w, hipEventRecord(w->ev_def, w->dstream));
 			SH_HIP(*w, hipStreamWaitEvent(w->stream, w->ev_def, 0));
 		}
+	if (has_tail && tail_start == 1) { int r1 = start_tail(H, ws); if (r1) return r1; }
 	int rc = SIFT3D_OK;
 	auto say = [&](Worker &w, const char *what, int r) { set_err(w, std::string(what) + ": " + sift3d_error_string(r) + " (" + sift3d_last_error() + ")"); };
-	if (H->partial) {
+	{
 		// extrema + orientation of EVERY sharded octave enqueued, then the counts (the GPU is busy with the later octaves while the host waits
 		// for the first), shared with the other ranks' threads behind one rendezvous
 		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++)
@@ -705,11 +737,22 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 				H->kp_count[(size_t)s][(size_t)w->rank] = n;
 			}
 		if (rc == SIFT3D_OK) rc = rendezvous(H, w0);
+		if (has_tail && tail_start == 2 && rc == SIFT3D_OK) rc = start_tail(H, ws);
+		// the descriptors: an octave whose windows are split along z exchanges records and partial histograms; an octave of slabs too thin for
+		// that (its level buffers carry the whole windows' reach) describes its own keypoints from its own buffers
 		std::vector<PartStage> PS((size_t)H->S);
-		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++) rc = partial_stage_enqueue(H, ws, s, PS[(size_t)s]);
+		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++) {
+			if (H->stage_partial[(size_t)s]) { rc = partial_stage_enqueue(H, ws, s, PS[(size_t)s]); continue; }
+			for (Worker *w : ws) {
+				if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
+				if ((rc = sift3d_slab_describe_launch(w->stages[(size_t)s].ctx)) != SIFT3D_OK) { say(*w, "sharded descriptors (whole windows)", rc); break; }
+			}
+		}
+		if (has_tail && tail_start == 3 && rc == SIFT3D_OK) rc = start_tail(H, ws);
 		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++)
 			for (Worker *w : ws) {
 				int nr = 0;
+				if (!H->stage_partial[(size_t)s]) { H->redo_count[(size_t)s][(size_t)w->rank] = 0; continue; }
 				if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
 				if ((rc = sift3d_slab_describe_finish_count(w->stages[(size_t)s].ctx, &nr)) != SIFT3D_OK) { say(*w, "sharded descriptors", rc); break; }
 				H->redo_count[(size_t)s][(size_t)w->rank] = nr;
@@ -717,16 +760,11 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		if (rc == SIFT3D_OK) rc = rendezvous(H, w0);
 		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++) {
 			const std::vector<int> &tot = H->redo_count[(size_t)s];
-			if (std::any_of(tot.begin(), tot.end(), [](int v) { return v > 0; })) rc = partial_stage_second(H, ws, s, PS[(size_t)s]);
+			if (!std::any_of(tot.begin(), tot.end(), [](int v) { return v > 0; })) continue;
+			if (H->solo) { set_err(w0, "a solo re-run of one rank does not repeat flagged records"); rc = SIFT3D_ERR_STATE; break; }
+			rc = partial_stage_second(H, ws, s, PS[(size_t)s]);
 		}
-	} else {
-		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++)
-			for (Worker *w : ws) {
-				if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
-				rc = sift3d_slab_detect(w->stages[(size_t)s].ctx);
-				if (rc == SIFT3D_OK) rc = sift3d_slab_describe(w->stages[(size_t)s].ctx);
-				if (rc != SIFT3D_OK) { say(*w, "sharded keypoints", rc); break; }
-			}
+		if (H->sim && !H->solo && rc == SIFT3D_OK) H->ps_last = PS;  // (simulated ranks: what a solo re-run of one rank reads its neighbours' lists from)
 	}
 	if (rc != SIFT3D_OK) abort_all(H);  // (peers may sit in a receive waiting for this rank)
 	// the tail's run is completed whatever happened above (an extractor with a run in flight must not be destroyed under it)
@@ -824,9 +862,17 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	if (sift3d_slab_min_halo(&H->p, &halo_whole) != SIFT3D_OK || sift3d_slab_min_halo_partial(&H->p, &halo_partial) != SIFT3D_OK) return fail(SIFT3D_ERR_ARG, "bad parameters");
 	H->noct = octaves_total(nx, ny, nz);
 	if (H->noct < 1) return fail(SIFT3D_ERR_ARG, "volume too small for one octave");
-	// sharded octaves: as asked, but none whose planes are smaller than the level kernel's tile (+ widest half width) or thinner than the ranks
-	int S = std::max(1, std::min(sharded_octaves > 0 ? sharded_octaves : 2, H->noct));
+	// sharded octaves: as asked, but none whose planes are smaller than the level kernel's tile (+ widest half width) or thinner than the ranks.
+	// Not asked (0): every octave that is worth it -- at least 2^22 voxels and 16 planes per rank (the 256 x 256 x 128 octave 2 of a
+	// 1024 x 1024 x 512 volume holds 45 % of that volume's keypoints: r05 ran it replicated on every rank, early r06 once on one rank, which then
+	// took 6.5 ms of a 3.5 ms step) -- and never fewer than two where two fit.
 	auto fits = [](int n) { return n == 32 || n >= 40; };  // one 32 x 32 tile, or room for a shifted last tile behind the widest mirror zone
+	int S;
+	if (sharded_octaves > 0) S = std::max(1, std::min(sharded_octaves, H->noct));
+	else {
+		S = std::max(1, std::min(2, H->noct));
+		while (S < H->noct && ((size_t)(nx >> S) * (size_t)(ny >> S) * (size_t)(nz >> S)) >= ((size_t)1 << 22) && ((nz >> S) / H->world) >= 16) S++;
+	}
 	while (S > 1 && (!fits(nx >> (S - 1)) || !fits(ny >> (S - 1)) || (nz >> S) < H->world)) S--;
 	H->S = S;
 	// the tail (octaves >= S) runs once, on the last rank, which owns fewer planes in exchange: the tail is a volume of nz / 2^S planes of
@@ -836,28 +882,34 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	const int tail_planes = H->tail_rank >= 0 ? (int)lround(2.6 * (double)nz / (double)(1 << (3 * S))) : 0;
 	Bounds b;
 	if (!slab_bounds(nz, H->world, 1 << S, b, tail_planes)) return fail(SIFT3D_ERR_ARG, "too few planes for this many slabs");
-	// descriptor windows: split along z over the ranks (partial integer histograms) unless the caller asks for whole windows -- or a slab is so
-	// thin that a window would span more ranks than one finish launch adds parts (the owner's and five z-neighbours'): then whole windows too,
-	// unless partial windows were asked for by name (refused, as in r05)
+	// descriptor windows, per sharded octave: split along z over the ranks (partial integer histograms) unless the caller asks for whole windows
+	// -- or the octave's slabs are so thin that a window would span more ranks than one finish launch adds parts (the owner's and five
+	// z-neighbours'): that octave carries whole windows on the wide halos instead, unless partial windows were asked for by name (refused)
 	{
-		H->partial = (flags & SIFT3D_SHARDED_WHOLE_WINDOWS) == 0;
 		const int reach = halo_whole - 1;  // planes a window reaches beyond its keypoint, in voxels of ITS octave: the same in every octave (scale / unit)
 		Bounds bo = b;
 		int dz = nz;
-		for (int o = 0; o < S && H->partial; o++) {
+		H->stage_partial.assign((size_t)S, 0);
+		H->stage_halo.assign((size_t)S, halo_whole);
+		for (int o = 0; o < S; o++) {
+			bool part = (flags & SIFT3D_SHARDED_WHOLE_WINDOWS) == 0;
+			static const int max_ranks = dev_tune_i("S3D_PARTIAL_MAX_RANKS", kDescSegs);
 			for (const std::vector<int> &nb : window_neighbours(bo, reach))
-				if ((int)nb.size() + 1 > kDescSegs) {
+				if (part && (int)nb.size() + 1 > std::min(max_ranks, kDescSegs)) {
 					if (flags & SIFT3D_SHARDED_PARTIAL_WINDOWS)
 						return fail(SIFT3D_ERR_ARG, "partial descriptor windows: a slab of octave " + std::to_string(o) + " is so thin that a window spans more than " +
 						                                std::to_string(kDescSegs) + " ranks; use fewer sharded octaves or whole windows");
-					H->partial = false;
-					break;
+					part = false;
 				}
+			H->stage_partial[(size_t)o] = part ? 1 : 0;
+			H->stage_halo[(size_t)o] = part ? halo_partial : halo_whole;
 			bo = halve_bounds(bo, dz);
 			dz /= 2;
 		}
+		H->partial = std::all_of(H->stage_partial.begin(), H->stage_partial.end(), [](char c) { return c != 0; });
 	}
-	H->halo = H->partial ? halo_partial : halo_whole;
+	H->halo = H->stage_halo[0];
+	H->need.assign((size_t)S, std::vector<int>());
 	if (!H->sim) {
 		std::lock_guard<std::mutex> lk(g_rccl_mu);
 		std::string e;
@@ -884,13 +936,13 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 			Stage &st = w.stages.back();
 			st.octave = o; st.nx = dx; st.ny = dy; st.nz = dz; st.bounds = bb; st.z0 = bb[(size_t)r].first; st.z1 = bb[(size_t)r].second;
 			st.plane = (size_t)dx * dy;
-			sift3d_slab_desc d{dx, dy, dz, st.z0, st.z1, H->halo, H->noct, o};
+			sift3d_slab_desc d{dx, dy, dz, st.z0, st.z1, H->stage_halo[(size_t)o], H->noct, o};
 			if (st.z1 > st.z0) {
 				CR_ABI(sift3d_slab_arena_floats(&d, &H->p, &st.arena_floats));
 				CR_HIP(hipMalloc(&st.arena, sizeof(float) * st.arena_floats));
 				CR_ABI(sift3d_slab_create(&st.ctx, &d, &H->p, w.device, st.arena, st.arena_floats));
 				CR_ABI(sift3d_set_stream(st.ctx, w.stream));
-				if (H->partial) CR_ABI(sift3d_slab_set_desc_partial(st.ctx, 1));
+				if (H->stage_partial[(size_t)o]) CR_ABI(sift3d_slab_set_desc_partial(st.ctx, 1));
 			} else {
 				return fail(SIFT3D_ERR_ARG, "a rank would own no planes of a sharded octave");
 			}
@@ -905,8 +957,14 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 			H->sx = dx; H->sy = dy; H->sz = dz;
 			H->counts2.clear();
 			for (auto &p : bb) H->counts2.push_back(p.second - p.first);
-			sift3d_handle c0 = w.stages[0].ctx;
-			for (int i = 0; i < H->ng; i++) { int v = 0; CR_ABI(sift3d_slab_halo_planes(c0, i, &v)); H->need.push_back(v); CR_ABI(sift3d_slab_level_hw(c0, i, &v)); H->hws.push_back(v); }
+			for (int o = 0; o < S; o++) {
+				sift3d_handle co = w.stages[(size_t)o].ctx;
+				for (int i = 0; i < H->ng; i++) {
+					int v = 0;
+					CR_ABI(sift3d_slab_halo_planes(co, i, &v)); H->need[(size_t)o].push_back(v);
+					if (o == 0) { CR_ABI(sift3d_slab_level_hw(co, i, &v)); H->hws.push_back(v); }
+				}
+			}
 		}
 		if (H->tail_rank >= 0) {
 			const size_t pl2 = (size_t)dx * dy;
@@ -1148,11 +1206,33 @@ extern "C" int sift3d_sharded_info(sift3d_sharded_handle H, int *world, int *sha
 	return SIFT3D_OK;
 }
 
-extern "C" int sift3d_sharded_plan(sift3d_sharded_handle H, int *partial_windows, int *tail_rank, int *planes /* [world] or NULL */) {
+extern "C" int sift3d_sharded_plan(sift3d_sharded_handle H, int *partial_windows, int *tail_rank, int *planes /* [world] or NULL */, int *stage_partial /* [sharded octaves] or NULL */) {
 	if (!H) return SIFT3D_ERR_ARG;
 	if (partial_windows) *partial_windows = H->partial ? 1 : 0;
+	if (stage_partial) for (int o = 0; o < H->S; o++) stage_partial[o] = H->stage_partial[(size_t)o] ? 1 : 0;
 	if (tail_rank) *tail_rank = H->tail_rank;
 	if (planes && !H->workers.empty())
 		for (int r = 0; r < H->world; r++) planes[r] = H->workers[(size_t)r].stages[0].z1 - H->workers[(size_t)r].stages[0].z0;
 	return SIFT3D_OK;
+}
+
+// TEST / MEASUREMENT entry (include/sift3d_hip_test.h): what ONE rank of a simulated run does in a step, alone on the GPU.  After a full run
+// (sift3d_sharded_run) every rank's level buffers, halos, record lists and partial histograms are still in place; the rank's whole step is
+// enqueued again -- its levels, the copies of the planes / records / histograms it RECEIVES (from what the last run left in its neighbours'
+// buffers: the same bytes), its extrema, orientation, its part of every window that reaches it, the finish of its own keypoints, the tail on
+// the tail rank -- and timed from the first launch to the drain.  That is the GPU time of that rank on a node of `world` GPUs, short of what
+// its transfers wait for.  Results are not touched (the rank recomputes what it held).  Partial windows only.
+extern "C" int sift3d_test_sharded_time_rank(sift3d_sharded_handle H, int rank, double *seconds) {
+	if (!H || !seconds || rank < 0 || rank >= H->world) return SIFT3D_ERR_ARG;
+	if (!H->sim || !H->ran || H->ps_last.size() != (size_t)H->S) { set_last_error("needs a simulated extractor that has run"); return SIFT3D_ERR_STATE; }
+	Worker &w = H->workers[(size_t)rank];
+	if (hipSetDevice(w.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return SIFT3D_ERR_HIP;
+	std::vector<Worker *> ws{&w};
+	H->solo = true;
+	const auto t0 = std::chrono::steady_clock::now();
+	const int rc = run_local(H, ws);
+	H->solo = false;
+	*seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	if (rc) { H->err = w.err; set_last_error(H->err); }
+	return rc;
 }

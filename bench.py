@@ -105,14 +105,25 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partia
     kp, _ = sh.GetKeypoints()
     t_get = time.perf_counter() - t0
     info = sh.info()
+    per_rank = None
+    if sim_ranks:
+        # what ONE rank does in a step, re-run alone on the GPU on the buffers the last run left behind (sift3d_test_sharded_time_rank): the
+        # GPU time of that rank on a node of sim_ranks GPUs, short of what its transfers wait for
+        try:
+            per_rank = [round(min(sh.time_rank(r) for _ in range(3)) * 1e3, 3) for r in range(info["world"])]
+        except Exception as e:  # noqa: BLE001 -- a side measurement
+            per_rank = f"{type(e).__name__}: {e}"
     sh.close()
     dt = float(np.median(ts))
     return {"workload": f"{nx}x{ny}x{nz} fp32 synthetic blob volume, z-slabs over {info['world']} rank(s), native C++ driver"
                         + (" SIMULATED on one GPU" if sim_ranks else " (RCCL)"),
             "value": nx * ny * nz / dt / 1e6, "unit": "Mvoxels/s", "ms_per_step": dt * 1e3, "ms_per_step_all": [round(t * 1e3, 3) for t in ts], "keypoints": int(len(kp)),
             "sharded_octaves": info["sharded_octaves"], "halo_planes": info["halo"], "slab_planes": info["planes"], "tail_rank": info["tail_rank"],
-            "descriptor_windows": "partial integer histograms" if info["partial_windows"] else "whole windows on plane halos", "ctor_s_incl_H2D_of_the_slabs": round(t_ctor, 3),
+            "descriptor_windows": "partial integer histograms" if info["partial_windows"] else ("whole windows on plane halos" if not any(info["stage_partial"]) else
+                                  "per sharded octave: " + ", ".join("partial integer histograms" if p else "whole windows on plane halos" for p in info["stage_partial"])),
+            "ctor_s_incl_H2D_of_the_slabs": round(t_ctor, 3),
             "get_keypoints_ms_D2H_of_every_rank_and_merge": round(t_get * 1e3, 3),
+            **({"sim_rank_alone_ms": per_rank, "sim_slowest_rank_alone_ms": max(per_rank)} if isinstance(per_rank, list) else ({"sim_rank_alone_ms": per_rank} if per_rank else {})),
             "note": "ms_per_step = host wall time of sift3d_sharded_run: KpSiftAlgorithm, results complete on the devices (like the single-GPU extractor's step; "
                     "r05 counted the D2H of every rank's results and the merge in it: now get_keypoints_ms)"}
 

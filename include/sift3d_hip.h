@@ -260,6 +260,9 @@ int sift3d_slab_keypoints_count(sift3d_handle h, int *n_kp);
 int sift3d_slab_describe_finish_launch(sift3d_handle h, const void *d_records, int n, int nparts, const int *const *d_hist,
                                        const float *const *d_mass, int *d_redo /* [n] out */, float *d_units_next /* [n] out */);
 int sift3d_slab_describe_finish_count(sift3d_handle h, int *n_redo);
+/* whole descriptor windows of the slab's own keypoints from its own level buffers (halo >= sift3d_slab_min_halo), enqueued behind
+ * sift3d_slab_keypoints_launch / _count: complete when the handle's stream has drained */
+int sift3d_slab_describe_launch(sift3d_handle h);
 /* DownSample_3D of the owned planes of G[octave][num_kp_levels] -> d_dst = (nx/2) x (ny/2) x ((z1-z0)/2) floats (device):
  * the owned planes of level 0 of the next octave (a sharded slab context of octave+1, or the all-gather buffer of the tail) */
 int sift3d_slab_decimate(sift3d_handle h, float *d_dst);
@@ -294,7 +297,8 @@ int sift3d_import_descriptors_device(sift3d_handle h, const float *d_desc_src);
  * back (GetKeypoints, :1686-1688; reference order).  devices[ndev]: one rank per listed GPU, halo exchange over RCCL (ncclSend /
  * ncclRecv between z-neighbours over xGMI, one host thread per GPU; librccl is opened at run time).  sim_ranks > 0 (ndev == 1):
  * that many ranks simulated on the one device -- device copies instead of sends -- which is how 1-GPU boxes test the driver.
- * sharded_octaves: octaves split into slabs (0 = default 2); the remaining octaves run ONCE, on the last rank, from a seed level gathered there.
+ * sharded_octaves: octaves split into slabs (0 = every octave of at least 2^22 voxels and 16 planes per rank, at least two); the remaining
+ * octaves run ONCE, on the last rank, from a seed level gathered there.
  * Results equal the single-GPU results: pyramid / extrema / orientation bit for bit, descriptors bit for bit as well (integer
  * histograms).  The C++ shell reaches it through CreateCSIFT3D when SIFT3D_DEVICES lists several GPUs.
  * ------------------------------------------------------------------------------------------------------------ */
@@ -315,9 +319,11 @@ int sift3d_sharded_get_keypoints(sift3d_sharded_handle h, sift3d_keypoint *out, 
 /* ranks, sharded octaves, halo planes; seconds[0] = wall time of the last run (KpSiftAlgorithm: the results are complete on the devices),
  * [1] = the same + the read-back of every rank's results and their merge, once sift3d_sharded_get_keypoints has run (r05 counted both in [0]) */
 int sift3d_sharded_info(sift3d_sharded_handle h, int *world, int *sharded_octaves, int *halo, double seconds[2]);
-/* the plan: descriptor windows split along z (1) or whole (0); the rank that also runs the octaves behind the sharded ones, once for the
- * node (-1: the volume has none), and the planes of octave 0 every rank owns (that rank owns fewer) */
-int sift3d_sharded_plan(sift3d_sharded_handle h, int *partial_windows, int *tail_rank, int *planes /* [world] or NULL */);
+/* the plan: descriptor windows split along z in every sharded octave (1) or not (0), and per sharded octave (stage_partial: an octave whose
+ * slabs are too thin for the split carries whole windows on wide halos); the rank that also runs the octaves behind the sharded ones, once
+ * for the node (-1: the volume has none), and the planes of octave 0 every rank owns (that rank owns fewer) */
+int sift3d_sharded_plan(sift3d_sharded_handle h, int *partial_windows, int *tail_rank, int *planes /* [world] or NULL */,
+                        int *stage_partial /* [sharded octaves] or NULL */);
 const char *sift3d_sharded_error(sift3d_sharded_handle h);
 int sift3d_sharded_destroy(sift3d_sharded_handle h);
 

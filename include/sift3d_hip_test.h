@@ -54,6 +54,11 @@ int sift3d_debug_face_lookup(const float *grad3, int n, int route, int *face, fl
  * tests/test_cabi_cpu.py checks that the nt ranges tile [0, n) for the sizes that r05's floor division left short. */
 int sift3d_test_staging_slice(size_t n, int nt, int t, size_t *o, size_t *e);
 
+/* Simulated ranks of the native z-slab driver (sift3d_sharded_create with sim_ranks > 0) after a run: the whole step of ONE rank enqueued again
+ * on the buffers the run left behind (what it receives is copied from its neighbours' buffers) and timed alone on the GPU -- the GPU time of
+ * that rank on a node of `world` GPUs, short of what its transfers wait for.  Results are not changed. */
+int sift3d_test_sharded_time_rank(sift3d_sharded_handle h, int rank, double *seconds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,7 +76,36 @@ def test_default_plan_splits_the_windows_and_runs_the_tail_once(vol_and_single, 
         assert np.array_equal(k2, kp), info
         assert np.array_equal(d2, ds), info
     assert sh.info()["seconds_incl_merge"] > sh.info()["seconds"] > 0
+    if True:
+        # the solo re-run of every rank on the buffers the run left behind (what bench.py times per rank) leaves the results as they are
+        ts = [sh.time_rank(r) for r in range(ranks)]
+        assert all(0 < t < 1.0 for t in ts), ts
+        k3, d3 = sh.GetKeypoints()
+        assert np.array_equal(k3, kp) and np.array_equal(d3, ds)
+        k4, d4 = sh.KpSiftAlgorithm().GetKeypoints()
+        assert np.array_equal(k4, kp) and np.array_equal(d4, ds)
     sh.close()
+
+
+def test_three_sharded_octaves_mixed_window_forms():
+    """256^3 over 8 simulated ranks with THREE sharded octaves: the 32-plane slabs of octave 0 split their descriptor windows along z, the 16-
+    and 8-plane slabs of octaves 1 and 2 (a window would span 7 and more ranks) carry whole windows on 38-plane halos -- one plan, per-octave
+    forms, the tail (octaves >= 3) once on the last rank; bit-identical to the single volume, also after every rank's solo re-run"""
+    import torch
+    vol = synth.blobs_torch((256, 256, 256), "cuda", seed=31).cpu().numpy()
+    ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+    kp, ds = ex.GetKeypoints()
+    ex.close()
+    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=8, sharded_octaves=3)
+    info = sh.info()
+    assert info["sharded_octaves"] == 3 and info["stage_partial"] == [True, False, False] and not info["partial_windows"], info
+    for _ in range(2):
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        assert np.array_equal(k2, kp) and np.array_equal(d2, ds)
+    assert all(0 < sh.time_rank(r) < 1.0 for r in range(8))
+    k3, d3 = sh.KpSiftAlgorithm().GetKeypoints()
+    sh.close()
+    assert np.array_equal(k3, kp) and np.array_equal(d3, ds)
 
 
 def test_native_list_regrow_without_readbacks(vol_and_single):
