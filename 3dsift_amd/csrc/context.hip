@@ -237,8 +237,6 @@ struct sift3d_ctx {
 	DescSplit dsplit{};             // scratch of the split descriptor windows (runs with few keypoints), one allocation at dsplit.gacc
 	bool desc_partial = false;      // slab contexts (r05): descriptor windows are split along z over the ranks -- the halo of G[1..levels] only has to carry the orientation windows
 	bool dsplit_dirty = false;      // a run ended in an error: the "every run leaves the scratch clean" invariant is re-established by the next run
-	float *d_psplit = nullptr;      // slab contexts: sub-part masses + arrival counters of split record lists (sift3d_slab_describe_partial; grow-only)
-	unsigned psplit_cap = 0;
 	float *d_peer = nullptr;        // sift3d_match_handles: a target's descriptors + coordinates copied from another GPU (grow-only)
 	size_t peer_floats = 0;
 
@@ -377,7 +375,6 @@ extern "C" int sift3d_destroy(sift3d_handle c) {
 	if (!c->ext_arena) hipFree(c->arena);
 	hipFree(c->in_own);
 	hipFree(c->d_peer);
-	hipFree(c->d_psplit);
 	hipFree(c->d_words);
 	if (c->h_words) (void)hipHostFree(c->h_words);
 	hipFree(c->d_slots_part);
@@ -2222,39 +2219,14 @@ extern "C" int sift3d_slab_describe_partial(sift3d_handle c, int nlists, const v
 			if ((rc = sift3d_slab_halo_planes(c, l, &planes)) != SIFT3D_OK) return rc;
 			pp.H[l] = std::max(0, planes - 1);  // (the outermost halo plane only serves the central difference)
 		}
-		unsigned first = 0, first_rec = 0;
-		bool any_split = false;
+		unsigned first = 0;
 		for (int i = i0; i < std::min(nlists, i0 + kDescSegs); i++) {
 			if (n[i] < 0 || (n[i] > 0 && (!d_records[i] || !d_hist[i] || !d_mass[i]))) return SIFT3D_ERR_ARG;
 			if (n[i] == 0) continue;
 			DescSeg &sg = pp.seg[pp.nseg++];
 			sg.recs = static_cast<const DevKp *>(d_records[i]); sg.units = d_units ? d_units[i] : nullptr;
-			sg.hist = d_hist[i]; sg.mass = d_mass[i]; sg.first = first; sg.first_rec = first_rec; sg.n = (unsigned)n[i]; sg.o0 = owner_z0[i]; sg.o1 = owner_z1[i];
-			// r06: the rank's OWN list -- nearly whole windows, a thousand of them at 1024 x 1024 x 512 over 8 ranks: fewer than the resident
-			// workgroups -- is split so that the launch ends with the work, not with its largest window (DescSeg::split).  Foreign lists hold
-			// the small caps of the neighbours' windows (or nothing): one workgroup each.
-			const bool own = owner_z0[i] == c->own0 && owner_z1[i] == c->own1;
-			static const int split_mode = dev_tune_i("S3D_PARTIAL_SPLIT", -1);  // (-1: the rule below)
-			sg.split = !own || hook(SIFT3D_HOOK_DESC_NOSPLIT) ? 1 : (split_mode > 0 ? split_mode : (n[i] < 500 ? 8 : (n[i] < 2000 ? 4 : (n[i] < 4000 ? 2 : 1))));
-			any_split = any_split || sg.split > 1;
-			first += (unsigned)n[i] * (unsigned)sg.split;
-			first_rec += (unsigned)n[i];
-		}
-		if (any_split) {
-			// scratch of the split lists: per record of the launch 8 sub-part masses + one arrival counter (grow-only; zeroed when allocated, every launch leaves the counters at zero)
-			if (first_rec > c->psplit_cap) {
-				S3D_HIP(hipStreamSynchronize(c->stream));
-				if (c->d_psplit) S3D_HIP(hipFree(c->d_psplit));
-				c->d_psplit = nullptr; c->psplit_cap = 0;
-				const unsigned cap = std::max(4096u, first_rec + first_rec / 2);
-				S3D_HIP(hipMalloc(&c->d_psplit, sizeof(float) * 9 * (size_t)cap));
-				S3D_HIP(hipMemsetAsync(c->d_psplit, 0, sizeof(float) * 9 * (size_t)cap, c->stream));
-				c->psplit_cap = cap;
-			}
-			pp.sub_mass = c->d_psplit;
-			pp.sub_done = reinterpret_cast<unsigned *>(c->d_psplit + (size_t)c->psplit_cap * 8);
-			for (int k = 0; k < pp.nseg; k++)
-				if (pp.seg[k].split > 1) S3D_HIP(hipMemsetAsync(pp.seg[k].hist, 0, sizeof(int) * kDesc * (size_t)pp.seg[k].n, c->stream));
+			sg.hist = d_hist[i]; sg.mass = d_mass[i]; sg.first = first; sg.n = (unsigned)n[i]; sg.o0 = owner_z0[i]; sg.o1 = owner_z1[i];
+			first += (unsigned)n[i];
 		}
 		launch_describe_partial(c->d_levels, c->d_luts, c->d_lutpool, pp, c->d_nkp + 1, c->stream, c->desc_lut_lds);
 	}

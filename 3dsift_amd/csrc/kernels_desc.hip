@@ -296,10 +296,7 @@ __device__ __forceinline__ float accumulate_voxel(bool valid, float bx, float by
 // outside the sphere.  Measured at 512^3, k_describe: tiles 4.92 ms, sorted single pairs 4.71, 1x4 units 4.39, 2x4 units 4.26,
 // 2x2 / 4x2 4.32, 4x4 4.46, 1x8 4.50.)
 // runs with fewer keypoints than this take eight waves per keypoint; measured crossover between 1100 (0.49 vs 0.60 ms) and 1850 keypoints (0.75 vs 0.71)
-#ifndef S3D_WIDE_BELOW
-#define S3D_WIDE_BELOW 1400
-#endif
-constexpr unsigned kWideBelow = S3D_WIDE_BELOW;
+constexpr unsigned kWideBelow = 1400;
 // r04: keypoint counts below which a window is split over 8 / 4 workgroups (DescSplit; 1024 workgroups are resident; two parts never
 // paid off against the eight-wave variant)
 constexpr unsigned kSplit8Below = 320, kSplit4Below = 700;
@@ -518,17 +515,15 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 		__syncthreads();
 		const unsigned item = s_item;
 		if (item >= nitems) break;  // block-uniform
-		// PARTIAL: the list the item belongs to (block-uniform scalar walk over at most kDescSegs lists), the record's place in it and the
-		// sub-part of a split list
+		const unsigned kpos = item / (unsigned)S0;  // position in the processing order
+		const int part = (int)(item % (unsigned)S0);
+		int S = S0;  // parts of THIS pass over the window (1 when the finisher repeats a split window alone with the exact unit)
+		// PARTIAL: the list the record belongs to (block-uniform scalar walk over at most kDescSegs lists) and its place in it
 		int sg = 0;
 		if (PARTIAL)
-			while (sg + 1 < pp.nseg && item >= pp.seg[sg + 1].first) sg++;
-		const int psplit = PARTIAL ? pp.seg[sg].split : 1;
-		const unsigned kpos = PARTIAL ? (item - pp.seg[sg].first) / (unsigned)psplit : item / (unsigned)S0;  // position in the processing order (PARTIAL: in the list)
-		const int part = PARTIAL ? (int)((item - pp.seg[sg].first) % (unsigned)psplit) : (int)(item % (unsigned)S0);
-		int S = PARTIAL ? psplit : S0;  // parts of THIS pass over the window (1 when the finisher repeats a split window alone with the exact unit)
+			while (sg + 1 < pp.nseg && kpos >= pp.seg[sg + 1].first) sg++;
 		const DevKp *__restrict__ kpb = PARTIAL ? pp.seg[sg].recs : kps;
-		const unsigned k = PARTIAL ? kpos : (unsigned)order[kpos * pw + pr];  // processing order: big windows first (k_slots)
+		const unsigned k = PARTIAL ? kpos - pp.seg[sg].first : (unsigned)order[kpos * pw + pr];  // processing order: big windows first (k_slots)
 		int *const p_hist = PARTIAL ? pp.seg[sg].hist + (size_t)k * kDesc : nullptr;
 		float *const p_mass = PARTIAL ? pp.seg[sg].mass + k : nullptr;
 		const int slot = kpb[k].slot;                        // row of the keypoint in the results (reference order)
@@ -568,9 +563,9 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 			else if (pp.zc1 <= o0) { c0 = pp.zc0; c1 = min(pp.zc1, o0 - H); }               // a rank below the owner
 			else { c0 = max(pp.zc0, o1 + H); c1 = pp.zc1; }                                  // a rank above
 			z0 = max(z0, c0); z1 = min(z1, c1 - 1);
-			if (z1 < z0) {  // (block-uniform, the same for every sub-part of a split record: its histogram was zeroed by the caller)
-				if (S == 1) for (int e = tid; e < kDesc; e += NT) p_hist[e] = 0;
-				if (tid == 0 && part == 0) *p_mass = 0.0f;
+			if (z1 < z0) {
+				for (int e = tid; e < kDesc; e += NT) p_hist[e] = 0;
+				if (tid == 0) *p_mass = 0.0f;
 				continue;
 			}
 		}
@@ -901,28 +896,9 @@ __global__ void __launch_bounds__(NT) S3D_DESC_ATTR k_describe(const DevKp *__re
 				int a = 0;
 #pragma unroll
 				for (int r = 0; r < kRep; r++) a += (int)(sbin_t)hist[bin_index(e) * kRep + (r + tp) % kRep];
-				if (S == 1) p_hist[e] = a;
-				else if (a != 0) atomicAdd(&p_hist[e], a);  // a split record: the sub-parts' integers add up in the (zeroed) histogram
+				p_hist[e] = a;
 			}
-			if (S == 1) {
-				if (tid == 0) *p_mass = mass_sum;
-			} else {
-				// the sub-part's mass, then the arrival (the pattern of the split windows below: device-scope payload, one acquire-release
-				// counter); the last sub-part adds the masses in sub-part order -- deterministic -- and leaves the counter clean
-				const unsigned rec = pp.seg[sg].first_rec + k;
-				if (tid == 0) __hip_atomic_store(&pp.sub_mass[(size_t)rec * 8 + part], mass_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				__syncthreads();
-				if (tid == 0) {
-					const unsigned last = __hip_atomic_fetch_add(&pp.sub_done[rec], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-					if (last == (unsigned)(S - 1)) {
-						float m = 0.0f;
-						for (int q = 0; q < S; q++) m = m + __hip_atomic_load(&pp.sub_mass[(size_t)rec * 8 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						*p_mass = m;
-						__hip_atomic_store(&pp.sub_done[rec], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					}
-				}
-			}
+			if (tid == 0) *p_mass = mass_sum;
 			break;  // (leaves the attempt loop with finished == false: the owner decides about a second round)
 		}
 		// (r05) the thread index of the epilogue is opaque: its lane constants (bin indices, result addresses: ~20 registers) were hoisted
@@ -1129,8 +1105,8 @@ void launch_export_records(const DevKp *ext, const int *order, unsigned n, DevKp
 
 void launch_describe_partial(const LevelRef *d_levels, const WinLut *d_luts, const float *d_lutpool, const DescPartial &pp, unsigned *d_work,
                              hipStream_t st, bool lut_in_lds) {
-	unsigned n = 0;  // work items: records x the split of their list
-	for (int i = 0; i < pp.nseg; i++) n += pp.seg[i].n * (unsigned)std::max(1, pp.seg[i].split);
+	unsigned n = 0;
+	for (int i = 0; i < pp.nseg; i++) n += pp.seg[i].n;
 	if (n == 0) return;
 	(void)hipMemsetAsync(d_work, 0, 2 * sizeof(unsigned), st);
 	const int dev_flags = (hook(SIFT3D_HOOK_DESC_NOCACHE) ? 1 : 0) | (hook(SIFT3D_HOOK_DESC_EXACT_CELLS) ? 2 : 0) | (hook(SIFT3D_HOOK_DESC_MASS_SHIFT) & 63) << 8;

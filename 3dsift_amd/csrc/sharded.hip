@@ -189,17 +189,24 @@ struct Stage {  // one sharded octave of one rank
 
 struct Worker {  // the sharded octaves of one rank (+ the tail's extractor on the last rank)
 	int rank = 0, device = 0;
-	hipStream_t stream = nullptr, dstream = nullptr;  // the rank's stream; the stream of its deferred halos (RCCL)
+	// r06: every sharded octave has a stream of its own (sstream[s]; stream == sstream[0]) -- octave s + 1 only depends on the seed level octave
+	// s decimates (ev_next[s]), and its launches are small and latency-bound: they run beside the machine-filling launches of the octave
+	// above, as the octaves of the single-GPU extractor do -- and, for RCCL, a stream for its deferred halos and a pair of communicators
+	// (operations of one communicator are issued in one order; the octaves' flows interleave freely)
+	hipStream_t stream = nullptr;
+	std::vector<hipStream_t> sstream, sdstream;
 	hipStream_t tstream = nullptr;                    // tail rank: the stream of the tail's extractor (the seed level is gathered on it)
-	bool own_stream = false;
-	hipEvent_t ev_level = nullptr, ev_def = nullptr, ev_seed = nullptr;
+	bool own_stream = false;                          // (simulated ranks share rank 0's streams)
+	std::vector<hipEvent_t> ev_level, ev_def, ev_next;
+	hipEvent_t ev_seed = nullptr;
 	std::vector<Stage> stages;
 	std::vector<float *> dogmax;  // per stage: 8 floats (device)
 	sift3d_handle tail = nullptr; // tail rank only: the seeded extractor of the octaves >= S
 	float *seed_dst = nullptr;    // tail rank: level 0 of the tail's first octave (inside the tail's arena)
 	float *seed_mine = nullptr;   // this rank's planes of that level (other ranks: a buffer of their own; tail rank: a pointer into seed_dst)
 	bool seed_mine_owned = false;
-	ncclComm_t c_urgent = nullptr, c_deferred = nullptr, c_tail = nullptr;
+	std::vector<ncclComm_t> c_urgent, c_deferred;     // per sharded octave
+	ncclComm_t c_tail = nullptr;
 	std::vector<char *> pscratch; std::vector<size_t> pscratch_bytes;  // partial descriptor windows: records / histograms / masses, per stage (grow-only, device)
 	std::string err;
 };
@@ -286,8 +293,13 @@ void abort_all(sift3d_sharded *H) {
 	// a pointer in the middle of a store.  A rank already inside an RCCL call when the wait above timed out is what the abort is for.
 	H->comms_aborted.store(true);  // (ncclCommAbort frees the communicator: destroy must not hand it to ncclCommDestroy again)
 	for (Worker &w : H->workers)
-		for (ncclComm_t c : {w.c_urgent, w.c_deferred, w.c_tail})
-			if (c) (void)g_rccl.CommAbort(c);
+		{
+			std::vector<ncclComm_t> all = w.c_urgent;
+			all.insert(all.end(), w.c_deferred.begin(), w.c_deferred.end());
+			all.push_back(w.c_tail);
+			for (ncclComm_t c : all)
+				if (c) (void)g_rccl.CommAbort(c);
+		}
 	if (locked) H->comm_mu.unlock();
 }
 #define SH_LIVE(H, w) do { if ((H)->failed.load()) { set_err((w), "aborted: another rank failed"); return SIFT3D_ERR_STATE; } } while (0)
@@ -296,8 +308,10 @@ void abort_all(sift3d_sharded *H) {
 // sends / receives of the one local rank on `comm` / `stream` of the given flow (0 urgent, 1 deferred).
 int exchange(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<Transfer> &ts, int flow) {
 	if (ts.empty()) return SIFT3D_OK;
+	const size_t sgi = (size_t)ts[0].stage;  // (a call's transfers belong to one sharded octave)
 	if (H->sim) {
 		Worker &w0 = *ws[0];
+		hipStream_t sst = w0.sstream[sgi];
 		CopySegs cs;
 		for (const Transfer &t : ts) {
 			if (H->solo && t.dst != w0.rank) continue;  // (solo: only what this rank RECEIVES; its neighbours' buffers hold the last full run's planes)
@@ -305,15 +319,15 @@ int exchange(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<Tra
 			float *sp = s.view(t.kind, t.idx, t.zg0, t.zg1), *dp = d.view(t.kind, t.idx, t.zg0, t.zg1);
 			if (!sp || !dp) { set_err(w0, "halo transfer outside a level buffer"); return SIFT3D_ERR_STATE; }
 			cs.src[cs.n] = sp; cs.dst[cs.n] = dp; cs.floats[cs.n] = s.plane * (size_t)(t.zg1 - t.zg0); cs.n++;
-			if (cs.n == kCopySegs) { launch_copy_segments(cs, w0.stream); cs.n = 0; }
+			if (cs.n == kCopySegs) { launch_copy_segments(cs, sst); cs.n = 0; }
 		}
-		launch_copy_segments(cs, w0.stream);
+		launch_copy_segments(cs, sst);
 		SH_HIP(w0, hipGetLastError());
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
-	ncclComm_t comm = flow ? w.c_deferred : w.c_urgent;
-	hipStream_t st = flow ? w.dstream : w.stream;
+	ncclComm_t comm = flow ? w.c_deferred[sgi] : w.c_urgent[sgi];
+	hipStream_t st = flow ? w.sdstream[sgi] : w.sstream[sgi];
 	bool any = false;
 	for (const Transfer &t : ts) any = any || t.src == w.rank || t.dst == w.rank;
 	if (!any) return SIFT3D_OK;
@@ -342,12 +356,12 @@ int allreduce_max_dev(sift3d_sharded *H, std::vector<Worker *> &ws, int stage, i
 			MaxMerge mm;
 			for (Worker *w : ws) mm.p[mm.np++] = w->dogmax[(size_t)stage];
 			mm.n = n;
-			launch_max_merge(mm, w0.stream);
+			launch_max_merge(mm, w0.sstream[(size_t)stage]);
 			SH_HIP(w0, hipGetLastError());
 			return SIFT3D_OK;
 		}
 		std::vector<float> m((size_t)n, 0.f), t((size_t)n);
-		SH_HIP(w0, hipStreamSynchronize(w0.stream));
+		SH_HIP(w0, hipStreamSynchronize(w0.sstream[(size_t)stage]));
 		for (Worker *w : ws) {
 			SH_HIP(w0, hipMemcpy(t.data(), w->dogmax[(size_t)stage], sizeof(float) * n, hipMemcpyDeviceToHost));
 			for (int i = 0; i < n; i++) m[(size_t)i] = std::max(m[(size_t)i], t[(size_t)i]);
@@ -358,7 +372,7 @@ int allreduce_max_dev(sift3d_sharded *H, std::vector<Worker *> &ws, int stage, i
 	Worker &w = *ws[0];
 	std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
 	SH_LIVE(H, w);
-	SH_NCCL(w, g_rccl.AllReduce(w.dogmax[(size_t)stage], w.dogmax[(size_t)stage], (size_t)n, ncclFloat, ncclMax, w.c_urgent, w.stream));
+	SH_NCCL(w, g_rccl.AllReduce(w.dogmax[(size_t)stage], w.dogmax[(size_t)stage], (size_t)n, ncclFloat, ncclMax, w.c_urgent[(size_t)stage], w.sstream[(size_t)stage]));
 	return SIFT3D_OK;
 }
 
@@ -370,6 +384,7 @@ int gather_seed(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	for (int r = 0; r < H->world; r++) off[(size_t)r + 1] = off[(size_t)r] + pl * (size_t)H->counts2[(size_t)r];
 	Worker *tw = nullptr;
 	for (Worker *w : ws) if (w->rank == H->tail_rank) tw = w;
+	const size_t sl = (size_t)H->S - 1;  // the last sharded octave decimates the tail's seed level: on its stream
 	if (H->sim) {
 		Worker &w0 = *ws[0];
 		if (!tw && H->solo) return SIFT3D_OK;  // (a solo rank that is not the tail rank: its piece was decimated, the send costs the GPU nothing)
@@ -381,10 +396,10 @@ int gather_seed(sift3d_sharded *H, std::vector<Worker *> &ws) {
 			const size_t cnt = off[(size_t)w->rank + 1] - off[(size_t)w->rank];
 			if (w == tw || !cnt) continue;
 			cs.src[cs.n] = w->seed_mine; cs.dst[cs.n] = tw->seed_dst + off[(size_t)w->rank]; cs.floats[cs.n] = cnt; cs.n++;
-			if (cs.n == kCopySegs) { launch_copy_segments(cs, w0.stream); cs.n = 0; }
+			if (cs.n == kCopySegs) { launch_copy_segments(cs, w0.sstream[sl]); cs.n = 0; }
 		}
-		launch_copy_segments(cs, w0.stream);
-		SH_HIP(w0, hipEventRecord(tw->ev_seed, w0.stream));
+		launch_copy_segments(cs, w0.sstream[sl]);
+		SH_HIP(w0, hipEventRecord(tw->ev_seed, w0.sstream[sl]));
 		SH_HIP(w0, hipStreamWaitEvent(tw->tstream, tw->ev_seed, 0));
 		return SIFT3D_OK;
 	}
@@ -394,7 +409,7 @@ int gather_seed(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		SH_LIVE(H, w);
 		if (&w != tw) {
 			const size_t cnt = off[(size_t)w.rank + 1] - off[(size_t)w.rank];
-			if (cnt) SH_NCCL(w, g_rccl.Send(w.seed_mine, cnt, ncclFloat, H->tail_rank, w.c_tail, w.stream));  // behind the decimation on the rank's stream
+			if (cnt) SH_NCCL(w, g_rccl.Send(w.seed_mine, cnt, ncclFloat, H->tail_rank, w.c_tail, w.sstream[sl]));  // behind the decimation on that octave's stream
 			return SIFT3D_OK;
 		}
 		SH_NCCL(w, g_rccl.GroupStart());
@@ -404,19 +419,16 @@ int gather_seed(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		}
 		SH_NCCL(w, g_rccl.GroupEnd());
 	}
-	SH_HIP(w, hipEventRecord(w.ev_seed, w.stream));            // the tail rank's own planes (decimated in place on its stream)
+	SH_HIP(w, hipEventRecord(w.ev_seed, w.sstream[sl]));       // the tail rank's own planes (decimated in place on that octave's stream)
 	SH_HIP(w, hipStreamWaitEvent(w.tstream, w.ev_seed, 0));
 	return SIFT3D_OK;
 }
 
-// the tail's whole KpSiftAlgorithm enqueued on its own streams (sift3d_run_async), behind the gathered seed level and behind what the tail
-// rank's stream holds at this point (see run_local for where that is)
+// the tail's whole KpSiftAlgorithm enqueued on its own streams (sift3d_run_async), behind the gathered seed level
 int start_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	for (Worker *w : ws) {
 		if (!w->tail || w->rank != H->tail_rank) continue;
 		SH_HIP(*w, hipSetDevice(w->device));
-		SH_HIP(*w, hipEventRecord(w->ev_seed, w->stream));
-		SH_HIP(*w, hipStreamWaitEvent(w->tstream, w->ev_seed, 0));
 		SH_ABI(*w, sift3d_run_async(w->tail));
 	}
 	return SIFT3D_OK;
@@ -445,18 +457,19 @@ int rendezvous(sift3d_sharded *H, Worker &w) {
 
 struct RawXfer { int src, dst; const void *sp; void *dp; size_t bytes; };  // sp valid where src is local, dp where dst is local
 
-int exchange_raw(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<RawXfer> &ts) {
+int exchange_raw(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<RawXfer> &ts, int stage) {
 	if (ts.empty()) return SIFT3D_OK;
 	if (H->sim) {
 		Worker &w0 = *ws[0];
+		hipStream_t sst = w0.sstream[(size_t)stage];
 		CopySegs cs;
 		for (const RawXfer &t : ts) {
 			if (!t.bytes) continue;
-			if (t.bytes & 3) { SH_HIP(w0, hipMemcpyAsync(t.dp, t.sp, t.bytes, hipMemcpyDeviceToDevice, w0.stream)); continue; }  // (never: records, histograms and masses are words)
+			if (t.bytes & 3) { SH_HIP(w0, hipMemcpyAsync(t.dp, t.sp, t.bytes, hipMemcpyDeviceToDevice, sst)); continue; }  // (never: records, histograms and masses are words)
 			cs.src[cs.n] = static_cast<const float *>(t.sp); cs.dst[cs.n] = static_cast<float *>(t.dp); cs.floats[cs.n] = t.bytes / 4; cs.n++;
-			if (cs.n == kCopySegs) { launch_copy_segments(cs, w0.stream); cs.n = 0; }
+			if (cs.n == kCopySegs) { launch_copy_segments(cs, sst); cs.n = 0; }
 		}
-		launch_copy_segments(cs, w0.stream);
+		launch_copy_segments(cs, sst);
 		SH_HIP(w0, hipGetLastError());
 		return SIFT3D_OK;
 	}
@@ -465,8 +478,8 @@ int exchange_raw(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector
 	SH_LIVE(H, w);
 	SH_NCCL(w, g_rccl.GroupStart());
 	for (const RawXfer &t : ts) {
-		if (t.src == w.rank) SH_NCCL(w, g_rccl.Send(t.sp, t.bytes, ncclInt8, t.dst, w.c_urgent, w.stream));
-		else if (t.dst == w.rank) SH_NCCL(w, g_rccl.Recv(t.dp, t.bytes, ncclInt8, t.src, w.c_urgent, w.stream));
+		if (t.src == w.rank) SH_NCCL(w, g_rccl.Send(t.sp, t.bytes, ncclInt8, t.dst, w.c_urgent[(size_t)stage], w.sstream[(size_t)stage]));
+		else if (t.dst == w.rank) SH_NCCL(w, g_rccl.Recv(t.dp, t.bytes, ncclInt8, t.src, w.c_urgent[(size_t)stage], w.sstream[(size_t)stage]));
 	}
 	SH_NCCL(w, g_rccl.GroupEnd());
 	return SIFT3D_OK;
@@ -485,7 +498,7 @@ int lay_out(Worker &w, int s, const std::vector<int> &counts, const std::vector<
 	if (w.pscratch.size() <= (size_t)s) { w.pscratch.resize((size_t)s + 1, nullptr); w.pscratch_bytes.resize((size_t)s + 1, 0); }
 	if (need > w.pscratch_bytes[(size_t)s]) {
 		// (a stage's scratch is only in use between the enqueue of its windows and the end of the run; the run before has drained)
-		SH_HIP(w, hipStreamSynchronize(w.stream));
+		SH_HIP(w, hipStreamSynchronize(w.sstream[(size_t)s]));
 		if (w.pscratch[(size_t)s]) SH_HIP(w, hipFree(w.pscratch[(size_t)s]));
 		w.pscratch[(size_t)s] = nullptr; w.pscratch_bytes[(size_t)s] = 0;
 		const size_t cap = need + need / 4;
@@ -534,7 +547,7 @@ int partial_round(sift3d_sharded *H, std::vector<Worker *> &ws, int s, const std
 			ts.push_back(RawXfer{r, q, Lr ? Lr->recs : nullptr, Lq ? Lq->recs_in[r] : nullptr, n * rb});
 			if (second) ts.push_back(RawXfer{r, q, Lr ? Lr->units : nullptr, Lq ? Lq->units_in[r] : nullptr, n * 4});
 		}
-	int rc = exchange_raw(H, ws, ts);
+	int rc = exchange_raw(H, ws, ts, s);
 	if (rc) return rc;
 	for (size_t i = 0; i < ws.size(); i++) {
 		Worker &w = *ws[i];
@@ -563,7 +576,7 @@ int partial_round(sift3d_sharded *H, std::vector<Worker *> &ws, int s, const std
 			ts.push_back(RawXfer{q, r, Lq ? Lq->part_h[r] : nullptr, Lr ? Lr->got_h[q] : nullptr, n * 768 * 4});
 			ts.push_back(RawXfer{q, r, Lq ? Lq->part_m[r] : nullptr, Lr ? Lr->got_m[q] : nullptr, n * 4});
 		}
-	rc = exchange_raw(H, ws, ts);
+	rc = exchange_raw(H, ws, ts, s);
 	if (rc) return rc;
 	for (size_t i = 0; i < ws.size(); i++) {
 		Worker &w = *ws[i];
@@ -626,10 +639,10 @@ int partial_stage_second(sift3d_sharded *H, std::vector<Worker *> &ws, int s, Pa
 		std::vector<int> redo(n);
 		std::vector<float> un(n);
 		SH_HIP(w, hipSetDevice(w.device));
-		SH_HIP(w, hipMemcpyAsync(recs.data(), L[i].recs, n * rb, hipMemcpyDeviceToHost, w.stream));
-		SH_HIP(w, hipMemcpyAsync(redo.data(), L[i].redo, n * 4, hipMemcpyDeviceToHost, w.stream));
-		SH_HIP(w, hipMemcpyAsync(un.data(), L[i].units_next, n * 4, hipMemcpyDeviceToHost, w.stream));
-		SH_HIP(w, hipStreamSynchronize(w.stream));
+		SH_HIP(w, hipMemcpyAsync(recs.data(), L[i].recs, n * rb, hipMemcpyDeviceToHost, w.sstream[(size_t)s]));
+		SH_HIP(w, hipMemcpyAsync(redo.data(), L[i].redo, n * 4, hipMemcpyDeviceToHost, w.sstream[(size_t)s]));
+		SH_HIP(w, hipMemcpyAsync(un.data(), L[i].units_next, n * 4, hipMemcpyDeviceToHost, w.sstream[(size_t)s]));
+		SH_HIP(w, hipStreamSynchronize(w.sstream[(size_t)s]));
 		for (size_t k = 0; k < n; k++)
 			if (redo[k]) { recs2[i].insert(recs2[i].end(), recs.begin() + (ptrdiff_t)(k * rb), recs.begin() + (ptrdiff_t)((k + 1) * rb)); units2[i].push_back(un[k]); }
 		if ((int)units2[i].size() != tot[(size_t)w.rank]) { set_err(w, "flagged records and their count disagree"); return SIFT3D_ERR_STATE; }
@@ -638,12 +651,12 @@ int partial_stage_second(sift3d_sharded *H, std::vector<Worker *> &ws, int s, Pa
 	for (size_t i = 0; i < ws.size(); i++) {
 		Worker &w = *ws[i];
 		SH_HIP(w, hipSetDevice(w.device));
-		SH_HIP(w, hipStreamSynchronize(w.stream));  // (simulated ranks share the stream: every rank's first round has drained before a scratch moves)
+		SH_HIP(w, hipStreamSynchronize(w.sstream[(size_t)s]));  // (simulated ranks share the stream: every rank's first round has drained before a scratch moves)
 		if ((rc = lay_out(w, s, tot, PS.neigh[(size_t)w.rank], rb, L[i])) != SIFT3D_OK) return rc;
 		if (tot[(size_t)w.rank]) {
-			SH_HIP(w, hipMemcpyAsync(L[i].recs, recs2[i].data(), recs2[i].size(), hipMemcpyHostToDevice, w.stream));
-			SH_HIP(w, hipMemcpyAsync(L[i].units, units2[i].data(), units2[i].size() * 4, hipMemcpyHostToDevice, w.stream));
-			SH_HIP(w, hipStreamSynchronize(w.stream));  // (the host vectors are pageable and go out of scope)
+			SH_HIP(w, hipMemcpyAsync(L[i].recs, recs2[i].data(), recs2[i].size(), hipMemcpyHostToDevice, w.sstream[(size_t)s]));
+			SH_HIP(w, hipMemcpyAsync(L[i].units, units2[i].data(), units2[i].size() * 4, hipMemcpyHostToDevice, w.sstream[(size_t)s]));
+			SH_HIP(w, hipStreamSynchronize(w.sstream[(size_t)s]));  // (the host vectors are pageable and go out of scope)
 		}
 	}
 	return partial_round(H, ws, s, PS.neigh, tot, L, rb, true, n_redo);
@@ -656,14 +669,16 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	Worker &w0 = *ws[0];
 	const int ng = H->ng;
 	const bool has_tail = H->noct > H->S;
-	// where the tail's pipeline is released on the tail rank's GPU: 0 as soon as its seed level has been gathered, 1 behind the rank's own
-	// pyramid, 2 behind its extrema + orientation, 3 behind its descriptor windows
-	static const int tail_start = dev_tune_i("S3D_TAIL_START", 0);
 	for (Worker *w : ws) SH_HIP(*w, hipSetDevice(w->device));
 	for (int s = 0; s < H->S; s++) {
 		const Stage &st0 = w0.stages[(size_t)s];
 		const Bounds &bounds = st0.bounds;
 		const int nzs = st0.nz;
+		if (s > 0)
+			for (Worker *w : ws) {  // this octave's stream starts behind the decimation that wrote its level 0 (on the stream of the octave above)
+				SH_HIP(*w, hipSetDevice(w->device));
+				SH_HIP(*w, hipStreamWaitEvent(w->sstream[(size_t)s], w->ev_next[(size_t)s - 1], 0));
+			}
 		for (int i = 0; i < ng; i++) {
 			for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_ABI(*w, sift3d_slab_level(w->stages[(size_t)s].ctx, i)); }
 			const int urgent_h = i + 1 < ng ? H->hws[(size_t)i + 1] + 1 : 0;  // planes p-hw-1 .. p+hw of the next level's z-march
@@ -679,8 +694,8 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 			if (!late.empty()) {
 				if (!H->sim)
 					for (Worker *w : ws) {  // the deferred stream picks up behind the level kernel
-						SH_HIP(*w, hipEventRecord(w->ev_level, w->stream));
-						SH_HIP(*w, hipStreamWaitEvent(w->dstream, w->ev_level, 0));
+						SH_HIP(*w, hipEventRecord(w->ev_level[(size_t)s], w->sstream[(size_t)s]));
+						SH_HIP(*w, hipStreamWaitEvent(w->sdstream[(size_t)s], w->ev_level[(size_t)s], 0));
 					}
 				rc = exchange(H, ws, late, 1);
 				if (rc) return rc;
@@ -701,9 +716,11 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 						SH_ABI(*w, sift3d_slab_decimate_async(w->stages[(size_t)s].ctx, w->seed_mine));
 					}
 				}
+				if (s + 1 < H->S)
+					for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_HIP(*w, hipEventRecord(w->ev_next[(size_t)s], w->sstream[(size_t)s])); }
 				if (s + 1 == H->S && has_tail) {
 					if ((rc = gather_seed(H, ws)) != SIFT3D_OK) return rc;
-					if (tail_start == 0 && (rc = start_tail(H, ws)) != SIFT3D_OK) return rc;
+					if ((rc = start_tail(H, ws)) != SIFT3D_OK) return rc;
 				}
 			}
 		}
@@ -714,11 +731,12 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_ABI(*w, sift3d_slab_import_dogmax_device(w->stages[(size_t)s].ctx, w->dogmax[(size_t)s])); }
 	}
 	if (!H->sim)
-		for (Worker *w : ws) {  // the deferred halos are complete before detection reads them
-			SH_HIP(*w, hipEventRecord(w->ev_def, w->dstream));
-			SH_HIP(*w, hipStreamWaitEvent(w->stream, w->ev_def, 0));
-		}
-	if (has_tail && tail_start == 1) { int r1 = start_tail(H, ws); if (r1) return r1; }
+		for (Worker *w : ws)
+			for (int s = 0; s < H->S; s++) {  // an octave's deferred halos are complete before its detection reads them
+				SH_HIP(*w, hipSetDevice(w->device));
+				SH_HIP(*w, hipEventRecord(w->ev_def[(size_t)s], w->sdstream[(size_t)s]));
+				SH_HIP(*w, hipStreamWaitEvent(w->sstream[(size_t)s], w->ev_def[(size_t)s], 0));
+			}
 	int rc = SIFT3D_OK;
 	auto say = [&](Worker &w, const char *what, int r) { set_err(w, std::string(what) + ": " + sift3d_error_string(r) + " (" + sift3d_last_error() + ")"); };
 	{
@@ -737,7 +755,6 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 				H->kp_count[(size_t)s][(size_t)w->rank] = n;
 			}
 		if (rc == SIFT3D_OK) rc = rendezvous(H, w0);
-		if (has_tail && tail_start == 2 && rc == SIFT3D_OK) rc = start_tail(H, ws);
 		// the descriptors: an octave whose windows are split along z exchanges records and partial histograms; an octave of slabs too thin for
 		// that (its level buffers carry the whole windows' reach) describes its own keypoints from its own buffers
 		std::vector<PartStage> PS((size_t)H->S);
@@ -748,7 +765,6 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 				if ((rc = sift3d_slab_describe_launch(w->stages[(size_t)s].ctx)) != SIFT3D_OK) { say(*w, "sharded descriptors (whole windows)", rc); break; }
 			}
 		}
-		if (has_tail && tail_start == 3 && rc == SIFT3D_OK) rc = start_tail(H, ws);
 		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++)
 			for (Worker *w : ws) {
 				int nr = 0;
@@ -776,8 +792,10 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		}
 	for (Worker *w : ws) {
 		(void)hipSetDevice(w->device);
-		const hipError_t e = hipStreamSynchronize(w->stream);
-		if (e != hipSuccess && rc == SIFT3D_OK) { set_err(*w, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); rc = SIFT3D_ERR_HIP; }
+		for (hipStream_t sst : w->sstream) {
+			const hipError_t e = hipStreamSynchronize(sst);
+			if (e != hipSuccess && rc == SIFT3D_OK) { set_err(*w, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); rc = SIFT3D_ERR_HIP; }
+		}
 	}
 	if (rc == SIFT3D_OK && H->failed.load()) { set_err(w0, "aborted: another rank failed"); rc = SIFT3D_ERR_STATE; }  // halos of an aborted exchange are garbage
 	return rc;
@@ -789,8 +807,8 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 void destroy_worker(Worker &w, int phase, bool comms_aborted) {
 	(void)hipSetDevice(w.device);
 	if (phase == 0) {
-		if (w.stream) (void)hipStreamSynchronize(w.stream);
-		if (w.dstream) (void)hipStreamSynchronize(w.dstream);
+		for (hipStream_t st : w.sstream) if (st) (void)hipStreamSynchronize(st);
+		for (hipStream_t st : w.sdstream) if (st) (void)hipStreamSynchronize(st);
 		if (w.tstream) (void)hipStreamSynchronize(w.tstream);
 		if (w.tail) { (void)sift3d_set_stream(w.tail, nullptr); sift3d_destroy(w.tail); }
 		w.tail = nullptr; w.seed_dst = nullptr;
@@ -804,21 +822,20 @@ void destroy_worker(Worker &w, int phase, bool comms_aborted) {
 		w.pscratch.clear(); w.pscratch_bytes.clear();
 		if (w.seed_mine && w.seed_mine_owned) (void)hipFree(w.seed_mine);
 		w.seed_mine = nullptr; w.seed_mine_owned = false;
-		if (w.ev_level) (void)hipEventDestroy(w.ev_level);
-		if (w.ev_def) (void)hipEventDestroy(w.ev_def);
+		for (auto *v : {&w.ev_level, &w.ev_def, &w.ev_next}) { for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
 		if (w.ev_seed) (void)hipEventDestroy(w.ev_seed);
-		w.ev_level = w.ev_def = w.ev_seed = nullptr;
+		w.ev_seed = nullptr;
 		if (!comms_aborted) {
-			if (w.c_urgent) (void)g_rccl.CommDestroy(w.c_urgent);
-			if (w.c_deferred) (void)g_rccl.CommDestroy(w.c_deferred);
+			for (ncclComm_t c : w.c_urgent) if (c) (void)g_rccl.CommDestroy(c);
+			for (ncclComm_t c : w.c_deferred) if (c) (void)g_rccl.CommDestroy(c);
 			if (w.c_tail) (void)g_rccl.CommDestroy(w.c_tail);
 		}
-		w.c_urgent = w.c_deferred = w.c_tail = nullptr;
+		w.c_urgent.clear(); w.c_deferred.clear(); w.c_tail = nullptr;
 	} else {
-		if (w.dstream) (void)hipStreamDestroy(w.dstream);
+		for (hipStream_t st : w.sdstream) if (st) (void)hipStreamDestroy(st);
 		if (w.tstream) (void)hipStreamDestroy(w.tstream);
-		if (w.own_stream && w.stream) (void)hipStreamDestroy(w.stream);
-		w.dstream = w.tstream = w.stream = nullptr;
+		if (w.own_stream) for (hipStream_t st : w.sstream) if (st) (void)hipStreamDestroy(st);
+		w.sstream.clear(); w.sdstream.clear(); w.tstream = w.stream = nullptr;
 	}
 }
 
@@ -916,18 +933,29 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 		if (!g_rccl.load(e)) return fail(SIFT3D_ERR_STATE, e);
 	}
 	H->workers.resize((size_t)H->world);
-	hipStream_t shared = nullptr;
+	std::vector<hipStream_t> shared;  // simulated ranks share ONE stream per sharded octave: their "sends" are copies ordered on it
 	for (int r = 0; r < H->world; r++) {
 		Worker &w = H->workers[(size_t)r];
 		w.rank = r; w.device = H->sim ? devices[0] : devices[r];
 #define CR_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(SIFT3D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 #define CR_ABI(call) do { int r_ = (call); if (r_ != SIFT3D_OK) return fail(r_, std::string(#call) + ": " + sift3d_last_error()); } while (0)
 		CR_HIP(hipSetDevice(w.device));
-		if (H->sim && shared) w.stream = shared;  // simulated ranks share ONE stream: their "sends" are copies ordered on it
-		else { CR_HIP(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking)); w.own_stream = true; if (H->sim) shared = w.stream; }
-		if (!H->sim) CR_HIP(hipStreamCreateWithFlags(&w.dstream, hipStreamNonBlocking));
-		CR_HIP(hipEventCreateWithFlags(&w.ev_level, hipEventDisableTiming));
-		CR_HIP(hipEventCreateWithFlags(&w.ev_def, hipEventDisableTiming));
+		if (H->sim && !shared.empty()) w.sstream = shared;
+		else {
+			w.sstream.assign((size_t)S, nullptr);
+			for (int o = 0; o < S; o++) CR_HIP(hipStreamCreateWithFlags(&w.sstream[(size_t)o], hipStreamNonBlocking));
+			w.own_stream = true;
+			if (H->sim) shared = w.sstream;
+		}
+		w.stream = w.sstream[0];
+		w.sdstream.assign((size_t)S, nullptr);
+		w.ev_level.assign((size_t)S, nullptr); w.ev_def.assign((size_t)S, nullptr); w.ev_next.assign((size_t)S, nullptr);
+		for (int o = 0; o < S; o++) {
+			if (!H->sim) CR_HIP(hipStreamCreateWithFlags(&w.sdstream[(size_t)o], hipStreamNonBlocking));
+			CR_HIP(hipEventCreateWithFlags(&w.ev_level[(size_t)o], hipEventDisableTiming));
+			CR_HIP(hipEventCreateWithFlags(&w.ev_def[(size_t)o], hipEventDisableTiming));
+			CR_HIP(hipEventCreateWithFlags(&w.ev_next[(size_t)o], hipEventDisableTiming));
+		}
 		CR_HIP(hipEventCreateWithFlags(&w.ev_seed, hipEventDisableTiming));
 		Bounds bb = b;
 		int dx = nx, dy = ny, dz = nz;
@@ -941,7 +969,7 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 				CR_ABI(sift3d_slab_arena_floats(&d, &H->p, &st.arena_floats));
 				CR_HIP(hipMalloc(&st.arena, sizeof(float) * st.arena_floats));
 				CR_ABI(sift3d_slab_create(&st.ctx, &d, &H->p, w.device, st.arena, st.arena_floats));
-				CR_ABI(sift3d_set_stream(st.ctx, w.stream));
+				CR_ABI(sift3d_set_stream(st.ctx, w.sstream[(size_t)o]));
 				if (H->stage_partial[(size_t)o]) CR_ABI(sift3d_slab_set_desc_partial(st.ctx, 1));
 			} else {
 				return fail(SIFT3D_ERR_ARG, "a rank would own no planes of a sharded octave");
@@ -988,12 +1016,19 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	H->kp_count.assign((size_t)S, std::vector<int>((size_t)H->world, 0));
 	H->redo_count = H->kp_count;
 	if (!H->sim) {
-		// three communicators over the same devices: urgent halos + reductions, deferred halos, the gather of the tail's seed level
+		// communicators over the same devices: per sharded octave one for its urgent halos, reductions and window exchange and one for its
+		// deferred halos; one for the gather of the tail's seed level
 		std::vector<ncclComm_t> c((size_t)H->world);
-		for (int k = 0; k < 3; k++) {
+		for (Worker &w : H->workers) { w.c_urgent.assign((size_t)S, nullptr); w.c_deferred.assign((size_t)S, nullptr); }
+		for (int k = 0; k < 2 * S + 1; k++) {
 			ncclResult_t r = g_rccl.CommInitAll(c.data(), H->world, H->devices.data());
 			if (r != ncclSuccess) return fail(SIFT3D_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r));
-			for (int q = 0; q < H->world; q++) (k == 0 ? H->workers[(size_t)q].c_urgent : k == 1 ? H->workers[(size_t)q].c_deferred : H->workers[(size_t)q].c_tail) = c[(size_t)q];
+			for (int q = 0; q < H->world; q++) {
+				Worker &w = H->workers[(size_t)q];
+				if (k < S) w.c_urgent[(size_t)k] = c[(size_t)q];
+				else if (k < 2 * S) w.c_deferred[(size_t)k - (size_t)S] = c[(size_t)q];
+				else w.c_tail = c[(size_t)q];
+			}
 		}
 	}
 	// ---- constructor work (Src/cSIFT3D.cc:146-163): copy the owned planes, max-abs normalise over the WHOLE volume, exchange the

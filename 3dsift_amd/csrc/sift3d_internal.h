@@ -252,25 +252,17 @@ struct DescSplit {
 // (its gradient mass); units: per-record fixed-point unit of a second round (entries <= 0 and a null pointer: the first-pass rule, a
 // function of the record alone).
 constexpr int kDescSegs = 6;
-// r06: a list may be SPLIT -- every record's part is marched by `split` workgroups (the units u with u % split == sub-part), which add their
-// integer histograms into hist (zeroed by the caller) with global atomics and leave their gradient masses in sub_mass; the sub-part that arrives
-// last (sub_done) adds the masses in sub-part order and writes mass.  A rank's own list of a sharded octave is a thousand windows of 75 .. 600 us
-// each on 1024 resident workgroups: un-split, the launch lasted as long as its largest window (0.71 ms for 0.27 ms of work).
 struct DescSeg {
 	const DevKp *recs = nullptr;
 	const float *units = nullptr;
 	int *hist = nullptr;
 	float *mass = nullptr;
-	unsigned first = 0, n = 0;  // first = work items (records x split) of the lists in front of this one
-	unsigned first_rec = 0;     // records of the lists in front of this one (index into sub_mass / sub_done)
-	int split = 1;
+	unsigned first = 0, n = 0;  // first = records of the lists in front of this one
 	int o0 = 0, o1 = 0;
 };
 struct DescPartial {
 	int zc0 = 0, zc1 = 0, nseg = 0;
 	int H[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // per keypoint level
-	float *sub_mass = nullptr;            // [records of the launch][8]
-	unsigned *sub_done = nullptr;         // [records of the launch], zero between launches
 	DescSeg seg[kDescSegs];
 };
 void launch_export_records(const DevKp *ext, const int *order, unsigned n, DevKp *dst, hipStream_t st);
