@@ -207,7 +207,9 @@ struct Worker {  // the sharded octaves of one rank (+ the tail's extractor on t
 	bool seed_mine_owned = false;
 	std::vector<ncclComm_t> c_urgent, c_deferred;     // per sharded octave
 	ncclComm_t c_tail = nullptr;
-	std::vector<char *> pscratch; std::vector<size_t> pscratch_bytes;  // partial descriptor windows: records / histograms / masses, per stage (grow-only, device)
+	// partial descriptor windows: records / histograms / masses, per stage (grow-only, device); [2 s] the first round's, [2 s + 1] the rare second
+	// round's (its own memory: the first round's lists stay in place, which is what a solo re-run of a neighbour reads)
+	std::vector<char *> pscratch; std::vector<size_t> pscratch_bytes;
 	std::string err;
 };
 
@@ -485,7 +487,9 @@ int exchange_raw(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector
 	return SIFT3D_OK;
 }
 
-int lay_out(Worker &w, int s, const std::vector<int> &counts, const std::vector<int> &nb, size_t rb, PartLayout &L) {
+int lay_out(Worker &w, int s, const std::vector<int> &counts, const std::vector<int> &nb, size_t rb, PartLayout &L, bool second = false) {
+	const hipStream_t sst = w.sstream[(size_t)s];
+	s = 2 * s + (second ? 1 : 0);  // (slot of the scratch)
 	auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
 	const size_t me = (size_t)counts[(size_t)w.rank];
 	size_t need = al(me * rb) + 3 * al(me * 4) + al(me * 768 * 4) + al(me * 4);
@@ -498,7 +502,7 @@ int lay_out(Worker &w, int s, const std::vector<int> &counts, const std::vector<
 	if (w.pscratch.size() <= (size_t)s) { w.pscratch.resize((size_t)s + 1, nullptr); w.pscratch_bytes.resize((size_t)s + 1, 0); }
 	if (need > w.pscratch_bytes[(size_t)s]) {
 		// (a stage's scratch is only in use between the enqueue of its windows and the end of the run; the run before has drained)
-		SH_HIP(w, hipStreamSynchronize(w.sstream[(size_t)s]));
+		SH_HIP(w, hipStreamSynchronize(sst));
 		if (w.pscratch[(size_t)s]) SH_HIP(w, hipFree(w.pscratch[(size_t)s]));
 		w.pscratch[(size_t)s] = nullptr; w.pscratch_bytes[(size_t)s] = 0;
 		const size_t cap = need + need / 4;
@@ -627,7 +631,8 @@ int partial_stage_second(sift3d_sharded *H, std::vector<Worker *> &ws, int s, Pa
 	const std::vector<int> tot = H->redo_count[(size_t)s];
 	const std::vector<int> &counts = PS.counts;
 	const size_t rb = PS.rb;
-	std::vector<PartLayout> &L = PS.L;
+	const std::vector<PartLayout> &L = PS.L;   // the first round's lists (read)
+	std::vector<PartLayout> L2(ws.size());    // the second round's, in a scratch of their own
 	int rc;
 	std::vector<std::vector<char>> recs2(ws.size());
 	std::vector<std::vector<float>> units2(ws.size());
@@ -652,14 +657,14 @@ int partial_stage_second(sift3d_sharded *H, std::vector<Worker *> &ws, int s, Pa
 		Worker &w = *ws[i];
 		SH_HIP(w, hipSetDevice(w.device));
 		SH_HIP(w, hipStreamSynchronize(w.sstream[(size_t)s]));  // (simulated ranks share the stream: every rank's first round has drained before a scratch moves)
-		if ((rc = lay_out(w, s, tot, PS.neigh[(size_t)w.rank], rb, L[i])) != SIFT3D_OK) return rc;
+		if ((rc = lay_out(w, s, tot, PS.neigh[(size_t)w.rank], rb, L2[i], true)) != SIFT3D_OK) return rc;
 		if (tot[(size_t)w.rank]) {
-			SH_HIP(w, hipMemcpyAsync(L[i].recs, recs2[i].data(), recs2[i].size(), hipMemcpyHostToDevice, w.sstream[(size_t)s]));
-			SH_HIP(w, hipMemcpyAsync(L[i].units, units2[i].data(), units2[i].size() * 4, hipMemcpyHostToDevice, w.sstream[(size_t)s]));
+			SH_HIP(w, hipMemcpyAsync(L2[i].recs, recs2[i].data(), recs2[i].size(), hipMemcpyHostToDevice, w.sstream[(size_t)s]));
+			SH_HIP(w, hipMemcpyAsync(L2[i].units, units2[i].data(), units2[i].size() * 4, hipMemcpyHostToDevice, w.sstream[(size_t)s]));
 			SH_HIP(w, hipStreamSynchronize(w.sstream[(size_t)s]));  // (the host vectors are pageable and go out of scope)
 		}
 	}
-	return partial_round(H, ws, s, PS.neigh, tot, L, rb, true, n_redo);
+	return partial_round(H, ws, s, PS.neigh, tot, L2, rb, true, n_redo);
 }
 
 // CSIFT3D::KpSiftAlgorithm (Src/cSIFT3D.cc:165-235) over the slabs of the local workers.  Host synchronisations of a step: the keypoint
@@ -777,7 +782,16 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++) {
 			const std::vector<int> &tot = H->redo_count[(size_t)s];
 			if (!std::any_of(tot.begin(), tot.end(), [](int v) { return v > 0; })) continue;
-			if (H->solo) { set_err(w0, "a solo re-run of one rank does not repeat flagged records"); rc = SIFT3D_ERR_STATE; break; }
+			if (H->solo) {
+				// a solo re-run times the first round only: the flagged rows keep what the full run's second round stored, and an empty
+				// final round marks the rank's results complete again
+				for (Worker *w : ws) {
+					int nr = 0;
+					if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
+					if ((rc = sift3d_slab_describe_finish(w->stages[(size_t)s].ctx, nullptr, 0, 0, nullptr, nullptr, nullptr, 1, nullptr, nullptr, &nr)) != SIFT3D_OK) { say(*w, "solo finish", rc); break; }
+				}
+				continue;
+			}
 			rc = partial_stage_second(H, ws, s, PS[(size_t)s]);
 		}
 		if (H->sim && !H->solo && rc == SIFT3D_OK) H->ps_last = PS;  // (simulated ranks: what a solo re-run of one rank reads its neighbours' lists from)
