@@ -4,10 +4,11 @@
 set -e
 cd "$(dirname "$0")/.."
 name=$1; extra=$2; src=${3:-kernels_march}
+# (the development switches -- -DS3D_DEV_SWITCHES: environment overrides of tuning values and hooks -- live in entry_test.hip)
 B=build/variants/$name   # under csrc/build: git-ignored and .gpurunignore'd (only the linked .so under variants/ travels)
 mkdir -p variants 3dsift_amd/csrc/$B
 cd 3dsift_amd/csrc
-for f in context staging sharded kernels_pyramid kernels_march kernels_small kernels_detect kernels_orient kernels_desc kernels_match; do
+for f in context tables entry_free entry_slab entry_test staging sharded kernels_pyramid kernels_march kernels_small kernels_detect kernels_orient kernels_desc kernels_match; do
   [ "$f" != "$src" ] && [ -f build/$f.o ] && cp -u build/$f.o $B/$f.o
 done
 FL="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -Wno-unused-value"

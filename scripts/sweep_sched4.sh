@@ -1,6 +1,6 @@
 #!/bin/bash
 # r04 (64 x 32 tiles for octave 0's levels up to the seed level, ring-less small octaves): the slot planning of the overlap region again
-# (a -DS3D_DEV_SWITCHES build: scripts/build_variant.sh dev "-DS3D_DEV_SWITCHES" context)
+# (a -DS3D_DEV_SWITCHES build: scripts/build_variant.sh dev "-DS3D_DEV_SWITCHES" entry_test)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 export S3D_LIB=$(realpath variants/libsift3d_hip_dev.so) S3D_AB_NOHASH=1
 run() { S3D_TAG="$*" env "$@" python3 scripts/ab_pyramid.py --child 2>&1 | grep pyramid; }
