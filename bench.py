@@ -82,7 +82,7 @@ def parse_dims(txt):
     return nx, ny, nz
 
 
-def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partial_windows=None):
+def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partial_windows=None, rank_times=True):
     """The same workload through the library's NATIVE driver (csrc/sharded.hip: one process, one host thread per GPU, RCCL halo
     exchange; or sim_ranks simulated on devices[0]).  The volume starts on the host, like CreateCSIFT3D(float*) gets it.
     partial_windows: None = the driver's rule (descriptor windows split along z), False = whole windows on the wide halos."""
@@ -106,7 +106,7 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partia
     t_get = time.perf_counter() - t0
     info = sh.info()
     per_rank = None
-    if sim_ranks:
+    if sim_ranks and rank_times:
         # what ONE rank does in a step, re-run alone on the GPU on the buffers the last run left behind (sift3d_test_sharded_time_rank): the
         # GPU time of that rank on a node of sim_ranks GPUs, short of what its transfers wait for
         try:
@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--strict-legs", action="store_true", help="exit non-zero when a side leg (slab / slab_native) failed; the JSON line is printed either way")
     ap.add_argument("--native", action="store_true", help="slab workload on one process: the library's native C++ driver (RCCL over --gpus devices, or --sim-ranks)")
     ap.add_argument("--partial-windows", action="store_true", help="with --native: descriptor windows split along z over the ranks or a refusal (the default is the driver's rule: split unless a slab is too thin)")
+    ap.add_argument("--no-rank-times", action="store_true", help="with --native --sim-ranks: skip the solo re-run of every rank (sim_rank_alone_ms)")
     ap.add_argument("--whole-windows", action="store_true", help="with --native: whole descriptor windows on the wide plane halos (r05's default)")
     args = ap.parse_args()
 
@@ -280,7 +281,7 @@ def main():
     if args.workload == "slab" and args.native and world == 1:
         dims = parse_dims(args.slab_dims)
         r = run_slab_native(dims, list(range(max(1, args.gpus))) if not args.sim_ranks else [local], args.steps, args.warmup, sim_ranks=args.sim_ranks,
-                            partial_windows=True if args.partial_windows else (False if args.whole_windows else None))
+                            partial_windows=True if args.partial_windows else (False if args.whole_windows else None), rank_times=not args.no_rank_times)
         print(json.dumps({"metric": "Mvoxels/s end-to-end KpSiftAlgorithm, one volume sharded as z-slabs (native driver)", "value": r["value"],
                           "unit": "Mvoxels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

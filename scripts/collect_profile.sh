@@ -43,9 +43,14 @@ PY
 cp $REPO/profiles/slab_1gpu.json $OUT/${TAG}_slab_1gpu.json
 head -12 $OUT/${TAG}_rocprofv3_kernel_stats.csv
 S3D_HOOKS=one_stream=1 python3 $REPO/scripts/pmc_kernel.py k_march_level 512 1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES > $OUT/${TAG}_pmc_k_march_level.json
-# z-slab workload on one GPU: the plain single-GPU run and the simulated 2- and 8-rank runs
+# z-slab workload on one GPU: the plain single-GPU run, the NATIVE driver on 2 / 4 / 8 simulated ranks (each with every rank's solo step:
+# sim_rank_alone_ms) and the python driver on 8
 cd $REPO
-( python3 bench.py --workload slab --steps 3 --warmup 1 2>/dev/null; python3 bench.py --workload slab --sim-ranks 2 --steps 3 --warmup 1 2>/dev/null; python3 bench.py --workload slab --sim-ranks 8 --steps 3 --warmup 1 2>/dev/null ) > $OUT/${TAG}_slab_sim.json
+( python3 bench.py --workload slab --steps 5 --warmup 2 2>/dev/null; for r in 2 4 8; do python3 bench.py --workload slab --native --sim-ranks $r --steps 5 --warmup 2 2>/dev/null; done;
+  python3 bench.py --workload slab --native --sim-ranks 8 --whole-windows --steps 5 --warmup 2 2>/dev/null; python3 bench.py --workload slab --sim-ranks 8 --steps 3 --warmup 1 2>/dev/null ) > $OUT/${TAG}_slab_sim.json
+bash $REPO/scripts/slab_kernel_sums.sh 8 native > $OUT/${TAG}_slab_kernel_sums.txt 2>&1
+bash $REPO/scripts/solo_rank_trace.sh 3 > $OUT/${TAG}_solo_rank3.txt 2>&1
+python3 $REPO/scripts/xfer_probe.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_xfer.txt
 bash $REPO/scripts/kernel_times.sh > $OUT/${TAG}_kernel_times.txt 2>&1
 bash $REPO/scripts/level_times.sh 512 > $OUT/${TAG}_levels_isolated.txt 2>&1
 bash $REPO/scripts/timeline.sh 512 > $OUT/${TAG}_timeline.txt 2>&1

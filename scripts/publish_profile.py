@@ -9,7 +9,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 names = ["rocprofv3_kernel_stats.csv", "bench_under_rocprof.json", "bench.json", "pyramid_traffic_512.json", "pmc_k_describe.json", "pmc_k_describe_512.json",
          "pmc_k_march_level.json", "slab_sim.json", "kernel_times.txt", "levels_isolated.txt", "timeline.txt"]
 for n in ["timeline_full.txt", "match_kernels.txt", "pmc_k_mark.json", "small_volumes.txt", "slab_1gpu.json", "step_times.txt",
-          "kernel_resources.txt", "desc_ring_check.txt", "slab_kernel_sums.txt"]:   # since r03b / r04 / r05
+          "kernel_resources.txt", "desc_ring_check.txt", "slab_kernel_sums.txt", "solo_rank3.txt", "xfer.txt"]:   # since r03b / r04 / r05 / r06
     if os.path.exists(os.path.join(ROOT, "gpurun_out", f"{tag}_{n}")): names.append(n)
 for n in names:
     shutil.copy(os.path.join(ROOT, "gpurun_out", f"{tag}_{n}"), os.path.join(ROOT, "profiles", f"{tag}_{n}"))
@@ -32,6 +32,6 @@ print("parity", b["parity"])
 for l in open(os.path.join(ROOT, "profiles", f"{tag}_slab_sim.json")):
     if l.startswith("{"):
         j = json.loads(l)
-        print("slab", j["config"]["workload"][-45:], "%.1f ms" % j["ms_per_step"])
+        print("slab", j["config"]["workload"][-60:], "%.1f ms" % j["ms_per_step"], j["slab"].get("sim_rank_alone_ms", ""))
 if os.path.exists(os.path.join(ROOT, "gpurun_out", f"{tag}_slab_1gpu.json")):
     shutil.copy(os.path.join(ROOT, "gpurun_out", f"{tag}_slab_1gpu.json"), os.path.join(ROOT, "profiles", "slab_1gpu.json"))

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 NATIVE=""; export S3D_NSTEPS=3
-if [ "$2" = "native" ]; then NATIVE="--native"; export S3D_NSTEPS=2; fi
+if [ "$2" = "native" ]; then NATIVE="--native --no-rank-times"; export S3D_NSTEPS=2; fi
 rm -rf /tmp/p_ss; rocprofv3 --kernel-trace -d /tmp/p_ss --output-format csv -- python3 $R/bench.py --workload slab $NATIVE --sim-ranks ${1:-8} --steps 1 --warmup 1 > /tmp/p_ss.out 2>/dev/null
 f=$(find /tmp/p_ss -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
@@ -17,6 +17,7 @@ s3=[r for r in rows if 's3d::' in r['Kernel_Name']]
 l0=[i for i,r in enumerate(s3) if 'k_march_level<2' in r['Kernel_Name']]
 nsteps=int(os.environ.get("S3D_NSTEPS","3"))
 last=s3[l0[len(l0)-len(l0)//nsteps]:]
+# (the native driver also launches the base blur in its constructor-free warm-up the same number of times per step: the split by count holds)
 t0=int(last[0]['Start_Timestamp']); t1=max(int(r['End_Timestamp']) for r in last)
 tot=collections.defaultdict(float); cnt=collections.Counter()
 busy=0; cur_end=0
