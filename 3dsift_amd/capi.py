@@ -51,7 +51,7 @@ SYMBOLS = [
     "sift3d_slab_orient_count",
     # r06: the same stages without host read-backs, the tail's seed level in place, the native driver's plan
     "sift3d_slab_keypoints_launch", "sift3d_slab_keypoints_count", "sift3d_slab_describe_finish_launch", "sift3d_slab_describe_finish_count",
-    "sift3d_seed_buffer", "sift3d_sharded_plan", "sift3d_slab_describe_launch",
+    "sift3d_seed_buffer", "sift3d_sharded_plan", "sift3d_slab_describe_launch", "sift3d_sharded_traffic",
     # test hooks / debug accessors / matcher timing
     # native driver of the z-slab sharding
     "sift3d_sharded_create", "sift3d_sharded_create_ex", "sift3d_sharded_run", "sift3d_sharded_num_keypoints", "sift3d_sharded_get_keypoints", "sift3d_sharded_info",
@@ -650,6 +650,14 @@ class ShardedCSIFT3D:
         _check(lib().sift3d_sharded_plan(self._h, C.byref(pw), C.byref(tr), pl, sp))
         return {"world": w.value, "sharded_octaves": s.value, "halo": h.value, "seconds": t[0], "seconds_incl_merge": t[1],
                 "partial_windows": bool(pw.value), "stage_partial": [bool(v) for v in sp][:s.value], "tail_rank": tr.value, "planes": [int(v) for v in pl][:w.value]}
+
+    def traffic(self):
+        """bytes every rank receives per step: (plane halos, records + partial histograms of the last run)"""
+        w = self.info()["world"]
+        a = (C.c_double * w)(); b = (C.c_double * w)()
+        lib().sift3d_sharded_traffic.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _check(lib().sift3d_sharded_traffic(self._h, a, b))
+        return [float(v) for v in a], [float(v) for v in b]
 
     def time_rank(self, rank):
         """simulated ranks, after a run: the GPU time (s) of one rank's whole step, re-run alone (sift3d_test_sharded_time_rank)"""

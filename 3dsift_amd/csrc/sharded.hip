@@ -1285,3 +1285,35 @@ extern "C" int sift3d_test_sharded_time_rank(sift3d_sharded_handle H, int rank, 
 	if (rc) { H->err = w.err; set_last_error(H->err); }
 	return rc;
 }
+
+// bytes every rank RECEIVES per step: the plane halos of the plan (what run_local posts per level and sharded octave) and, from the keypoint
+// counts of the last run, the records and partial histograms of the octaves whose windows are split along z.  halo[r], window[r]: bytes.
+extern "C" int sift3d_sharded_traffic(sift3d_sharded_handle H, double *halo /* [world] */, double *window /* [world] */) {
+	if (!H || !halo || !window) return SIFT3D_ERR_ARG;
+	for (int r = 0; r < H->world; r++) { halo[r] = 0.0; window[r] = 0.0; }
+	const Worker &w0 = H->workers[0];
+	int rbi = 0;
+	(void)sift3d_slab_record_bytes(&rbi);
+	for (int s = 0; s < H->S; s++) {
+		const Stage &st = w0.stages[(size_t)s];
+		std::vector<Transfer> all;
+		for (int i = 0; i < H->ng; i++) {
+			const int urgent_h = i + 1 < H->ng ? H->hws[(size_t)i + 1] + 1 : 0;
+			for (const std::vector<Transfer> &ts : {halo_transfers(st.bounds, st.nz, KIND_GSS, i, 0, urgent_h, s), halo_transfers(st.bounds, st.nz, KIND_GSS, i, urgent_h, H->need[(size_t)s][(size_t)i], s),
+			                                         (i - 1 >= 1 && i - 1 <= H->levels) ? halo_transfers(st.bounds, st.nz, KIND_DOG, i - 1, 0, 1, s) : std::vector<Transfer>()})
+				all.insert(all.end(), ts.begin(), ts.end());
+		}
+		for (const Transfer &t : all) halo[t.dst] += (double)(t.zg1 - t.zg0) * (double)st.plane * 4.0;
+		if (!H->ran || !H->stage_partial[(size_t)s]) continue;
+		int reach = 0;
+		if (sift3d_slab_desc_reach(st.ctx, &reach) != SIFT3D_OK) continue;
+		const std::vector<std::vector<int>> neigh = window_neighbours(st.bounds, reach);
+		const std::vector<int> &cnt = H->kp_count[(size_t)s];
+		for (int r = 0; r < H->world; r++)
+			for (int q : neigh[(size_t)r]) {
+				window[r] += (double)cnt[(size_t)q] * (double)rbi;                 // q's records
+				window[r] += (double)cnt[(size_t)r] * (768.0 * 4.0 + 4.0);         // q's part of r's windows
+			}
+	}
+	return SIFT3D_OK;
+}

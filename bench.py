@@ -105,6 +105,7 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partia
     kp, _ = sh.GetKeypoints()
     t_get = time.perf_counter() - t0
     info = sh.info()
+    hb, wb = sh.traffic()
     per_rank = None
     if sim_ranks and rank_times:
         # what ONE rank does in a step, re-run alone on the GPU on the buffers the last run left behind (sift3d_test_sharded_time_rank): the
@@ -123,6 +124,8 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partia
                                   "per sharded octave: " + ", ".join("partial integer histograms" if p else "whole windows on plane halos" for p in info["stage_partial"])),
             "ctor_s_incl_H2D_of_the_slabs": round(t_ctor, 3),
             "get_keypoints_ms_D2H_of_every_rank_and_merge": round(t_get * 1e3, 3),
+            "GB_received_per_rank_per_step": {"max": round(max(a + b for a, b in zip(hb, wb)) / 1e9, 3), "per_side_of_an_inner_rank": round(max(a + b for a, b in zip(hb, wb)) / 2e9, 3),
+                                              "plane_halos_max": round(max(hb) / 1e9, 3), "window_records_and_histograms_max": round(max(wb) / 1e9, 3)},
             **({"sim_rank_alone_ms": per_rank, "sim_slowest_rank_alone_ms": max(per_rank)} if isinstance(per_rank, list) else ({"sim_rank_alone_ms": per_rank} if per_rank else {})),
             "note": "ms_per_step = host wall time of sift3d_sharded_run: KpSiftAlgorithm, results complete on the devices (like the single-GPU extractor's step; "
                     "r05 counted the D2H of every rank's results and the merge in it: now get_keypoints_ms)"}

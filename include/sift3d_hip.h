@@ -324,6 +324,9 @@ int sift3d_sharded_info(sift3d_sharded_handle h, int *world, int *sharded_octave
  * for the node (-1: the volume has none), and the planes of octave 0 every rank owns (that rank owns fewer) */
 int sift3d_sharded_plan(sift3d_sharded_handle h, int *partial_windows, int *tail_rank, int *planes /* [world] or NULL */,
                         int *stage_partial /* [sharded octaves] or NULL */);
+/* bytes every rank receives per step: plane halos (from the plan) and -- from the keypoint counts of the last run -- the records and partial
+ * histograms of the octaves whose windows are split along z */
+int sift3d_sharded_traffic(sift3d_sharded_handle h, double *halo_bytes /* [world] */, double *window_bytes /* [world] */);
 const char *sift3d_sharded_error(sift3d_sharded_handle h);
 int sift3d_sharded_destroy(sift3d_sharded_handle h);
 
