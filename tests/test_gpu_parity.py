@@ -711,6 +711,14 @@ def test_async_run_two_volumes_in_flight(capi, synth):
             ea.KpSiftAlgorithmAsync()          # a run is in flight
         eb.Wait(); ea.Wait(); ea.Wait()        # any order; a wait with nothing in flight is a no-op
         assert [_full_hash(capi, e, with_extrema=True) for e in (ea, eb)] == base, rep
+    # r06, sift3d_run_async_after: the second volume's pipeline is gated behind the first one's orientation stage; same results; with nothing in
+    # flight on the other handle (or the handle itself) it is a plain run_async
+    for rep in range(2):
+        ea.KpSiftAlgorithmAsync(); eb.KpSiftAlgorithmAsync(after=ea)
+        ea.Wait(); eb.Wait()
+        assert [_full_hash(capi, e, with_extrema=True) for e in (ea, eb)] == base, rep
+    eb.KpSiftAlgorithmAsync(after=ea).Wait(); ea.KpSiftAlgorithmAsync(after=ea).Wait()
+    assert [_full_hash(capi, e, with_extrema=True) for e in (ea, eb)] == base
     ea.KpSiftAlgorithmAsync()
     assert len(ea.GetKeypoints()[0]) == base[0][1]   # no Wait(): the accessor completes the run
     with capi.hook("list_cap", 64):   # the regrow + rerun of an overflowing list happens inside the wait
