@@ -75,16 +75,30 @@ for case in range(N):
             okp, odesc = o.keypoints()
             compare_keypoints(kp, desc, okp, odesc)
             # the native z-slab driver on the same volume (default parameters only take the hooks' paths; its own parameters: the draw's)
-            ranks = int(rng.integers(2, 6)); octs = int(rng.integers(1, 3)); partial = bool(rng.integers(0, 2))
-            try:
-                sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=partial, **params)
-            except capi.Sift3dError:
-                sh = None
+            # (r06: up to 8 ranks and three sharded octaves, the driver's own plan / forced partial / forced whole windows; every rank's solo
+            # re-run must leave the results as they are)
+            ranks = int(rng.integers(2, 9)); octs = int(rng.integers(0, 4)); partial = (None, True, False)[int(rng.integers(0, 3))]
+            sh = None
+            while sh is None and ranks >= 2:   # (small draws: fewer ranks until the planes suffice; a forced form that is refused: the driver's rule)
+                try:
+                    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=partial, **params)
+                except capi.Sift3dError:
+                    if partial is True:
+                        partial = None
+                    else:
+                        ranks -= 1
             if sh is not None:
                 k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+                assert np.array_equal(k2, kp), ("sharded keypoints", ranks, octs, partial, sh.info())
+                assert np.array_equal(d2, desc), ("sharded descriptors", ranks, octs, partial, sh.info())
+                for r in range(ranks):
+                    sh.time_rank(r)
+                k2, d2 = sh.GetKeypoints()
+                assert np.array_equal(k2, kp) and np.array_equal(d2, desc), ("after the solo re-runs", ranks, octs, partial, sh.info())
+                k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+                plan = sh.info()["stage_partial"]
                 sh.close()
-                assert np.array_equal(k2, kp), ("sharded keypoints", ranks, octs, partial)
-                assert np.array_equal(d2, desc), ("sharded descriptors", ranks, octs, partial)
+                assert np.array_equal(k2, kp) and np.array_equal(d2, desc), ("second run", ranks, octs, partial)
             # every other draw: the python z-slab driver (3dsift_amd/slab.py, ranks simulated on this GPU) with the draw's parameters
             if case % 2 == 1:
                 slab = importlib.import_module("3dsift_amd.slab")
@@ -121,6 +135,6 @@ for case in range(N):
             sys.exit(1)
         nkp += len(kp)
         pys = "  py-slabs %d/%d%s" % (w2, o2, " partial" if p2 else "") if (case % 2 == 1 and ex is not None) else ""
-        print("draw %3d ok  %-16s levels %d sigma %.2f hooks %s  kp %d%s%s" % (case, shape, levels, sd, hooks, len(kp), "" if sh is None else "  slabs %d/%d%s" % (ranks, octs, " partial" if partial else ""), pys), flush=True)
+        print("draw %3d ok  %-16s levels %d sigma %.2f hooks %s  kp %d%s%s" % (case, shape, levels, sd, hooks, len(kp), "" if sh is None else "  slabs %d/%d %s" % (ranks, octs, "".join("p" if p else "w" for p in plan)), pys), flush=True)
         g.close()
 print("soak: %d draws, %d keypoints, %.0f s, all equal" % (N, nkp, time.time() - t0))
