@@ -211,6 +211,10 @@ struct Worker {  // the sharded octaves of one rank (+ the tail's extractor on t
 	// round's (its own memory: the first round's lists stay in place, which is what a solo re-run of a neighbour reads)
 	std::vector<char *> pscratch; std::vector<size_t> pscratch_bytes;
 	std::string err;
+	// tail rank: the thread that enqueues the tail's pipeline beside this rank's own launches (start_tail), and what it came back with
+	std::thread tail_thread;
+	int tail_rc = 0;
+	std::string tail_err;
 };
 
 // device scratch of one rank for one round of one stage: pointers into Worker::pscratch
@@ -426,14 +430,34 @@ int gather_seed(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	return SIFT3D_OK;
 }
 
-// the tail's whole KpSiftAlgorithm enqueued on its own streams (sift3d_run_async), behind the gathered seed level
+// the tail's whole KpSiftAlgorithm enqueued on its own streams (sift3d_run_async), behind the gathered seed level -- by a thread of its own:
+// ~70 launches and as many event calls take 0.4-0.6 ms of a host thread, and the rank's thread has its own launches to place meanwhile
+// (enqueued inline right behind the gather it held back the rank's extrema by 0.45 ms; behind the rank's extrema and orientation launches
+// it held back the rank's descriptor launches instead: the tail rank's step alone 4.1 / 3.9 ms against 3.3-3.7 for the others,
+// profiles/r06q_solo_rank7.txt, r06q_solo_rank7b.txt).  join_tail collects the thread; every exit of run_local passes through it.
 int start_tail(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	for (Worker *w : ws) {
 		if (!w->tail || w->rank != H->tail_rank) continue;
-		SH_HIP(*w, hipSetDevice(w->device));
-		SH_ABI(*w, sift3d_run_async(w->tail));
+		if (w->tail_thread.joinable()) w->tail_thread.join();  // (never: a step joins what it started)
+		w->tail_rc = SIFT3D_OK; w->tail_err.clear();
+		w->tail_thread = std::thread([w] {
+			int rc = hipSetDevice(w->device) == hipSuccess ? SIFT3D_OK : SIFT3D_ERR_HIP;
+			if (rc != SIFT3D_OK) w->tail_err = "hipSetDevice failed on the tail's thread";
+			else if ((rc = sift3d_run_async(w->tail)) != SIFT3D_OK) w->tail_err = std::string(sift3d_error_string(rc)) + " (" + sift3d_last_error() + ")";  // (the error text is thread-local)
+			w->tail_rc = rc;
+		});
 	}
 	return SIFT3D_OK;
+}
+// the tail's enqueue is complete (or has failed): first error of the ranks in ws, SIFT3D_OK otherwise
+int join_tail(std::vector<Worker *> &ws) {
+	int rc = SIFT3D_OK;
+	for (Worker *w : ws) {
+		if (!w->tail_thread.joinable()) continue;
+		w->tail_thread.join();
+		if (w->tail_rc != SIFT3D_OK && rc == SIFT3D_OK) { set_err(*w, "tail: " + w->tail_err); rc = w->tail_rc; }
+	}
+	return rc;
 }
 
 // ---- partial descriptor windows (r05, opt-in; the protocol of 3dsift_amd/slab.py _describe_partial) ---------------------
@@ -675,6 +699,7 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	const int ng = H->ng;
 	const bool has_tail = H->noct > H->S;
 	for (Worker *w : ws) SH_HIP(*w, hipSetDevice(w->device));
+	struct TailJoin { std::vector<Worker *> &ws; ~TailJoin() { (void)join_tail(ws); } } tail_join{ws};  // (whatever way this function is left)
 	for (int s = 0; s < H->S; s++) {
 		const Stage &st0 = w0.stages[(size_t)s];
 		const Bounds &bounds = st0.bounds;
@@ -723,6 +748,7 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 				}
 				if (s + 1 < H->S)
 					for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_HIP(*w, hipEventRecord(w->ev_next[(size_t)s], w->sstream[(size_t)s])); }
+				// the octaves behind the sharded ones, once, on the tail rank: the seed level gathered, the whole pipeline enqueued by a thread of its own
 				if (s + 1 == H->S && has_tail) {
 					if ((rc = gather_seed(H, ws)) != SIFT3D_OK) return rc;
 					if ((rc = start_tail(H, ws)) != SIFT3D_OK) return rc;
@@ -798,8 +824,12 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 	}
 	if (rc != SIFT3D_OK) abort_all(H);  // (peers may sit in a receive waiting for this rank)
 	// the tail's run is completed whatever happened above (an extractor with a run in flight must not be destroyed under it)
+	{
+		const int jrc = join_tail(ws);
+		if (jrc != SIFT3D_OK && rc == SIFT3D_OK) { rc = jrc; abort_all(H); }
+	}
 	for (Worker *w : ws)
-		if (w->tail && has_tail) {
+		if (w->tail && has_tail && w->rank == H->tail_rank && w->tail_rc == SIFT3D_OK) {
 			(void)hipSetDevice(w->device);
 			const int trc = sift3d_wait(w->tail);
 			if (trc != SIFT3D_OK && rc == SIFT3D_OK) { say(*w, "tail", trc); rc = trc; abort_all(H); }
@@ -823,6 +853,7 @@ void destroy_worker(Worker &w, int phase, bool comms_aborted) {
 	if (phase == 0) {
 		for (hipStream_t st : w.sstream) if (st) (void)hipStreamSynchronize(st);
 		for (hipStream_t st : w.sdstream) if (st) (void)hipStreamSynchronize(st);
+		if (w.tail_thread.joinable()) w.tail_thread.join();
 		if (w.tstream) (void)hipStreamSynchronize(w.tstream);
 		if (w.tail) { (void)sift3d_set_stream(w.tail, nullptr); sift3d_destroy(w.tail); }
 		w.tail = nullptr; w.seed_dst = nullptr;
@@ -1013,7 +1044,22 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 			if (r == H->tail_rank) {
 				// the tail: an ordinary seeded extractor of the octaves >= S on a stream of its own; its level 0 is where the seed level is gathered
 				CR_ABI(sift3d_create_seeded(&w.tail, dx, dy, dz, S, H->noct, &H->p, w.device));
-				CR_HIP(hipStreamCreateWithFlags(&w.tstream, hipStreamNonBlocking));
+				// ... created with a CU mask of ALL compute units: HIP gives such a stream a hardware queue of its own (the others are dealt onto four
+				// shared ones, and launches that share a queue run one after the other -- the tail's pyramid sat behind octave 1's extrema in
+				// theirs): the tail rank's step alone 3.95-3.97 -> 3.83-3.88 ms (S3D_TAIL_OWNQ=0 in a -DS3D_DEV_SWITCHES build; profiles/r06q_ownq.txt).
+				// Measured and not kept: the tail's streams at the lowest / highest queue priority (4.8 / 5.3 ms: every wait across priorities
+				// is slow, r06q_tail_prio.txt), more hardware queues for everybody (GPU_MAX_HW_QUEUES 5 .. 8: 4.4-4.6 ms, r06q_hwq2.txt), partial-
+				// window workgroups that leave after 1 / 2 / 4 records instead of staying to the end (4.28 / 3.93 / 3.86 ms, r06q_perwg.txt)
+				{
+					static const int own_q = dev_tune_i("S3D_TAIL_OWNQ", 1);
+					hipDeviceProp_t pr;
+					if (own_q && hipGetDeviceProperties(&pr, w.device) == hipSuccess && pr.multiProcessorCount > 0) {
+						std::vector<uint32_t> mask((size_t)(pr.multiProcessorCount + 31) / 32, 0u);
+						for (int cu = 0; cu < pr.multiProcessorCount; cu++) mask[(size_t)cu / 32] |= 1u << (cu % 32);
+						CR_HIP(hipExtStreamCreateWithCUMask(&w.tstream, (uint32_t)mask.size(), mask.data()));
+					} else
+						CR_HIP(hipStreamCreateWithFlags(&w.tstream, hipStreamNonBlocking));
+				}
 				CR_ABI(sift3d_set_stream(w.tail, w.tstream));
 				size_t nf = 0;
 				CR_ABI(sift3d_seed_buffer(w.tail, &w.seed_dst, &nf));

@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel sums of ONE rank's solo step (sift3d_test_sharded_time_rank) of the simulated 8-rank native z-slab run at 1024x1024x512:
-#   solo_rank_trace.sh [rank=3]
+#   solo_rank_trace.sh [rank=3]      (FULL=1: every launch in the list, not only the keypoint stages')
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cat > /tmp/solo_one.py <<PY
@@ -43,6 +43,7 @@ for n, v in sorted(tot.items(), key=lambda x: -x[1])[:30]: print("  %-40s %4d la
 print("in launch order (start offset, duration, queue):")
 for r in last:
     n = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('s3d::', '')
-    if 'k_describe' in n or 'k_orient' in n or 'k_mark' in n or 'k_lazy' in n:
+    import os
+    if os.environ.get('FULL') or 'k_describe' in n or 'k_orient' in n or 'k_mark' in n or 'k_lazy' in n:
         print("   +%8.1f us %8.1f us  q%s grid %s  %s" % ((int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r.get('Queue_Id', '?'), r.get('Grid_Size', r.get('Grid_Size_X', '?')), n))
 PY
