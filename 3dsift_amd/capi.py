@@ -64,6 +64,7 @@ HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "des
 ORIENT_WORDS = 34
 SHARDED_PARTIAL_WINDOWS = 1   # sift3d_sharded_create_ex flags
 SHARDED_WHOLE_WINDOWS = 2
+SHARDED_COPY_TRANSPORT = 4
 
 
 class Params(C.Structure):
@@ -616,9 +617,10 @@ class ShardedCSIFT3D:
     over RCCL, or sim_ranks = n ranks simulated on devices[0].  partial_windows: descriptor windows split along z over the ranks
     (sift3d_sharded_create_ex, SIFT3D_SHARDED_PARTIAL_WINDOWS) instead of whole windows on wide halos."""
 
-    def __init__(self, volume, devices=(0,), sim_ranks=0, sharded_octaves=0, partial_windows=None, **kw):
+    def __init__(self, volume, devices=(0,), sim_ranks=0, sharded_octaves=0, partial_windows=None, transport="rccl", **kw):
         """partial_windows: None = the driver's rule (descriptor windows split along z unless a slab is too thin for that), True = split or
-        refuse, False = whole windows on the wide halos"""
+        refuse, False = whole windows on the wide halos.  transport: "rccl" (one rank per device) or "copies" (SIFT3D_SHARDED_COPY_TRANSPORT:
+        event + device / peer copies; `devices` may repeat a device -- rank threads sharing one GPU)"""
         vol = np.ascontiguousarray(volume, np.float32)
         assert vol.ndim == 3
         nz, ny, nx = vol.shape
@@ -626,6 +628,9 @@ class ShardedCSIFT3D:
         p = _params(kw)
         devs = (C.c_int * len(devices))(*devices)
         flags = 0 if partial_windows is None else (SHARDED_PARTIAL_WINDOWS if partial_windows else SHARDED_WHOLE_WINDOWS)
+        assert transport in ("rccl", "copies")
+        if transport == "copies":
+            flags |= SHARDED_COPY_TRANSPORT
         _check(lib().sift3d_sharded_create_ex(C.byref(self._h), vol.ctypes.data_as(C.c_void_p), nx, ny, nz, C.byref(p), devs, len(devices),
                                               int(sim_ranks), int(sharded_octaves), flags))
 

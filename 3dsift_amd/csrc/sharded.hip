@@ -44,6 +44,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <map>
 #include <mutex>
 #include <shared_mutex>
@@ -215,6 +217,11 @@ struct Worker {  // the sharded octaves of one rank (+ the tail's extractor on t
 	std::thread tail_thread;
 	int tail_rc = 0;
 	std::string tail_err;
+	// copy transport: the events this rank has recorded for its sends in the current step (reused from step to step: a step ends with every
+	// stream of every rank drained), and where its peers' DoG maxima land
+	std::vector<hipEvent_t> evp;
+	size_t evp_i = 0;
+	std::vector<float *> dogmax_in;  // per stage: world x 8 floats (device)
 };
 
 // device scratch of one rank for one round of one stage: pointers into Worker::pscratch
@@ -274,6 +281,16 @@ struct sift3d_sharded {
 	std::atomic<bool> failed{false};
 	std::atomic<bool> comms_aborted{false};  // abort_all ran: the communicators are gone (their pointers are left alone)
 	std::shared_timed_mutex comm_mu;
+	// r06, the COPY transport (SIFT3D_SHARDED_COPY_TRANSPORT): the same rank threads, streams and plan as the RCCL transport, but a "send" is a message
+	// -- an event recorded on the sender's stream behind the producer + the source address -- in the mailbox of the (sender, receiver) pair, and a
+	// "receive" waits for the message (host), makes its stream wait for the event and copies (one copy launch per exchange step on one device,
+	// hipMemcpyPeerAsync between devices).  Both sides walk the same transfer list in the same order, so a FIFO per pair matches them.  A step
+	// writes every buffer it sends from once, and ends with every rank's streams drained: a sender never overwrites what a peer still reads.
+	// `devices` may name one device several times: N rank THREADS on one GPU -- what a one-GPU box can run of the multi-threaded driver.
+	bool copies = false;
+	struct Msg { hipEvent_t ev; const void *p; };
+	struct Mailbox { std::mutex mu; std::condition_variable cv; std::deque<Msg> q; };
+	std::unique_ptr<Mailbox[]> mail;  // [src * world + dst]
 };
 
 namespace {
@@ -294,6 +311,10 @@ void set_err(W &w, const std::string &msg) {
 // INSIDE a call (connection set-up waiting for the rank that failed) holds it shared, and aborting under it is what frees that peer.
 void abort_all(sift3d_sharded *H) {
 	if (H->sim || H->failed.exchange(true)) return;
+	if (H->copies) {  // (no communicators: the flag alone frees the ranks that wait for a message or at a rendezvous)
+		for (int i = 0; i < H->world * H->world; i++) H->mail[(size_t)i].cv.notify_all();
+		return;
+	}
 	const bool locked = H->comm_mu.try_lock_for(std::chrono::seconds(2));
 	// The communicator POINTERS are never written after creation: a rank that reads one (under the shared lock, after SH_LIVE) cannot see
 	// a pointer in the middle of a store.  A rank already inside an RCCL call when the wait above timed out is what the abort is for.
@@ -309,6 +330,50 @@ void abort_all(sift3d_sharded *H) {
 	if (locked) H->comm_mu.unlock();
 }
 #define SH_LIVE(H, w) do { if ((H)->failed.load()) { set_err((w), "aborted: another rank failed"); return SIFT3D_ERR_STATE; } } while (0)
+
+// ---- the copy transport's three moves --------------------------------------------------------------------------------------------
+// an event of this rank, recorded on `st` (behind everything the rank has enqueued there)
+int mb_mark(Worker &w, hipStream_t st, hipEvent_t &ev) {
+	if (w.evp_i == w.evp.size()) {
+		hipEvent_t e = nullptr;
+		SH_HIP(w, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		w.evp.push_back(e);
+	}
+	ev = w.evp[w.evp_i++];
+	SH_HIP(w, hipEventRecord(ev, st));
+	return SIFT3D_OK;
+}
+void mb_post(sift3d_sharded *H, int src, int dst, hipEvent_t ev, const void *p) {
+	sift3d_sharded::Mailbox &mb = H->mail[(size_t)src * (size_t)H->world + (size_t)dst];
+	{ std::lock_guard<std::mutex> g(mb.mu); mb.q.push_back(sift3d_sharded::Msg{ev, p}); }
+	mb.cv.notify_all();
+}
+// the next message of src for this rank: `st` waits for its event; a dead handle lets the waiter go
+int mb_take(sift3d_sharded *H, Worker &w, int src, hipStream_t st, const void *&p) {
+	sift3d_sharded::Mailbox &mb = H->mail[(size_t)src * (size_t)H->world + (size_t)w.rank];
+	sift3d_sharded::Msg m{nullptr, nullptr};
+	{
+		std::unique_lock<std::mutex> lk(mb.mu);
+		while (mb.q.empty()) {
+			if (H->failed.load()) { set_err(w, "aborted: another rank failed"); return SIFT3D_ERR_STATE; }
+			mb.cv.wait_for(lk, std::chrono::milliseconds(20));
+		}
+		m = mb.q.front(); mb.q.pop_front();
+	}
+	SH_HIP(w, hipStreamWaitEvent(st, m.ev, 0));
+	p = m.p;
+	return SIFT3D_OK;
+}
+// n bytes from a peer's buffer into this rank's, on this rank's stream: collected into `cs` on one device, a peer copy between devices
+int mb_copy(sift3d_sharded *H, Worker &w, int src, const void *sp, void *dp, size_t bytes, CopySegs &cs, hipStream_t st) {
+	const int sdev = H->workers[(size_t)src].device;
+	if (!bytes) return SIFT3D_OK;
+	if (sdev != w.device) { SH_HIP(w, hipMemcpyPeerAsync(dp, w.device, sp, sdev, bytes, st)); return SIFT3D_OK; }
+	if (bytes & 3) { SH_HIP(w, hipMemcpyAsync(dp, sp, bytes, hipMemcpyDeviceToDevice, st)); return SIFT3D_OK; }
+	cs.src[cs.n] = static_cast<const float *>(sp); cs.dst[cs.n] = static_cast<float *>(dp); cs.floats[cs.n] = bytes / 4; cs.n++;
+	if (cs.n == kCopySegs) { launch_copy_segments(cs, st); cs.n = 0; }
+	return SIFT3D_OK;
+}
 
 // posts the transfers this set of local workers takes part in.  SIM: device copies on the shared stream.  RCCL: one group of
 // sends / receives of the one local rank on `comm` / `stream` of the given flow (0 urgent, 1 deferred).
@@ -332,11 +397,36 @@ int exchange(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector<Tra
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
-	ncclComm_t comm = flow ? w.c_deferred[sgi] : w.c_urgent[sgi];
 	hipStream_t st = flow ? w.sdstream[sgi] : w.sstream[sgi];
-	bool any = false;
-	for (const Transfer &t : ts) any = any || t.src == w.rank || t.dst == w.rank;
+	bool any = false, sends = false;
+	for (const Transfer &t : ts) { any = any || t.src == w.rank || t.dst == w.rank; sends = sends || t.src == w.rank; }
 	if (!any) return SIFT3D_OK;
+	if (H->copies) {
+		SH_LIVE(H, w);
+		hipEvent_t ev = nullptr;
+		int rc;
+		if (sends && (rc = mb_mark(w, st, ev)) != SIFT3D_OK) return rc;
+		for (const Transfer &t : ts) {  // every send first (none of them waits), then the receives
+			if (t.src != w.rank) continue;
+			float *p = w.stages[(size_t)t.stage].view(t.kind, t.idx, t.zg0, t.zg1);
+			if (!p) { set_err(w, "halo transfer outside a level buffer"); return SIFT3D_ERR_STATE; }
+			mb_post(H, w.rank, t.dst, ev, p);
+		}
+		CopySegs cs;
+		for (const Transfer &t : ts) {
+			if (t.dst != w.rank) continue;
+			Stage &s = w.stages[(size_t)t.stage];
+			float *p = s.view(t.kind, t.idx, t.zg0, t.zg1);
+			if (!p) { set_err(w, "halo transfer outside a level buffer"); return SIFT3D_ERR_STATE; }
+			const void *sp = nullptr;
+			if ((rc = mb_take(H, w, t.src, st, sp)) != SIFT3D_OK) return rc;
+			if ((rc = mb_copy(H, w, t.src, sp, p, sizeof(float) * s.plane * (size_t)(t.zg1 - t.zg0), cs, st)) != SIFT3D_OK) return rc;
+		}
+		launch_copy_segments(cs, st);
+		SH_HIP(w, hipGetLastError());
+		return SIFT3D_OK;
+	}
+	ncclComm_t comm = flow ? w.c_deferred[sgi] : w.c_urgent[sgi];
 	std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
 	SH_LIVE(H, w);
 	SH_NCCL(w, g_rccl.GroupStart());
@@ -376,6 +466,32 @@ int allreduce_max_dev(sift3d_sharded *H, std::vector<Worker *> &ws, int stage, i
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
+	if (H->copies) {
+		// every rank's n values into this rank's scratch, then the MAX over them and its own (a peer's array may already hold ITS merge: a maximum
+		// of maxima, the same result)
+		SH_LIVE(H, w);
+		hipStream_t st = w.sstream[(size_t)stage];
+		hipEvent_t ev = nullptr;
+		int rc = mb_mark(w, st, ev);
+		if (rc) return rc;
+		for (int r = 0; r < H->world; r++) if (r != w.rank) mb_post(H, w.rank, r, ev, w.dogmax[(size_t)stage]);
+		MaxMerge mm;
+		mm.p[mm.np++] = w.dogmax[(size_t)stage];
+		mm.n = n;
+		for (int r = 0; r < H->world; r++) {
+			if (r == w.rank) continue;
+			const void *sp = nullptr;
+			if ((rc = mb_take(H, w, r, st, sp)) != SIFT3D_OK) return rc;
+			float *slot = w.dogmax_in[(size_t)stage] + (size_t)r * 8;
+			const int sdev = H->workers[(size_t)r].device;
+			if (sdev != w.device) SH_HIP(w, hipMemcpyPeerAsync(slot, w.device, sp, sdev, sizeof(float) * (size_t)n, st));
+			else SH_HIP(w, hipMemcpyAsync(slot, sp, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, st));
+			mm.p[mm.np++] = slot;
+		}
+		launch_max_merge(mm, st);
+		SH_HIP(w, hipGetLastError());
+		return SIFT3D_OK;
+	}
 	std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
 	SH_LIVE(H, w);
 	SH_NCCL(w, g_rccl.AllReduce(w.dogmax[(size_t)stage], w.dogmax[(size_t)stage], (size_t)n, ncclFloat, ncclMax, w.c_urgent[(size_t)stage], w.sstream[(size_t)stage]));
@@ -410,6 +526,30 @@ int gather_seed(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
+	if (H->copies) {
+		SH_LIVE(H, w);
+		int rc;
+		if (&w != tw) {  // behind the decimation on that octave's stream
+			hipEvent_t ev = nullptr;
+			if (off[(size_t)w.rank + 1] == off[(size_t)w.rank]) return SIFT3D_OK;
+			if ((rc = mb_mark(w, w.sstream[sl], ev)) != SIFT3D_OK) return rc;
+			mb_post(H, w.rank, H->tail_rank, ev, w.seed_mine);
+			return SIFT3D_OK;
+		}
+		CopySegs cs;
+		for (int r = 0; r < H->world; r++) {
+			const size_t cnt = off[(size_t)r + 1] - off[(size_t)r];
+			if (r == w.rank || !cnt) continue;
+			const void *sp = nullptr;
+			if ((rc = mb_take(H, w, r, w.tstream, sp)) != SIFT3D_OK) return rc;
+			if ((rc = mb_copy(H, w, r, sp, w.seed_dst + off[(size_t)r], sizeof(float) * cnt, cs, w.tstream)) != SIFT3D_OK) return rc;
+		}
+		launch_copy_segments(cs, w.tstream);
+		SH_HIP(w, hipGetLastError());
+		SH_HIP(w, hipEventRecord(w.ev_seed, w.sstream[sl]));
+		SH_HIP(w, hipStreamWaitEvent(w.tstream, w.ev_seed, 0));
+		return SIFT3D_OK;
+	}
 	{
 		std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
 		SH_LIVE(H, w);
@@ -500,6 +640,26 @@ int exchange_raw(sift3d_sharded *H, std::vector<Worker *> &ws, const std::vector
 		return SIFT3D_OK;
 	}
 	Worker &w = *ws[0];
+	if (H->copies) {
+		SH_LIVE(H, w);
+		hipStream_t st = w.sstream[(size_t)stage];
+		hipEvent_t ev = nullptr;
+		int rc;
+		bool sends = false;
+		for (const RawXfer &t : ts) sends = sends || (t.src == w.rank && t.bytes);
+		if (sends && (rc = mb_mark(w, st, ev)) != SIFT3D_OK) return rc;
+		for (const RawXfer &t : ts) if (t.src == w.rank && t.bytes) mb_post(H, w.rank, t.dst, ev, t.sp);
+		CopySegs cs;
+		for (const RawXfer &t : ts) {
+			if (t.dst != w.rank || !t.bytes) continue;
+			const void *sp = nullptr;
+			if ((rc = mb_take(H, w, t.src, st, sp)) != SIFT3D_OK) return rc;
+			if ((rc = mb_copy(H, w, t.src, sp, t.dp, t.bytes, cs, st)) != SIFT3D_OK) return rc;
+		}
+		launch_copy_segments(cs, st);
+		SH_HIP(w, hipGetLastError());
+		return SIFT3D_OK;
+	}
 	std::shared_lock<std::shared_timed_mutex> live(H->comm_mu);
 	SH_LIVE(H, w);
 	SH_NCCL(w, g_rccl.GroupStart());
@@ -863,6 +1023,9 @@ void destroy_worker(Worker &w, int phase, bool comms_aborted) {
 			s.arena = nullptr;
 		}
 		for (float *&d : w.dogmax) { if (d) (void)hipFree(d); d = nullptr; }
+		for (float *&d : w.dogmax_in) { if (d) (void)hipFree(d); d = nullptr; }
+		for (hipEvent_t e : w.evp) if (e) (void)hipEventDestroy(e);
+		w.evp.clear(); w.evp_i = 0;
 		for (char *&ps : w.pscratch) { if (ps) (void)hipFree(ps); ps = nullptr; }
 		w.pscratch.clear(); w.pscratch_bytes.clear();
 		if (w.seed_mine && w.seed_mine_owned) (void)hipFree(w.seed_mine);
@@ -918,6 +1081,15 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	if (params) H->p = *params; else sift3d_default_params(&H->p);
 	H->sim = sim_ranks > 0;
 	H->world = H->sim ? sim_ranks : ndev;
+	H->copies = !H->sim && (flags & SIFT3D_SHARDED_COPY_TRANSPORT) != 0;
+	if (H->copies) {
+		if (H->world > kMaxMergePtrs) return fail(SIFT3D_ERR_ARG, "the copy transport takes at most " + std::to_string(kMaxMergePtrs) + " ranks");
+		H->mail.reset(new sift3d_sharded::Mailbox[(size_t)H->world * (size_t)H->world]);
+	} else if (!H->sim) {
+		for (int i = 0; i < ndev; i++)
+			for (int j = 0; j < i; j++)
+				if (devices[i] == devices[j]) return fail(SIFT3D_ERR_ARG, "RCCL takes one rank per device (several ranks on one device: SIFT3D_SHARDED_COPY_TRANSPORT, or simulated ranks)");
+	}
 	H->devices.assign(devices, devices + ndev);
 	H->levels = H->p.num_kp_levels; H->ng = H->levels + 3;
 	int halo_whole = 0, halo_partial = 0;
@@ -972,7 +1144,7 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	}
 	H->halo = H->stage_halo[0];
 	H->need.assign((size_t)S, std::vector<int>());
-	if (!H->sim) {
+	if (!H->sim && !H->copies) {
 		std::lock_guard<std::mutex> lk(g_rccl_mu);
 		std::string e;
 		if (!g_rccl.load(e)) return fail(SIFT3D_ERR_STATE, e);
@@ -1023,6 +1195,12 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 			CR_HIP(hipMalloc(&dm, sizeof(float) * 8));
 			CR_HIP(hipMemset(dm, 0, sizeof(float) * 8));
 			w.dogmax.push_back(dm);
+			if (H->copies) {
+				float *di = nullptr;
+				CR_HIP(hipMalloc(&di, sizeof(float) * 8 * (size_t)H->world));
+				CR_HIP(hipMemset(di, 0, sizeof(float) * 8 * (size_t)H->world));
+				w.dogmax_in.push_back(di);
+			}
 			bb = halve_bounds(bb, dz);
 			dx /= 2; dy /= 2; dz /= 2;
 		}
@@ -1075,7 +1253,7 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	}
 	H->kp_count.assign((size_t)S, std::vector<int>((size_t)H->world, 0));
 	H->redo_count = H->kp_count;
-	if (!H->sim) {
+	if (!H->sim && !H->copies) {
 		// communicators over the same devices: per sharded octave one for its urgent halos, reductions and window exchange and one for its
 		// deferred halos; one for the gather of the tail's seed level
 		std::vector<ncclComm_t> c((size_t)H->world);
@@ -1176,6 +1354,7 @@ extern "C" int sift3d_sharded_run(sift3d_sharded_handle H) {
 		for (int r = 0; r < H->world; r++)
 			th.emplace_back([&, r] {
 				std::vector<Worker *> ws{&H->workers[(size_t)r]};
+				H->workers[(size_t)r].evp_i = 0;  // (copy transport: the last step's events are free again, every stream has drained)
 				rcs[(size_t)r] = run_local(H, ws);
 				if (rcs[(size_t)r] != SIFT3D_OK) abort_all(H);  // frees the z-neighbours blocked in a receive / reduction with this rank
 			});

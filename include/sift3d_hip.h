@@ -311,6 +311,11 @@ int sift3d_sharded_create(sift3d_sharded_handle *out, const float *volume, int n
  * always; SIFT3D_SHARDED_PARTIAL_WINDOWS for partial windows or a refusal (no silent change of form).  Same results bit for bit. */
 #define SIFT3D_SHARDED_PARTIAL_WINDOWS 1u
 #define SIFT3D_SHARDED_WHOLE_WINDOWS 2u
+/* r06: the COPY transport instead of RCCL: the same rank threads, streams and plan, but a neighbour's planes / records / histograms are fetched by
+ * device copies behind an event the sender recorded (one copy launch per exchange step on one device, hipMemcpyPeerAsync between devices; no
+ * communicator, no librccl).  `devices` may then name a device several times -- N rank threads on ONE GPU, which is how the multi-threaded driver
+ * is tested on a one-GPU box -- and at most 16 ranks are taken.  Same results bit for bit.  Ignored with sim_ranks > 0. */
+#define SIFT3D_SHARDED_COPY_TRANSPORT 4u
 int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
                              const int *devices, int ndev, int sim_ranks, int sharded_octaves, unsigned flags);
 int sift3d_sharded_run(sift3d_sharded_handle h);

@@ -226,5 +226,59 @@ def test_bench_runs_the_native_legs_in_a_child_process():
         assert err is None, err
         assert res["keypoints"] > 100 and res["ms_per_step"] > 0
         assert res["descriptor_windows"] == ("whole windows on plane halos" if partial is False else "partial integer histograms")
+    res, err = bench.run_slab_native_child("256x192x128", 1, 2, 1, None, 240, transport="copies")   # (r06: the leg over the copy transport)
+    assert err is None and res["keypoints"] > 100 and "copy transport" in res["workload"], (res, err)
     res, err = bench.run_slab_native_child("8x8x4", 1, 1, 0, False, 120)
     assert res is None and err
+
+
+# ---- r06: the COPY transport -- the multi-threaded driver (one host thread per rank, its own streams, rendezvous, the tail's thread) on ONE GPU ----
+@pytest.mark.parametrize("ranks,octs,partial", [(2, 1, None), (2, 2, True), (3, 2, None), (4, 2, False), (5, 1, True), (8, 2, None), (8, 2, False)])
+def test_rank_threads_on_one_gpu_equal_the_single_volume(vol_and_single, ranks, octs, partial):
+    """SIFT3D_SHARDED_COPY_TRANSPORT with `devices` = the one GPU named `ranks` times: every rank has its host thread, its streams per sharded
+    octave and its deferred streams, exactly as over RCCL -- only a neighbour's data is fetched by a device copy behind the sender's event instead
+    of ncclSend / ncclRecv.  What the simulated ranks (one thread, shared streams) cannot show: the rendezvous of the counts, the ranks' threads
+    enqueueing against each other, the tail's own thread.  Keypoints and descriptors bit-identical to the single volume, run after run."""
+    vol, kp, ds = vol_and_single
+    sh = capi.ShardedCSIFT3D(vol, devices=(0,) * ranks, sharded_octaves=octs, partial_windows=partial, transport="copies")
+    info = sh.info()
+    assert info["world"] == ranks and 1 <= info["sharded_octaves"] <= octs
+    for _ in range(3):
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        assert np.array_equal(k2, kp), (ranks, octs, partial)
+        assert np.array_equal(d2, ds), (ranks, octs, partial)
+    sh.close()
+
+
+def test_rank_threads_three_sharded_octaves_and_the_second_round():
+    """256 x 256 x 256 over 8 rank threads: three sharded octaves (partial / whole / whole windows by the driver's rule), the tail on the last
+    rank); then 4 rank threads with the first fixed-point unit forced to fail (hook desc_mass_shift): the second round of the flagged records."""
+    vol = synth.blobs((256, 256, 256), seed=31, noise=0.01)
+    ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+    kp, ds = ex.GetKeypoints()
+    ex.close()
+    sh = capi.ShardedCSIFT3D(vol, devices=(0,) * 8, sharded_octaves=3, transport="copies")
+    assert sh.info()["sharded_octaves"] == 3 and sh.info()["stage_partial"] == [True, False, False] and sh.info()["tail_rank"] == 7
+    for _ in range(2):
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        assert np.array_equal(k2, kp) and np.array_equal(d2, ds)
+    sh.close()
+    with capi.hook("desc_mass_shift", 9):
+        ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+        kp9, ds9 = ex.GetKeypoints()
+        assert ex.debug_counters()["desc_second_passes"] > 0
+        ex.close()
+        sh = capi.ShardedCSIFT3D(vol, devices=(0,) * 4, sharded_octaves=2, partial_windows=True, transport="copies")
+        for _ in range(2):
+            k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+            assert np.array_equal(k2, kp9) and np.array_equal(d2, ds9)
+        sh.close()
+
+
+def test_rccl_refuses_a_device_named_twice_and_copies_take_it():
+    vol = synth.blobs((64, 64, 64), seed=5)
+    with pytest.raises(capi.Sift3dError, match="one rank per device"):
+        capi.ShardedCSIFT3D(vol, devices=(0, 0))
+    sh = capi.ShardedCSIFT3D(vol, devices=(0, 0), transport="copies")
+    assert sh.info()["world"] == 2
+    sh.close()
