@@ -60,7 +60,7 @@ SYMBOLS = [
     "sift3d_match_warmup", "sift3d_test_staging_slice", "sift3d_test_sharded_time_rank",
 ]
 HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "desc_nocache": 4, "match_nodma": 5, "one_stream": 6,
-         "desc_mass_shift": 7, "list_cap": 8, "peer_copy": 9, "desc_nosplit": 10, "march_tiles": 11, "desc_exact_cells": 12, "lazy_generic": 13}
+         "desc_mass_shift": 7, "list_cap": 8, "peer_copy": 9, "desc_nosplit": 10, "march_tiles": 11, "desc_exact_cells": 12, "lazy_generic": 13, "sharded_fail_rank": 14}
 ORIENT_WORDS = 34
 SHARDED_PARTIAL_WINDOWS = 1   # sift3d_sharded_create_ex flags
 SHARDED_WHOLE_WINDOWS = 2

@@ -26,7 +26,7 @@ double dev_tune_d(const char *env_name, double dflt) { const char *e = getenv(en
 static const bool g_env_hooks = [] {
 	static const char *names[SIFT3D_HOOK_COUNT] = {"S3D_DOG_EAGER", "S3D_GLAST_EAGER", "S3D_DET_SERIAL", "S3D_SEPARABLE", "S3D_DESC_NOCACHE",
 	                                               "S3D_MATCH_NODMA", "S3D_ONE_STREAM", "S3D_DESC_MASS_SHIFT", "S3D_LIST_CAP", "S3D_PEER_COPY", "S3D_DESC_NOSPLIT",
-	                                               "S3D_MARCH_TILES", "S3D_DESC_EXACT_CELLS", "S3D_LAZY_GENERIC"};
+	                                               "S3D_MARCH_TILES", "S3D_DESC_EXACT_CELLS", "S3D_LAZY_GENERIC", "S3D_SHARDED_FAIL_RANK"};
 	static_assert(sizeof(names) / sizeof(names[0]) == SIFT3D_HOOK_COUNT, "one environment name per hook");
 	for (int i = 0; i < SIFT3D_HOOK_COUNT; i++) { const char *e = names[i] ? getenv(names[i]) : nullptr; if (e) g_hooks[i] = atoi(e); }
 	return true;

@@ -921,6 +921,9 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		if (rc) return rc;
 		for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_ABI(*w, sift3d_slab_import_dogmax_device(w->stages[(size_t)s].ctx, w->dogmax[(size_t)s])); }
 	}
+	// SIFT3D_HOOK_SHARDED_FAIL_RANK (tests): this rank gives up here, with its pyramid enqueued and its peers on their way to the rendezvous
+	for (Worker *w : ws)
+		if (hook(SIFT3D_HOOK_SHARDED_FAIL_RANK) == w->rank + 1) { set_err(*w, "injected failure (SIFT3D_HOOK_SHARDED_FAIL_RANK)"); return SIFT3D_ERR_STATE; }
 	if (!H->sim)
 		for (Worker *w : ws)
 			for (int s = 0; s < H->S; s++) {  // an octave's deferred halos are complete before its detection reads them

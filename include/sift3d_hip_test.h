@@ -35,7 +35,8 @@ enum {
 	SIFT3D_HOOK_MARCH_TILES = 11,   /* 1: the 64 x 32 tiles of the pyramid kernel wherever a level's geometry allows them (default: big levels only); 2: never */
 	SIFT3D_HOOK_DESC_EXACT_CELLS = 12, /* 1: k_describe forms the cell coordinates of EVERY voxel with the reference's arithmetic (default: only next to a discontinuity) */
 	SIFT3D_HOOK_LAZY_GENERIC = 13,  /* 1: every parked candidate of the lazy last level takes the one-workgroup form (default: interior ones one wave each) */
-	SIFT3D_HOOK_COUNT = 14
+	SIFT3D_HOOK_SHARDED_FAIL_RANK = 14, /* r + 1: rank r of the native z-slab driver gives up behind its pyramid -> the failure protocol (the other ranks are released, the handle is dead) */
+	SIFT3D_HOOK_COUNT = 15
 };
 int sift3d_test_hook(int which, int value);
 /* how often the rare paths ran: c[0] list regrows of the last run, c[1] keypoints whose descriptor took the second pass in

@@ -282,3 +282,27 @@ def test_rccl_refuses_a_device_named_twice_and_copies_take_it():
     sh = capi.ShardedCSIFT3D(vol, devices=(0, 0), transport="copies")
     assert sh.info()["world"] == 2
     sh.close()
+
+
+@pytest.mark.parametrize("transport,devices,victim", [("copies", (0, 0, 0, 0), 2), ("copies", (0, 0, 0), 0), ("rccl", (0,), 0)])
+def test_a_failing_rank_releases_the_others_and_kills_the_handle(vol_and_single, transport, devices, victim):
+    """The failure protocol of the rank threads (never taken in a healthy run): hook sharded_fail_rank makes ONE rank give up behind its pyramid
+    while the others go on to the rendezvous of the counts.  The run must come back (no rank left waiting), name the rank that failed first,
+    leave the handle dead -- a second run is refused -- and destroy must return (streams drained, the tail's run in flight dropped; over RCCL the
+    communicators aborted, not destroyed twice).  A fresh handle afterwards gives the single volume's result."""
+    import time
+    vol, kp, ds = vol_and_single
+    sh = capi.ShardedCSIFT3D(vol, devices=devices, sharded_octaves=2, transport=transport)
+    sh.KpSiftAlgorithm()
+    with capi.hook("sharded_fail_rank", victim + 1):
+        t0 = time.time()
+        with pytest.raises(capi.Sift3dError, match=f"rank {victim}: injected failure"):
+            sh.KpSiftAlgorithm()
+        assert time.time() - t0 < 20
+    with pytest.raises(capi.Sift3dError, match="dead"):
+        sh.KpSiftAlgorithm()
+    sh.close()
+    sh = capi.ShardedCSIFT3D(vol, devices=devices, sharded_octaves=2, transport=transport)
+    k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+    assert np.array_equal(k2, kp) and np.array_equal(d2, ds)
+    sh.close()
