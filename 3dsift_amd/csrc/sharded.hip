@@ -1088,6 +1088,11 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	if (H->copies) {
 		if (H->world > kMaxMergePtrs) return fail(SIFT3D_ERR_ARG, "the copy transport takes at most " + std::to_string(kMaxMergePtrs) + " ranks");
 		H->mail.reset(new sift3d_sharded::Mailbox[(size_t)H->world * (size_t)H->world]);
+		// peer access between the devices of ranks that exchange (every pair: the DoG maxima travel between all of them), so that the peer copies go
+		// over xGMI directly; a refusal (already enabled, or no peer path: the copies are then staged by the runtime) is not an error
+		for (int i = 0; i < ndev; i++)
+			for (int j = 0; j < ndev; j++)
+				if (devices[i] != devices[j] && hipSetDevice(devices[i]) == hipSuccess) { (void)hipDeviceEnablePeerAccess(devices[j], 0); (void)hipGetLastError(); }
 	} else if (!H->sim) {
 		for (int i = 0; i < ndev; i++)
 			for (int j = 0; j < i; j++)

@@ -132,10 +132,15 @@ static int sim_ranks() {
 }
 // SIFT3D_PARTIAL_WINDOWS: unset = the driver's rule (descriptor windows split along z over the ranks unless a slab is too thin for it),
 // 1 = split or refuse, 0 = whole windows on the wide halos (sift3d_sharded_create_ex)
+// SIFT3D_TRANSPORT=copies: the driver's copy transport instead of RCCL (events + device / peer copies; SIFT3D_DEVICES may then name a device
+// several times: that many rank threads on it)
 static unsigned shard_flags() {
+	unsigned f = 0u;
+	const char *t = getenv("SIFT3D_TRANSPORT");
+	if (t && strcmp(t, "copies") == 0) f |= SIFT3D_SHARDED_COPY_TRANSPORT;
 	const char *e = getenv("SIFT3D_PARTIAL_WINDOWS");
-	if (!e) return 0u;
-	return atoi(e) > 0 ? SIFT3D_SHARDED_PARTIAL_WINDOWS : SIFT3D_SHARDED_WHOLE_WINDOWS;
+	if (!e) return f;
+	return f | (atoi(e) > 0 ? SIFT3D_SHARDED_PARTIAL_WINDOWS : SIFT3D_SHARDED_WHOLE_WINDOWS);
 }
 
 struct CSIFT3D::Impl {

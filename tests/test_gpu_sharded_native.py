@@ -205,7 +205,8 @@ def test_cpp_shell_shards_for_the_unchanged_user():
         subprocess.check_call(["g++", "-std=c++14", "-I" + os.path.join(PKG, "host"), "-o", os.path.join(t, "m"), os.path.join(t, "m.cpp"),
                                "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-Wl,-rpath," + PKG])
         outs = []
-        for env in ({}, {"SIFT3D_SIM_RANKS": "4"}, {"SIFT3D_DEVICES": "0"}, {"SIFT3D_SIM_RANKS": "3", "SIFT3D_PARTIAL_WINDOWS": "1"}, {"SIFT3D_SIM_RANKS": "3", "SIFT3D_PARTIAL_WINDOWS": "0"}):
+        for env in ({}, {"SIFT3D_SIM_RANKS": "4"}, {"SIFT3D_DEVICES": "0"}, {"SIFT3D_SIM_RANKS": "3", "SIFT3D_PARTIAL_WINDOWS": "1"}, {"SIFT3D_SIM_RANKS": "3", "SIFT3D_PARTIAL_WINDOWS": "0"},
+                    {"SIFT3D_DEVICES": "0,0,0", "SIFT3D_TRANSPORT": "copies"}):   # (r06: three rank THREADS on the one GPU, copy transport)
             e = dict(os.environ, **env)
             o = subprocess.check_output([os.path.join(t, "m"), os.path.join(t, "v.bin"), os.path.join(t, "k.bin")], env=e, stderr=subprocess.STDOUT).decode()
             outs.append((o.strip().splitlines()[-1].split()[1], open(os.path.join(t, "k.bin"), "rb").read()))
