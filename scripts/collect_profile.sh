@@ -47,9 +47,11 @@ S3D_HOOKS=one_stream=1 python3 $REPO/scripts/pmc_kernel.py k_march_level 512 1 S
 # sim_rank_alone_ms) and the python driver on 8
 cd $REPO
 ( python3 bench.py --workload slab --steps 5 --warmup 2 2>/dev/null; for r in 2 4 8; do python3 bench.py --workload slab --native --sim-ranks $r --steps 5 --warmup 2 2>/dev/null; done;
-  python3 bench.py --workload slab --native --sim-ranks 8 --whole-windows --steps 5 --warmup 2 2>/dev/null; python3 bench.py --workload slab --sim-ranks 8 --steps 3 --warmup 1 2>/dev/null ) > $OUT/${TAG}_slab_sim.json
+  python3 bench.py --workload slab --native --sim-ranks 8 --whole-windows --steps 5 --warmup 2 2>/dev/null; python3 bench.py --workload slab --sim-ranks 8 --steps 3 --warmup 1 2>/dev/null;
+  python3 bench.py --workload slab --native --rank-threads 8 --steps 5 --warmup 2 2>/dev/null ) > $OUT/${TAG}_slab_sim.json   # (last: 8 rank THREADS on the one GPU, copy transport)
 bash $REPO/scripts/slab_kernel_sums.sh 8 native > $OUT/${TAG}_slab_kernel_sums.txt 2>&1
 bash $REPO/scripts/solo_rank_trace.sh 3 > $OUT/${TAG}_solo_rank3.txt 2>&1
+FULL=1 bash $REPO/scripts/solo_rank_trace.sh 7 > $OUT/${TAG}_solo_rank7.txt 2>&1   # (the tail rank, every launch)
 python3 $REPO/scripts/xfer_probe.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_xfer.txt
 bash $REPO/scripts/kernel_times.sh > $OUT/${TAG}_kernel_times.txt 2>&1
 bash $REPO/scripts/level_times.sh 512 > $OUT/${TAG}_levels_isolated.txt 2>&1

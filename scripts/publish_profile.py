@@ -9,7 +9,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 names = ["rocprofv3_kernel_stats.csv", "bench_under_rocprof.json", "bench.json", "pyramid_traffic_512.json", "pmc_k_describe.json", "pmc_k_describe_512.json",
          "pmc_k_march_level.json", "slab_sim.json", "kernel_times.txt", "levels_isolated.txt", "timeline.txt"]
 for n in ["timeline_full.txt", "match_kernels.txt", "pmc_k_mark.json", "small_volumes.txt", "slab_1gpu.json", "step_times.txt",
-          "kernel_resources.txt", "desc_ring_check.txt", "slab_kernel_sums.txt", "solo_rank3.txt", "xfer.txt"]:   # since r03b / r04 / r05 / r06
+          "kernel_resources.txt", "desc_ring_check.txt", "slab_kernel_sums.txt", "solo_rank3.txt", "solo_rank7.txt", "xfer.txt"]:   # since r03b / r04 / r05 / r06
     if os.path.exists(os.path.join(ROOT, "gpurun_out", f"{tag}_{n}")): names.append(n)
 for n in names:
     shutil.copy(os.path.join(ROOT, "gpurun_out", f"{tag}_{n}"), os.path.join(ROOT, "profiles", f"{tag}_{n}"))
