@@ -920,27 +920,27 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		int rc = allreduce_max_dev(H, ws, s, 8);
 		if (rc) return rc;
 		for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_ABI(*w, sift3d_slab_import_dogmax_device(w->stages[(size_t)s].ctx, w->dogmax[(size_t)s])); }
+		// extrema + orientation of this octave right behind its pyramid, BEFORE the next octave's levels are enqueued: on the GPU they then run
+		// beside the next octaves' small level launches.  (Enqueued behind every octave's pyramid -- the order until late r06 -- octave 0's masks
+		// started when the LAST octave's levels had been placed, 0.25 ms after its own pyramid had ended: profiles/r06x_solo3_all.txt.)  The counts
+		// are read further down, when every octave's launches are in the queues.
+		for (Worker *w : ws) {
+			SH_HIP(*w, hipSetDevice(w->device));
+			if (!H->sim) {  // the octave's deferred halos are complete before its detection reads them
+				SH_HIP(*w, hipEventRecord(w->ev_def[(size_t)s], w->sdstream[(size_t)s]));
+				SH_HIP(*w, hipStreamWaitEvent(w->sstream[(size_t)s], w->ev_def[(size_t)s], 0));
+			}
+			SH_ABI(*w, sift3d_slab_keypoints_launch(w->stages[(size_t)s].ctx));
+		}
 	}
 	// SIFT3D_HOOK_SHARDED_FAIL_RANK (tests): this rank gives up here, with its pyramid enqueued and its peers on their way to the rendezvous
 	for (Worker *w : ws)
 		if (hook(SIFT3D_HOOK_SHARDED_FAIL_RANK) == w->rank + 1) { set_err(*w, "injected failure (SIFT3D_HOOK_SHARDED_FAIL_RANK)"); return SIFT3D_ERR_STATE; }
-	if (!H->sim)
-		for (Worker *w : ws)
-			for (int s = 0; s < H->S; s++) {  // an octave's deferred halos are complete before its detection reads them
-				SH_HIP(*w, hipSetDevice(w->device));
-				SH_HIP(*w, hipEventRecord(w->ev_def[(size_t)s], w->sdstream[(size_t)s]));
-				SH_HIP(*w, hipStreamWaitEvent(w->sstream[(size_t)s], w->ev_def[(size_t)s], 0));
-			}
 	int rc = SIFT3D_OK;
 	auto say = [&](Worker &w, const char *what, int r) { set_err(w, std::string(what) + ": " + sift3d_error_string(r) + " (" + sift3d_last_error() + ")"); };
 	{
-		// extrema + orientation of EVERY sharded octave enqueued, then the counts (the GPU is busy with the later octaves while the host waits
-		// for the first), shared with the other ranks' threads behind one rendezvous
-		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++)
-			for (Worker *w : ws) {
-				if (hipSetDevice(w->device) != hipSuccess) { rc = SIFT3D_ERR_HIP; break; }
-				if ((rc = sift3d_slab_keypoints_launch(w->stages[(size_t)s].ctx)) != SIFT3D_OK) { say(*w, "sharded keypoints", rc); break; }
-			}
+		// the counts of every sharded octave's extrema + orientation launches (enqueued above, octave by octave: the GPU is busy with the later
+		// octaves while the host waits for the first), shared with the other ranks' threads behind one rendezvous
 		for (int s = 0; s < H->S && rc == SIFT3D_OK; s++)
 			for (Worker *w : ws) {
 				int n = 0;

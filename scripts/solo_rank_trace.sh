@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel sums of ONE rank's solo step (sift3d_test_sharded_time_rank) of the simulated 8-rank native z-slab run at 1024x1024x512:
-#   solo_rank_trace.sh [rank=3]      (FULL=1: every launch in the list, not only the keypoint stages')
+#   solo_rank_trace.sh [rank=3]      (FULL=1: every launch in the list, not only the keypoint stages'; ALLK=1: the runtime's own kernels too)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cat > /tmp/solo_one.py <<PY
@@ -28,7 +28,8 @@ import csv, sys, collections
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 last_foreign = max(i for i, r in enumerate(rows) if 's3d::' not in r['Kernel_Name'] and 'rocclr' not in r['Kernel_Name'])
-last = [r for r in rows[last_foreign + 1:] if 's3d::' in r['Kernel_Name']]
+import os
+last = [r for r in rows[last_foreign + 1:] if 's3d::' in r['Kernel_Name'] or os.environ.get('ALLK')]   # ALLK=1: the runtime's fill / copy kernels too
 t0 = int(last[0]['Start_Timestamp']); t1 = max(int(r['End_Timestamp']) for r in last)
 tot = collections.defaultdict(float); cnt = collections.Counter()
 for r in last:
