@@ -78,10 +78,14 @@ for case in range(N):
             # (r06: up to 8 ranks and three sharded octaves, the driver's own plan / forced partial / forced whole windows; every rank's solo
             # re-run must leave the results as they are)
             ranks = int(rng.integers(2, 9)); octs = int(rng.integers(0, 4)); partial = (None, True, False)[int(rng.integers(0, 3))]
+            threads = bool(rng.integers(0, 2))   # (late r06) rank THREADS over the copy transport instead of ranks simulated by one thread
             sh = None
             while sh is None and ranks >= 2:   # (small draws: fewer ranks until the planes suffice; a forced form that is refused: the driver's rule)
                 try:
-                    sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=partial, **params)
+                    if threads:
+                        sh = capi.ShardedCSIFT3D(vol, devices=(0,) * ranks, sharded_octaves=octs, partial_windows=partial, transport="copies", **params)
+                    else:
+                        sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=partial, **params)
                 except capi.Sift3dError:
                     if partial is True:
                         partial = None
@@ -91,7 +95,7 @@ for case in range(N):
                 k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
                 assert np.array_equal(k2, kp), ("sharded keypoints", ranks, octs, partial, sh.info())
                 assert np.array_equal(d2, desc), ("sharded descriptors", ranks, octs, partial, sh.info())
-                for r in range(ranks):
+                for r in range(0 if threads else ranks):   # (the solo re-run of a rank: simulated ranks only)
                     sh.time_rank(r)
                 k2, d2 = sh.GetKeypoints()
                 assert np.array_equal(k2, kp) and np.array_equal(d2, desc), ("after the solo re-runs", ranks, octs, partial, sh.info())
@@ -135,6 +139,6 @@ for case in range(N):
             sys.exit(1)
         nkp += len(kp)
         pys = "  py-slabs %d/%d%s" % (w2, o2, " partial" if p2 else "") if (case % 2 == 1 and ex is not None) else ""
-        print("draw %3d ok  %-16s levels %d sigma %.2f hooks %s  kp %d%s%s" % (case, shape, levels, sd, hooks, len(kp), "" if sh is None else "  slabs %d/%d %s" % (ranks, octs, "".join("p" if p else "w" for p in plan)), pys), flush=True)
+        print("draw %3d ok  %-16s levels %d sigma %.2f hooks %s  kp %d%s%s" % (case, shape, levels, sd, hooks, len(kp), "" if sh is None else "  slabs %d/%d %s%s" % (ranks, octs, "".join("p" if p else "w" for p in plan), " threads" if threads else ""), pys), flush=True)
         g.close()
 print("soak: %d draws, %d keypoints, %.0f s, all equal" % (N, nkp, time.time() - t0))
