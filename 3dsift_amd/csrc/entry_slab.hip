@@ -153,10 +153,9 @@ extern "C" int sift3d_run_describe(sift3d_handle c) {
 }
 
 static int slab_cfg(const sift3d_slab_desc *d, CreateCfg &cfg) {
-	// even start so that DownSample_3D's plane 2k stays inside one slab; an odd end is only possible at the top of the volume
-	if (!d || d->nx <= 0 || d->ny <= 0 || d->nz <= 0 || d->z0 < 0 || d->z1 > d->nz || d->z1 <= d->z0 || (d->z0 & 1) ||
-	    ((d->z1 & 1) && d->z1 != d->nz) || d->halo < 1) {
-		set_last_error("bad slab description (owned range must be non-empty, start and end on even planes, inside the volume)");
+	// (r06: any integer boundaries -- DownSample_3D's plane 2k belongs to the slab that owns plane 2k, sift3d_slab_decimate; until then even starts)
+	if (!d || d->nx <= 0 || d->ny <= 0 || d->nz <= 0 || d->z0 < 0 || d->z1 > d->nz || d->z1 <= d->z0 || d->halo < 1) {
+		set_last_error("bad slab description (owned range must be non-empty and inside the volume)");
 		return SIFT3D_ERR_ARG;
 	}
 	if (d->octave < 0 || d->octave > 20) { set_last_error("bad slab octave"); return SIFT3D_ERR_ARG; }
@@ -766,10 +765,11 @@ static int slab_decimate_impl(sift3d_handle c, float *d_dst, bool sync) {
 	if (rc) return rc;
 	const Level &P = c->gss[c->p.num_kp_levels];
 	const size_t pl = (size_t)P.nx * P.ny;
-	// owned planes start at an even global z, so dst plane k = src global plane own0 + 2k (Src/cSIFT3D.cc:321-344)
-	const int nz2 = std::min(c->own1 / 2, c->nz / 2) - c->own0 / 2;
+	// dst plane k = src global plane 2k for the planes 2k this slab owns: k in [ceil(own0 / 2), ceil(own1 / 2)) (Src/cSIFT3D.cc:321-344; r06: own0 may be odd)
+	const int k0 = std::min((c->own0 + 1) / 2, c->nz / 2), k1 = std::min((c->own1 + 1) / 2, c->nz / 2);
+	const int nz2 = k1 - k0;
 	if (nz2 > 0)
-		launch_downsample(P.d + pl * (size_t)(c->own0 - P.zoff), P.nx, P.ny, d_dst, P.nx / 2, P.ny / 2, nz2, c->stream);
+		launch_downsample(P.d + pl * (size_t)(2 * k0 - P.zoff), P.nx, P.ny, d_dst, P.nx / 2, P.ny / 2, nz2, c->stream);
 	if (sync) S3D_HIP(hipStreamSynchronize(c->stream));
 	return SIFT3D_OK;
 }

@@ -102,9 +102,49 @@ bool slab_bounds(int nz, int world, int align, Bounds &out, int tail_planes = 0)
 	return true;
 }
 
-Bounds halve_bounds(const Bounds &b, int nz) {  // plane k of octave o+1 is plane 2k of octave o (Src/cSIFT3D.cc:321-344)
+// r06 (late): owned plane ranges by WEIGHT, any integer boundaries.  A rank's step costs a + b * planes, and a is not the same for every rank: a rank
+// exchanges halos and window parts with one z-neighbour (the first and the last rank) or with two, and one rank also runs the tail -- measured at
+// 1024 x 1024 x 512 over 2 / 4 / 8 ranks (profiles/r06aa_slab_sim.json): b = 43.6 us per plane, a side 0.4 ms = 9 planes, the tail 0.65 ms = 15 planes;
+// the even deal left the first rank at 3.2 ms, the inner ones at 3.65 and the tail rank at 3.9-4.15.  side_w / tail_w: those costs in planes.  Every
+// rank owns at least min_planes.
+bool slab_bounds_weighted(int nz, int world, int min_planes, double side_w, double tail_w, int tail_rank, Bounds &out) {
+	if (world < 1 || min_planes < 1 || (long)world * min_planes > nz) return false;
+	std::vector<double> cost((size_t)world, 0.0), p((size_t)world, 0.0);
+	for (int r = 0; r < world; r++) cost[(size_t)r] = side_w * (double)((r > 0 ? 1 : 0) + (r + 1 < world ? 1 : 0)) + (r == tail_rank ? tail_w : 0.0);
+	std::vector<char> pinned((size_t)world, 0);  // ranks held at min_planes
+	for (int it = 0; it <= world; it++) {
+		double fixed = 0.0, held = 0.0;
+		int nfree = 0;
+		for (int r = 0; r < world; r++) { if (pinned[(size_t)r]) held += (double)min_planes; else { fixed += cost[(size_t)r]; nfree++; } }
+		if (nfree == 0) break;
+		const double T = ((double)nz - held + fixed) / (double)nfree;
+		bool again = false;
+		for (int r = 0; r < world; r++) {
+			if (pinned[(size_t)r]) { p[(size_t)r] = (double)min_planes; continue; }
+			p[(size_t)r] = T - cost[(size_t)r];
+			if (p[(size_t)r] < (double)min_planes) { pinned[(size_t)r] = 1; again = true; }
+		}
+		if (!again) break;
+	}
+	out.clear();
+	double cum = 0.0;
+	int z = 0;
+	for (int r = 0; r < world; r++) {
+		cum += p[(size_t)r];
+		int z1 = r + 1 == world ? nz : (int)lround(cum);
+		z1 = std::max(z1, z + min_planes);
+		z1 = std::min(z1, nz - (world - 1 - r) * min_planes);
+		out.push_back({z, z1});
+		z = z1;
+	}
+	return true;
+}
+
+// plane k of octave o+1 is plane 2k of octave o (Src/cSIFT3D.cc:321-344): a rank owns the planes k whose plane 2k it owns in the octave above --
+// [ceil(z0 / 2), ceil(z1 / 2)), any integer boundaries (r06; the aligned deal made them even)
+Bounds halve_bounds(const Bounds &b, int nz) {
 	Bounds o;
-	for (auto &p : b) o.push_back({p.first / 2, std::min(p.second / 2, nz / 2)});
+	for (auto &p : b) o.push_back({std::min((p.first + 1) / 2, nz / 2), std::min((p.second + 1) / 2, nz / 2)});
 	return o;
 }
 
@@ -1123,7 +1163,17 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	H->tail_rank = H->noct > S ? H->world - 1 : -1;
 	const int tail_planes = H->tail_rank >= 0 ? (int)lround(2.6 * (double)nz / (double)(1 << (3 * S))) : 0;
 	Bounds b;
-	if (!slab_bounds(nz, H->world, 1 << S, b, tail_planes)) return fail(SIFT3D_ERR_ARG, "too few planes for this many slabs");
+	static const int balance = dev_tune_i("S3D_BALANCE", 1);  // 0: the aligned deal of r05 / early r06 (multiples of 2^S planes, even shares)
+	if (balance && H->world > 1) {
+		// weights in planes of octave 0 (see slab_bounds_weighted): a side = 0.7 x the halo its exchanges and window parts reach over; the tail = its
+		// latency-bound pipeline beside the rank's own launches (0.7 ms) + its voxels at the big levels' rate, over the time of one plane (41.6 ps per voxel)
+		const int halo0 = (flags & SIFT3D_SHARDED_WHOLE_WINDOWS) ? halo_whole : halo_partial;
+		const double plane_s = 41.6e-12 * (double)nx * (double)ny;
+		const double tail_vox = (double)(nx >> S) * (double)(ny >> S) * (double)(nz >> S) * 8.0 / 7.0;
+		const double tail_w = H->tail_rank >= 0 ? (0.7e-3 + 51e-12 * tail_vox) / plane_s : 0.0;
+		const int min_planes = std::max(1 << S, nz / H->world / 2);
+		if (!slab_bounds_weighted(nz, H->world, min_planes, 0.7 * (double)halo0, tail_w, H->tail_rank, b)) return fail(SIFT3D_ERR_ARG, "too few planes for this many slabs");
+	} else if (!slab_bounds(nz, H->world, 1 << S, b, tail_planes)) return fail(SIFT3D_ERR_ARG, "too few planes for this many slabs");
 	// descriptor windows, per sharded octave: split along z over the ranks (partial integer histograms) unless the caller asks for whole windows
 	// -- or the octave's slabs are so thin that a window would span more ranks than one finish launch adds parts (the owner's and five
 	// z-neighbours'): that octave carries whole windows on the wide halos instead, unless partial windows were asked for by name (refused)

@@ -187,7 +187,7 @@ int sift3d_device_count(int *n);
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct sift3d_slab_desc {
 	int nx, ny, nz;      /* GLOBAL dims of the volume */
-	int z0, z1;          /* owned global planes [z0, z1) of octave 0; z0 even, z1 even or == nz */
+	int z0, z1;          /* owned global planes [z0, z1) of this octave; any integers since r06 (the slab of the octave below then owns [ceil(z0/2), ceil(z1/2))) */
 	int halo;            /* margin planes per side; >= 38 for default parameters (descriptor window reach) */
 	int noct_total;      /* octaves of the ORIGINAL volume: (int)log2f(min dim) - 2 */
 	int octave;          /* absolute octave this context holds (0 = the input octave).  octave > 0: nx,ny,nz,z0,z1 are in
