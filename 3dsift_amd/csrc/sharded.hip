@@ -64,7 +64,7 @@ enum { KIND_INPUT = 0, KIND_GSS = 1, KIND_DOG = 2 };
 struct Transfer { int src, dst, kind, idx, zg0, zg1, stage; };
 typedef std::vector<std::pair<int, int>> Bounds;
 
-// ---- planning (identical to 3dsift_amd/slab.py, which the CPU tests cover) ---------------------------------------------
+// ---- planning (halo / window plans as in 3dsift_amd/slab.py, which the CPU tests cover; the slab boundaries: weighted, see slab_bounds_weighted) ----
 int octaves_total(int nx, int ny, int nz) {  // Src/cSIFT3D.cc:254-255
 	const int mn = std::min(nx, std::min(ny, nz));
 	return std::max(0, (int)log2f((float)mn) - 2);
