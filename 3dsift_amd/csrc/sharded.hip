@@ -1165,9 +1165,9 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	Bounds b;
 	static const int balance = dev_tune_i("S3D_BALANCE", 1);  // 0: the aligned deal of r05 / early r06 (multiples of 2^S planes, even shares)
 	if (balance && H->world > 1) {
-		// weights in planes of octave 0 (see slab_bounds_weighted): a side = 0.7 x the halo its exchanges and window parts reach over; the tail = its
+		// weights in planes of octave 0 (see slab_bounds_weighted): a side = 0.7 x the orientation windows' halo (13 planes by default: 9 planes); the tail = its
 		// latency-bound pipeline beside the rank's own launches (0.7 ms) + its voxels at the big levels' rate, over the time of one plane (41.6 ps per voxel)
-		const int halo0 = (flags & SIFT3D_SHARDED_WHOLE_WINDOWS) ? halo_whole : halo_partial;
+		const int halo0 = halo_partial;  // (whole windows on the wide halos: the same 0.4 ms per side, measured -- with 0.7 x 38 planes the first rank took 4.7 ms of a 3.8 ms step)
 		const double plane_s = 41.6e-12 * (double)nx * (double)ny;
 		const double tail_vox = (double)(nx >> S) * (double)(ny >> S) * (double)(nz >> S) * 8.0 / 7.0;
 		const double tail_w = H->tail_rank >= 0 ? (0.7e-3 + 51e-12 * tail_vox) / plane_s : 0.0;
