@@ -41,7 +41,7 @@ SYMBOLS = [
     "sift3d_slab_min_halo", "sift3d_slab_arena_floats", "sift3d_slab_create", "sift3d_slab_buffer", "sift3d_slab_upload",
     "sift3d_slab_input_absmax", "sift3d_slab_input_scale", "sift3d_slab_level", "sift3d_slab_level_hw", "sift3d_slab_halo_planes",
     "sift3d_slab_sync", "sift3d_slab_get_dogmax", "sift3d_slab_set_dogmax", "sift3d_slab_detect", "sift3d_slab_describe",
-    "sift3d_slab_decimate", "sift3d_create_seeded", "sift3d_seed_upload", "sift3d_set_describe_partition",
+    "sift3d_slab_decimate", "sift3d_slab_admits", "sift3d_create_seeded", "sift3d_seed_upload", "sift3d_set_describe_partition",
     "sift3d_export_device", "sift3d_import_descriptors_device", "sift3d_run_partial_orientation",
     "sift3d_export_orientation_device", "sift3d_import_orientation_device", "sift3d_run_describe",
     "sift3d_set_stream", "sift3d_slab_export_dogmax_device", "sift3d_slab_import_dogmax_device", "sift3d_slab_decimate_async",
@@ -407,6 +407,14 @@ def slab_min_halo(**kw):
     p = _params(kw); h = C.c_int(0)
     _check(lib().sift3d_slab_min_halo(C.byref(p), C.byref(h)))
     return h.value
+
+
+def slab_admits(nx, ny, nz, first_octave=True, **kw):
+    """can slab contexts hold an octave of these GLOBAL dims with these parameters (sift3d_slab_admits)?"""
+    p = _params(kw); ok = C.c_int(0)
+    lib().sift3d_slab_admits.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    _check(lib().sift3d_slab_admits(C.byref(p), int(nx), int(ny), int(nz), int(bool(first_octave)), C.byref(ok)))
+    return bool(ok.value)
 
 
 def slab_min_halo_partial(**kw):

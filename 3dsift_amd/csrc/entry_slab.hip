@@ -68,6 +68,31 @@ extern "C" int sift3d_slab_min_halo(const sift3d_params *params, int *halo) {
 	return SIFT3D_OK;
 }
 
+// would the slab contexts take an octave of these GLOBAL dims?  Every level a slab builds goes through the z-march kernel (no separable fallback for
+// slabs): half widths 2 .. 8, planes of one tile or >= 32 + hw, and a column of at least 2 hw + 2 planes (r06: a sharding plan whose deepest octave
+// was thinner than that -- 32 planes, three sharded octaves -- was accepted and failed in its first run)
+extern "C" int sift3d_slab_admits(const sift3d_params *params, int nx, int ny, int nz, int first_octave, int *ok) {
+	if (!ok || nx <= 0 || ny <= 0 || nz <= 0) return SIFT3D_ERR_ARG;
+	*ok = 0;
+	sift3d_params p;
+	if (params) p = *params; else sift3d_default_params(&p);
+	if (p.num_kp_levels < 1 || p.num_kp_levels > 5) return SIFT3D_ERR_ARG;
+	std::vector<float> sig;
+	float base_sigma;
+	level_sigmas(p, sig, base_sigma);
+	const int ng = (int)sig.size();
+	Taps t;
+	for (int i = 1; i < ng; i++) {
+		if (!build_taps(sig[(size_t)i], t)) return SIFT3D_OK;
+		// the last Gaussian level is evaluated at parked candidates instead of being built while its kernel fits k_lazy_next (sift3d_slab_level)
+		if (i == ng - 1 && 2 * (2 * t.hw + 1) <= kLazySlots) continue;
+		if (!march_applicable(nx, ny, nz, t)) return SIFT3D_OK;
+	}
+	if (first_octave && (!build_taps(base_sigma, t) || !march_applicable(nx, ny, nz, t))) return SIFT3D_OK;  // the base blur of the input
+	*ok = 1;
+	return SIFT3D_OK;
+}
+
 // D2D copy of the results into caller-owned device buffers (n*768 and n*3 floats), so that a communication layer that
 // only knows its own allocations can reduce / gather them
 extern "C" int sift3d_export_device(sift3d_handle c, float *d_desc_dst, float *d_xyz_dst) {

@@ -1156,6 +1156,14 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 		while (S < H->noct && ((size_t)(nx >> S) * (size_t)(ny >> S) * (size_t)(nz >> S)) >= ((size_t)1 << 22) && ((nz >> S) / H->world) >= 16) S++;
 	}
 	while (S > 1 && (!fits(nx >> (S - 1)) || !fits(ny >> (S - 1)) || (nz >> S) < H->world)) S--;
+	// ... and none the slab contexts cannot hold (a level thinner than its kernel's column: no separable fallback for slabs)
+	for (;;) {
+		int ok = 0;
+		if (sift3d_slab_admits(&H->p, nx >> (S - 1), ny >> (S - 1), nz >> (S - 1), S == 1, &ok) != SIFT3D_OK) return fail(SIFT3D_ERR_ARG, "bad parameters");
+		if (ok) break;
+		if (S == 1) return fail(SIFT3D_ERR_ARG, "this volume / these parameters do not fit the slab kernels (half widths 2 .. 8, planes of 32 or >= 32 + hw voxels per side, at least 2 hw + 2 planes)");
+		S--;
+	}
 	H->S = S;
 	// the tail (octaves >= S) runs once, on the last rank, which owns fewer planes in exchange: the tail is a volume of nz / 2^S planes of
 	// 1 / 4^S the size, i.e. nz / 8^S planes of the first octave (x 8/7 for its own octaves), and small volumes cost ~2.3x as much per voxel as

@@ -365,6 +365,12 @@ class SlabWorker:
         fits = lambda n: n == 32 or n >= 40   # planes the level kernel tiles: one 32 x 32 tile, or room for a shifted last tile behind the widest mirror zone
         while S > 1 and (not fits(nx >> (S - 1)) or not fits(ny >> (S - 1)) or (nz >> S) < world):
             S -= 1
+        # ... and none the slab contexts cannot hold (r06, sift3d_slab_admits: a level thinner than its kernel's column -- 2 hw + 2 planes -- has no
+        # separable fallback in a slab; such a plan used to be accepted and failed in its first run)
+        while not capi.slab_admits(nx >> (S - 1), ny >> (S - 1), nz >> (S - 1), S == 1, **params):
+            if S == 1:
+                raise ValueError("this volume / these parameters do not fit the slab kernels (half widths 2 .. 8, planes of 32 or >= 32 + hw voxels per side, at least 2 hw + 2 planes)")
+            S -= 1
         self.S = S
         self.stages = []
         b = slab_bounds(nz, world, align=1 << S)

@@ -197,6 +197,9 @@ typedef struct sift3d_slab_desc {
 
 /* smallest admissible halo for `params`: the z reach of a descriptor window in octave 0 (38 for the defaults) */
 int sift3d_slab_min_halo(const sift3d_params *params, int *halo);
+/* r06: *ok = 1 if slab contexts can hold an octave of these GLOBAL dims with these parameters (every level a slab builds takes the z-march kernel:
+ * half widths 2 .. 8, planes of 32 or >= 32 + hw voxels per side, at least 2 hw + 2 planes); first_octave != 0: the base blur of the input too */
+int sift3d_slab_admits(const sift3d_params *params, int nx, int ny, int nz, int first_octave, int *ok);
 /* floats the caller must provide for the level buffers (input, GSS and DoG levels of octave 0) */
 int sift3d_slab_arena_floats(const sift3d_slab_desc *d, const sift3d_params *params, size_t *n);
 int sift3d_slab_create(sift3d_handle *out, const sift3d_slab_desc *d, const sift3d_params *params, int device,

@@ -307,3 +307,34 @@ def test_a_failing_rank_releases_the_others_and_kills_the_handle(vol_and_single,
     k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
     assert np.array_equal(k2, kp) and np.array_equal(d2, ds)
     sh.close()
+
+
+def test_thin_volumes_get_a_plan_that_runs():
+    """r06 (scripts/soak_random.py): a volume of 32 planes asked for three sharded octaves was ACCEPTED -- octave 1 has 16 planes, octave 2 has 8, fewer
+    than the 2 hw + 2 a z-march column needs, and slabs have no separable fallback -- and failed in its first run ("no fused kernel for this level").
+    The plan now stops at the last octave the slab contexts admit (sift3d_slab_admits), in both drivers; parameters no slab takes are refused at
+    create."""
+    slab = importlib.import_module("3dsift_amd.slab")
+    vol = synth.blobs((32, 96, 128), seed=3, noise=0.01)
+    ex = capi.CreateCSIFT3D(vol).KpSiftAlgorithm()
+    kp, ds = ex.GetKeypoints()
+    ex.close()
+    assert len(kp) > 10
+    assert capi.slab_admits(128, 96, 32) and capi.slab_admits(64, 48, 16, False) and not capi.slab_admits(32, 24, 8, False)
+    for kw in (dict(sim_ranks=2), dict(sim_ranks=4), dict(devices=(0, 0, 0), transport="copies")):
+        sh = capi.ShardedCSIFT3D(vol, sharded_octaves=3, **kw)
+        assert sh.info()["sharded_octaves"] == 2
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        sh.close()
+        assert np.array_equal(k2, kp) and np.array_equal(d2, ds)
+    pex = slab.SlabExtractor((128, 96, 32), slab.SimComm(2), sharded_octaves=3)
+    assert pex.S == 2
+    pex.load(volume=vol)
+    pex.KpSiftAlgorithm()
+    k3, d3 = pex.GetKeypoints()
+    pex.close()
+    for f in kp.dtype.names:
+        assert np.array_equal(k3[f], kp[f]), f
+    assert np.array_equal(d3, ds)
+    with pytest.raises(capi.Sift3dError, match="do not fit the slab kernels"):
+        capi.ShardedCSIFT3D(vol, sim_ranks=2, sigma_default=2.4)   # half widths beyond 8
