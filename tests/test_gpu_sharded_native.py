@@ -283,6 +283,19 @@ def test_rccl_refuses_a_device_named_twice_and_copies_take_it():
     sh = capi.ShardedCSIFT3D(vol, devices=(0, 0), transport="copies")
     assert sh.info()["world"] == 2
     sh.close()
+    with pytest.raises(capi.Sift3dError, match="at most 16 ranks"):
+        capi.ShardedCSIFT3D(vol, devices=(0,) * 17, transport="copies")
+
+
+def test_sixteen_rank_threads(vol_and_single):
+    """the copy transport's upper end: sixteen rank threads on the one GPU (ten planes each: whole windows, one sharded octave, halos from several ranks)"""
+    vol, kp, ds = vol_and_single
+    sh = capi.ShardedCSIFT3D(vol, devices=(0,) * 16, sharded_octaves=1, transport="copies")
+    assert sh.info()["world"] == 16 and not any(sh.info()["stage_partial"])
+    for _ in range(2):
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        assert np.array_equal(k2, kp) and np.array_equal(d2, ds)
+    sh.close()
 
 
 @pytest.mark.parametrize("transport,devices,victim", [("copies", (0, 0, 0, 0), 2), ("copies", (0, 0, 0), 0), ("rccl", (0,), 0)])
