@@ -41,7 +41,7 @@ SYMBOLS = [
     "sift3d_slab_min_halo", "sift3d_slab_arena_floats", "sift3d_slab_create", "sift3d_slab_buffer", "sift3d_slab_upload",
     "sift3d_slab_input_absmax", "sift3d_slab_input_scale", "sift3d_slab_level", "sift3d_slab_level_hw", "sift3d_slab_halo_planes",
     "sift3d_slab_sync", "sift3d_slab_get_dogmax", "sift3d_slab_set_dogmax", "sift3d_slab_detect", "sift3d_slab_describe",
-    "sift3d_slab_decimate", "sift3d_slab_admits", "sift3d_create_seeded", "sift3d_seed_upload", "sift3d_set_describe_partition",
+    "sift3d_slab_decimate", "sift3d_slab_admits", "sift3d_slab_set_ghost", "sift3d_slab_min_halo_ghost", "sift3d_create_seeded", "sift3d_seed_upload", "sift3d_set_describe_partition",
     "sift3d_export_device", "sift3d_import_descriptors_device", "sift3d_run_partial_orientation",
     "sift3d_export_orientation_device", "sift3d_import_orientation_device", "sift3d_run_describe",
     "sift3d_set_stream", "sift3d_slab_export_dogmax_device", "sift3d_slab_import_dogmax_device", "sift3d_slab_decimate_async",
@@ -65,6 +65,7 @@ ORIENT_WORDS = 34
 SHARDED_PARTIAL_WINDOWS = 1   # sift3d_sharded_create_ex flags
 SHARDED_WHOLE_WINDOWS = 2
 SHARDED_COPY_TRANSPORT = 4
+SHARDED_GHOST_OCTAVE0 = 8
 
 
 class Params(C.Structure):
@@ -625,7 +626,7 @@ class ShardedCSIFT3D:
     over RCCL, or sim_ranks = n ranks simulated on devices[0].  partial_windows: descriptor windows split along z over the ranks
     (sift3d_sharded_create_ex, SIFT3D_SHARDED_PARTIAL_WINDOWS) instead of whole windows on wide halos."""
 
-    def __init__(self, volume, devices=(0,), sim_ranks=0, sharded_octaves=0, partial_windows=None, transport="rccl", **kw):
+    def __init__(self, volume, devices=(0,), sim_ranks=0, sharded_octaves=0, partial_windows=None, transport="rccl", ghost_octave0=False, **kw):
         """partial_windows: None = the driver's rule (descriptor windows split along z unless a slab is too thin for that), True = split or
         refuse, False = whole windows on the wide halos.  transport: "rccl" (one rank per device) or "copies" (SIFT3D_SHARDED_COPY_TRANSPORT:
         event + device / peer copies; `devices` may repeat a device -- rank threads sharing one GPU)"""
@@ -639,6 +640,8 @@ class ShardedCSIFT3D:
         assert transport in ("rccl", "copies")
         if transport == "copies":
             flags |= SHARDED_COPY_TRANSPORT
+        if ghost_octave0:   # SIFT3D_SHARDED_GHOST_OCTAVE0: octave 0 recomputed on ghost planes instead of exchanged level by level
+            flags |= SHARDED_GHOST_OCTAVE0
         _check(lib().sift3d_sharded_create_ex(C.byref(self._h), vol.ctypes.data_as(C.c_void_p), nx, ny, nz, C.byref(p), devs, len(devices),
                                               int(sim_ranks), int(sharded_octaves), flags))
 

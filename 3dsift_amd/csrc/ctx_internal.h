@@ -85,6 +85,7 @@ struct sift3d_ctx {
 	sift3d_keypoint *d_kpout = nullptr;
 	float *d_desc = nullptr, *d_xyz = nullptr;
 	DescSplit dsplit{};             // scratch of the split descriptor windows (runs with few keypoints), one allocation at dsplit.gacc
+	bool ghost = false;             // slab contexts (r06): every level is produced on ghost planes beyond the owned range too (sift3d_slab_set_ghost): no per-level halo exchange
 	bool desc_partial = false;      // slab contexts (r05): descriptor windows are split along z over the ranks -- the halo of G[1..levels] only has to carry the orientation windows
 	bool dsplit_dirty = false;      // a run ended in an error: the "every run leaves the scratch clean" invariant is re-established by the next run
 	float *d_peer = nullptr;        // sift3d_match_handles: a target's descriptors + coordinates copied from another GPU (grow-only)

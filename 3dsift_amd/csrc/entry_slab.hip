@@ -307,6 +307,69 @@ extern "C" int sift3d_slab_halo_planes(sift3d_handle c, int i, int *planes) {
 	return SIFT3D_OK;
 }
 
+// ---- ghost zones (r06) ---------------------------------------------------------------------------------------------------------------------
+// Instead of receiving, per level, the hw + 1 planes the next level's z-march reads beyond the owned range (an exchange the level chain WAITS for),
+// a slab can produce every level on a range that shrinks level by level: level i on [own0 - g_i, own1 + g_i) with g_i = what its readers need --
+// the next level's march (g_{i+1} + hw_{i+1} + 1; hw_{i+1} + 1 where that level is evaluated lazily), the orientation / descriptor windows of the
+// keypoint levels, one plane for the DoG neighbours of the extremum test -- from an input that holds g_0 + hw_0 + 1 planes per side.  Every ghost
+// plane holds exactly what its owner computes for it (same kernels, same inputs, boundary rule in global z), so nothing downstream changes; the
+// abs-max of a DoG level then covers ghost planes too, which leaves the maximum over all slabs what it is.
+static void slab_ghost_extents(const sift3d_ctx *c, bool last_lazy, int *g /* [ng] */) {
+	for (int i = c->ng - 1; i >= 0; i--) {
+		int need = 1;  // the z neighbours of the extremum test (every Gaussian level feeds a DoG level)
+		if (i >= 1 && i <= c->p.num_kp_levels) {
+			const float sc = c->dog[(size_t)i].scale, u = c->dog[(size_t)i].unit;
+			const int desc_reach = (int)ceilf(__builtin_fabsf(2.0f * (sc * 7.071067812f)) / u) + 2, ori_reach = (int)floorf(4.5f * sc / u) + 1;
+			need = std::max(need, c->desc_partial ? ori_reach : desc_reach);
+		}
+		if (i + 1 < c->ng) {
+			const int hw1 = c->taps[i + 1].hw;
+			const bool built = !(last_lazy && i + 1 == c->ng - 1);
+			need = std::max(need, built ? g[i + 1] + hw1 + 1 : hw1 + 1);
+		}
+		g[i] = need;
+	}
+}
+static bool slab_last_lazy(const sift3d_ctx *c) {  // (the rule of sift3d_slab_level)
+	return !hook(SIFT3D_HOOK_DOG_EAGER) && c->nd >= 3 && !hook(SIFT3D_HOOK_GLAST_EAGER) && 2 * (2 * c->taps[c->ng - 1].hw + 1) <= kLazySlots;
+}
+extern "C" int sift3d_slab_set_ghost(sift3d_handle c, int on) {
+	if (!c || !c->slab) return SIFT3D_ERR_ARG;
+	if (on) {
+		int g[16];
+		for (int lazy = 0; lazy < 2; lazy++) {  // (whichever form the last level takes when the hooks change)
+			slab_ghost_extents(c, lazy != 0, g);
+			const int in_need = c->seeded ? 0 : g[0] + c->base_taps.hw + 1;
+			for (int i = 0; i < c->ng; i++)
+				if (g[i] > c->halo || in_need > c->halo) { set_last_error("ghost zones need a halo of sift3d_slab_min_halo_ghost planes"); return SIFT3D_ERR_ARG; }
+		}
+	}
+	c->ghost = on != 0;
+	return SIFT3D_OK;
+}
+// halo planes per side a slab context needs for ghost zones (partial: descriptor windows split along z; else whole windows)
+extern "C" int sift3d_slab_min_halo_ghost(const sift3d_params *params, int partial, int *halo) {
+	if (!halo) return SIFT3D_ERR_ARG;
+	int win = 0;
+	int rc = partial ? sift3d_slab_min_halo_partial(params, &win) : sift3d_slab_min_halo(params, &win);
+	if (rc) return rc;
+	sift3d_params p;
+	if (params) p = *params; else sift3d_default_params(&p);
+	std::vector<float> sig;
+	float base_sigma;
+	level_sigmas(p, sig, base_sigma);
+	const int ng = (int)sig.size();
+	std::vector<int> hw((size_t)ng, 0);
+	Taps t;
+	for (int i = 1; i < ng; i++) { if (!build_taps(sig[(size_t)i], t)) return SIFT3D_ERR_ARG; hw[(size_t)i] = t.hw; }
+	if (!build_taps(base_sigma, t)) return SIFT3D_ERR_ARG;
+	// (every keypoint level with the widest window's reach, the last level built: an upper bound of slab_ghost_extents)
+	int g = 1;
+	for (int i = ng - 2; i >= 0; i--) g = std::max(i >= 1 && i <= p.num_kp_levels ? win : 1, g + hw[(size_t)i + 1] + 1);
+	*halo = g + t.hw + 1;
+	return SIFT3D_OK;
+}
+
 extern "C" int sift3d_slab_level_hw(sift3d_handle c, int i, int *hw) {
 	if (!c || !c->slab || !hw || i < 0 || i >= c->ng) return SIFT3D_ERR_ARG;
 	*hw = i == 0 ? c->base_taps.hw : c->taps[i].hw;
@@ -349,7 +412,9 @@ extern "C" int sift3d_slab_level(sift3d_handle c, int i) {
 	int rc = set_device(c->device);
 	if (rc) return rc;
 	const Level &L = c->gss[i];
-	const ZRange zr = L.zr(c->own0 - L.zoff, c->own1 - L.zoff);
+	int ext = 0;
+	if (c->ghost) { int g[16]; slab_ghost_extents(c, slab_last_lazy(c), g); ext = g[i]; }
+	const ZRange zr = L.zr(std::max(0, c->own0 - ext) - L.zoff, std::min(L.nz, c->own1 + ext) - L.zoff);
 	bool ok;
 	if (i == 0) {
 		c->g_last_built.assign(1, 0);

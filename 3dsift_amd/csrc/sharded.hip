@@ -327,6 +327,7 @@ struct sift3d_sharded {
 	// hipMemcpyPeerAsync between devices).  Both sides walk the same transfer list in the same order, so a FIFO per pair matches them.  A step
 	// writes every buffer it sends from once, and ends with every rank's streams drained: a sender never overwrites what a peer still reads.
 	// `devices` may name one device several times: N rank THREADS on one GPU -- what a one-GPU box can run of the multi-threaded driver.
+	bool ghost0 = false;  // SIFT3D_SHARDED_GHOST_OCTAVE0: octave 0's levels on ghost zones, nothing of octave 0 is exchanged
 	bool copies = false;
 	struct Msg { hipEvent_t ev; const void *p; };
 	struct Mailbox { std::mutex mu; std::condition_variable cv; std::deque<Msg> q; };
@@ -912,12 +913,14 @@ int run_local(sift3d_sharded *H, std::vector<Worker *> &ws) {
 		for (int i = 0; i < ng; i++) {
 			for (Worker *w : ws) { SH_HIP(*w, hipSetDevice(w->device)); SH_ABI(*w, sift3d_slab_level(w->stages[(size_t)s].ctx, i)); }
 			const int urgent_h = i + 1 < ng ? H->hws[(size_t)i + 1] + 1 : 0;  // planes p-hw-1 .. p+hw of the next level's z-march
+			const bool ghost = H->ghost0 && s == 0;  // (ghost zones: this octave's slabs computed what they would receive)
 			// urgent: ordered behind the level kernel on the rank's stream, in front of the next level
-			int rc = exchange(H, ws, halo_transfers(bounds, nzs, KIND_GSS, i, 0, urgent_h, s), 0);
+			int rc = ghost ? SIFT3D_OK : exchange(H, ws, halo_transfers(bounds, nzs, KIND_GSS, i, 0, urgent_h, s), 0);
 			if (rc) return rc;
 			// deferred: the wider keypoint-window halo of G[1..levels] and the DoG plane behind it, on the deferred flow
-			std::vector<Transfer> late = halo_transfers(bounds, nzs, KIND_GSS, i, urgent_h, H->need[(size_t)s][(size_t)i], s);
-			if (i - 1 >= 1 && i - 1 <= H->levels) {
+			std::vector<Transfer> late;
+			if (!ghost) late = halo_transfers(bounds, nzs, KIND_GSS, i, urgent_h, H->need[(size_t)s][(size_t)i], s);
+			if (!ghost && i - 1 >= 1 && i - 1 <= H->levels) {
 				std::vector<Transfer> dg = halo_transfers(bounds, nzs, KIND_DOG, i - 1, 0, 1, s);
 				late.insert(late.end(), dg.begin(), dg.end());
 			}
@@ -1180,7 +1183,14 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 		const double tail_vox = (double)(nx >> S) * (double)(ny >> S) * (double)(nz >> S) * 8.0 / 7.0;
 		const double tail_w = H->tail_rank >= 0 ? (0.7e-3 + 51e-12 * tail_vox) / plane_s : 0.0;
 		const int min_planes = std::max(1 << S, nz / H->world / 2);
-		if (!slab_bounds_weighted(nz, H->world, min_planes, 0.7 * (double)halo0, tail_w, H->tail_rank, b)) return fail(SIFT3D_ERR_ARG, "too few planes for this many slabs");
+		// (octave 0 on ghost zones: a side also costs the levels' work on its ghost planes -- on average 0.62 x the ghost halo, at about half the pyramid's 0.35 share
+		// of a plane's time (the rest hides under the chain of the octaves below): 3.9 planes more with the defaults; measured at 8 ranks: 4.12 ms (inner) / 3.91 (first) with no extra weight, 4.03 / 4.19 with twice this one)
+		double side_w = 0.7 * (double)halo0;
+		if (flags & SIFT3D_SHARDED_GHOST_OCTAVE0) {
+			int gh = 0;
+			if (sift3d_slab_min_halo_ghost(&H->p, (flags & SIFT3D_SHARDED_WHOLE_WINDOWS) ? 0 : 1, &gh) == SIFT3D_OK) side_w += 0.11 * (double)gh;
+		}
+		if (!slab_bounds_weighted(nz, H->world, min_planes, side_w, tail_w, H->tail_rank, b)) return fail(SIFT3D_ERR_ARG, "too few planes for this many slabs");
 	} else if (!slab_bounds(nz, H->world, 1 << S, b, tail_planes)) return fail(SIFT3D_ERR_ARG, "too few planes for this many slabs");
 	// descriptor windows, per sharded octave: split along z over the ranks (partial integer histograms) unless the caller asks for whole windows
 	// -- or the octave's slabs are so thin that a window would span more ranks than one finish launch adds parts (the owner's and five
@@ -1207,6 +1217,12 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 			dz /= 2;
 		}
 		H->partial = std::all_of(H->stage_partial.begin(), H->stage_partial.end(), [](char c) { return c != 0; });
+	}
+	H->ghost0 = (flags & SIFT3D_SHARDED_GHOST_OCTAVE0) != 0;
+	if (H->ghost0) {
+		int gh = 0;
+		if (sift3d_slab_min_halo_ghost(&H->p, H->stage_partial[0] ? 1 : 0, &gh) != SIFT3D_OK) return fail(SIFT3D_ERR_ARG, "bad parameters");
+		H->stage_halo[0] = std::max(H->stage_halo[0], gh);
 	}
 	H->halo = H->stage_halo[0];
 	H->need.assign((size_t)S, std::vector<int>());
@@ -1254,6 +1270,7 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 				CR_ABI(sift3d_slab_create(&st.ctx, &d, &H->p, w.device, st.arena, st.arena_floats));
 				CR_ABI(sift3d_set_stream(st.ctx, w.sstream[(size_t)o]));
 				if (H->stage_partial[(size_t)o]) CR_ABI(sift3d_slab_set_desc_partial(st.ctx, 1));
+				if (H->ghost0 && o == 0) CR_ABI(sift3d_slab_set_ghost(st.ctx, 1));  // (behind the window form: the ghost extents depend on it)
 			} else {
 				return fail(SIFT3D_ERR_ARG, "a rank would own no planes of a sharded octave");
 			}
@@ -1340,11 +1357,15 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	const size_t pl = (size_t)nx * ny;
 	float gmax = 0.f;
 	std::vector<float> lmax((size_t)H->world, 0.f);
+	// (ghost zones: a rank uploads the planes its input buffer holds on either side of its own -- the halo it would otherwise receive from its
+	// z-neighbours, and more: the host has the whole volume)
+	auto up0 = [&](const Stage &st) { return H->ghost0 ? std::max(0, st.z0 - H->stage_halo[0]) : st.z0; };
+	auto up1 = [&](const Stage &st) { return H->ghost0 ? std::min(nz, st.z1 + H->stage_halo[0]) : st.z1; };
 	if (H->sim) {
 		for (Worker &w : H->workers) {
 			CR_HIP(hipSetDevice(w.device));
 			Stage &st = w.stages[0];
-			CR_ABI(sift3d_slab_upload(st.ctx, volume + pl * (size_t)st.z0, st.z0, st.z1, 0));
+			CR_ABI(sift3d_slab_upload(st.ctx, volume + pl * (size_t)up0(st), up0(st), up1(st), 0));
 			CR_ABI(sift3d_slab_input_absmax(st.ctx, &lmax[(size_t)w.rank]));
 		}
 	} else {
@@ -1358,7 +1379,7 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 				Worker &w = H->workers[(size_t)r];
 				Stage &st = w.stages[0];
 				int rc = hipSetDevice(w.device) == hipSuccess ? SIFT3D_OK : SIFT3D_ERR_HIP;
-				if (rc == SIFT3D_OK) rc = sift3d_slab_upload(st.ctx, volume + pl * (size_t)st.z0, st.z0, st.z1, 0);
+				if (rc == SIFT3D_OK) rc = sift3d_slab_upload(st.ctx, volume + pl * (size_t)up0(st), up0(st), up1(st), 0);
 				if (rc == SIFT3D_OK) rc = sift3d_slab_input_absmax(st.ctx, &lmax[(size_t)r]);
 				if (rc != SIFT3D_OK) errs[(size_t)r] = sift3d_last_error();  // (the error text is thread-local)
 				rcs[(size_t)r] = rc;
@@ -1368,7 +1389,7 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 	}
 	for (float v : lmax) gmax = std::max(gmax, v);  // (one process holds every rank: the MAX all-reduce is a host loop)
 	for (Worker &w : H->workers) { CR_HIP(hipSetDevice(w.device)); CR_ABI(sift3d_slab_input_scale(w.stages[0].ctx, gmax)); }
-	{
+	if (!H->ghost0) {
 		const std::vector<Transfer> ts = halo_transfers(b, nz, KIND_INPUT, 0, 0, H->hws[0] + 1, 0);
 		int rc = SIFT3D_OK;
 		if (H->sim) {
@@ -1588,13 +1609,15 @@ extern "C" int sift3d_sharded_traffic(sift3d_sharded_handle H, double *halo /* [
 	for (int s = 0; s < H->S; s++) {
 		const Stage &st = w0.stages[(size_t)s];
 		std::vector<Transfer> all;
+
 		for (int i = 0; i < H->ng; i++) {
 			const int urgent_h = i + 1 < H->ng ? H->hws[(size_t)i + 1] + 1 : 0;
 			for (const std::vector<Transfer> &ts : {halo_transfers(st.bounds, st.nz, KIND_GSS, i, 0, urgent_h, s), halo_transfers(st.bounds, st.nz, KIND_GSS, i, urgent_h, H->need[(size_t)s][(size_t)i], s),
 			                                         (i - 1 >= 1 && i - 1 <= H->levels) ? halo_transfers(st.bounds, st.nz, KIND_DOG, i - 1, 0, 1, s) : std::vector<Transfer>()})
 				all.insert(all.end(), ts.begin(), ts.end());
 		}
-		for (const Transfer &t : all) halo[t.dst] += (double)(t.zg1 - t.zg0) * (double)st.plane * 4.0;
+		if (!(H->ghost0 && s == 0))  // (ghost zones: no plane of octave 0 travels)
+			for (const Transfer &t : all) halo[t.dst] += (double)(t.zg1 - t.zg0) * (double)st.plane * 4.0;
 		if (!H->ran || !H->stage_partial[(size_t)s]) continue;
 		int reach = 0;
 		if (sift3d_slab_desc_reach(st.ctx, &reach) != SIFT3D_OK) continue;

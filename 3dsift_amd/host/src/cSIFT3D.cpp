@@ -132,12 +132,14 @@ static int sim_ranks() {
 }
 // SIFT3D_PARTIAL_WINDOWS: unset = the driver's rule (descriptor windows split along z over the ranks unless a slab is too thin for it),
 // 1 = split or refuse, 0 = whole windows on the wide halos (sift3d_sharded_create_ex)
-// SIFT3D_TRANSPORT=copies: the driver's copy transport instead of RCCL (events + device / peer copies; SIFT3D_DEVICES may then name a device
+// SIFT3D_GHOST_OCTAVE0=1 (see below); SIFT3D_TRANSPORT=copies: the driver's copy transport instead of RCCL (events + device / peer copies; SIFT3D_DEVICES may then name a device
 // several times: that many rank threads on it)
 static unsigned shard_flags() {
 	unsigned f = 0u;
 	const char *t = getenv("SIFT3D_TRANSPORT");
 	if (t && strcmp(t, "copies") == 0) f |= SIFT3D_SHARDED_COPY_TRANSPORT;
+	const char *g = getenv("SIFT3D_GHOST_OCTAVE0");  // 1: octave 0 on ghost zones (recomputed instead of exchanged level by level; for link-bound nodes)
+	if (g && atoi(g) > 0) f |= SIFT3D_SHARDED_GHOST_OCTAVE0;
 	const char *e = getenv("SIFT3D_PARTIAL_WINDOWS");
 	if (!e) return f;
 	return f | (atoi(e) > 0 ? SIFT3D_SHARDED_PARTIAL_WINDOWS : SIFT3D_SHARDED_WHOLE_WINDOWS);

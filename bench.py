@@ -82,7 +82,7 @@ def parse_dims(txt):
     return nx, ny, nz
 
 
-def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partial_windows=None, rank_times=True, transport="rccl"):
+def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partial_windows=None, rank_times=True, transport="rccl", ghost=False):
     """The same workload through the library's NATIVE driver (csrc/sharded.hip: one process, one host thread per GPU, RCCL halo
     exchange; or sim_ranks simulated on devices[0]).  The volume starts on the host, like CreateCSIFT3D(float*) gets it.
     partial_windows: None = the driver's rule (descriptor windows split along z), False = whole windows on the wide halos."""
@@ -92,7 +92,7 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partia
     nx, ny, nz = dims
     vol = synth.blobs_torch((nz, ny, nx), torch.device("cuda", devices[0]), seed=seed).cpu().numpy()
     t0 = time.perf_counter()
-    sh = capi.ShardedCSIFT3D(vol, devices=tuple(devices), sim_ranks=sim_ranks, partial_windows=partial_windows, transport=transport)
+    sh = capi.ShardedCSIFT3D(vol, devices=tuple(devices), sim_ranks=sim_ranks, partial_windows=partial_windows, transport=transport, ghost_octave0=ghost)
     t_ctor = time.perf_counter() - t0
     del vol
     for _ in range(warmup):
@@ -120,6 +120,7 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partia
                         + (" SIMULATED on one GPU" if sim_ranks else (" (RCCL)" if transport == "rccl" else
                            (" (copy transport: events + peer copies, no RCCL)" if len(set(devices)) > 1 else " (copy transport: %d rank THREADS on one GPU)" % len(devices)))),
             "value": nx * ny * nz / dt / 1e6, "unit": "Mvoxels/s", "ms_per_step": dt * 1e3, "ms_per_step_all": [round(t * 1e3, 3) for t in ts], "keypoints": int(len(kp)),
+            "octave0_on_ghost_zones": bool(ghost),
             "sharded_octaves": info["sharded_octaves"], "halo_planes": info["halo"], "slab_planes": info["planes"], "tail_rank": info["tail_rank"],
             "descriptor_windows": "partial integer histograms" if info["partial_windows"] else ("whole windows on plane halos" if not any(info["stage_partial"]) else
                                   "per sharded octave: " + ", ".join("partial integer histograms" if p else "whole windows on plane halos" for p in info["stage_partial"])),
@@ -132,13 +133,13 @@ def run_slab_native(dims, devices, steps, warmup, sim_ranks=0, seed=4321, partia
                     "r05 counted the D2H of every rank's results and the merge in it: now get_keypoints_ms)"}
 
 
-def run_slab_native_child(dims_txt, gpus, steps, warmup, partial_windows, timeout, transport="rccl"):
+def run_slab_native_child(dims_txt, gpus, steps, warmup, partial_windows, timeout, transport="rccl", ghost=False):
     """run_slab_native in a CHILD process (N > 1: rank 0's process starts it while the other ranks idle).  The native driver's RCCL
     point-to-point transport meets its first second GPU in the driver's run: a hard fault there (one host thread per GPU inside librccl)
     must not take the process that holds the headline measurement with it.  Returns (slab dict, None) or (None, reason)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "slab", "--native", "--gpus", str(gpus), "--slab-dims", dims_txt,
-           "--steps", str(steps), "--warmup", str(warmup), "--transport", transport] + ([] if partial_windows is None else ["--partial-windows"] if partial_windows else ["--whole-windows"])
+           "--steps", str(steps), "--warmup", str(warmup), "--transport", transport] + (["--ghost"] if ghost else []) + ([] if partial_windows is None else ["--partial-windows"] if partial_windows else ["--whole-windows"])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
                                                               "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "GROUP_WORLD_SIZE", "ROLE_NAME")}
     try:
@@ -269,6 +270,7 @@ def main():
     ap.add_argument("--no-rank-times", action="store_true", help="with --native --sim-ranks: skip the solo re-run of every rank (sim_rank_alone_ms)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "copies"], help="with --native: RCCL point-to-point (one rank per GPU), or the copy transport (events + device / peer copies)")
     ap.add_argument("--rank-threads", type=int, default=0, help="with --native on ONE GPU: that many rank threads sharing the GPU over the copy transport (the multi-threaded driver without a second GPU)")
+    ap.add_argument("--ghost", action="store_true", help="with --native: octave 0 on ghost zones (SIFT3D_SHARDED_GHOST_OCTAVE0): recomputed instead of exchanged level by level")
     ap.add_argument("--whole-windows", action="store_true", help="with --native: whole descriptor windows on the wide plane halos (r05's default)")
     args = ap.parse_args()
 
@@ -289,7 +291,7 @@ def main():
         devs = [local] * args.rank_threads if args.rank_threads else (list(range(max(1, args.gpus))) if not args.sim_ranks else [local])
         r = run_slab_native(dims, devs, args.steps, args.warmup, sim_ranks=args.sim_ranks,
                             partial_windows=True if args.partial_windows else (False if args.whole_windows else None), rank_times=not args.no_rank_times,
-                            transport="copies" if args.rank_threads else args.transport)
+                            transport="copies" if args.rank_threads else args.transport, ghost=args.ghost)
         print(json.dumps({"metric": "Mvoxels/s end-to-end KpSiftAlgorithm, one volume sharded as z-slabs (native driver)", "value": r["value"],
                           "unit": "Mvoxels/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -687,6 +689,8 @@ def main():
         #   slab.native (first class since r06)  the library's own driver (csrc/sharded.hip): one process, one host thread per GPU, RCCL
         #                         point-to-point halos, descriptor windows split along z, the tail once on the last rank -- what a C++ user
         #                         of SIFT3D_DEVICES=0-7 gets.  Runs in a CHILD process of rank 0 while the other ranks wait on the host-side store.
+        #   slab.native_ghost_octave0   the native driver with octave 0 recomputed on ghost zones instead of exchanged (r06): the plan for nodes whose
+        #                         links bound the step
         #   slab.python           3dsift_amd/slab.py over torch.distributed (one process per GPU): the driver the protocol is tested with over gloo
         #   slab.native_copy_transport  the native driver without RCCL: a neighbour's data fetched by peer copies behind the sender's event (r06; the
         #                         transport the multi-threaded driver is TESTED with, as rank threads sharing one GPU)
@@ -724,6 +728,13 @@ def main():
             slab["native_copy_transport"] = cres if c_err is None else {"error": c_err}
             if c_err is None:
                 speedup(slab["native_copy_transport"])
+            # ... and with octave 0 on ghost zones (3.5x fewer bytes, none of octave 0's level-by-level exchanges, + 0.5 ms of work per rank): over
+            # whichever transport ran
+            if nat_err is None or c_err is None:
+                gres, g_err = run_slab_native_child(args.slab_dims, world, SLAB_STEPS, SLAB_WARMUP, None, 150, transport="rccl" if nat_err is None else "copies", ghost=True)
+                slab["native_ghost_octave0"] = gres if g_err is None else {"error": g_err}
+                if g_err is None:
+                    speedup(slab["native_ghost_octave0"])
             if store is not None:
                 try:
                     store.set("s3d_native_done", "1")
@@ -734,7 +745,7 @@ def main():
             # child's threads use them)
             try:
                 import datetime
-                store.wait(["s3d_native_done"], datetime.timedelta(seconds=360))
+                store.wait(["s3d_native_done"], datetime.timedelta(seconds=500))
             except Exception:
                 pass
         res, slab_err = guarded(lambda: run_slab(parse_dims(args.slab_dims), world, rank, local, dev, SLAB_STEPS, SLAB_WARMUP), 240)
@@ -757,7 +768,7 @@ def main():
         # the line's contract is the headline metric, measured above; a side leg that failed says so IN the line (and on stderr)
         legs = {"slab": out.get("slab")}
         if isinstance(out.get("slab"), dict):
-            legs.update({"slab." + k: out["slab"].get(k) for k in ("native", "python", "native_copy_transport")})
+            legs.update({"slab." + k: out["slab"].get(k) for k in ("native", "python", "native_copy_transport", "native_ghost_octave0")})
         failed = [k for k, v in legs.items() if isinstance(v, dict) and "error" in v]
         if failed:
             out["legs_failed"] = failed

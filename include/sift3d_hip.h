@@ -237,6 +237,12 @@ int sift3d_slab_describe(sift3d_handle h);                          /* orientati
  * (sift3d_slab_describe_finish).  A record whose fixed-point unit fails is flagged and repeated once by all parts with the exact unit.
  * sift3d_slab_set_desc_partial makes sift3d_slab_halo_planes answer with the orientation window's reach for G[1..levels]. */
 int sift3d_slab_set_desc_partial(sift3d_handle h, int on);
+/* r06 -- ghost zones: sift3d_slab_level(h, i) then produces level i on [z0 - g_i, z1 + g_i) with g_i shrinking level by level down to what the
+ * windows and the extremum test read, from an input (octave 0) or a level 0 (octave > 0) that holds sift3d_slab_min_halo_ghost planes per side --
+ * and NO halo of any level has to be exchanged (the exchange between consecutive levels is the one a slab's level chain waits for).  Costs the
+ * levels' work on the ghost planes (defaults, 64-plane slabs: + 60 %); every plane holds what its owner computes for it, results unchanged. */
+int sift3d_slab_set_ghost(sift3d_handle h, int on);
+int sift3d_slab_min_halo_ghost(const sift3d_params *params, int partial_windows, int *halo);
 int sift3d_slab_min_halo_partial(const sift3d_params *params, int *halo);  /* planes per side a level buffer needs in that mode */
 int sift3d_slab_record_bytes(int *bytes);
 int sift3d_slab_desc_reach(sift3d_handle h, int *planes);
@@ -319,6 +325,10 @@ int sift3d_sharded_create(sift3d_sharded_handle *out, const float *volume, int n
  * communicator, no librccl).  `devices` may then name a device several times -- N rank threads on ONE GPU, which is how the multi-threaded driver
  * is tested on a one-GPU box -- and at most 16 ranks are taken.  Same results bit for bit.  Ignored with sim_ranks > 0. */
 #define SIFT3D_SHARDED_COPY_TRANSPORT 4u
+/* r06: octave 0 on ghost zones (sift3d_slab_set_ghost): every rank uploads its planes + 33 (defaults) per side of the INPUT and recomputes what it
+ * would otherwise receive -- no exchange at all for octave 0 (0.19 of the 0.28 GB a rank receives per side and step at 1024 x 1024 x 512 over 8, and
+ * 6 of the 18 exchanges its level chains wait for), for + 0.5 ms of pyramid work per rank.  For nodes whose links, not whose GPUs, bound the step. */
+#define SIFT3D_SHARDED_GHOST_OCTAVE0 8u
 int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float *volume, int nx, int ny, int nz, const sift3d_params *params,
                              const int *devices, int ndev, int sim_ranks, int sharded_octaves, unsigned flags);
 int sift3d_sharded_run(sift3d_sharded_handle h);

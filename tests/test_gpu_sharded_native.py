@@ -206,7 +206,8 @@ def test_cpp_shell_shards_for_the_unchanged_user():
                                "-L" + PKG, "-lsift3d", "-lsift3d_hip", "-Wl,-rpath," + PKG])
         outs = []
         for env in ({}, {"SIFT3D_SIM_RANKS": "4"}, {"SIFT3D_DEVICES": "0"}, {"SIFT3D_SIM_RANKS": "3", "SIFT3D_PARTIAL_WINDOWS": "1"}, {"SIFT3D_SIM_RANKS": "3", "SIFT3D_PARTIAL_WINDOWS": "0"},
-                    {"SIFT3D_DEVICES": "0,0,0", "SIFT3D_TRANSPORT": "copies"}):   # (r06: three rank THREADS on the one GPU, copy transport)
+                    {"SIFT3D_DEVICES": "0,0,0", "SIFT3D_TRANSPORT": "copies"},    # (r06: three rank THREADS on the one GPU, copy transport)
+                    {"SIFT3D_SIM_RANKS": "3", "SIFT3D_GHOST_OCTAVE0": "1"}):        # (r06: octave 0 on ghost zones)
             e = dict(os.environ, **env)
             o = subprocess.check_output([os.path.join(t, "m"), os.path.join(t, "v.bin"), os.path.join(t, "k.bin")], env=e, stderr=subprocess.STDOUT).decode()
             outs.append((o.strip().splitlines()[-1].split()[1], open(os.path.join(t, "k.bin"), "rb").read()))
@@ -351,3 +352,23 @@ def test_thin_volumes_get_a_plan_that_runs():
     assert np.array_equal(d3, ds)
     with pytest.raises(capi.Sift3dError, match="do not fit the slab kernels"):
         capi.ShardedCSIFT3D(vol, sim_ranks=2, sigma_default=2.4)   # half widths beyond 8
+
+
+@pytest.mark.parametrize("kw", [dict(sim_ranks=2, sharded_octaves=1), dict(sim_ranks=3, sharded_octaves=2, partial_windows=True), dict(sim_ranks=4, sharded_octaves=2, partial_windows=False),
+                                dict(sim_ranks=8, sharded_octaves=2), dict(devices=(0,) * 4, sharded_octaves=2, transport="copies"), dict(devices=(0,) * 5, sharded_octaves=1, transport="copies", partial_windows=True)])
+def test_octave0_on_ghost_zones_equals_the_single_volume(vol_and_single, kw):
+    """SIFT3D_SHARDED_GHOST_OCTAVE0 (r06): every rank holds its planes + 35 per side of the input and produces octave 0's levels on ghost ranges that shrink
+    level by level -- no plane of octave 0 is exchanged (sift3d_sharded_traffic: only the octaves below and the window records / histograms).  The same keypoints
+    and descriptors bit for bit: a ghost plane holds exactly what its owner computes for it."""
+    vol, kp, ds = vol_and_single
+    sh = capi.ShardedCSIFT3D(vol, ghost_octave0=True, **kw)
+    ref = capi.ShardedCSIFT3D(vol, **kw)
+    for _ in range(2):
+        k2, d2 = sh.KpSiftAlgorithm().GetKeypoints()
+        assert np.array_equal(k2, kp) and np.array_equal(d2, ds), kw
+    ref.KpSiftAlgorithm()
+    h_g, w_g = sh.traffic(); h_r, w_r = ref.traffic()
+    assert sum(h_g) < sum(h_r) and (sum(w_g) > 0) == (sum(w_r) > 0)   # (the slabs' weights differ with ghost zones: other boundaries, other window neighbours)
+    if sh.info()["sharded_octaves"] == 1:
+        assert sum(h_g) == 0
+    sh.close(); ref.close()
