@@ -79,6 +79,7 @@ for case in range(N):
             # re-run must leave the results as they are)
             ranks = int(rng.integers(2, 9)); octs = int(rng.integers(0, 4)); partial = (None, True, False)[int(rng.integers(0, 3))]
             threads = bool(rng.integers(0, 2))   # (late r06) rank THREADS over the copy transport instead of ranks simulated by one thread
+            ghost = bool(rng.integers(0, 2))     # ... and octave 0 on ghost zones
             sh = None; why = ""
             # the slab contexts only take half widths 2 .. 8 and planes of >= 40 voxels: a draw outside that runs the driver with a sigma schedule inside
             # it (against the single-volume extractor with the same parameters; the oracle comparison above stays the draw's own)
@@ -92,9 +93,9 @@ for case in range(N):
             while sh is None and ranks >= 2:   # (small draws: fewer ranks until the planes suffice; a forced form that is refused: the driver's rule)
                 try:
                     if threads:
-                        sh = capi.ShardedCSIFT3D(vol, devices=(0,) * ranks, sharded_octaves=octs, partial_windows=partial, transport="copies", **params_n)
+                        sh = capi.ShardedCSIFT3D(vol, devices=(0,) * ranks, sharded_octaves=octs, partial_windows=partial, transport="copies", ghost_octave0=ghost, **params_n)
                     else:
-                        sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=partial, **params_n)
+                        sh = capi.ShardedCSIFT3D(vol, devices=(0,), sim_ranks=ranks, sharded_octaves=octs, partial_windows=partial, ghost_octave0=ghost, **params_n)
                 except capi.Sift3dError as e:
                     why = str(e)[:90]   # (the last refusal is printed with the draw: most small draws have no plane shape / depth the slab contexts take)
                     if partial is True:
@@ -152,6 +153,6 @@ for case in range(N):
             sys.exit(1)
         nkp += len(kp)
         pys = "  py-slabs %d/%d%s" % (w2, o2, " partial" if p2 else "") if (case % 2 == 1 and ex is not None) else ""
-        print("draw %3d ok  %-16s levels %d sigma %.2f hooks %s  kp %d%s%s" % (case, shape, levels, sd, hooks, len(kp), ("  no slabs: " + why) if sh is None else "  slabs %d/%d %s%s" % (ranks, octs, "".join("p" if p else "w" for p in plan), " threads" if threads else "") + " planes %s" % planes, pys), flush=True)
+        print("draw %3d ok  %-16s levels %d sigma %.2f hooks %s  kp %d%s%s" % (case, shape, levels, sd, hooks, len(kp), ("  no slabs: " + why) if sh is None else "  slabs %d/%d %s%s" % (ranks, octs, "".join("p" if p else "w" for p in plan), " threads" if threads else "") + (" ghost" if ghost else "") + " planes %s" % planes, pys), flush=True)
         g.close()
 print("soak: %d draws, %d keypoints, %.0f s, all equal" % (N, nkp, time.time() - t0))
