@@ -48,7 +48,8 @@ S3D_HOOKS=one_stream=1 python3 $REPO/scripts/pmc_kernel.py k_march_level 512 1 S
 cd $REPO
 ( python3 bench.py --workload slab --steps 5 --warmup 2 2>/dev/null; for r in 2 4 8; do python3 bench.py --workload slab --native --sim-ranks $r --steps 5 --warmup 2 2>/dev/null; done;
   python3 bench.py --workload slab --native --sim-ranks 8 --whole-windows --steps 5 --warmup 2 2>/dev/null; python3 bench.py --workload slab --sim-ranks 8 --steps 3 --warmup 1 2>/dev/null;
-  python3 bench.py --workload slab --native --rank-threads 8 --steps 5 --warmup 2 2>/dev/null ) > $OUT/${TAG}_slab_sim.json   # (last: 8 rank THREADS on the one GPU, copy transport)
+  python3 bench.py --workload slab --native --rank-threads 8 --steps 5 --warmup 2 2>/dev/null;
+  python3 bench.py --workload slab --native --sim-ranks 8 --ghost --steps 5 --warmup 2 2>/dev/null ) > $OUT/${TAG}_slab_sim.json   # (the last two: 8 rank THREADS on the one GPU over the copy transport; octave 0 on ghost zones)
 bash $REPO/scripts/slab_kernel_sums.sh 8 native > $OUT/${TAG}_slab_kernel_sums.txt 2>&1
 bash $REPO/scripts/solo_rank_trace.sh 3 > $OUT/${TAG}_solo_rank3.txt 2>&1
 FULL=1 bash $REPO/scripts/solo_rank_trace.sh 7 > $OUT/${TAG}_solo_rank7.txt 2>&1   # (the tail rank, every launch)
