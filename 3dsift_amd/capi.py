@@ -57,7 +57,7 @@ SYMBOLS = [
     "sift3d_sharded_create", "sift3d_sharded_create_ex", "sift3d_sharded_run", "sift3d_sharded_num_keypoints", "sift3d_sharded_get_keypoints", "sift3d_sharded_info",
     "sift3d_sharded_error", "sift3d_sharded_destroy",
     "sift3d_test_hook", "sift3d_debug_counters", "sift3d_debug_face_lookup", "sift3d_match_times", "sift3d_debug_copy_bandwidth",
-    "sift3d_match_warmup", "sift3d_test_staging_slice", "sift3d_test_sharded_time_rank",
+    "sift3d_match_warmup", "sift3d_test_staging_slice", "sift3d_test_slab_plan", "sift3d_test_sharded_time_rank",
 ]
 HOOKS = {"dog_eager": 0, "glast_eager": 1, "det_serial": 2, "separable": 3, "desc_nocache": 4, "match_nodma": 5, "one_stream": 6,
          "desc_mass_shift": 7, "list_cap": 8, "peer_copy": 9, "desc_nosplit": 10, "march_tiles": 11, "desc_exact_cells": 12, "lazy_generic": 13, "sharded_fail_rank": 14}

@@ -1598,6 +1598,19 @@ extern "C" int sift3d_test_sharded_time_rank(sift3d_sharded_handle H, int rank, 
 	return rc;
 }
 
+extern "C" int sift3d_test_slab_plan(int nz, int world, int min_planes, double side_w, double tail_w, int tail_rank, int halvings, int *z0, int *z1) {
+	if (nz <= 0 || world < 1 || halvings < 0 || !z0 || !z1) return SIFT3D_ERR_ARG;
+	Bounds b;
+	if (!slab_bounds_weighted(nz, world, min_planes, side_w, tail_w, tail_rank, b)) return SIFT3D_ERR_ARG;
+	int dz = nz;
+	for (int o = 0; o <= halvings; o++) {
+		for (int r = 0; r < world; r++) { z0[o * world + r] = b[(size_t)r].first; z1[o * world + r] = b[(size_t)r].second; }
+		b = halve_bounds(b, dz);
+		dz /= 2;
+	}
+	return SIFT3D_OK;
+}
+
 // bytes every rank RECEIVES per step: the plane halos of the plan (what run_local posts per level and sharded octave) and, from the keypoint
 // counts of the last run, the records and partial histograms of the octaves whose windows are split along z.  halo[r], window[r]: bytes.
 extern "C" int sift3d_sharded_traffic(sift3d_sharded_handle H, double *halo /* [world] */, double *window /* [world] */) {

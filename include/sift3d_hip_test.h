@@ -54,6 +54,10 @@ int sift3d_debug_face_lookup(const float *grad3, int n, int route, int *face, fl
 /* the byte range [*o, *e) of an n-byte staging chunk that copy thread t of nt moves (csrc/staging.hip): host arithmetic only, no GPU.
  * tests/test_cabi_cpu.py checks that the nt ranges tile [0, n) for the sizes that r05's floor division left short. */
 int sift3d_test_staging_slice(size_t n, int nt, int t, size_t *o, size_t *e);
+/* r06: the native z-slab driver's plan, host only: the owned plane ranges [z0[r], z1[r]) of `world` slabs of an octave of nz planes dealt by weight
+ * (a z-neighbour side costs side_w planes, the rank tail_rank -- or none: -1 -- tail_w more, every rank owns at least min_planes), and of the
+ * `halvings` octaves below (a rank owns the planes k whose plane 2k it owns above): z0 / z1 hold (halvings + 1) * world entries, octave major */
+int sift3d_test_slab_plan(int nz, int world, int min_planes, double side_w, double tail_w, int tail_rank, int halvings, int *z0, int *z1);
 
 /* Simulated ranks of the native z-slab driver (sift3d_sharded_create with sim_ranks > 0) after a run: the whole step of ONE rank enqueued again
  * on the buffers the run left behind (what it receives is copied from its neighbours' buffers) and timed alone on the GPU -- the GPU time of

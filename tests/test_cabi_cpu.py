@@ -60,6 +60,44 @@ def test_staging_slices_tile_every_chunk(capi):
             assert pos == n, (n, nt, pos)
 
 
+def test_native_slab_plan_weighted_and_halved(capi):
+    """csrc/sharded.hip (r06): slabs dealt by weight with any integer boundaries, and the rule that carries them down the octaves -- a rank owns the
+    planes k of the next octave whose plane 2k it owns.  Host only (sift3d_test_slab_plan).  For random (nz, world, weights): the slabs tile [0, nz) in
+    rank order, every rank owns at least min_planes, costlier ranks own fewer planes; in every octave below the ranges still tile [0, nz >> o) and rank r
+    owns plane k exactly when it owns plane 2k above (odd depths: the last plane has no image)."""
+    import ctypes as C
+    L = capi.lib()
+    L.sift3d_test_slab_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rng = np.random.default_rng(11)
+    draws = [(512, 8, 32, 9.1, 17.4, 7, 3), (512, 2, 128, 9.1, 17.4, 1, 3), (160, 8, 10, 9.1, 900.0, 7, 2), (33, 3, 4, 0.0, 0.0, -1, 2), (64, 1, 8, 9.1, 5.0, 0, 3)]
+    for _ in range(300):
+        world = int(rng.integers(1, 17)); S = int(rng.integers(1, 4))
+        minp = int(rng.integers(1 << S, 40)); nz = int(rng.integers(world * minp, world * minp + 600))
+        draws.append((nz, world, minp, float(rng.uniform(0, 30)), float(rng.choice([0.0, rng.uniform(0, 60), 5000.0])), int(rng.integers(-1, world)), S))
+    for nz, world, minp, sw, tw, tr, S in draws:
+        z0 = (C.c_int * ((S + 1) * world))(); z1 = (C.c_int * ((S + 1) * world))()
+        assert L.sift3d_test_slab_plan(nz, world, minp, sw, tw, tr, S, z0, z1) == 0, (nz, world, minp)
+        a = np.array(z0).reshape(S + 1, world); b = np.array(z1).reshape(S + 1, world)
+        assert a[0, 0] == 0 and b[0, -1] == nz and (a[0, 1:] == b[0, :-1]).all() and (b[0] - a[0] >= minp).all(), (nz, world, minp, a[0], b[0])
+        n0 = b[0] - a[0]
+        if world >= 3 and tr != 0:   # an inner rank pays two sides, the first rank one (and no tail): never more planes inside than at the front (within rounding)
+            inner = [n0[r] for r in range(1, world - 1) if r != tr or tw == 0]
+            assert not inner or max(inner) <= n0[0] + 1, (n0, sw, tr)
+            if tr == world - 1 and tw > 0:
+                assert n0[-1] <= n0[0] + 1, (n0, tw)
+        dz = nz
+        for o in range(1, S + 1):
+            up_a, up_b = a[o - 1], b[o - 1]
+            dz2 = dz // 2
+            assert a[o, 0] == 0 and b[o, -1] == dz2 and (a[o, 1:] == b[o, :-1]).all(), (o, a[o], b[o])
+            for r in range(world):
+                want = [k for k in range(dz2) if up_a[r] <= 2 * k < up_b[r]]
+                got = list(range(a[o, r], b[o, r]))
+                assert got == want, (nz, world, o, r)
+            dz = dz2
+    assert L.sift3d_test_slab_plan(10, 4, 8, 1.0, 1.0, 3, 1, z0, z1) != 0   # 4 x 8 planes do not fit 10
+
+
 def test_struct_layouts(capi):
     # sift3d_keypoint mirrors CPUSIFT::Keypoint minus the desc pointer: 168 bytes, rx at 24, Rotation at 96
     dt = capi.KP_DTYPE
