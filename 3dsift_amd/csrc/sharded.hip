@@ -1317,9 +1317,9 @@ extern "C" int sift3d_sharded_create_ex(sift3d_sharded_handle *out, const float 
 					if (own_q && hipGetDeviceProperties(&pr, w.device) == hipSuccess && pr.multiProcessorCount > 0) {
 						std::vector<uint32_t> mask((size_t)(pr.multiProcessorCount + 31) / 32, 0u);
 						for (int cu = 0; cu < pr.multiProcessorCount; cu++) mask[(size_t)cu / 32] |= 1u << (cu % 32);
-						CR_HIP(hipExtStreamCreateWithCUMask(&w.tstream, (uint32_t)mask.size(), mask.data()));
-					} else
-						CR_HIP(hipStreamCreateWithFlags(&w.tstream, hipStreamNonBlocking));
+						if (hipExtStreamCreateWithCUMask(&w.tstream, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); w.tstream = nullptr; }  // (a pooled stream then)
+					}
+					if (!w.tstream) CR_HIP(hipStreamCreateWithFlags(&w.tstream, hipStreamNonBlocking));
 				}
 				CR_ABI(sift3d_set_stream(w.tail, w.tstream));
 				size_t nf = 0;
