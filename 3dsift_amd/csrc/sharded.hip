@@ -1535,24 +1535,34 @@ extern "C" int sift3d_sharded_get_keypoints(sift3d_sharded_handle H, sift3d_keyp
 		}
 		pos += (size_t)n;
 	}
-	// 4. the descriptors: one staged pipeline per GPU (its own pinned pool), the GPUs side by side
+	// 4. the descriptors: one staged pipeline per GPU (its own pinned pool), the GPUs side by side.  Ranks that share a device (simulated ranks, rank
+	// threads of the copy transport) share ONE pipeline: eight calls one after the other took 6.7 ms for 112 MB, one takes what the bytes take.
 	if (desc) {
-		std::vector<int> rcs((size_t)W, SIFT3D_OK);
-		std::vector<std::string> errs((size_t)W);
-		auto pull = [&](int r) {
+		std::map<int, std::vector<D2HSeg>> by_dev;
+		std::map<int, hipStream_t> dev_stream;
+		for (int r = 0; r < W; r++) {
 			Worker &w = H->workers[(size_t)r];
-			if (segs[(size_t)r].empty()) return;
-			if (hipSetDevice(w.device) != hipSuccess) { rcs[(size_t)r] = SIFT3D_ERR_HIP; return; }
-			rcs[(size_t)r] = staged_d2h_v(segs[(size_t)r].data(), (int)segs[(size_t)r].size(), w.device, w.stream);
-			if (rcs[(size_t)r]) errs[(size_t)r] = sift3d_last_error();
+			if (segs[(size_t)r].empty()) continue;
+			std::vector<D2HSeg> &v = by_dev[w.device];
+			v.insert(v.end(), segs[(size_t)r].begin(), segs[(size_t)r].end());
+			if (!dev_stream.count(w.device)) dev_stream[w.device] = w.stream;
+		}
+		std::map<int, int> rcs;
+		std::map<int, std::string> errs;
+		for (auto &kv : by_dev) { rcs[kv.first] = SIFT3D_OK; errs[kv.first] = std::string(); }  // (no insertion from the threads below)
+		auto pull = [&](int dev) {
+			if (hipSetDevice(dev) != hipSuccess) { rcs[dev] = SIFT3D_ERR_HIP; return; }
+			std::vector<D2HSeg> &v = by_dev[dev];
+			rcs[dev] = staged_d2h_v(v.data(), (int)v.size(), dev, dev_stream[dev]);
+			if (rcs[dev]) errs[dev] = sift3d_last_error();
 		};
-		if (H->sim || W == 1) for (int r = 0; r < W; r++) pull(r);
+		if (by_dev.size() <= 1) { for (auto &kv : by_dev) pull(kv.first); }
 		else {
 			std::vector<std::thread> th;
-			for (int r = 0; r < W; r++) th.emplace_back(pull, r);
+			for (auto &kv : by_dev) th.emplace_back(pull, kv.first);
 			for (auto &t : th) t.join();
 		}
-		for (int r = 0; r < W; r++) if (rcs[(size_t)r]) { H->err = "rank " + std::to_string(r) + ": " + errs[(size_t)r]; set_last_error(H->err); return rcs[(size_t)r]; }
+		for (auto &kv : rcs) if (kv.second) { H->err = "device " + std::to_string(kv.first) + ": " + errs[kv.first]; set_last_error(H->err); return kv.second; }
 	}
 	H->times[1] = H->times[0] + std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	return SIFT3D_OK;
